@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the PCG hot path (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one batched SQP-linsolve: `batch` independent IIWA-14 trajectories (N=128 knots,
+symmetric-stair preconditioner, lambda0 = 0, pcg_max_iter = 167, pcg_exit_tol = 1e-4) solved by ONE
+launch of the persistent PCG kernel on every GPU.  Trajectories are independent, so ranks just get
+their own `batch` (weak scaling) and the only collectives are the barrier, the max-over-ranks of
+the time and the sum of the iteration counts (RCCL).  Inputs are synthetic (mpcgpu_amd.synth),
+built on the host and resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0: value = PCG iterations / second over all GPUs, plus `roofline`
+(HBM, algorithmic bytes of the dominant kernel / its HIP-event duration) and, at N=1,
+`cpu_baseline` (the reference's QDLDL CPU path, restated in oracle/, timed on this host).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mpcgpu_amd import PcgSolver, pcg_config, synth  # noqa: E402
+from mpcgpu_amd import dist as D  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_inputs(N, batch, seed0, precond, chunk=128):
+    """Host-side synthetic Schur systems for trajectories seed0 .. seed0+batch-1 (float32)."""
+    S = np.empty((batch, 3 * 196 * N), np.float32)
+    P = np.empty_like(S)
+    g = np.empty((batch, 14 * N), np.float32)
+    for lo in range(0, batch, chunk):
+        hi = min(batch, lo + chunk)
+        # trajectory b of make_kkt(seed) depends only on (seed, b): offset through the seed pair
+        k = synth.make_kkt(N, hi - lo, 900000 + seed0 + lo)
+        S[lo:hi], P[lo:hi], g[lo:hi] = synth.form_schur(k, precond=precond, poison_unused=True)
+    return S, P, g
+
+
+def cpu_baseline(N, S_host, g_host, mean_iters, budget_s=12.0):
+    """Reference CPU path (include/qdldl/sqp.cuh:22-49: numeric LDL^T factor + solve per linsolve,
+    symbolic part amortised) — restated in oracle/ because the qdldl submodule is absent
+    ("kind": "port").  Single thread: QDLDL is serial and the reference calls it from one thread."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    ns = min(32, S_host.shape[0])
+    L = orc.LdlSolver(N, np.float32)
+    vals = [orc.bd_to_csr_lowertri(np.nan_to_num(S_host[b]), N) for b in range(ns)]
+    x = L.solve(vals[0], g_host[0])          # warm
+    t0 = time.perf_counter()
+    cnt = 0
+    while time.perf_counter() - t0 < budget_s:
+        for b in range(ns):
+            x = L.solve(vals[b], g_host[b])
+        cnt += ns
+    dt = time.perf_counter() - t0
+    resid = float(np.abs(orc.bt_spmv(np.nan_to_num(S_host[ns - 1]).astype(np.float64), x, N) - g_host[ns - 1]).max()
+                  / np.abs(g_host[ns - 1]).max())
+    # same algorithm as the GPU (fp32 PCG, SS) on one CPU core, for a same-unit comparison
+    t1 = time.perf_counter()
+    it_cpu = 0
+    nb = min(4, S_host.shape[0])
+    for b in range(nb):
+        r = orc.pcg(np.nan_to_num(S_host[b]), np.nan_to_num(P_HOST[b]), g_host[b], np.zeros(14 * N, np.float32),
+                    N, synth.pcg_max_iter(N), 1e-4, "ss")
+        it_cpu += r["iters"]
+    dt_pcg = time.perf_counter() - t1
+    solves_per_s = cnt / dt
+    return {
+        "value": solves_per_s, "unit": "linsolves/s", "cores": 1, "kind": "port",
+        "ms_per_linsolve": 1e3 / solves_per_s,
+        "equiv_pcg_iters_per_sec": solves_per_s * mean_iters,
+        "cpu_pcg_port_iters_per_sec": it_cpu / dt_pcg,
+        "sample": f"{cnt} QDLDL-style float32 LDL^T factor+solve calls over the first {ns} trajectories of the "
+                  f"workload ({dt:.1f} s, 1 thread, nnz={len(vals[0])}, dim={14 * N}); last rel. residual {resid:.1e}; "
+                  f"reference also pays D2H(values,gamma)+H2D(lambda) per solve (include/qdldl/sqp.cuh:261-282), not included",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+P_HOST = None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--knots", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=1024, help="trajectories PER GPU (weak scaling)")
+    ap.add_argument("--precond", default="ss", choices=["ss", "jacobi"])
+    ap.add_argument("--exit-tol", type=float, default=1e-4)
+    ap.add_argument("--max-iter", type=int, default=0, help="0 = reference table (settings.cuh:123-139)")
+    ap.add_argument("--pcg-waves", type=int, default=0)
+    ap.add_argument("--nt", type=int, default=-1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--spmv", action="store_true", help="also time the stand-alone block-tridiagonal SpMV")
+    args = ap.parse_args()
+
+    rank, local_rank, world = D.init()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    N, B = args.knots, args.batch
+    max_iter = args.max_iter or synth.pcg_max_iter(N)
+    cfg = pcg_config(pcg_exit_tol=args.exit_tol, pcg_max_iter=max_iter)
+
+    global P_HOST
+    S_h, P_h, g_h = build_inputs(N, B, rank * B, args.precond)
+    P_HOST = P_h
+    d_S, d_P, d_g = (torch.from_numpy(a).to(dev) for a in (S_h, P_h, g_h))
+    d_lam = torch.zeros(B, 14 * N, device=dev)
+    d_it = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_ex = torch.zeros(B, dtype=torch.uint8, device=dev)
+
+    sol = PcgSolver(N, max_batch=B, device=local_rank)
+    if args.pcg_waves:
+        sol.set_option("pcg_waves", args.pcg_waves)
+    if args.nt >= 0:
+        sol.set_option("nt_loads", args.nt)
+
+    def step():
+        d_lam.zero_()                       # every step is the same cold-start solve
+        sol.solve(d_S, d_P, d_g, d_lam, cfg, args.precond, iters=d_it, exits=d_ex)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # --- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks ---
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        d_lam.zero_()
+        ev[i][0].record()                   # HIP events on the stream the kernel is launched on
+        sol.solve(d_S, d_P, d_g, d_lam, cfg, args.precond, iters=d_it, exits=d_ex)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    D.barrier()
+    t_local = time.perf_counter() - t0
+    t_all = D.max_over_ranks(t_local, dev)
+
+    it_host = d_it.cpu().numpy().astype(np.int64)
+    ex_host = d_ex.cpu().numpy()
+    iters_step_local = int(it_host.sum())
+    iters_step_all = D.sum_over_ranks(iters_step_local, dev)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms_all = D.max_over_ranks(kern_ms, dev)
+
+    ms_per_step = 1e3 * t_all / args.steps
+    value = iters_step_all / (t_all / args.steps)
+    bytes_iter = synth.algorithmic_bytes(N, precond=args.precond)["pcg_iter"]
+    achieved = iters_step_local * bytes_iter / (kern_ms * 1e-3) / 1e9     # GB/s, this rank's kernel
+
+    out = {
+        "metric": "pcg_iterations_per_sec", "value": value, "unit": "iter/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"IIWA-14 (n=14) N={N} knots, {args.precond} preconditioner, batch {B} trajectories/GPU "
+                               f"(BASELINE config 4's batch, HBM-resident 616 MB > 256 MiB MALL), lambda0=0, "
+                               f"max_iter={max_iter}, exit_tol={args.exit_tol:g}",
+                   "knot_points": N, "state_size": 14, "batch_per_gpu": B, "global_batch": B * world,
+                   "precond": args.precond, "pcg_max_iter": max_iter, "pcg_exit_tol": args.exit_tol,
+                   "parallelism": f"batch-sharded x{world}", "pcg_waves": sol.get_option("pcg_waves"),
+                   "nt_loads": sol.get_option("nt_loads")},
+        "ms_per_linsolve": ms_per_step / B,
+        "linsolves_per_sec": B * world / (ms_per_step * 1e-3),
+        "mean_pcg_iters": float(it_host.mean()), "max_iter_exit_rate": float(ex_host.mean()),
+        "resident_trajectories_per_gpu": sol.checkPcgOccupancy(),
+        "roofline": {"bound": "hbm", "kernel": "pcg_traj_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_all,
+                     "algorithmic_bytes_per_launch": iters_step_local * bytes_iter,
+                     "bytes_per_unit": bytes_iter, "units_per_launch": iters_step_local,
+                     "unit_of_work": "one PCG iteration of one trajectory"},
+    }
+
+    if args.spmv:
+        x = torch.randn(B, 14 * N, device=dev)
+        y = torch.empty_like(x)
+        for _ in range(3):
+            sol.bt_spmv(d_S, x, y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            sol.bt_spmv(d_S, x, y)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        b = synth.algorithmic_bytes(N)["spmv"] * B
+        out["spmv"] = {"kernel": "bt_spmv_kernel", "ms": ms, "achieved": b / (ms * 1e-3) / 1e9, "unit": "GB/s",
+                       "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b,
+                       "trajectory_spmv_per_sec": B / (ms * 1e-3)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, S_h, g_h, float(it_host.mean()), args.cpu_seconds)
+        out["cpu_baseline"]["gpu_linsolves_per_sec"] = out["linsolves_per_sec"]
+
+    if rank == 0:
+        print(json.dumps(out))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

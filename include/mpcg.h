@@ -1,0 +1,120 @@
+/* mpcg.h — C ABI of libmpcg_hip.so: MI355X (gfx950) PCG solver for MPCGPU's block-tridiagonal
+ * Schur system  S * lambda = gamma.
+ *
+ * This is the drop-in boundary for ONE path of A2R-Lab/MPCGPU: the linear-system solve inside
+ * sqpSolvePcg (reference include/pcg/sqp.cuh:230).  Citations below are file:line in the reference
+ * tree.  The reference's implementation of that path (pcg<T,STATE_SIZE,KNOT_POINTS>, pcg_config,
+ * pcgSharedMemSize, checkPcgOccupancy) lives in its un-vendored submodule A2R-Lab/GBD-PCG; the
+ * entry points here replace its call sites.
+ *
+ * Conventions (identical to the reference's device buffers):
+ *   - S, Pinv: "bd" layout, per trajectory [N][3][n*n] floats; block (k,col) column-major at
+ *     k*3n^2 + col*n^2; col 0/1/2 = left / diagonal / right block of block row k
+ *     (include/pcg/linsys_setup.cuh:36-57, 490-507).  Stored NEGATED (:15-19).  Blocks (0,col 0) and
+ *     (N-1,col 2) are never written by the reference (:97,118) and are never read here.
+ *   - gamma, lambda: [N][n] floats per trajectory; lambda is in/out (warm start,
+ *     include/mpcsim.cuh:186,267,337).
+ *   - every pointer named d_* is a DEVICE pointer on the handle's device; `stream` is a hipStream_t
+ *     passed as void* (NULL = default stream).  Calls are stream-ordered and never synchronise.
+ *   - batched entry points take `batch` independent trajectories stored back to back.
+ *
+ * All functions return MPCG_OK (0) or a negative mpcg_status; mpcg_last_error() gives the text.
+ * Nothing here falls back to a CPU implementation: without a gfx950 device every compute entry
+ * point fails with MPCG_ERR_HIP.
+ */
+#ifndef MPCG_H
+#define MPCG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCG_ABI_VERSION 1
+
+typedef enum mpcg_status {
+    MPCG_OK = 0,
+    MPCG_ERR_INVALID = -1,      /* bad argument (null pointer, batch > max_batch, ...) */
+    MPCG_ERR_UNSUPPORTED = -2,  /* state_size / knot_points outside the compiled specialisations */
+    MPCG_ERR_HIP = -3,          /* a HIP runtime call failed (text in mpcg_last_error) */
+    MPCG_ERR_NOMEM = -4
+} mpcg_status;
+
+/* Preconditioner stored in d_Pinv (include/pcg/linsys_setup.cuh):
+ * block-Jacobi = only the diagonal blocks Pinv[k,1] are read (:202-210, 510-524);
+ * symmetric stair = all three block columns (:97-136). */
+typedef enum mpcg_precond {
+    MPCG_PRECOND_JACOBI = 1,
+    MPCG_PRECOND_SS = 3
+} mpcg_precond;
+
+typedef struct mpcg_handle mpcg_handle;
+
+/* Library / build identification. */
+int mpcg_abi_version(void);
+const char *mpcg_build_info(void);
+
+/* Handle = per-device solver context for fixed (state_size, knot_points).  Replaces the
+ * per-call cudaMalloc of PCG scratch in sqpSolvePcg (include/pcg/sqp.cuh:116-135): the solver
+ * needs no global scratch at all (r, p, upsilon live in LDS), the handle only caches launch
+ * configuration.  max_batch bounds `batch` of later calls.  device < 0 = current device. */
+int mpcg_create(mpcg_handle **out, int device, uint32_t state_size, uint32_t knot_points, uint32_t max_batch);
+int mpcg_destroy(mpcg_handle *h);
+const char *mpcg_last_error(const mpcg_handle *h);   /* h may be NULL: last error of mpcg_create */
+
+/* Replaces pcgSharedMemSize<T>(state_size, knot_points) (include/pcg/sqp.cuh:151): dynamic LDS
+ * bytes one trajectory's workgroup uses.  0 if the shape is unsupported. */
+size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points);
+
+/* Replaces checkPcgOccupancy<T>(kernel, threads, n, N) (examples/track_iiwa_pcg.cu:24).  The
+ * reference aborts when its N cooperative blocks cannot be co-resident; this solver has no
+ * inter-workgroup dependency, so the check cannot fail for a supported shape.  Writes the number
+ * of trajectories one GPU solves concurrently (workgroups/CU * CUs) to *resident_trajectories. */
+int mpcg_check_pcg_occupancy(mpcg_handle *h, uint32_t *resident_trajectories);
+
+/* THE HOT PATH.  Replaces
+ *   cudaLaunchCooperativeKernel(pcg<T,n,N>, N, PCG_NUM_THREADS, args, smem)  (include/pcg/sqp.cuh:230)
+ * for `batch` trajectories at once.  For trajectory b:
+ *   r = gamma - S lambda; rt = Pinv r; p = rt; eta = r.rt
+ *   repeat <= max_iter: ups = S p; alpha = eta / (p.ups); lambda += alpha p; r -= alpha ups;
+ *                       rt = Pinv r; eta' = r.rt; if |eta'| < exit_tol stop;
+ *                       p = rt + (eta'/eta) p; eta = eta'
+ * d_iters[b]         = completed lambda updates            (reference: d_pcg_iters, sqp.cuh:131-132)
+ * d_max_iter_exit[b] = 1 if the loop ran out of iterations (reference: d_pcg_exit,  sqp.cuh:133-135,
+ *                      meaning include/mpcsim.cuh:382-387), 0 if |eta| fell below exit_tol.
+ * If |eta| < exit_tol already after the setup step, 0 iterations are done and the flag is 0.
+ * max_iter / exit_tol are pcg_config<T>::pcg_max_iter / pcg_exit_tol (include/mpcsim.cuh:213-216). */
+int mpcg_pcg_solve(mpcg_handle *h,
+                   const float *d_S, const float *d_Pinv, const float *d_gamma, float *d_lambda,
+                   uint32_t batch, uint32_t max_iter, float exit_tol, mpcg_precond precond,
+                   uint32_t *d_iters, uint8_t *d_max_iter_exit, void *stream);
+
+/* Same solve for ONE trajectory with exactly the reference kernel's 12 arguments, in order
+ * (include/pcg/sqp.cuh:137-150).  d_r and d_p receive the final residual and search direction
+ * (the reference uses them as global scratch); d_v_temp and d_eta_new_temp (the reference's
+ * per-block partial-sum buffers, :124-125) are accepted and left untouched.  d_pcg_exit points
+ * to a 1-byte bool as in the reference.  The symmetric-stair preconditioner is assumed, as in the
+ * reference (its Pinv always carries the off-diagonal blocks). */
+int mpcg_pcg_solve_ref(mpcg_handle *h,
+                       float *d_S, float *d_Pinv, float *d_gamma, float *d_lambda,
+                       float *d_r, float *d_p, float *d_v_temp, float *d_eta_new_temp,
+                       uint32_t *d_pcg_iters, uint8_t *d_pcg_exit,
+                       uint32_t pcg_max_iter, float pcg_exit_tol, void *stream);
+
+/* Building block P2/P3 of the path, exposed for measurement and reuse: batched block-tridiagonal
+ * matrix-vector product  y = M x  with M in bd layout (cols = 3) or its diagonal blocks only
+ * (cols = 1).  x, y: [batch][N][n]. */
+int mpcg_bt_spmv(mpcg_handle *h, const float *d_M, const float *d_x, float *d_y,
+                 uint32_t batch, int cols, void *stream);
+
+/* Launch-configuration knobs (tuning / experiments; defaults are chosen by mpcg_create):
+ * key "pcg_waves" (8 or 16 wavefronts per trajectory workgroup), "nt_loads" (0/1). */
+int mpcg_set_option(mpcg_handle *h, const char *key, int value);
+int mpcg_get_option(const mpcg_handle *h, const char *key, int *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCG_H */

@@ -1,0 +1,228 @@
+// mpcg_capi.hip — C ABI (include/mpcg.h) over the gfx950 kernels in pcg_kernels.hip.h.
+// Host side is plain C++/HIP: no torch types, no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <string>
+
+#include "../../include/mpcg.h"
+#include "pcg_kernels.hip.h"
+
+using namespace mpcg;
+
+struct mpcg_handle {
+    int device = 0;
+    uint32_t n = 0, N = 0, max_batch = 0;
+    int num_cus = 0;
+    int pcg_waves = 16;       // wavefronts per trajectory workgroup (8 or 16)
+    int nt_loads = 1;         // non-temporal hint on the matrix stream
+    int spmv_blocks_per_cu = 8;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(mpcg_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+#define HIP_TRY(h, expr)                                                                    \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((h), MPCG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static bool shape_supported(uint32_t n, uint32_t N) { return n == (uint32_t)NS && N >= 2 && N <= 2048; }
+
+static size_t lds_bytes_for(uint32_t N, int nw) { return pcg_lds_floats((int)N, nw) * sizeof(float); }
+static constexpr size_t kLdsMax = 160 * 1024;
+
+extern "C" {
+
+int mpcg_abi_version(void) { return MPCG_ABI_VERSION; }
+
+const char* mpcg_build_info(void) {
+    return "libmpcg_hip gfx950 fp32 n=14 (persistent per-trajectory PCG, wave64 7x7 float4 block mapping)";
+}
+
+size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
+    if (!shape_supported(state_size, knot_points)) return 0;
+    size_t b = lds_bytes_for(knot_points, 16);
+    return b <= kLdsMax ? b : 0;
+}
+
+int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t knot_points, uint32_t max_batch) {
+    if (!out) return fail(nullptr, MPCG_ERR_INVALID, "mpcg_create: out is null");
+    *out = nullptr;
+    if (!shape_supported(state_size, knot_points) || lds_bytes_for(knot_points, 16) > kLdsMax)
+        return fail(nullptr, MPCG_ERR_UNSUPPORTED,
+                    "mpcg_create: only state_size=14 and 2 <= knot_points with the iterate vectors fitting "
+                    "160 KiB of LDS are compiled in");
+    if (max_batch == 0) return fail(nullptr, MPCG_ERR_INVALID, "mpcg_create: max_batch is 0");
+    int ndev = 0;
+    HIP_TRY(nullptr, hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(nullptr, MPCG_ERR_HIP, "mpcg_create: no HIP device");
+    if (device < 0) HIP_TRY(nullptr, hipGetDevice(&device));
+    if (device >= ndev) return fail(nullptr, MPCG_ERR_INVALID, "mpcg_create: device out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, MPCG_ERR_UNSUPPORTED, std::string("mpcg_create: built for gfx950, device is ") + prop.gcnArchName);
+    mpcg_handle* h = new (std::nothrow) mpcg_handle();
+    if (!h) return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: out of host memory");
+    h->device = device; h->n = state_size; h->N = knot_points; h->max_batch = max_batch;
+    h->num_cus = prop.multiProcessorCount;
+    *out = h;
+    return MPCG_OK;
+}
+
+int mpcg_destroy(mpcg_handle* h) {
+    delete h;
+    return MPCG_OK;
+}
+
+const char* mpcg_last_error(const mpcg_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
+    if (!h || !key) return MPCG_ERR_INVALID;
+    if (!strcmp(key, "pcg_waves")) {
+        if (value != 4 && value != 8 && value != 16) return fail(h, MPCG_ERR_INVALID, "pcg_waves must be 4, 8 or 16");
+        h->pcg_waves = value; return MPCG_OK;
+    }
+    if (!strcmp(key, "nt_loads")) { h->nt_loads = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "spmv_blocks_per_cu")) {
+        if (value < 1 || value > 64) return fail(h, MPCG_ERR_INVALID, "spmv_blocks_per_cu out of range");
+        h->spmv_blocks_per_cu = value; return MPCG_OK;
+    }
+    return fail(h, MPCG_ERR_INVALID, std::string("unknown option ") + key);
+}
+
+int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
+    if (!h || !key || !value) return MPCG_ERR_INVALID;
+    if (!strcmp(key, "pcg_waves")) { *value = h->pcg_waves; return MPCG_OK; }
+    if (!strcmp(key, "nt_loads")) { *value = h->nt_loads; return MPCG_OK; }
+    if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
+    if (!strcmp(key, "num_cus")) { *value = h->num_cus; return MPCG_OK; }
+    return MPCG_ERR_INVALID;
+}
+
+}  // extern "C"
+
+// ---- launch helpers -----------------------------------------------------------------------------
+template <int NW, bool NT>
+static int launch_pcg_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    const size_t lds = lds_bytes_for((uint32_t)a.N, NW);
+    auto kern = pcg_traj_kernel<NW, NT>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(batch), dim3(NW * 64), lds, st, a);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
+
+static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    const bool nt = h->nt_loads != 0;
+    switch (h->pcg_waves) {
+        case 4:  return nt ? launch_pcg_t<4, true>(h, a, batch, st) : launch_pcg_t<4, false>(h, a, batch, st);
+        case 8:  return nt ? launch_pcg_t<8, true>(h, a, batch, st) : launch_pcg_t<8, false>(h, a, batch, st);
+        default: return nt ? launch_pcg_t<16, true>(h, a, batch, st) : launch_pcg_t<16, false>(h, a, batch, st);
+    }
+}
+
+template <int NW, bool NT>
+static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
+    const size_t lds = lds_bytes_for(h->N, NW);
+    auto kern = pcg_traj_kernel<NW, NT>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kern, NW * 64, lds));
+    return MPCG_OK;
+}
+
+extern "C" {
+
+int mpcg_check_pcg_occupancy(mpcg_handle* h, uint32_t* resident_trajectories) {
+    if (!h || !resident_trajectories) return MPCG_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int per_cu = 0, rc;
+    switch (h->pcg_waves) {
+        case 4:  rc = occupancy_t<4, true>(h, &per_cu); break;
+        case 8:  rc = occupancy_t<8, true>(h, &per_cu); break;
+        default: rc = occupancy_t<16, true>(h, &per_cu); break;
+    }
+    if (rc != MPCG_OK) return rc;
+    if (per_cu < 1) return fail(h, MPCG_ERR_UNSUPPORTED, "PCG workgroup does not fit on a CU");
+    *resident_trajectories = (uint32_t)per_cu * (uint32_t)h->num_cus;
+    return MPCG_OK;
+}
+
+int mpcg_pcg_solve(mpcg_handle* h, const float* d_S, const float* d_Pinv, const float* d_gamma, float* d_lambda,
+                   uint32_t batch, uint32_t max_iter, float exit_tol, mpcg_precond precond,
+                   uint32_t* d_iters, uint8_t* d_max_iter_exit, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_S || !d_Pinv || !d_gamma || !d_lambda || !d_iters || !d_max_iter_exit)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve: null device pointer");
+    if (batch == 0) return MPCG_OK;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve: batch exceeds max_batch");
+    if (precond != MPCG_PRECOND_JACOBI && precond != MPCG_PRECOND_SS)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve: bad preconditioner");
+    if (max_iter > 0x7fffffffu) return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve: max_iter too large");
+    if ((reinterpret_cast<uintptr_t>(d_S) | reinterpret_cast<uintptr_t>(d_Pinv)) & 15u)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve: d_S / d_Pinv must be 16-byte aligned");
+    PcgArgs a;
+    a.S = d_S; a.Pinv = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda;
+    a.r_out = nullptr; a.p_out = nullptr;
+    a.iters = d_iters; a.max_iter_exit = d_max_iter_exit;
+    a.N = (int)h->N; a.max_iter = (int)max_iter; a.exit_tol = exit_tol; a.pcols = (int)precond;
+    return launch_pcg(h, a, batch, static_cast<hipStream_t>(stream));
+}
+
+int mpcg_pcg_solve_ref(mpcg_handle* h, float* d_S, float* d_Pinv, float* d_gamma, float* d_lambda,
+                       float* d_r, float* d_p, float* d_v_temp, float* d_eta_new_temp,
+                       uint32_t* d_pcg_iters, uint8_t* d_pcg_exit,
+                       uint32_t pcg_max_iter, float pcg_exit_tol, void* stream) {
+    (void)d_v_temp; (void)d_eta_new_temp;   // reference's per-block partial-sum scratch: not needed
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_S || !d_Pinv || !d_gamma || !d_lambda || !d_pcg_iters || !d_pcg_exit)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_ref: null device pointer");
+    if ((reinterpret_cast<uintptr_t>(d_S) | reinterpret_cast<uintptr_t>(d_Pinv)) & 15u)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_ref: d_S / d_Pinv must be 16-byte aligned");
+    if (pcg_max_iter > 0x7fffffffu) return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_ref: max_iter too large");
+    PcgArgs a;
+    a.S = d_S; a.Pinv = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda;
+    a.r_out = d_r; a.p_out = d_p;
+    a.iters = d_pcg_iters; a.max_iter_exit = d_pcg_exit;
+    a.N = (int)h->N; a.max_iter = (int)pcg_max_iter; a.exit_tol = pcg_exit_tol; a.pcols = 3;
+    return launch_pcg(h, a, 1, static_cast<hipStream_t>(stream));
+}
+
+int mpcg_bt_spmv(mpcg_handle* h, const float* d_M, const float* d_x, float* d_y, uint32_t batch, int cols, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_M || !d_x || !d_y) return fail(h, MPCG_ERR_INVALID, "mpcg_bt_spmv: null device pointer");
+    if (cols != 1 && cols != 3) return fail(h, MPCG_ERR_INVALID, "mpcg_bt_spmv: cols must be 1 or 3");
+    if (batch == 0) return MPCG_OK;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_bt_spmv: batch exceeds max_batch");
+    if (reinterpret_cast<uintptr_t>(d_M) & 15u) return fail(h, MPCG_ERR_INVALID, "mpcg_bt_spmv: d_M must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_y)) & 7u)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_bt_spmv: d_x / d_y must be 8-byte aligned");
+    HIP_TRY(h, hipSetDevice(h->device));
+    SpmvArgs a{d_M, d_x, d_y, (int)h->N, (int)batch, cols};
+    constexpr int NW = 4;
+    const long total = (long)batch * h->N;
+    long blocks = (total + NW - 1) / NW;
+    const long cap = (long)h->num_cus * h->spmv_blocks_per_cu;
+    if (blocks > cap) blocks = cap;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (h->nt_loads) hipLaunchKernelGGL((bt_spmv_kernel<NW, true>), dim3((unsigned)blocks), dim3(NW * 64), 0, st, a);
+    else hipLaunchKernelGGL((bt_spmv_kernel<NW, false>), dim3((unsigned)blocks), dim3(NW * 64), 0, st, a);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,375 @@
+// pcg_kernels.hip.h — hand-written CDNA4 (gfx950) kernels for the block-tridiagonal PCG.
+//
+// Design: ONE workgroup solves ONE trajectory, start to finish, inside one
+// launch.  There is no inter-workgroup communication, hence no grid barrier (the reference's
+// structure — one block per knot + cooperative grid sync, include/pcg/sqp.cuh:230 — costs 26-100 us
+// per sync on this chip).  The iterate vectors live in LDS for the whole solve; S and Pinv are
+// streamed from HBM/L2 every iteration with fully coalesced 16-byte loads; wavefront shuffles do
+// the per-block-row reductions and the PCG inner products.
+//
+// Lane mapping for a 14x14 column-major block (196 floats = 49 float4, 16-byte aligned because
+// 196*4 = 49*16): float4 #f of a block covers flat elements 4f..4f+3; since lcm(4,14) = 28 the
+// (row, column-parity) pattern of a float4 depends only on f mod 7.  Lane l < 49 takes float4
+// f = l of each block, i.e. residue r = l % 7 and column pair g = l / 7 (columns 2g, 2g+1):
+//     r : rows of column a=2g            rows of column b=2g+1
+//     0 : 0 1 2 3
+//     1 : 4 5 6 7
+//     2 : 8 9 10 11
+//     3 : 12 13                           0 1
+//     4 :                                 2 3 4 5
+//     5 :                                 6 7 8 9
+//     6 :                                 10 11 12 13
+// so every lane has 4 accumulators with FIXED rows, a wave-level load instruction reads 784
+// contiguous bytes, and one block row (3 blocks, 2352 contiguous bytes) is 3 such loads.
+// Partial sums are combined with shuffles: over g (lane stride 7: offsets 28, 14, 7; lanes >= 49
+// hold zeros), then slot e with slot e+14 (same row, other column parity).  Result: lane q < 4
+// holds rows 4q..4q+3 of the block row's 14-vector (lane 3: rows 12, 13, and two zero pads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mpcg {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int NS = 14;          // state size this specialisation is written for
+constexpr int BLK4 = 49;        // float4 per 14x14 block
+constexpr int ROW4 = 147;       // float4 per block row (3 blocks)
+constexpr int ROWF = 588;       // floats per block row
+constexpr int KS = 16;          // LDS stride of one knot's 14-vector (2 zero pads -> float4-aligned)
+
+// Workgroup barrier that waits only for this wave's LDS traffic.  __syncthreads() would also wait
+// for vmcnt(0), i.e. drain the matrix prefetch that is deliberately in flight across the barrier.
+// All cross-wave data in these kernels goes through LDS, so lgkmcnt(0) + s_barrier is sufficient.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Matrix loads go through a buffer resource (SRD) per trajectory matrix: the hardware bounds check
+// returns 0.0 WITHOUT memory traffic for any lane whose offset is >= num_records.  That gives a
+// branch-free, fixed count of 3 loads per block row — which is what lets s_waitcnt vmcnt(3) keep the
+// next row's loads in flight while this row is consumed — and covers every masked case by sending
+// the lane to OOB_OFF: lanes 49..63, the never-written blocks (0,left)/(N-1,right), the off-diagonal
+// blocks in block-Jacobi mode and the padded steps of a wave with an odd row count.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr uint32_t OOB_OFF = 0x40000000u;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), /*stride*/ 0, (int)bytes, 0x00020000);
+}
+
+template <bool NT>
+__device__ __forceinline__ f4 buf_load4(rsrc_t r, uint32_t voff) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, NT ? 2 : 0);   // aux 2 = nt
+    return __builtin_bit_cast(f4, v);
+}
+
+struct Rows { f4 m0, m1, m2; };   // this lane's float4 of the left / diagonal / right block
+
+// Issue the 3 loads of block row k (bd layout, matrix starts at byte 0 of the SRD).
+// cols: 3 or 1 (wave-uniform); lane_off = lane*16 for lanes < 49, OOB_OFF otherwise.
+template <bool NT>
+__device__ __forceinline__ Rows load_rows(rsrc_t M, int k, int N, int cols, uint32_t lane_off) {
+    const bool valid = k < N;
+    const uint32_t row = (uint32_t)k * (ROWF * 4u) + lane_off;
+    const uint32_t o0 = (valid && cols == 3 && k > 0) ? row : OOB_OFF;
+    const uint32_t o1 = valid ? row + BLK4 * 16u : OOB_OFF;
+    const uint32_t o2 = (valid && cols == 3 && k < N - 1) ? row + 2u * BLK4 * 16u : OOB_OFF;
+    Rows R;
+    R.m0 = buf_load4<NT>(M, o0);
+    R.m1 = buf_load4<NT>(M, o1);
+    R.m2 = buf_load4<NT>(M, o2);
+    return R;
+}
+
+// Per-lane constants of the mapping above.
+struct LaneMap {
+    int g2;        // 2*g : first column of this lane's column pair (clamped for idle lanes)
+    bool a01;      // accumulators 0,1 multiply column a (else b)
+    bool a23;      // accumulators 2,3 multiply column a (else b)
+    __device__ __forceinline__ explicit LaneMap(int lane) {
+        const int l = lane < BLK4 ? lane : 0;
+        const int r = l % 7;
+        g2 = 2 * (l / 7);
+        a01 = r <= 3;
+        a23 = r <= 2;
+    }
+};
+
+// acc += block * x  for this lane's float4; xk points at the 14(+2)-vector the block multiplies.
+__device__ __forceinline__ void fma_block(f4& acc, const f4 m, const float* xk, const LaneMap& L) {
+    const f2 x = *reinterpret_cast<const f2*>(xk + L.g2);   // 8-byte aligned: KS*4 and 2g*4 are
+    const float x01 = L.a01 ? x.x : x.y;
+    const float x23 = L.a23 ? x.x : x.y;
+    acc.x = fmaf(m.x, x01, acc.x);
+    acc.y = fmaf(m.y, x01, acc.y);
+    acc.z = fmaf(m.z, x23, acc.z);
+    acc.w = fmaf(m.w, x23, acc.w);
+}
+
+__device__ __forceinline__ f4 shfl_down4(f4 v, int d) {
+    f4 o;
+    o.x = __shfl_down(v.x, d); o.y = __shfl_down(v.y, d);
+    o.z = __shfl_down(v.z, d); o.w = __shfl_down(v.w, d);
+    return o;
+}
+
+// Combine the 49 lanes' partial sums; valid result in lanes 0..3 (see header comment).
+__device__ __forceinline__ f4 reduce_rows(f4 a, int lane) {
+    a += shfl_down4(a, 28);
+    a += shfl_down4(a, 14);
+    a += shfl_down4(a, 7);
+    f4 o;
+    o.x = a.x + __shfl_down(a.z, 3);
+    o.y = a.y + __shfl_down(a.w, 3);
+    o.z = a.z + __shfl_down(a.x, 4);
+    o.w = a.w + __shfl_down(a.y, 4);
+    if (lane == 3) { o.z = 0.f; o.w = 0.f; }   // rows 14,15 do not exist: keep the LDS pads zero
+    return o;
+}
+
+__device__ __forceinline__ float dot4(f4 a, f4 b) {
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent per-trajectory PCG.  grid = batch, block = NW*64.
+// LDS (floats): xp[(N+2)*KS] p padded by a zero knot either side | xr[(N+2)*KS] r likewise |
+//               lam[N*KS] | tmp[N*KS] (upsilon, then r~) | red[2*NW]
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr size_t pcg_lds_floats(int N, int NW) {
+    return (size_t)(N + 2) * KS * 2 + (size_t)N * KS * 2 + 2 * NW;
+}
+
+struct PcgArgs {
+    const float* S; const float* Pinv; const float* gamma; float* lambda;
+    float* r_out; float* p_out;            // optional [batch][N][n] (may be null)
+    uint32_t* iters; uint8_t* max_iter_exit;
+    int N; int max_iter; float exit_tol; int pcols;   // pcols: 3 = SS, 1 = block-Jacobi
+};
+
+template <int NW, bool NT>
+__global__ __launch_bounds__(NW * 64) void pcg_traj_kernel(PcgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int N = a.N;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int NT_THREADS = NW * 64;
+
+    float* xp = lds;                       // knot j at xp + (j+1)*KS
+    float* xr = xp + (N + 2) * KS;
+    float* lam = xr + (N + 2) * KS;        // knot j at lam + j*KS
+    float* tmp = lam + N * KS;
+    float* red_v = tmp + N * KS;
+    float* red_e = red_v + NW;
+
+    const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;
+    const rsrc_t rS = make_rsrc(a.S + (size_t)b * mstride, (uint32_t)(mstride * sizeof(float)));
+    const rsrc_t rP = make_rsrc(a.Pinv + (size_t)b * mstride, (uint32_t)(mstride * sizeof(float)));
+    const uint32_t lane_off = lane < BLK4 ? (uint32_t)lane * 16u : OOB_OFF;
+    const float* gam = a.gamma + (size_t)b * vstride;
+    float* lam_g = a.lambda + (size_t)b * vstride;
+
+    const LaneMap L(lane);
+    // Block rows owned by this wave: k = w + NW*t, t < TP.  TP is padded to an even count so the two
+    // register buffers (rowA/rowB) keep fixed roles across passes; a padded step has k >= N, loads
+    // nothing and computes nothing.
+    const int TP = (((N - w + NW - 1) / NW) + 1) & ~1;
+
+    // ---- matrix stream: S rows, Pinv rows, S rows, ... always one block row ahead of use, and
+    //      NOT drained at workgroup barriers (lds_barrier) ----
+    int st_t = 0, st_pass = 0;             // position of the NEXT row to load
+    auto load_next = [&]() -> Rows {
+        const int k = w + NW * st_t;
+        Rows R = st_pass ? load_rows<NT>(rP, k, N, a.pcols, lane_off) : load_rows<NT>(rS, k, N, 3, lane_off);
+        if (++st_t >= TP) { st_t = 0; st_pass ^= 1; }
+        return R;
+    };
+    Rows rowA, rowB;
+    rowA = load_next();                    // (a wave with no rows gets zeros from the OOB path)
+
+    // ---- stage vectors: xp <- lambda0 (operand of the setup SpMV), lam <- lambda0, xr <- gamma ----
+    for (int e = tid; e < (N + 2) * KS; e += NT_THREADS) { xp[e] = 0.f; xr[e] = 0.f; }
+    for (int e = tid; e < N * KS; e += NT_THREADS) { lam[e] = 0.f; tmp[e] = 0.f; }
+    lds_barrier();
+    for (int e = tid; e < N * NS; e += NT_THREADS) {
+        const int k = e / NS, i = e - k * NS;
+        const float l0 = lam_g[e];
+        xp[(k + 1) * KS + i] = l0;
+        lam[k * KS + i] = l0;
+        xr[(k + 1) * KS + i] = gam[e];
+    }
+    lds_barrier();
+
+    // one pass over this wave's block rows: tmp[k] = M[k,:] * x ; returns sum_k d[k] . tmp[k]
+    auto step = [&](const Rows& use, int t, const float* xv, const float* dv, float& part) {
+        const int k = w + NW * t;
+        if (k < N) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            fma_block(acc, use.m0, xv + (k + 0) * KS, L);
+            fma_block(acc, use.m1, xv + (k + 1) * KS, L);
+            fma_block(acc, use.m2, xv + (k + 2) * KS, L);
+            const f4 y = reduce_rows(acc, lane);
+            if (lane < 4) {
+                *reinterpret_cast<f4*>(tmp + k * KS + 4 * lane) = y;
+                const f4 d = *reinterpret_cast<const f4*>(dv + (k + 1) * KS + 4 * lane);
+                part += dot4(d, y);
+            }
+        }
+    };
+    auto pass = [&](const float* xv, const float* dv) -> float {
+        float part = 0.f;
+        for (int t = 0; t < TP; t += 2) {
+            rowB = load_next();
+            step(rowA, t, xv, dv, part);
+            rowA = load_next();
+            step(rowB, t + 1, xv, dv, part);
+        }
+        part += __shfl_down(part, 2);
+        part += __shfl_down(part, 1);
+        return part;                        // lane 0
+    };
+    auto block_sum = [&](const float* red) -> float {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) s += red[i];
+        return s;
+    };
+    const int NV4 = N * (KS / 4);           // float4 count of an unpadded [N][KS] vector
+
+    // ---- setup: r = gamma - S lambda0 ; r~ = Pinv r ; p = r~ ; eta = r . r~ ----
+    (void)pass(xp, xp);
+    lds_barrier();
+    for (int e = tid; e < NV4; e += NT_THREADS) {
+        f4* rr = reinterpret_cast<f4*>(xr + KS) + e;
+        *rr = *rr - reinterpret_cast<const f4*>(tmp)[e];
+    }
+    lds_barrier();
+    {
+        const float part = pass(xr, xr);
+        if (lane == 0) red_e[w] = part;
+    }
+    lds_barrier();
+    float eta = block_sum(red_e);
+    for (int e = tid; e < NV4; e += NT_THREADS)
+        reinterpret_cast<f4*>(xp + KS)[e] = reinterpret_cast<const f4*>(tmp)[e];
+    lds_barrier();
+
+    uint32_t iters = 0;
+    uint32_t max_iter_exit = 1;
+    if (fabsf(eta) < a.exit_tol) {
+        max_iter_exit = 0;
+    } else {
+        for (int it = 0; it < a.max_iter; ++it) {
+            // upsilon = S p ; v = p . upsilon
+            {
+                const float part = pass(xp, xp);
+                if (lane == 0) red_v[w] = part;
+            }
+            lds_barrier();
+            const float alpha = eta / block_sum(red_v);
+            // lambda += alpha p ; r -= alpha upsilon
+            for (int e = tid; e < NV4; e += NT_THREADS) {
+                const f4 pk = reinterpret_cast<const f4*>(xp + KS)[e];
+                const f4 uk = reinterpret_cast<const f4*>(tmp)[e];
+                f4* lk = reinterpret_cast<f4*>(lam) + e;
+                f4* rk = reinterpret_cast<f4*>(xr + KS) + e;
+                *lk = *lk + alpha * pk;
+                *rk = *rk - alpha * uk;
+            }
+            lds_barrier();
+            // r~ = Pinv r ; eta' = r . r~
+            {
+                const float part = pass(xr, xr);
+                if (lane == 0) red_e[w] = part;
+            }
+            lds_barrier();
+            const float eta_new = block_sum(red_e);
+            iters = (uint32_t)(it + 1);
+            if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
+            const float beta = eta_new / eta;
+            // p = r~ + beta p
+            for (int e = tid; e < NV4; e += NT_THREADS) {
+                f4* pk = reinterpret_cast<f4*>(xp + KS) + e;
+                *pk = reinterpret_cast<const f4*>(tmp)[e] + beta * (*pk);
+            }
+            eta = eta_new;
+            lds_barrier();
+        }
+    }
+
+    // ---- write back ----
+    for (int e = tid; e < N * NS; e += NT_THREADS) {
+        const int k = e / NS, i = e - k * NS;
+        lam_g[e] = lam[k * KS + i];
+        if (a.r_out) a.r_out[(size_t)b * vstride + e] = xr[(k + 1) * KS + i];
+        if (a.p_out) a.p_out[(size_t)b * vstride + e] = xp[(k + 1) * KS + i];
+    }
+    if (tid == 0) {
+        a.iters[b] = iters;
+        a.max_iter_exit[b] = (uint8_t)max_iter_exit;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone batched block-tridiagonal SpMV  y = M x  (roofline kernel).
+// One wave per block row, waves stride over the (trajectory, knot) list so that the chip reads
+// one contiguous region at a time; x is read from global (L1/L2-resident, 56 B per knot).
+// ------------------------------------------------------------------------------------------------
+struct SpmvArgs { const float* M; const float* x; float* y; int N; int batch; int cols; };
+
+template <int NW, bool NT>
+__global__ __launch_bounds__(NW * 64) void bt_spmv_kernel(SpmvArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = a.N;
+    const long total = (long)a.batch * N;
+    const long gw = (long)blockIdx.x * NW + w, GW = (long)gridDim.x * NW;
+    const LaneMap L(lane);
+    // One SRD per launch would need > 4 GiB of range at large batch, so the descriptor is rebuilt
+    // per task from the (wave-uniform) trajectory index.
+    const uint32_t lane_off = lane < BLK4 ? (uint32_t)lane * 16u : OOB_OFF;
+    const size_t mstride = (size_t)N * ROWF;
+    auto load_task = [&](long q) -> Rows {
+        const bool valid = q < total;
+        const long qq = valid ? q : 0;
+        const int bt = (int)(qq / N);
+        const int k = valid ? (int)(qq - (long)bt * N) : N;        // k = N -> all three loads OOB
+        const rsrc_t r = make_rsrc(a.M + (size_t)bt * mstride, (uint32_t)(mstride * sizeof(float)));
+        return load_rows<NT>(r, k, N, a.cols, lane_off);
+    };
+
+    auto compute = [&](const Rows& use, long q) {
+        if (q >= total) return;
+        const int k = (int)(q % N);
+        const float* xk = a.x + (size_t)q * NS;            // x of knot k of this trajectory
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        // a neighbour that does not exist has an all-zero block; point at xk to stay in range
+        const float* xl = (k > 0) ? xk - NS : xk;
+        const float* xrr = (k < N - 1) ? xk + NS : xk;
+        fma_block(acc, use.m0, xl, L);
+        fma_block(acc, use.m1, xk, L);
+        fma_block(acc, use.m2, xrr, L);
+        const f4 y = reduce_rows(acc, lane);
+        float* yk = a.y + (size_t)q * NS + 4 * lane;       // 56q + 16*lane bytes: 8-byte aligned
+        if (lane < 3) {
+            *reinterpret_cast<f2*>(yk) = f2{y.x, y.y};
+            *reinterpret_cast<f2*>(yk + 2) = f2{y.z, y.w};
+        } else if (lane == 3) {
+            *reinterpret_cast<f2*>(yk) = f2{y.x, y.y};
+        }
+    };
+    Rows rowA = load_task(gw), rowB;
+    for (long q = gw; q < total; q += 2 * GW) {
+        rowB = load_task(q + GW);
+        compute(rowA, q);
+        rowA = load_task(q + 2 * GW);
+        compute(rowB, q + GW);
+    }
+}
+
+}  // namespace mpcg

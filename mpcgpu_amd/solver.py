@@ -1,0 +1,128 @@
+"""Host-side mirror of the reference's PCG interface, over the C ABI (include/mpcg.h).
+
+Names follow the reference (GBD-PCG as used by include/pcg/sqp.cuh and include/mpcsim.cuh):
+`pcg_config` (fields pcg_block, pcg_exit_tol, pcg_max_iter — include/mpcsim.cuh:213-216),
+`pcgSharedMemSize` (include/pcg/sqp.cuh:151), `checkPcgOccupancy`
+(examples/track_iiwa_pcg.cu:24).  Tensors are torch CUDA tensors used purely as device memory;
+all arithmetic happens in libmpcg_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from .synth import STATE_SIZE, pcg_max_iter
+
+PCG_NUM_THREADS = 128   # include/common/settings.cuh:111-113 (reference launch shape; informational)
+
+
+@dataclass
+class pcg_config:
+    """include/mpcsim.cuh:213-216."""
+    pcg_block: int = PCG_NUM_THREADS
+    pcg_exit_tol: float = 1e-4
+    pcg_max_iter: int = 167
+
+
+def pcgSharedMemSize(state_size: int, knot_points: int) -> int:
+    """Dynamic LDS bytes of one trajectory's workgroup (0 = unsupported shape)."""
+    return int(_lib.load().mpcg_pcg_lds_bytes(state_size, knot_points))
+
+
+def _ptr(t: torch.Tensor | None):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class PcgSolver:
+    """One handle per (device, state_size, knot_points).  `solve` is the batched hot path,
+    `solve_ref` the reference's single-trajectory 12-argument launch."""
+
+    def __init__(self, knot_points: int, max_batch: int = 1, state_size: int = STATE_SIZE, device: int | None = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("mpcgpu_amd.PcgSolver needs a HIP device (no CPU fallback)")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.n, self.N, self.max_batch = int(state_size), int(knot_points), int(max_batch)
+        h = C.c_void_p()
+        rc = self.lib.mpcg_create(C.byref(h), self.device, self.n, self.N, self.max_batch)
+        if rc != _lib.MPCG_OK:
+            raise _lib.MpcgError(rc, self.lib.mpcg_last_error(None).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mpcg_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != _lib.MPCG_OK:
+            raise _lib.MpcgError(rc, self.lib.mpcg_last_error(self._h).decode())
+
+    def set_option(self, key: str, value: int):
+        self._check(self.lib.mpcg_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int()
+        self._check(self.lib.mpcg_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def checkPcgOccupancy(self) -> int:
+        """Number of trajectories resident on the GPU at once (never aborts: no grid sync here)."""
+        v = C.c_uint32()
+        self._check(self.lib.mpcg_check_pcg_occupancy(self._h, C.byref(v)))
+        return v.value
+
+    def _chk(self, t, numel, dtype, name):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == dtype and t.numel() == numel):
+            raise ValueError(f"{name}: need contiguous cuda {dtype} tensor with {numel} elements, "
+                             f"got {tuple(t.shape)} {t.dtype} {t.device}")
+
+    def solve(self, S, Pinv, gamma, lam, config: pcg_config | None = None, precond: str = "ss",
+              iters: torch.Tensor | None = None, exits: torch.Tensor | None = None):
+        """In-place batched solve.  S, Pinv: [B, 3*n*n*N]; gamma, lam: [B, n*N] (lam in/out).
+        Returns (iters uint32-as-int32 [B], max_iter_exit uint8 [B]) device tensors; no sync."""
+        cfg = config or pcg_config(pcg_max_iter=pcg_max_iter(self.N))
+        B = lam.shape[0] if lam.dim() > 1 else 1
+        n, N = self.n, self.N
+        self._chk(S, B * 3 * n * n * N, torch.float32, "S")
+        self._chk(Pinv, B * 3 * n * n * N, torch.float32, "Pinv")
+        self._chk(gamma, B * n * N, torch.float32, "gamma")
+        self._chk(lam, B * n * N, torch.float32, "lambda")
+        if iters is None:
+            iters = torch.empty(B, dtype=torch.int32, device=lam.device)
+        if exits is None:
+            exits = torch.empty(B, dtype=torch.uint8, device=lam.device)
+        pc = _lib.MPCG_PRECOND_SS if precond == "ss" else _lib.MPCG_PRECOND_JACOBI
+        if precond not in ("ss", "jacobi"):
+            raise ValueError("precond must be 'ss' or 'jacobi'")
+        self._check(self.lib.mpcg_pcg_solve(self._h, _ptr(S), _ptr(Pinv), _ptr(gamma), _ptr(lam), B,
+                                            int(cfg.pcg_max_iter), float(cfg.pcg_exit_tol), pc,
+                                            _ptr(iters), _ptr(exits), _stream()))
+        return iters, exits
+
+    def solve_ref(self, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp,
+                  d_pcg_iters, d_pcg_exit, pcg_max_iter: int, pcg_exit_tol: float):
+        """The reference kernel's argument list, in order (include/pcg/sqp.cuh:137-150)."""
+        self._check(self.lib.mpcg_pcg_solve_ref(self._h, _ptr(d_S), _ptr(d_Pinv), _ptr(d_gamma), _ptr(d_lambda),
+                                                _ptr(d_r), _ptr(d_p), _ptr(d_v_temp), _ptr(d_eta_new_temp),
+                                                _ptr(d_pcg_iters), _ptr(d_pcg_exit),
+                                                int(pcg_max_iter), float(pcg_exit_tol), _stream()))
+
+    def bt_spmv(self, M, x, y=None, cols: int = 3):
+        B = x.shape[0] if x.dim() > 1 else 1
+        n, N = self.n, self.N
+        self._chk(M, B * 3 * n * n * N, torch.float32, "M")
+        self._chk(x, B * n * N, torch.float32, "x")
+        if y is None:
+            y = torch.empty_like(x)
+        self._check(self.lib.mpcg_bt_spmv(self._h, _ptr(M), _ptr(x), _ptr(y), B, int(cols), _stream()))
+        return y

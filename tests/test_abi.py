@@ -1,0 +1,78 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mpcg.h declares; argument
+validation that needs no device works; without a GPU the compute path fails loudly (no fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mpcg.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpcg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(hiplib):
+    from mpcgpu_amd import _lib
+    names = _declared()
+    assert len(names) >= 12
+    for nm in names:
+        assert hasattr(hiplib, nm), f"{nm} declared in include/mpcg.h but not exported"
+        assert nm in _lib.SYMBOLS, f"{nm} has no ctypes signature in mpcgpu_amd/_lib.py"
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_exports_are_plain_c(hiplib):
+    from mpcgpu_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(_declared()) <= exported
+    # no torch / python symbols pulled into the product library
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "torch" not in und.lower() and "Py_" not in und
+
+
+def test_version_and_lds_size(hiplib):
+    assert hiplib.mpcg_abi_version() == 1
+    assert b"gfx950" in hiplib.mpcg_build_info()
+    # xp, xr: (N+2)*16 floats, lam, tmp: N*16 floats, 32 partials  (DESIGN.md §LDS layout)
+    for N in (2, 32, 128, 512):
+        assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * ((N + 2) * 16 * 2 + N * 16 * 2 + 32)
+    assert hiplib.mpcg_pcg_lds_bytes(14, 128) == 33152
+    assert hiplib.mpcg_pcg_lds_bytes(12, 128) == 0          # only n = 14 is compiled in
+    assert hiplib.mpcg_pcg_lds_bytes(14, 1024) == 0         # vectors would not fit 160 KiB LDS
+
+
+def test_create_argument_errors(hiplib):
+    from mpcgpu_amd import _lib
+    h = C.c_void_p()
+    assert hiplib.mpcg_create(None, 0, 14, 32, 1) == _lib.MPCG_ERR_INVALID
+    assert hiplib.mpcg_create(C.byref(h), 0, 12, 32, 1) == _lib.MPCG_ERR_UNSUPPORTED
+    assert b"state_size" in hiplib.mpcg_last_error(None)
+    assert hiplib.mpcg_create(C.byref(h), 0, 14, 32, 0) == _lib.MPCG_ERR_INVALID
+    assert hiplib.mpcg_destroy(None) == _lib.MPCG_OK
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly(hiplib):
+    from mpcgpu_amd import PcgSolver, _lib
+    h = C.c_void_p()
+    assert hiplib.mpcg_create(C.byref(h), 0, 14, 32, 1) == _lib.MPCG_ERR_HIP
+    assert not h.value
+    with pytest.raises(RuntimeError):
+        PcgSolver(32)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under mpcgpu_amd/ or include/ may reference it."""
+    for base in ("mpcgpu_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".h", ".hip", ".hpp", ".cpp")):
+                    txt = open(os.path.join(dp, f)).read()
+                    assert "libmpcg_oracle" not in txt and "import oracle" not in txt and "orc_" not in txt, f

@@ -1,0 +1,262 @@
+"""GPU (MI355X): parity of the HIP path — called through the C ABI (libmpcg_hip.so via
+mpcgpu_amd.PcgSolver) — against the CPU oracle and the committed golden vectors.
+
+Stated fp32 tolerance: for a FIXED iteration count K (exit_tol = 0) on the
+golden systems,  |lam_hip - lam_f64|_inf / |lam_f64|_inf <= max(1e-3, 4*d32)  where d32 is the same
+distance for the CPU float32 restatement (reduction order differs, fp32 CG drifts at cond ~1e5).
+With tolerance exit: flag 0, iteration count within 10 % (+-2) of the float64 count, and the true
+residual no worse than 2x the CPU float32 restatement's.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from mpcgpu_amd import synth
+from util import golden, relinf, rel_residual
+
+pytestmark = pytest.mark.gpu
+n = 14
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+@pytest.fixture(scope="module")
+def P():
+    from mpcgpu_amd import PcgSolver, pcg_config, _lib
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    _lib.load()          # fails loudly if the extension is missing: there is no fallback
+    return PcgSolver, pcg_config
+
+
+def solve(P, N, S, Pinv, gamma, lam0, max_iter, tol, precond="ss", waves=None):
+    PcgSolver, pcg_config = P
+    B = S.shape[0]
+    sol = PcgSolver(N, max_batch=B)
+    if waves:
+        sol.set_option("pcg_waves", waves)
+    lam = dev(lam0, torch.float32)
+    it, ex = sol.solve(dev(S), dev(Pinv), dev(gamma), lam,
+                       pcg_config(pcg_exit_tol=tol, pcg_max_iter=max_iter), precond)
+    torch.cuda.synchronize()
+    return lam.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [8, 32])
+@pytest.mark.parametrize("cols", [3, 1])
+def test_spmv_matches_golden_and_oracle(P, orc, N, cols):
+    G = golden(N)
+    M = G["S"].copy().reshape(N, 3, 196)
+    M[0, 0] = np.nan          # never-written slots must not be read
+    M[-1, 2] = np.nan
+    sol = P[0](N, max_batch=1)
+    y = sol.bt_spmv(dev(M.reshape(1, -1)), dev(G["spmv_x"].reshape(1, -1)), cols=cols).cpu().numpy()[0]
+    ref = orc.bt_spmv(G["S"].astype(np.float64), G["spmv_x"], N, cols=cols)
+    assert np.isfinite(y).all() and relinf(y, ref) < 2e-6
+    if cols == 3:
+        assert relinf(y, G["spmv_y"]) < 2e-6
+
+
+def test_spmv_batched_full_size_properties(P, orc):
+    """N=128, batch 64: oracle parity on sampled trajectories + linearity + symmetry x^T S y = y^T S x."""
+    N, B = 128, 64
+    k = synth.make_kkt(N, B, 5)
+    S, _, _ = synth.form_schur(k, poison_unused=True)
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(B, n * N)).astype(np.float32)
+    z = rng.normal(size=(B, n * N)).astype(np.float32)
+    sol = P[0](N, max_batch=B)
+    dS = dev(S)
+    yx = sol.bt_spmv(dS, dev(x)).cpu().numpy()
+    yz = sol.bt_spmv(dS, dev(z)).cpu().numpy()
+    yxz = sol.bt_spmv(dS, dev(2.0 * x - 0.5 * z)).cpu().numpy()
+    assert np.isfinite(yx).all()
+    for b in (0, 17, 63):
+        assert relinf(yx[b], orc.bt_spmv(np.nan_to_num(S[b]).astype(np.float64), x[b], N)) < 5e-6
+    assert relinf(yxz, 2.0 * yx - 0.5 * yz) < 5e-6
+    a = np.einsum("bi,bi->b", z.astype(np.float64), yx.astype(np.float64))
+    c = np.einsum("bi,bi->b", x.astype(np.float64), yz.astype(np.float64))
+    assert np.abs(a - c).max() / np.abs(a).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [8, 32])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+@pytest.mark.parametrize("waves", [4, 8, 16])
+def test_pcg_fixed_iterations_vs_golden(P, orc, N, pc, waves):
+    G = golden(N)
+    Pm = G["Pinv"].copy().reshape(N, 3, 196)
+    Sm = G["S"].copy().reshape(N, 3, 196)
+    for M in (Pm, Sm):
+        M[0, 0] = np.nan
+        M[-1, 2] = np.nan
+    if pc == "jacobi":        # block-Jacobi must not read the off-diagonal blocks at all
+        Pm[:, 0] = np.nan
+        Pm[:, 2] = np.nan
+    for K in (5, 20, 50):
+        lam, it, ex = solve(P, N, Sm.reshape(1, -1), Pm.reshape(1, -1), G["gamma"].reshape(1, -1),
+                            np.zeros((1, n * N), np.float32), K, 0.0, pc, waves)
+        want = G[f"lam_{pc}_K{K}"]
+        cpu32 = orc.pcg(G["S"], G["Pinv"], G["gamma"], np.zeros(n * N, np.float32), N, K, 0.0, pc)
+        d32 = relinf(cpu32["lam"], want)
+        assert it[0] == K and ex[0] == 1
+        assert relinf(lam[0], want) <= max(1e-3, 4 * d32), (K, relinf(lam[0], want), d32)
+
+
+@pytest.mark.parametrize("N", [8, 32])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+def test_pcg_tolerance_exit_vs_golden(P, orc, N, pc):
+    G = golden(N)
+    want_it = int(G[f"iters_tol_{pc}"])
+    lam, it, ex = solve(P, N, G["S"].reshape(1, -1), G["Pinv"].reshape(1, -1), G["gamma"].reshape(1, -1),
+                        np.zeros((1, n * N), np.float32), 5000, 1e-4, pc)
+    assert ex[0] == 0
+    assert abs(int(it[0]) - want_it) <= max(2, 0.1 * want_it)
+    cpu32 = orc.pcg(G["S"], G["Pinv"], G["gamma"], np.zeros(n * N, np.float32), N, 5000, 1e-4, pc)
+    r_hip = rel_residual(G["S"], G["gamma"], lam[0], N)
+    r_cpu = rel_residual(G["S"], G["gamma"], cpu32["lam"], N)
+    assert r_hip <= 2 * r_cpu + 1e-6
+    assert relinf(lam[0], G["lam_direct"]) < 0.15        # loose tolerance => ~5 % from the exact solve
+
+
+def test_pcg_max_iter_flag_and_warm_start(P, orc):
+    G = golden(8)
+    N = 8
+    args = (G["S"].reshape(1, -1), G["Pinv"].reshape(1, -1), G["gamma"].reshape(1, -1))
+    lam, it, ex = solve(P, N, *args, np.zeros((1, n * N), np.float32), 7, 1e-4)
+    assert it[0] == 7 and ex[0] == 1                      # ran out of iterations (mpcsim.cuh:382-387)
+    lam, it, ex = solve(P, N, *args, G["lam_warm"].reshape(1, -1), 20, 0.0)
+    assert relinf(lam[0], G["lam_warm_ss_K20"]) < 1e-3    # lambda is in/out: warm start honoured
+    # already converged: no update, flag cleared, lambda untouched bit for bit
+    lam0 = G["lam_direct"].astype(np.float32).reshape(1, -1)
+    lam, it, ex = solve(P, N, *args, lam0, 50, 1e-2)
+    assert it[0] == 0 and ex[0] == 0
+    np.testing.assert_array_equal(lam, lam0)
+    # max_iter = 0: setup only
+    lam, it, ex = solve(P, N, *args, np.zeros((1, n * N), np.float32), 0, 1e-9)
+    assert it[0] == 0 and ex[0] == 1 and (lam == 0).all()
+
+
+@pytest.mark.parametrize("N,waves", [(2, 16), (3, 4), (5, 8), (17, 16), (33, 8), (64, 16), (100, 16), (128, 8),
+                                     (128, 16), (256, 16), (512, 16)])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+def test_pcg_shapes_vs_oracle(P, orc, N, waves, pc):
+    """Ragged / odd / maximum horizon lengths, 3 trajectories each, vs the float32 and float64 oracle."""
+    B, K = 3, 25
+    k = synth.make_kkt(N, B, 1000 + N)
+    S, Pinv, g = synth.form_schur(k, precond="ss", poison_unused=True)
+    lam, it, ex = solve(P, N, S, Pinv, g, np.zeros((B, n * N), np.float32), K, 0.0, pc, waves)
+    assert (it == K).all() and (ex == 1).all() and np.isfinite(lam).all()
+    for b in range(B):
+        Sz, Pz = np.nan_to_num(S[b]), np.nan_to_num(Pinv[b])
+        r64 = orc.pcg(Sz.astype(np.float64), Pz.astype(np.float64), g[b].astype(np.float64), np.zeros(n * N), N, K, 0.0, pc)
+        r32 = orc.pcg(Sz, Pz, g[b], np.zeros(n * N, np.float32), N, K, 0.0, pc)
+        d32 = relinf(r32["lam"], r64["lam"])
+        assert relinf(lam[b], r64["lam"]) <= max(1e-3, 4 * d32)
+
+
+def test_pcg_batched_full_size(P, orc):
+    """BASELINE config 3/4 shape: N=128, SS, max_iter 167, tol 1e-4, batch 96 with mixed warm starts so
+    that trajectories leave the loop at different iterations; sampled oracle parity, residual
+    decrease for all, bitwise run-to-run determinism, batch-composition independence."""
+    N, B = 128, 96
+    k = synth.make_kkt(N, B, 2024)
+    S, Pinv, g = synth.form_schur(k, poison_unused=True)
+    lam0 = np.zeros((B, n * N), np.float32)
+    for b in range(0, B, 3):          # every third trajectory starts close to its solution
+        exact = orc.direct_solve(S[b], g[b], N)
+        lam0[b] = (exact * (1 + 1e-3 * np.sin(np.arange(n * N)))).astype(np.float32)
+    lam, it, ex = solve(P, N, S, Pinv, g, lam0, 167, 1e-4)
+    lam2, it2, ex2 = solve(P, N, S, Pinv, g, lam0, 167, 1e-4)
+    np.testing.assert_array_equal(lam, lam2)
+    np.testing.assert_array_equal(it, it2)
+    assert len(set(it.tolist())) > 1 and (it[ex == 1] == 167).all() and (it[ex == 0] < 167 + 1).all()
+    for b in (0, 1, 2, 47, 95):
+        Sz, Pz = np.nan_to_num(S[b]), np.nan_to_num(Pinv[b])
+        r32 = orc.pcg(Sz, Pz, g[b], lam0[b], N, 167, 1e-4, "ss")
+        assert abs(int(it[b]) - r32["iters"]) <= max(2, 0.1 * r32["iters"])
+        assert ex[b] == r32["max_iter_exit"] or abs(int(it[b]) - r32["iters"]) > 0
+        r_hip, r_cpu, r_0 = (rel_residual(S[b], g[b], v, N) for v in (lam[b], r32["lam"], lam0[b]))
+        assert r_hip <= 2 * r_cpu + 1e-6 and (r_hip < r_0 or it[b] == 0)
+    # a trajectory's result does not depend on what else is in the batch
+    sub = [5, 6, 7]
+    lam_s, it_s, _ = solve(P, N, S[sub], Pinv[sub], g[sub], lam0[sub], 167, 1e-4)
+    np.testing.assert_array_equal(lam_s, lam[sub])
+    np.testing.assert_array_equal(it_s, it[sub])
+
+
+def test_solve_ref_twelve_argument_entry(P, orc):
+    """The reference's kernel argument list (include/pcg/sqp.cuh:137-150), incl. d_r / d_p contents and
+    the 1-byte bool exit flag."""
+    G = golden(32)
+    N = 32
+    sol = P[0](N)
+    d_S, d_Pinv, d_gamma = dev(G["S"]), dev(G["Pinv"]), dev(G["gamma"])
+    d_lambda = torch.zeros(n * N, device="cuda")
+    d_r = torch.full((n * N,), 7.0, device="cuda")
+    d_p = torch.full((n * N,), 7.0, device="cuda")
+    d_v_temp = torch.full((N,), 3.0, device="cuda")
+    d_eta_new_temp = torch.full((N,), 3.0, device="cuda")
+    d_iters = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d_exit = torch.zeros(1, dtype=torch.bool, device="cuda")
+    sol.solve_ref(d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp, d_iters, d_exit, 20, 0.0)
+    torch.cuda.synchronize()
+    r64 = orc.pcg(G["S"].astype(np.float64), G["Pinv"].astype(np.float64), G["gamma"].astype(np.float64),
+                  np.zeros(n * N), N, 20, 0.0, "ss")
+    assert int(d_iters.item()) == 20 and bool(d_exit.item()) is True
+    assert relinf(d_lambda.cpu().numpy(), G["lam_ss_K20"]) < 1e-3
+    assert relinf(d_r.cpu().numpy(), r64["r"]) < 5e-2 and relinf(d_p.cpu().numpy(), r64["p"]) < 5e-2
+    assert (d_v_temp == 3.0).all() and (d_eta_new_temp == 3.0).all()       # accepted, untouched
+    # inputs are not modified
+    np.testing.assert_array_equal(d_S.cpu().numpy(), G["S"])
+    np.testing.assert_array_equal(d_gamma.cpu().numpy(), G["gamma"])
+
+
+def test_error_behaviour(P):
+    from mpcgpu_amd import _lib
+    N = 8
+    sol = P[0](N, max_batch=2)
+    G = golden(N)
+    S3 = np.tile(G["S"], (3, 1))
+    g3 = np.tile(G["gamma"], (3, 1))
+    with pytest.raises(_lib.MpcgError) as e:
+        sol.solve(dev(S3), dev(S3), dev(g3), torch.zeros(3, n * N, device="cuda"))
+    assert e.value.code == _lib.MPCG_ERR_INVALID and "max_batch" in str(e.value)
+    lib = sol.lib
+    buf = torch.zeros(4 * 3 * 196 * N + 64, device="cuda")
+    it = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ex = torch.zeros(1, dtype=torch.uint8, device="cuda")
+    p = buf.data_ptr()
+    rc = lib.mpcg_pcg_solve(sol._h, C.c_void_p(p + 4), C.c_void_p(p), C.c_void_p(p), C.c_void_p(p), 1, 5, 0.0, 3,
+                            C.c_void_p(it.data_ptr()), C.c_void_p(ex.data_ptr()), None)
+    assert rc == _lib.MPCG_ERR_INVALID and b"aligned" in lib.mpcg_last_error(sol._h)
+    rc = lib.mpcg_pcg_solve(sol._h, None, C.c_void_p(p), C.c_void_p(p), C.c_void_p(p), 1, 5, 0.0, 3,
+                            C.c_void_p(it.data_ptr()), C.c_void_p(ex.data_ptr()), None)
+    assert rc == _lib.MPCG_ERR_INVALID
+    rc = lib.mpcg_pcg_solve(sol._h, C.c_void_p(p), C.c_void_p(p), C.c_void_p(p), C.c_void_p(p), 1, 5, 0.0, 2,
+                            C.c_void_p(it.data_ptr()), C.c_void_p(ex.data_ptr()), None)
+    assert rc == _lib.MPCG_ERR_INVALID
+    assert sol.checkPcgOccupancy() >= 256            # at least one trajectory per CU resident
+    with pytest.raises(_lib.MpcgError):
+        P[0](1024)                                    # vectors do not fit LDS -> unsupported, loudly
+
+
+def test_runs_on_non_default_stream(P):
+    G = golden(8)
+    N = 8
+    sol = P[0](N)
+    s = torch.cuda.Stream()
+    lam = torch.zeros(1, n * N, device="cuda")
+    dS, dP, dg = dev(G["S"].reshape(1, -1)), dev(G["Pinv"].reshape(1, -1)), dev(G["gamma"].reshape(1, -1))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        it, ex = sol.solve(dS, dP, dg, lam, P[1](pcg_exit_tol=0.0, pcg_max_iter=20))
+    s.synchronize()
+    assert relinf(lam.cpu().numpy()[0], G["lam_ss_K20"]) < 1e-3

