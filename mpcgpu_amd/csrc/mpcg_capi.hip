@@ -18,6 +18,7 @@ struct mpcg_handle {
     int num_cus = 0;
     int pcg_waves = 16;       // wavefronts per trajectory workgroup (8 or 16)
     int nt_loads = 1;         // non-temporal hint on the matrix stream
+    int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
     int spmv_blocks_per_cu = 8;
     std::string err;
 };
@@ -93,6 +94,10 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
         h->pcg_waves = value; return MPCG_OK;
     }
     if (!strcmp(key, "nt_loads")) { h->nt_loads = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "pcg_max_wg_per_cu")) {
+        if (value < 0 || value > 8) return fail(h, MPCG_ERR_INVALID, "pcg_max_wg_per_cu out of range");
+        h->max_wg_per_cu = value; return MPCG_OK;
+    }
     if (!strcmp(key, "spmv_blocks_per_cu")) {
         if (value < 1 || value > 64) return fail(h, MPCG_ERR_INVALID, "spmv_blocks_per_cu out of range");
         h->spmv_blocks_per_cu = value; return MPCG_OK;
@@ -104,6 +109,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!h || !key || !value) return MPCG_ERR_INVALID;
     if (!strcmp(key, "pcg_waves")) { *value = h->pcg_waves; return MPCG_OK; }
     if (!strcmp(key, "nt_loads")) { *value = h->nt_loads; return MPCG_OK; }
+    if (!strcmp(key, "pcg_max_wg_per_cu")) { *value = h->max_wg_per_cu; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "num_cus")) { *value = h->num_cus; return MPCG_OK; }
     return MPCG_ERR_INVALID;
@@ -112,9 +118,21 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
 }  // extern "C"
 
 // ---- launch helpers -----------------------------------------------------------------------------
+// LDS bytes requested at launch: the real need, raised to floor(160 KiB / k) when the handle limits
+// residency to k workgroups per CU (fewer resident trajectories = smaller re-read set = more of it
+// stays in the 256 MiB Infinity Cache between PCG iterations).
+static size_t lds_request(const mpcg_handle* h, int nw) {
+    size_t need = lds_bytes_for(h->N, nw);
+    if (h->max_wg_per_cu > 0) {
+        size_t pad = (kLdsMax / (size_t)h->max_wg_per_cu) & ~(size_t)15;
+        if (pad > need) need = pad;
+    }
+    return need;
+}
+
 template <int NW, bool NT>
 static int launch_pcg_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
-    const size_t lds = lds_bytes_for((uint32_t)a.N, NW);
+    const size_t lds = lds_request(h, NW);
     auto kern = pcg_traj_kernel<NW, NT>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -136,7 +154,7 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
 
 template <int NW, bool NT>
 static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
-    const size_t lds = lds_bytes_for(h->N, NW);
+    const size_t lds = lds_request(h, NW);
     auto kern = pcg_traj_kernel<NW, NT>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -1,9 +1,12 @@
 """GPU (MI355X): parity of the HIP path — called through the C ABI (libmpcg_hip.so via
 mpcgpu_amd.PcgSolver) — against the CPU oracle and the committed golden vectors.
 
-Stated fp32 tolerance: for a FIXED iteration count K (exit_tol = 0) on the
-golden systems,  |lam_hip - lam_f64|_inf / |lam_f64|_inf <= max(1e-3, 4*d32)  where d32 is the same
-distance for the CPU float32 restatement (reduction order differs, fp32 CG drifts at cond ~1e5).
+Stated fp32 tolerance, E = |lam_hip - lam_f64|_inf / |lam_f64|_inf against the
+float64 iterate after the SAME number of iterations (exit_tol = 0):
+  K <= 3  : E <= max(2e-5, 4*band), band < 5e-4 (before CG amplifies rounding: pins the arithmetic)
+  K <= 50 : E <= max(1e-3, 4*band), band = util.fp32_band = what the CPU float32 restatement does on
+            the same and on 1-ulp-perturbed inputs (fp32 CG at cond ~1e5 drifts 1e-4..4e-3 by K=25-50
+            whatever the summation order).
 With tolerance exit: flag 0, iteration count within 10 % (+-2) of the float64 count, and the true
 residual no worse than 2x the CPU float32 restatement's.
 """
@@ -14,7 +17,7 @@ import pytest
 import torch
 
 from mpcgpu_amd import synth
-from util import golden, relinf, rel_residual
+from util import fp32_band, golden, relinf, rel_residual
 
 pytestmark = pytest.mark.gpu
 n = 14
@@ -104,10 +107,28 @@ def test_pcg_fixed_iterations_vs_golden(P, orc, N, pc, waves):
         lam, it, ex = solve(P, N, Sm.reshape(1, -1), Pm.reshape(1, -1), G["gamma"].reshape(1, -1),
                             np.zeros((1, n * N), np.float32), K, 0.0, pc, waves)
         want = G[f"lam_{pc}_K{K}"]
-        cpu32 = orc.pcg(G["S"], G["Pinv"], G["gamma"], np.zeros(n * N, np.float32), N, K, 0.0, pc)
-        d32 = relinf(cpu32["lam"], want)
+        band = fp32_band(orc, G["S"], G["Pinv"], G["gamma"], np.zeros(n * N), N, K, pc, want)
         assert it[0] == K and ex[0] == 1
-        assert relinf(lam[0], want) <= max(1e-3, 4 * d32), (K, relinf(lam[0], want), d32)
+        assert relinf(lam[0], want) <= max(1e-3, 4 * band), (K, relinf(lam[0], want), band)
+
+
+@pytest.mark.parametrize("N", [8, 32, 128, 512])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+def test_pcg_first_iterations_tight(P, orc, N, pc):
+    """K = 1, 2, 3 from a random warm start: rounding has not been amplified yet, so the HIP arithmetic
+    must agree with float64 to a few 1e-5 (4x what the CPU float32 restatement manages, itself
+    < 5e-4) — a wrong block, row, sign or reduction would show as O(1)."""
+    k = synth.make_kkt(N, 2, 31 + N)
+    S, Pinv, g = synth.form_schur(k, poison_unused=True)
+    lam0 = np.random.default_rng(N).normal(0, 0.5, (2, n * N)).astype(np.float32)
+    for K in (1, 2, 3):
+        lam, it, ex = solve(P, N, S, Pinv, g, lam0, K, 0.0, pc)
+        for b in range(2):
+            r64 = orc.pcg(np.nan_to_num(S[b]).astype(np.float64), np.nan_to_num(Pinv[b]).astype(np.float64),
+                          g[b].astype(np.float64), lam0[b].astype(np.float64), N, K, 0.0, pc)
+            band = fp32_band(orc, S[b], Pinv[b], g[b], lam0[b], N, K, pc, r64["lam"])
+            assert band < 5e-4
+            assert relinf(lam[b], r64["lam"]) <= max(2e-5, 4 * band), (K, b, relinf(lam[b], r64["lam"]), band)
 
 
 @pytest.mark.parametrize("N", [8, 32])
@@ -157,9 +178,8 @@ def test_pcg_shapes_vs_oracle(P, orc, N, waves, pc):
     for b in range(B):
         Sz, Pz = np.nan_to_num(S[b]), np.nan_to_num(Pinv[b])
         r64 = orc.pcg(Sz.astype(np.float64), Pz.astype(np.float64), g[b].astype(np.float64), np.zeros(n * N), N, K, 0.0, pc)
-        r32 = orc.pcg(Sz, Pz, g[b], np.zeros(n * N, np.float32), N, K, 0.0, pc)
-        d32 = relinf(r32["lam"], r64["lam"])
-        assert relinf(lam[b], r64["lam"]) <= max(1e-3, 4 * d32)
+        band = fp32_band(orc, Sz, Pz, g[b], np.zeros(n * N), N, K, pc, r64["lam"])
+        assert relinf(lam[b], r64["lam"]) <= max(1e-3, 4 * band), (relinf(lam[b], r64["lam"]), band)
 
 
 def test_pcg_batched_full_size(P, orc):

@@ -22,3 +22,22 @@ def rel_residual(S_bd, gamma, lam, N):
     Sd = synth.bd_to_dense(np.nan_to_num(S_bd), N)
     g = np.asarray(gamma, np.float64)
     return np.linalg.norm(g - Sd @ np.asarray(lam, np.float64)) / np.linalg.norm(g)
+
+
+def fp32_band(orc, S, Pinv, g, lam0, N, K, pc, ref64, trials=4):
+    """Self-calibrating fp32 tolerance for a FIXED iteration count K: the largest distance from the
+    float64 iterate reached by the CPU float32 restatement on (a) the same inputs and (b) inputs
+    perturbed by one float32 ulp (relative 6e-8 gaussian) — i.e. what rounding-level noise does to
+    fp32 CG on this system (cond ~1e5).  Any correct fp32 implementation with a different summation
+    order lands inside a small multiple of this band."""
+    S = np.nan_to_num(np.asarray(S, np.float32))
+    P = np.nan_to_num(np.asarray(Pinv, np.float32))
+    g = np.asarray(g, np.float32)
+    lam0 = np.asarray(lam0, np.float32)
+    band = relinf(orc.pcg(S, P, g, lam0, N, K, 0.0, pc)["lam"], ref64)
+    rng = np.random.default_rng(K * 1000 + N)
+    for _ in range(trials):
+        Sp = (S.astype(np.float64) * (1 + 6e-8 * rng.standard_normal(S.shape))).astype(np.float32)
+        gp = (g.astype(np.float64) * (1 + 6e-8 * rng.standard_normal(g.shape))).astype(np.float32)
+        band = max(band, relinf(orc.pcg(Sp, P, gp, lam0, N, K, 0.0, pc)["lam"], ref64))
+    return band
