@@ -194,6 +194,17 @@ def main():
                      "unit_of_work": "one PCG iteration of one trajectory"},
     }
 
+    # HBM traffic of this exact workload from the committed PMC passes (bench cannot run rocprofv3 on itself)
+    try:
+        key = (f"N{N}_B{B}_{args.precond}_it{max_iter}_tol{args.exit_tol:g}_w{sol.get_option('pcg_waves')}"
+               f"_nt{sol.get_option('nt_loads')}")
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+        if tr:
+            out["roofline"]["traffic"] = tr["hbm_traffic_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr["source"]
+    except (OSError, ValueError):
+        pass
+
     if args.spmv:
         x = torch.randn(B, 14 * N, device=dev)
         y = torch.empty_like(x)
