@@ -1,0 +1,97 @@
+// gpu_pcg.cuh — source-level shim with the names the reference takes from its GBD-PCG submodule,
+// implemented over the C ABI of libmpcg_hip.so (include/mpcg.h).  Put this directory on the include
+// path in place of -IGBD-PCG/include (reference Makefile:5) and link -lmpcg_hip.
+//
+//   reference use                                        here
+//   pcg_config<T>            include/mpcsim.cuh:213-216  same fields
+//   pcgSharedMemSize<T>(n,N) include/pcg/sqp.cuh:151     mpcg_pcg_lds_bytes
+//   checkPcgOccupancy<T>(..) examples/track_iiwa_pcg.cu:24  mpcg_check_pcg_occupancy (never aborts for a supported shape)
+//   pcg<T,n,N>               include/pcg/sqp.cuh:129     a HOST launcher with the kernel's 12 parameters
+//   cudaLaunchCooperativeKernel(pcg_kernel, N, threads, args, smem)   include/pcg/sqp.cuh:230
+//                                                        -> mpcgLaunchPcg(pcg_kernel, N, threads, args, smem)
+//                                                           (the ONE line of sqp.cuh that changes)
+// Only T = float (linsys_t with USE_DOUBLES=0, include/common/settings.cuh:41-49) and STATE_SIZE = 14.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <type_traits>
+#include <utility>
+
+#include "../mpcg.h"
+#include "gpuassert.cuh"
+#include "utils.cuh"
+
+template <typename T>
+struct pcg_config {
+    T pcg_exit_tol = static_cast<T>(1e-6);
+    uint32_t pcg_max_iter = 200;
+    unsigned pcg_block = 128;          // reference launch shape (PCG_NUM_THREADS); informational here
+    unsigned pcg_grid = 0;
+    bool empty_pinv = false;
+};
+
+namespace mpcg_compat {
+
+inline void die(const char* what, const mpcg_handle* h) {
+    fprintf(stderr, "mpcg: %s: %s\n", what, mpcg_last_error(h));
+    exit(EXIT_FAILURE);                 // the reference's error convention: gpuErrchk aborts
+}
+
+// one cached handle per (device, knot_points); the solver keeps no per-call global scratch
+inline mpcg_handle* handle_for(uint32_t state_size, uint32_t knot_points) {
+    static std::map<std::pair<int, uint32_t>, mpcg_handle*> cache;
+    int dev = 0;
+    gpuErrchk(hipGetDevice(&dev));
+    auto key = std::make_pair(dev, knot_points);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    mpcg_handle* h = nullptr;
+    if (mpcg_create(&h, dev, state_size, knot_points, 1) != MPCG_OK) die("mpcg_create", nullptr);
+    cache[key] = h;
+    return h;
+}
+
+}  // namespace mpcg_compat
+
+template <typename T>
+size_t pcgSharedMemSize(uint32_t state_size, uint32_t knot_points) {
+    static_assert(std::is_same<T, float>::value, "libmpcg_hip is built for linsys_t = float");
+    return mpcg_pcg_lds_bytes(state_size, knot_points);
+}
+
+template <typename T>
+bool checkPcgOccupancy(void* /*kernel*/, dim3 /*block*/, uint32_t state_size, uint32_t knot_points) {
+    static_assert(std::is_same<T, float>::value, "libmpcg_hip is built for linsys_t = float");
+    uint32_t resident = 0;
+    mpcg_handle* h = mpcg_compat::handle_for(state_size, knot_points);
+    if (mpcg_check_pcg_occupancy(h, &resident) != MPCG_OK) mpcg_compat::die("checkPcgOccupancy", h);
+    return resident > 0;
+}
+
+// Host launcher carrying the reference kernel's parameter list (include/pcg/sqp.cuh:137-150).
+template <typename T, uint32_t STATE_SIZE, uint32_t KNOT_POINTS>
+void pcg(T* d_S, T* d_Pinv, T* d_gamma, T* d_lambda, T* d_r, T* d_p, T* d_v_temp, T* d_eta_new_temp,
+         uint32_t* d_iters, bool* d_max_iter_exit, uint32_t max_iter, T exit_tol) {
+    static_assert(std::is_same<T, float>::value, "libmpcg_hip is built for linsys_t = float");
+    static_assert(sizeof(bool) == 1, "exit flag is one byte");
+    mpcg_handle* h = mpcg_compat::handle_for(STATE_SIZE, KNOT_POINTS);
+    if (mpcg_pcg_solve_ref(h, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp, d_iters,
+                           reinterpret_cast<uint8_t*>(d_max_iter_exit), max_iter, exit_tol, /*stream*/ nullptr) != MPCG_OK)
+        mpcg_compat::die("pcg", h);
+}
+
+// Replaces cudaLaunchCooperativeKernel at include/pcg/sqp.cuh:230.  `kernel` is the void* the call
+// site made from pcg<T,n,N>; `args` is its pcgKernelArgs array (addresses of the 12 arguments).
+// Grid/block/smem are accepted and ignored: the launch shape is the library's business.
+inline hipError_t mpcgLaunchPcg(void* kernel, unsigned /*grid*/, unsigned /*block*/, void** args, size_t /*smem*/) {
+    using F = void (*)(float*, float*, float*, float*, float*, float*, float*, float*, uint32_t*, bool*, uint32_t, float);
+    F f = reinterpret_cast<F>(kernel);
+    f(*static_cast<float**>(args[0]), *static_cast<float**>(args[1]), *static_cast<float**>(args[2]),
+      *static_cast<float**>(args[3]), *static_cast<float**>(args[4]), *static_cast<float**>(args[5]),
+      *static_cast<float**>(args[6]), *static_cast<float**>(args[7]), *static_cast<uint32_t**>(args[8]),
+      *static_cast<bool**>(args[9]), *static_cast<uint32_t*>(args[10]), *static_cast<float*>(args[11]));
+    return hipGetLastError();
+}

@@ -30,5 +30,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+EXAMPLE_SRC = os.path.join(_ROOT, "examples", "sqp_pcg_callsite.cpp")
+EXAMPLE_BIN = os.path.join(_ROOT, "examples", "sqp_pcg_callsite")
+
+
+def build_example(force: bool = False, verbose: bool = False) -> str:
+    """C++ host program: the reference's PCG call site over the shim headers + the C ABI."""
+    deps = [EXAMPLE_SRC, LIB_PATH, os.path.join(_ROOT, "include", "gbd_pcg_compat", "gpu_pcg.cuh")]
+    if force or not os.path.exists(EXAMPLE_BIN) or any(os.path.getmtime(d) > os.path.getmtime(EXAMPLE_BIN) for d in deps):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(_ROOT, "include", "gbd_pcg_compat"),
+               EXAMPLE_SRC, "-L" + _HERE, "-lmpcg_hip", "-Wl,-rpath,$ORIGIN/../mpcgpu_amd", "-o", EXAMPLE_BIN]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return EXAMPLE_BIN
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_example(force="--force" in sys.argv, verbose=True))

@@ -280,3 +280,21 @@ def test_runs_on_non_default_stream(P):
         it, ex = sol.solve(dS, dP, dg, lam, P[1](pcg_exit_tol=0.0, pcg_max_iter=20))
     s.synchronize()
     assert relinf(lam.cpu().numpy()[0], G["lam_ss_K20"]) < 1e-3
+
+
+def test_cpp_callsite_over_shim_headers():
+    """examples/sqp_pcg_callsite.cpp = the reference's call site (include/pcg/sqp.cuh:116-151, 230-232)
+    compiled against include/gbd_pcg_compat/gpu_pcg.cuh and linked to libmpcg_hip.so; it checks its own
+    residual on the CPU and exits non-zero on failure."""
+    import json
+    import os
+    import subprocess
+    from mpcgpu_amd import build
+    exe = build.EXAMPLE_BIN
+    if not os.path.exists(exe):
+        exe = build.build_example()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["pcg_exit"] == 0 and 0 < out["pcg_iters"] < 200 and out["rel_residual"] < 1e-4
+    assert out["smem"] == 4 * ((32 + 2) * 16 * 2 + 32 * 16 * 2 + 32)
