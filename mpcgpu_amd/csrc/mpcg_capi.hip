@@ -18,6 +18,8 @@ struct mpcg_handle {
     int num_cus = 0;
     int pcg_waves = 16;       // wavefronts per trajectory workgroup (8 or 16)
     int nt_loads = 1;         // non-temporal hint on the matrix stream
+    int reg_rows = 0;         // RR: block rows per matrix per wave kept in registers (compiled variants only)
+    int lds_rows = -1;        // RL: rows per matrix per wave cached in LDS; -1 = as many as fit when reg_rows > 0, else 0
     int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
     int spmv_blocks_per_cu = 8;
     std::string err;
@@ -94,6 +96,8 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
         h->pcg_waves = value; return MPCG_OK;
     }
     if (!strcmp(key, "nt_loads")) { h->nt_loads = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "pcg_reg_rows")) { h->reg_rows = value; return MPCG_OK; }     // validated at launch
+    if (!strcmp(key, "pcg_lds_rows")) { h->lds_rows = value; return MPCG_OK; }
     if (!strcmp(key, "pcg_max_wg_per_cu")) {
         if (value < 0 || value > 8) return fail(h, MPCG_ERR_INVALID, "pcg_max_wg_per_cu out of range");
         h->max_wg_per_cu = value; return MPCG_OK;
@@ -110,6 +114,8 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "pcg_waves")) { *value = h->pcg_waves; return MPCG_OK; }
     if (!strcmp(key, "nt_loads")) { *value = h->nt_loads; return MPCG_OK; }
     if (!strcmp(key, "pcg_max_wg_per_cu")) { *value = h->max_wg_per_cu; return MPCG_OK; }
+    if (!strcmp(key, "pcg_reg_rows")) { *value = h->reg_rows; return MPCG_OK; }
+    if (!strcmp(key, "pcg_lds_rows")) { *value = h->lds_rows; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "num_cus")) { *value = h->num_cus; return MPCG_OK; }
     return MPCG_ERR_INVALID;
@@ -118,11 +124,26 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
 }  // extern "C"
 
 // ---- launch helpers -----------------------------------------------------------------------------
-// LDS bytes requested at launch: the real need, raised to floor(160 KiB / k) when the handle limits
-// residency to k workgroups per CU (fewer resident trajectories = smaller re-read set = more of it
-// stays in the 256 MiB Infinity Cache between PCG iterations).
+// Rows per matrix per wave cached in LDS for this launch configuration.
+static int lds_rows_for(const mpcg_handle* h, int nw) {
+    const size_t base = lds_bytes_for(h->N, nw);
+    const int T = ((int)h->N + nw - 1) / nw;                      // rows per matrix of wave 0
+    const int want_max = T > h->reg_rows ? T - h->reg_rows : 0;
+    int rl = h->lds_rows;
+    if (rl < 0) {
+        if (h->reg_rows <= 0) return 0;
+        const size_t per_row_pair = pcg_lds_cache_floats(nw, 1) * sizeof(float);
+        rl = base < kLdsMax ? (int)((kLdsMax - base) / per_row_pair) : 0;
+    }
+    if (rl > want_max) rl = want_max;
+    return rl;
+}
+
+// LDS bytes requested at launch: vectors + matrix cache, raised to floor(160 KiB / k) when the handle
+// limits residency to k workgroups per CU (fewer resident trajectories = smaller re-read set = more
+// of it stays in the 256 MiB Infinity Cache between PCG iterations).
 static size_t lds_request(const mpcg_handle* h, int nw) {
-    size_t need = lds_bytes_for(h->N, nw);
+    size_t need = lds_bytes_for(h->N, nw) + pcg_lds_cache_floats(nw, lds_rows_for(h, nw)) * sizeof(float);
     if (h->max_wg_per_cu > 0) {
         size_t pad = (kLdsMax / (size_t)h->max_wg_per_cu) & ~(size_t)15;
         if (pad > need) need = pad;
@@ -130,10 +151,12 @@ static size_t lds_request(const mpcg_handle* h, int nw) {
     return need;
 }
 
-template <int NW, bool NT>
-static int launch_pcg_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+template <int NW, int RR, bool NT>
+static int launch_pcg_t(mpcg_handle* h, PcgArgs a, uint32_t batch, hipStream_t st) {
     const size_t lds = lds_request(h, NW);
-    auto kern = pcg_traj_kernel<NW, NT>;
+    if (lds > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
+    a.lds_rows = lds_rows_for(h, NW);
+    auto kern = pcg_traj_kernel<NW, RR, NT>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -142,20 +165,11 @@ static int launch_pcg_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStr
     return MPCG_OK;
 }
 
-static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
-    HIP_TRY(h, hipSetDevice(h->device));
-    const bool nt = h->nt_loads != 0;
-    switch (h->pcg_waves) {
-        case 4:  return nt ? launch_pcg_t<4, true>(h, a, batch, st) : launch_pcg_t<4, false>(h, a, batch, st);
-        case 8:  return nt ? launch_pcg_t<8, true>(h, a, batch, st) : launch_pcg_t<8, false>(h, a, batch, st);
-        default: return nt ? launch_pcg_t<16, true>(h, a, batch, st) : launch_pcg_t<16, false>(h, a, batch, st);
-    }
-}
-
-template <int NW, bool NT>
+template <int NW, int RR, bool NT>
 static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
     const size_t lds = lds_request(h, NW);
-    auto kern = pcg_traj_kernel<NW, NT>;
+    if (lds > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
+    auto kern = pcg_traj_kernel<NW, RR, NT>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -163,17 +177,35 @@ static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
     return MPCG_OK;
 }
 
+// Compiled (waves, register rows) variants.  X(NW, RR)
+#define MPCG_PCG_VARIANTS(X) X(16, 0) X(8, 0) X(4, 0) X(16, 2) X(8, 4) X(8, 6) X(8, 7) X(4, 8) X(4, 12) X(4, 16)
+
+static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    const bool nt = h->nt_loads != 0;
+#define X(NW_, RR_)                                                                            \
+    if (h->pcg_waves == NW_ && h->reg_rows == RR_)                                             \
+        return nt ? launch_pcg_t<NW_, RR_, true>(h, a, batch, st) : launch_pcg_t<NW_, RR_, false>(h, a, batch, st);
+    MPCG_PCG_VARIANTS(X)
+#undef X
+    return fail(h, MPCG_ERR_UNSUPPORTED, "no compiled kernel variant for this (pcg_waves, pcg_reg_rows)");
+}
+
+static int occupancy(mpcg_handle* h, int* per_cu) {
+#define X(NW_, RR_) \
+    if (h->pcg_waves == NW_ && h->reg_rows == RR_) return occupancy_t<NW_, RR_, true>(h, per_cu);
+    MPCG_PCG_VARIANTS(X)
+#undef X
+    return fail(h, MPCG_ERR_UNSUPPORTED, "no compiled kernel variant for this (pcg_waves, pcg_reg_rows)");
+}
+
 extern "C" {
 
 int mpcg_check_pcg_occupancy(mpcg_handle* h, uint32_t* resident_trajectories) {
     if (!h || !resident_trajectories) return MPCG_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
-    int per_cu = 0, rc;
-    switch (h->pcg_waves) {
-        case 4:  rc = occupancy_t<4, true>(h, &per_cu); break;
-        case 8:  rc = occupancy_t<8, true>(h, &per_cu); break;
-        default: rc = occupancy_t<16, true>(h, &per_cu); break;
-    }
+    int per_cu = 0;
+    int rc = occupancy(h, &per_cu);
     if (rc != MPCG_OK) return rc;
     if (per_cu < 1) return fail(h, MPCG_ERR_UNSUPPORTED, "PCG workgroup does not fit on a CU");
     *resident_trajectories = (uint32_t)per_cu * (uint32_t)h->num_cus;
@@ -197,7 +229,7 @@ int mpcg_pcg_solve(mpcg_handle* h, const float* d_S, const float* d_Pinv, const 
     a.S = d_S; a.Pinv = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda;
     a.r_out = nullptr; a.p_out = nullptr;
     a.iters = d_iters; a.max_iter_exit = d_max_iter_exit;
-    a.N = (int)h->N; a.max_iter = (int)max_iter; a.exit_tol = exit_tol; a.pcols = (int)precond;
+    a.N = (int)h->N; a.max_iter = (int)max_iter; a.exit_tol = exit_tol; a.pcols = (int)precond; a.lds_rows = 0;
     return launch_pcg(h, a, batch, static_cast<hipStream_t>(stream));
 }
 
@@ -216,7 +248,7 @@ int mpcg_pcg_solve_ref(mpcg_handle* h, float* d_S, float* d_Pinv, float* d_gamma
     a.S = d_S; a.Pinv = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda;
     a.r_out = d_r; a.p_out = d_p;
     a.iters = d_pcg_iters; a.max_iter_exit = d_pcg_exit;
-    a.N = (int)h->N; a.max_iter = (int)pcg_max_iter; a.exit_tol = pcg_exit_tol; a.pcols = 3;
+    a.N = (int)h->N; a.max_iter = (int)pcg_max_iter; a.exit_tol = pcg_exit_tol; a.pcols = 3; a.lds_rows = 0;
     return launch_pcg(h, a, 1, static_cast<hipStream_t>(stream));
 }
 

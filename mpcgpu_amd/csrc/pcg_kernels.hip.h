@@ -27,6 +27,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace mpcg {
 
@@ -142,16 +143,24 @@ __device__ __forceinline__ float dot4(f4 a, f4 b) {
 __host__ __device__ constexpr size_t pcg_lds_floats(int N, int NW) {
     return (size_t)(N + 2) * KS * 2 + (size_t)N * KS * 2 + 2 * NW;
 }
+// LDS matrix cache: per wave, per matrix, RL rows of 3 blocks of 49 lane-private float4
+__host__ __device__ constexpr size_t pcg_lds_cache_floats(int NW, int RL) {
+    return (size_t)NW * 2 * RL * 3 * BLK4 * 4;
+}
 
 struct PcgArgs {
     const float* S; const float* Pinv; const float* gamma; float* lambda;
     float* r_out; float* p_out;            // optional [batch][N][n] (may be null)
     uint32_t* iters; uint8_t* max_iter_exit;
     int N; int max_iter; float exit_tol; int pcols;   // pcols: 3 = SS, 1 = block-Jacobi
+    int lds_rows;                          // RL: block rows per matrix per wave cached in LDS
 };
 
-template <int NW, bool NT>
-__global__ __launch_bounds__(NW * 64) void pcg_traj_kernel(PcgArgs a) {
+// RR = block rows per matrix per wave held in REGISTERS for the whole solve (loaded once), then
+// a.lds_rows rows per matrix per wave held in LDS, the remaining rows streamed every iteration.
+// Wave w owns rows k = w + NW*t; t < RR: registers, RR <= t < RR+RL: LDS, t >= RR+RL: stream.
+template <int NW, int RR, bool NT>
+__global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kernel(PcgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int N = a.N;
     const int tid = threadIdx.x;
@@ -175,22 +184,46 @@ __global__ __launch_bounds__(NW * 64) void pcg_traj_kernel(PcgArgs a) {
     float* lam_g = a.lambda + (size_t)b * vstride;
 
     const LaneMap L(lane);
-    // Block rows owned by this wave: k = w + NW*t, t < TP.  TP is padded to an even count so the two
-    // register buffers (rowA/rowB) keep fixed roles across passes; a padded step has k >= N, loads
-    // nothing and computes nothing.
-    const int TP = (((N - w + NW - 1) / NW) + 1) & ~1;
+    // Block rows owned by this wave: k = w + NW*t, t < T.
+    const int T = max(0, (N - w + NW - 1) / NW);
+    const int RL = a.lds_rows;
+    const int t0s = min(T, RR + RL);                 // first streamed row index
+    // streamed step count, padded to even so the two register buffers (rowA/rowB) keep fixed roles
+    // across passes; a padded step has k >= N, loads nothing (OOB) and computes nothing.
+    const int TS = ((T - t0s) + 1) & ~1;
+
+    // ---- resident rows: registers ----
+    Rows regS[RR > 0 ? RR : 1], regP[RR > 0 ? RR : 1];
+#pragma unroll
+    for (int t = 0; t < RR; ++t) {
+        regS[t] = load_rows<NT>(rS, w + NW * t, N, 3, lane_off);
+        regP[t] = load_rows<NT>(rP, w + NW * t, N, a.pcols, lane_off);
+    }
+    // ---- resident rows: LDS cache (lane-private float4 slots, filled once) ----
+    f4* mc = reinterpret_cast<f4*>(red_e + NW) + (size_t)w * 2 * RL * 3 * BLK4;
+    for (int j = 0; j < RL; ++j) {
+        const int k = w + NW * (RR + j);
+        const Rows a0 = load_rows<NT>(rS, k, N, 3, lane_off);
+        const Rows a1 = load_rows<NT>(rP, k, N, a.pcols, lane_off);
+        if (lane < BLK4) {
+            f4* d0 = mc + (size_t)(j * 3) * BLK4 + lane;
+            f4* d1 = mc + (size_t)((RL + j) * 3) * BLK4 + lane;
+            d0[0] = a0.m0; d0[BLK4] = a0.m1; d0[2 * BLK4] = a0.m2;
+            d1[0] = a1.m0; d1[BLK4] = a1.m1; d1[2 * BLK4] = a1.m2;
+        }
+    }
 
     // ---- matrix stream: S rows, Pinv rows, S rows, ... always one block row ahead of use, and
     //      NOT drained at workgroup barriers (lds_barrier) ----
     int st_t = 0, st_pass = 0;             // position of the NEXT row to load
     auto load_next = [&]() -> Rows {
-        const int k = w + NW * st_t;
+        const int k = w + NW * (t0s + st_t);
         Rows R = st_pass ? load_rows<NT>(rP, k, N, a.pcols, lane_off) : load_rows<NT>(rS, k, N, 3, lane_off);
-        if (++st_t >= TP) { st_t = 0; st_pass ^= 1; }
+        if (++st_t >= TS) { st_t = 0; st_pass ^= 1; }
         return R;
     };
     Rows rowA, rowB;
-    rowA = load_next();                    // (a wave with no rows gets zeros from the OOB path)
+    rowA = load_next();                    // (a wave with no streamed rows gets zeros from the OOB path)
 
     // ---- stage vectors: xp <- lambda0 (operand of the setup SpMV), lam <- lambda0, xr <- gamma ----
     for (int e = tid; e < (N + 2) * KS; e += NT_THREADS) { xp[e] = 0.f; xr[e] = 0.f; }
@@ -221,18 +254,30 @@ __global__ __launch_bounds__(NW * 64) void pcg_traj_kernel(PcgArgs a) {
             }
         }
     };
-    auto pass = [&](const float* xv, const float* dv) -> float {
+    auto pass = [&](auto which, const float* xv, const float* dv) -> float {
+        constexpr int MAT = decltype(which)::value;       // 0: S, 1: Pinv (must alternate, S first)
         float part = 0.f;
-        for (int t = 0; t < TP; t += 2) {
+#pragma unroll
+        for (int t = 0; t < RR; ++t) step(MAT ? regP[t] : regS[t], t, xv, dv, part);
+        for (int j = 0; j < RL; ++j) {
+            Rows R;
+            const f4* src = mc + (size_t)((MAT * RL + j) * 3) * BLK4 + (lane < BLK4 ? lane : 0);
+            R.m0 = src[0]; R.m1 = src[BLK4]; R.m2 = src[2 * BLK4];
+            if (lane >= BLK4) { const f4 z = {0.f, 0.f, 0.f, 0.f}; R.m0 = z; R.m1 = z; R.m2 = z; }
+            step(R, RR + j, xv, dv, part);
+        }
+        for (int t = 0; t < TS; t += 2) {
             rowB = load_next();
-            step(rowA, t, xv, dv, part);
+            step(rowA, t0s + t, xv, dv, part);
             rowA = load_next();
-            step(rowB, t + 1, xv, dv, part);
+            step(rowB, t0s + t + 1, xv, dv, part);
         }
         part += __shfl_down(part, 2);
         part += __shfl_down(part, 1);
         return part;                        // lane 0
     };
+    using MatS = std::integral_constant<int, 0>;
+    using MatP = std::integral_constant<int, 1>;
     auto block_sum = [&](const float* red) -> float {
         float s = 0.f;
 #pragma unroll
@@ -242,7 +287,7 @@ __global__ __launch_bounds__(NW * 64) void pcg_traj_kernel(PcgArgs a) {
     const int NV4 = N * (KS / 4);           // float4 count of an unpadded [N][KS] vector
 
     // ---- setup: r = gamma - S lambda0 ; r~ = Pinv r ; p = r~ ; eta = r . r~ ----
-    (void)pass(xp, xp);
+    (void)pass(MatS{}, xp, xp);
     lds_barrier();
     for (int e = tid; e < NV4; e += NT_THREADS) {
         f4* rr = reinterpret_cast<f4*>(xr + KS) + e;
@@ -250,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) void pcg_traj_kernel(PcgArgs a) {
     }
     lds_barrier();
     {
-        const float part = pass(xr, xr);
+        const float part = pass(MatP{}, xr, xr);
         if (lane == 0) red_e[w] = part;
     }
     lds_barrier();
@@ -267,7 +312,7 @@ __global__ __launch_bounds__(NW * 64) void pcg_traj_kernel(PcgArgs a) {
         for (int it = 0; it < a.max_iter; ++it) {
             // upsilon = S p ; v = p . upsilon
             {
-                const float part = pass(xp, xp);
+                const float part = pass(MatS{}, xp, xp);
                 if (lane == 0) red_v[w] = part;
             }
             lds_barrier();
@@ -284,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void pcg_traj_kernel(PcgArgs a) {
             lds_barrier();
             // r~ = Pinv r ; eta' = r . r~
             {
-                const float part = pass(xr, xr);
+                const float part = pass(MatP{}, xr, xr);
                 if (lane == 0) red_e[w] = part;
             }
             lds_barrier();

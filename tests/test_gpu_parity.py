@@ -298,3 +298,32 @@ def test_cpp_callsite_over_shim_headers():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["pcg_exit"] == 0 and 0 < out["pcg_iters"] < 200 and out["rel_residual"] < 1e-4
     assert out["smem"] == 4 * ((32 + 2) * 16 * 2 + 32 * 16 * 2 + 32)
+
+
+@pytest.mark.parametrize("waves,reg_rows,lds_rows", [(16, 2, -1), (8, 4, 0), (8, 6, -1), (8, 6, 2), (4, 8, -1), (4, 12, -1), (4, 16, 3)])
+@pytest.mark.parametrize("N", [5, 32, 128, 200])
+def test_resident_row_variants_bitwise_equal_streaming(P, N, waves, reg_rows, lds_rows):
+    """Keeping block rows in registers / LDS across iterations changes where the matrix bytes come from,
+    not the arithmetic: every variant must reproduce the streaming kernel of the same wave count bit for bit."""
+    PcgSolver, pcg_config = P
+    B = 3
+    k = synth.make_kkt(N, B, 4242 + N)
+    S, Pinv, g = synth.form_schur(k, poison_unused=True)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    cfg = pcg_config(pcg_exit_tol=1e-5, pcg_max_iter=40)
+    outs = []
+    for rr, rl in ((0, 0), (reg_rows, lds_rows)):
+        for pc in ("ss", "jacobi"):
+            sol = PcgSolver(N, max_batch=B)
+            sol.set_option("pcg_waves", waves)
+            sol.set_option("pcg_reg_rows", rr)
+            sol.set_option("pcg_lds_rows", rl)
+            lam = torch.zeros(B, n * N, device="cuda")
+            it, ex = sol.solve(dS, dP, dg, lam, cfg, pc)
+            torch.cuda.synchronize()
+            outs.append((lam.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy()))
+    for a, b in ((outs[0], outs[2]), (outs[1], outs[3])):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(a[2], b[2])
+    assert np.isfinite(outs[0][0]).all()

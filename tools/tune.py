@@ -16,6 +16,7 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--waves", default="4,8,16")
 ap.add_argument("--wgs", default="0,1,2,3,4")
 ap.add_argument("--nts", default="0,1")
+ap.add_argument("--regs", default="0", help="comma list of waves:reg_rows[:lds_rows] variants, e.g. 8:6:-1,4:12:-1")
 args = ap.parse_args()
 N, B = args.knots, args.batch
 S, P, g = bench.build_inputs(N, B, 0, args.precond)
@@ -24,9 +25,19 @@ lam = torch.zeros(B, 14 * N, device="cuda")
 cfg = pcg_config(pcg_exit_tol=1e-4, pcg_max_iter=synth.pcg_max_iter(N))
 bytes_it = synth.algorithmic_bytes(N, precond=args.precond)["pcg_iter"]
 sol = PcgSolver(N, max_batch=B)
-for waves, wg, nt in itertools.product([int(x) for x in args.waves.split(",")], [int(x) for x in args.wgs.split(",")],
-                                       [int(x) for x in args.nts.split(",")]):
+combos = []
+if args.regs != "0":
+    for spec in args.regs.split(","):
+        f = [int(x) for x in spec.split(":")]
+        for nt in [int(x) for x in args.nts.split(",")]:
+            combos.append((f[0], 0, nt, f[1], f[2] if len(f) > 2 else -1))
+else:
+    for waves, wg, nt in itertools.product([int(x) for x in args.waves.split(",")], [int(x) for x in args.wgs.split(",")],
+                                           [int(x) for x in args.nts.split(",")]):
+        combos.append((waves, wg, nt, 0, -1))
+for waves, wg, nt, rr, rl in combos:
     sol.set_option("pcg_waves", waves); sol.set_option("pcg_max_wg_per_cu", wg); sol.set_option("nt_loads", nt)
+    sol.set_option("pcg_reg_rows", rr); sol.set_option("pcg_lds_rows", rl)
     try:
         res = sol.checkPcgOccupancy()
     except Exception as e:
@@ -40,5 +51,5 @@ for waves, wg, nt in itertools.product([int(x) for x in args.waves.split(",")], 
         if i: ts.append(e0.elapsed_time(e1))
     its = int(it.sum().item())
     ms = float(np.median(ts))
-    print(f"waves={waves:2d} wg/cu={wg} nt={nt} resident={res:5d}  {ms:8.3f} ms  {its/ms/1e3:7.3f} Miter/s  "
+    print(f"waves={waves:2d} wg/cu={wg} nt={nt} regrows={rr:2d} ldsrows={rl:2d} resident={res:5d}  {ms:8.3f} ms  {its/ms/1e3:7.3f} Miter/s  "
           f"{its*bytes_it/ms/1e6:8.1f} GB/s algorithmic", flush=True)
