@@ -38,7 +38,6 @@ constexpr int NS = 14;          // state size this specialisation is written for
 constexpr int BLK4 = 49;        // float4 per 14x14 block
 constexpr int ROW4 = 147;       // float4 per block row (3 blocks)
 constexpr int ROWF = 588;       // floats per block row
-constexpr int KS = 16;          // LDS stride of one knot's 14-vector (2 zero pads -> float4-aligned)
 
 // Workgroup barrier that waits only for this wave's LDS traffic.  __syncthreads() would also wait
 // for vmcnt(0), i.e. drain the matrix prefetch that is deliberately in flight across the barrier.
@@ -137,11 +136,29 @@ __device__ __forceinline__ float dot4(f4 a, f4 b) {
 
 // ------------------------------------------------------------------------------------------------
 // Persistent per-trajectory PCG.  grid = batch, block = NW*64.
-// LDS (floats): xp[(N+2)*KS] p padded by a zero knot either side | xr[(N+2)*KS] r likewise |
-//               lam[N*KS] | tmp[N*KS] (upsilon, then r~) | red[2*NW]
+//
+// Lane mapping of THIS kernel (differs from the SpMV kernel's in where r and g sit in the lane id):
+// lane = 8*r + g, r = float4 residue (0..6), g = column pair (0..6); lanes with r == 7 or g == 7
+// idle (their loads go to the SRD's out-of-bounds path and return 0).  Lane (r,g) still loads
+// float4 #(7g + r) of every block, so a wave instruction still covers one contiguous 784-byte
+// block.  With g in the low 3 bits the sum over g is a reduction inside groups of 8 consecutive
+// lanes = three v_add_f32 with DPP row_shl:4/2/1 — pure VALU, no LDS crossbar in that part.
+// Lane 8r then holds the 4 "slots" e = 4r..4r+3 (e < 28); row i of the result is slot i + slot i+14
+// (the two column-parity halves), fetched from lanes 8(r+3) / 8(r+4) with one round of 4
+// ds_bpermute.  The summation tree is the same as the SpMV kernel's:
+// ((g0+g4)+(g2+g6)) + ((g1+g5)+g3), then half a + half b.
+// Forming the rows BEFORE the inner products matters numerically: the halves cancel, and dotting
+// the un-combined slots (tried) made fp32 CG drift ~10x faster.
+//
+// LDS (floats, each region rounded to 4): xp[(N+2)*14] p with a zero knot either side |
+//   xr[(N+2)*14] r likewise | lam[N*14] | tmp[N*14] upsilon, then r~ | red[2*NW] |
+//   matrix cache: per wave, per matrix, RL rows x 3 blocks x 49 float4.
+// All vector accesses are 8-byte (float2): 14 floats = 56 B keeps every knot 8-byte aligned.
 // ------------------------------------------------------------------------------------------------
+
+__host__ __device__ constexpr size_t r4(size_t x) { return (x + 3) & ~(size_t)3; }
 __host__ __device__ constexpr size_t pcg_lds_floats(int N, int NW) {
-    return (size_t)(N + 2) * KS * 2 + (size_t)N * KS * 2 + 2 * NW;
+    return 2 * r4((size_t)(N + 2) * NS) + 2 * r4((size_t)N * NS) + r4(2 * (size_t)NW);
 }
 // LDS matrix cache: per wave, per matrix, RL rows of 3 blocks of 49 lane-private float4
 __host__ __device__ constexpr size_t pcg_lds_cache_floats(int NW, int RL) {
@@ -156,6 +173,20 @@ struct PcgArgs {
     int lds_rows;                          // RL: block rows per matrix per wave cached in LDS
 };
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov0(float v) {     // lanes whose source is outside the row read 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 8 consecutive lanes of each group; valid in the group's lane 0.
+// Order: ((g0+g4)+(g2+g6)) + ((g1+g5)+(g3+g7)), g7 == 0.
+__device__ __forceinline__ f4 reduce_g(f4 a) {
+    constexpr int SHL = 0x100;                            // DPP row_shl:n — lane i reads lane i+n
+    a.x += dpp_mov0<SHL + 4>(a.x); a.y += dpp_mov0<SHL + 4>(a.y); a.z += dpp_mov0<SHL + 4>(a.z); a.w += dpp_mov0<SHL + 4>(a.w);
+    a.x += dpp_mov0<SHL + 2>(a.x); a.y += dpp_mov0<SHL + 2>(a.y); a.z += dpp_mov0<SHL + 2>(a.z); a.w += dpp_mov0<SHL + 2>(a.w);
+    a.x += dpp_mov0<SHL + 1>(a.x); a.y += dpp_mov0<SHL + 1>(a.y); a.z += dpp_mov0<SHL + 1>(a.z); a.w += dpp_mov0<SHL + 1>(a.w);
+    return a;
+}
+
 // RR = block rows per matrix per wave held in REGISTERS for the whole solve (loaded once), then
 // a.lds_rows rows per matrix per wave held in LDS, the remaining rows streamed every iteration.
 // Wave w owns rows k = w + NW*t; t < RR: registers, RR <= t < RR+RL: LDS, t >= RR+RL: stream.
@@ -167,23 +198,31 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
-    const int NT_THREADS = NW * 64;
+    constexpr int NTHR = NW * 64;
 
-    float* xp = lds;                       // knot j at xp + (j+1)*KS
-    float* xr = xp + (N + 2) * KS;
-    float* lam = xr + (N + 2) * KS;        // knot j at lam + j*KS
-    float* tmp = lam + N * KS;
-    float* red_v = tmp + N * KS;
+    float* xp = lds;                                   // knot j at xp + (j+1)*NS
+    float* xr = xp + r4((size_t)(N + 2) * NS);
+    float* lam = xr + r4((size_t)(N + 2) * NS);        // knot j at lam + j*NS
+    float* tmp = lam + r4((size_t)N * NS);             // knot j at tmp + j*NS
+    float* red_v = tmp + r4((size_t)N * NS);
     float* red_e = red_v + NW;
+    f4* mc_base = reinterpret_cast<f4*>(red_v + r4(2 * (size_t)NW));
 
     const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;
     const rsrc_t rS = make_rsrc(a.S + (size_t)b * mstride, (uint32_t)(mstride * sizeof(float)));
     const rsrc_t rP = make_rsrc(a.Pinv + (size_t)b * mstride, (uint32_t)(mstride * sizeof(float)));
-    const uint32_t lane_off = lane < BLK4 ? (uint32_t)lane * 16u : OOB_OFF;
     const float* gam = a.gamma + (size_t)b * vstride;
     float* lam_g = a.lambda + (size_t)b * vstride;
 
-    const LaneMap L(lane);
+    // ---- lane roles ----
+    const int lr = lane >> 3, lg = lane & 7;
+    const bool active = lr < 7 && lg < 7;
+    const int f_idx = active ? 7 * lg + lr : 0;        // which float4 of a block this lane owns
+    const uint32_t lane_off = active ? (uint32_t)f_idx * 16u : OOB_OFF;
+    const int g2 = active ? 2 * lg : 0;                // first column of the lane's column pair
+    const bool a01 = lr <= 3, a23 = lr <= 2;           // accumulators 0,1 / 2,3 multiply column a (else b)
+    const bool head = lg == 0 && lr < 4;               // lanes 0, 8, 16, 24 end up with rows 4r..4r+3
+
     // Block rows owned by this wave: k = w + NW*t, t < T.
     const int T = max(0, (N - w + NW - 1) / NW);
     const int RL = a.lds_rows;
@@ -200,14 +239,14 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
         regP[t] = load_rows<NT>(rP, w + NW * t, N, a.pcols, lane_off);
     }
     // ---- resident rows: LDS cache (lane-private float4 slots, filled once) ----
-    f4* mc = reinterpret_cast<f4*>(red_e + NW) + (size_t)w * 2 * RL * 3 * BLK4;
+    f4* mc = mc_base + (size_t)w * 2 * RL * 3 * BLK4;
     for (int j = 0; j < RL; ++j) {
         const int k = w + NW * (RR + j);
         const Rows a0 = load_rows<NT>(rS, k, N, 3, lane_off);
         const Rows a1 = load_rows<NT>(rP, k, N, a.pcols, lane_off);
-        if (lane < BLK4) {
-            f4* d0 = mc + (size_t)(j * 3) * BLK4 + lane;
-            f4* d1 = mc + (size_t)((RL + j) * 3) * BLK4 + lane;
+        if (active) {
+            f4* d0 = mc + (size_t)(j * 3) * BLK4 + f_idx;
+            f4* d1 = mc + (size_t)((RL + j) * 3) * BLK4 + f_idx;
             d0[0] = a0.m0; d0[BLK4] = a0.m1; d0[2 * BLK4] = a0.m2;
             d1[0] = a1.m0; d1[BLK4] = a1.m1; d1[2 * BLK4] = a1.m2;
         }
@@ -226,31 +265,49 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
     rowA = load_next();                    // (a wave with no streamed rows gets zeros from the OOB path)
 
     // ---- stage vectors: xp <- lambda0 (operand of the setup SpMV), lam <- lambda0, xr <- gamma ----
-    for (int e = tid; e < (N + 2) * KS; e += NT_THREADS) { xp[e] = 0.f; xr[e] = 0.f; }
-    for (int e = tid; e < N * KS; e += NT_THREADS) { lam[e] = 0.f; tmp[e] = 0.f; }
+    for (int e = tid; e < (N + 2) * NS; e += NTHR) { xp[e] = 0.f; xr[e] = 0.f; }
     lds_barrier();
-    for (int e = tid; e < N * NS; e += NT_THREADS) {
-        const int k = e / NS, i = e - k * NS;
+    for (int e = tid; e < N * NS; e += NTHR) {
         const float l0 = lam_g[e];
-        xp[(k + 1) * KS + i] = l0;
-        lam[k * KS + i] = l0;
-        xr[(k + 1) * KS + i] = gam[e];
+        xp[NS + e] = l0;
+        lam[e] = l0;
+        xr[NS + e] = gam[e];
     }
     lds_barrier();
 
-    // one pass over this wave's block rows: tmp[k] = M[k,:] * x ; returns sum_k d[k] . tmp[k]
+    // acc += block * x for this lane's float4; xk = the 14-vector the block multiplies
+    auto fma_blk = [&](f4& acc, const f4 m, const float* xk) {
+        const f2 x = *reinterpret_cast<const f2*>(xk + g2);      // 56k + 8g bytes: 8-byte aligned
+        const float x01 = a01 ? x.x : x.y;
+        const float x23 = a23 ? x.x : x.y;
+        acc.x = fmaf(m.x, x01, acc.x);
+        acc.y = fmaf(m.y, x01, acc.y);
+        acc.z = fmaf(m.z, x23, acc.z);
+        acc.w = fmaf(m.w, x23, acc.w);
+    };
+    // one block row: tmp[k] (28 slots) = M[k,:] * x ;  part += d[k] . (M[k,:] x)
     auto step = [&](const Rows& use, int t, const float* xv, const float* dv, float& part) {
         const int k = w + NW * t;
         if (k < N) {
             f4 acc = {0.f, 0.f, 0.f, 0.f};
-            fma_block(acc, use.m0, xv + (k + 0) * KS, L);
-            fma_block(acc, use.m1, xv + (k + 1) * KS, L);
-            fma_block(acc, use.m2, xv + (k + 2) * KS, L);
-            const f4 y = reduce_rows(acc, lane);
-            if (lane < 4) {
-                *reinterpret_cast<f4*>(tmp + k * KS + 4 * lane) = y;
-                const f4 d = *reinterpret_cast<const f4*>(dv + (k + 1) * KS + 4 * lane);
-                part += dot4(d, y);
+            fma_blk(acc, use.m0, xv + (k + 0) * NS);
+            fma_blk(acc, use.m1, xv + (k + 1) * NS);
+            fma_blk(acc, use.m2, xv + (k + 2) * NS);
+            const f4 h = reduce_g(acc);
+            f4 y;                                                             // slot e + slot e+14
+            y.x = h.x + __shfl_down(h.z, 24);
+            y.y = h.y + __shfl_down(h.w, 24);
+            y.z = h.z + __shfl_down(h.x, 32);
+            y.w = h.w + __shfl_down(h.y, 32);
+            if (head) {
+                if (lr == 3) { y.z = 0.f; y.w = 0.f; }                       // rows 14, 15 do not exist
+                f2* out = reinterpret_cast<f2*>(tmp + k * NS + 4 * lr);       // 56k + 16r bytes
+                const f2* d2 = reinterpret_cast<const f2*>(dv + (k + 1) * NS + 4 * lr);
+                const f2 da = d2[0];
+                const f2 db = d2[1];      // lane 24 reads rows 14,15 = next knot's 0,1 (padded array): times 0
+                out[0] = f2{y.x, y.y};
+                if (lr < 3) out[1] = f2{y.z, y.w};
+                part += fmaf(y.w, db.y, fmaf(y.z, db.x, fmaf(y.y, da.y, y.x * da.x)));
             }
         }
     };
@@ -261,9 +318,9 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
         for (int t = 0; t < RR; ++t) step(MAT ? regP[t] : regS[t], t, xv, dv, part);
         for (int j = 0; j < RL; ++j) {
             Rows R;
-            const f4* src = mc + (size_t)((MAT * RL + j) * 3) * BLK4 + (lane < BLK4 ? lane : 0);
+            const f4* src = mc + (size_t)((MAT * RL + j) * 3) * BLK4 + f_idx;
             R.m0 = src[0]; R.m1 = src[BLK4]; R.m2 = src[2 * BLK4];
-            if (lane >= BLK4) { const f4 z = {0.f, 0.f, 0.f, 0.f}; R.m0 = z; R.m1 = z; R.m2 = z; }
+            if (!active) { const f4 z = {0.f, 0.f, 0.f, 0.f}; R.m0 = z; R.m1 = z; R.m2 = z; }
             step(R, RR + j, xv, dv, part);
         }
         for (int t = 0; t < TS; t += 2) {
@@ -272,8 +329,9 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
             rowA = load_next();
             step(rowB, t0s + t + 1, xv, dv, part);
         }
-        part += __shfl_down(part, 2);
-        part += __shfl_down(part, 1);
+        // heads sit in lanes 0, 8, 16, 24: fold them into lane 0 (once per pass): (r0+r2)+(r1+r3)
+        part += __shfl_down(part, 16);
+        part += __shfl_down(part, 8);
         return part;                        // lane 0
     };
     using MatS = std::integral_constant<int, 0>;
@@ -284,15 +342,18 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
         for (int i = 0; i < NW; ++i) s += red[i];
         return s;
     };
-    const int NV4 = N * (KS / 4);           // float4 count of an unpadded [N][KS] vector
+    // vector items: float2 #e of an [N][14] vector
+    const int NV2 = N * (NS / 2);
+    f2* xp2 = reinterpret_cast<f2*>(xp + NS);
+    f2* xr2 = reinterpret_cast<f2*>(xr + NS);
+    f2* lam2 = reinterpret_cast<f2*>(lam);
+    const f2* tmp2 = reinterpret_cast<const f2*>(tmp);
+    auto tmp_row = [&](int e) -> f2 { return tmp2[e]; };
 
     // ---- setup: r = gamma - S lambda0 ; r~ = Pinv r ; p = r~ ; eta = r . r~ ----
     (void)pass(MatS{}, xp, xp);
     lds_barrier();
-    for (int e = tid; e < NV4; e += NT_THREADS) {
-        f4* rr = reinterpret_cast<f4*>(xr + KS) + e;
-        *rr = *rr - reinterpret_cast<const f4*>(tmp)[e];
-    }
+    for (int e = tid; e < NV2; e += NTHR) xr2[e] = xr2[e] - tmp_row(e);
     lds_barrier();
     {
         const float part = pass(MatP{}, xr, xr);
@@ -300,8 +361,7 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
     }
     lds_barrier();
     float eta = block_sum(red_e);
-    for (int e = tid; e < NV4; e += NT_THREADS)
-        reinterpret_cast<f4*>(xp + KS)[e] = reinterpret_cast<const f4*>(tmp)[e];
+    for (int e = tid; e < NV2; e += NTHR) xp2[e] = tmp_row(e);
     lds_barrier();
 
     uint32_t iters = 0;
@@ -318,13 +378,9 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
             lds_barrier();
             const float alpha = eta / block_sum(red_v);
             // lambda += alpha p ; r -= alpha upsilon
-            for (int e = tid; e < NV4; e += NT_THREADS) {
-                const f4 pk = reinterpret_cast<const f4*>(xp + KS)[e];
-                const f4 uk = reinterpret_cast<const f4*>(tmp)[e];
-                f4* lk = reinterpret_cast<f4*>(lam) + e;
-                f4* rk = reinterpret_cast<f4*>(xr + KS) + e;
-                *lk = *lk + alpha * pk;
-                *rk = *rk - alpha * uk;
+            for (int e = tid; e < NV2; e += NTHR) {
+                lam2[e] = lam2[e] + alpha * xp2[e];
+                xr2[e] = xr2[e] - alpha * tmp_row(e);
             }
             lds_barrier();
             // r~ = Pinv r ; eta' = r . r~
@@ -338,21 +394,17 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
             if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
             const float beta = eta_new / eta;
             // p = r~ + beta p
-            for (int e = tid; e < NV4; e += NT_THREADS) {
-                f4* pk = reinterpret_cast<f4*>(xp + KS) + e;
-                *pk = reinterpret_cast<const f4*>(tmp)[e] + beta * (*pk);
-            }
+            for (int e = tid; e < NV2; e += NTHR) xp2[e] = tmp_row(e) + beta * xp2[e];
             eta = eta_new;
             lds_barrier();
         }
     }
 
     // ---- write back ----
-    for (int e = tid; e < N * NS; e += NT_THREADS) {
-        const int k = e / NS, i = e - k * NS;
-        lam_g[e] = lam[k * KS + i];
-        if (a.r_out) a.r_out[(size_t)b * vstride + e] = xr[(k + 1) * KS + i];
-        if (a.p_out) a.p_out[(size_t)b * vstride + e] = xp[(k + 1) * KS + i];
+    for (int e = tid; e < N * NS; e += NTHR) {
+        lam_g[e] = lam[e];
+        if (a.r_out) a.r_out[(size_t)b * vstride + e] = xr[NS + e];
+        if (a.p_out) a.p_out[(size_t)b * vstride + e] = xp[NS + e];
     }
     if (tid == 0) {
         a.iters[b] = iters;

@@ -40,10 +40,10 @@ def test_exports_are_plain_c(hiplib):
 def test_version_and_lds_size(hiplib):
     assert hiplib.mpcg_abi_version() == 1
     assert b"gfx950" in hiplib.mpcg_build_info()
-    # xp, xr: (N+2)*16 floats, lam, tmp: N*16 floats, 32 partials  (DESIGN.md §LDS layout)
+    # xp, xr: (N+2)*14 floats, lam, tmp: N*14 floats, 32 partials  (DESIGN.md §LDS layout)
     for N in (2, 32, 128, 512):
-        assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * ((N + 2) * 16 * 2 + N * 16 * 2 + 32)
-    assert hiplib.mpcg_pcg_lds_bytes(14, 128) == 33152
+        assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * ((N + 2) * 14 * 2 + N * 14 * 2 + 32)
+    assert hiplib.mpcg_pcg_lds_bytes(14, 128) == 29024
     assert hiplib.mpcg_pcg_lds_bytes(12, 128) == 0          # only n = 14 is compiled in
     assert hiplib.mpcg_pcg_lds_bytes(14, 1024) == 0         # vectors would not fit 160 KiB LDS
 

@@ -297,7 +297,7 @@ def test_cpp_callsite_over_shim_headers():
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["pcg_exit"] == 0 and 0 < out["pcg_iters"] < 200 and out["rel_residual"] < 1e-4
-    assert out["smem"] == 4 * ((32 + 2) * 16 * 2 + 32 * 16 * 2 + 32)
+    assert out["smem"] == 4 * ((32 + 2) * 14 * 2 + 32 * 14 * 2 + 32)
 
 
 @pytest.mark.parametrize("waves,reg_rows,lds_rows", [(16, 2, -1), (8, 4, 0), (8, 6, -1), (8, 6, 2), (4, 8, -1), (4, 12, -1), (4, 16, 3)])
