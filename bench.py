@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--max-iter", type=int, default=0, help="0 = reference table (settings.cuh:123-139)")
     ap.add_argument("--pcg-waves", type=int, default=0)
     ap.add_argument("--nt", type=int, default=-1)
+    ap.add_argument("--reg-rows", type=int, default=-1)
+    ap.add_argument("--lds-rows", type=int, default=-2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spmv", action="store_true", help="also time the stand-alone block-tridiagonal SpMV")
@@ -135,6 +137,10 @@ def main():
         sol.set_option("pcg_waves", args.pcg_waves)
     if args.nt >= 0:
         sol.set_option("nt_loads", args.nt)
+    if args.reg_rows >= 0:
+        sol.set_option("pcg_reg_rows", args.reg_rows)
+    if args.lds_rows >= -1:
+        sol.set_option("pcg_lds_rows", args.lds_rows)
 
     def step():
         d_lam.zero_()                       # every step is the same cold-start solve
@@ -181,6 +187,7 @@ def main():
                    "knot_points": N, "state_size": 14, "batch_per_gpu": B, "global_batch": B * world,
                    "precond": args.precond, "pcg_max_iter": max_iter, "pcg_exit_tol": args.exit_tol,
                    "parallelism": f"batch-sharded x{world}", "pcg_waves": sol.get_option("pcg_waves"),
+                   "pcg_reg_rows": sol.get_option("pcg_reg_rows"), "pcg_lds_rows": sol.get_option("pcg_lds_rows"),
                    "nt_loads": sol.get_option("nt_loads")},
         "ms_per_linsolve": ms_per_step / B,
         "linsolves_per_sec": B * world / (ms_per_step * 1e-3),
@@ -197,7 +204,7 @@ def main():
     # HBM traffic of this exact workload from the committed PMC passes (bench cannot run rocprofv3 on itself)
     try:
         key = (f"N{N}_B{B}_{args.precond}_it{max_iter}_tol{args.exit_tol:g}_w{sol.get_option('pcg_waves')}"
-               f"_nt{sol.get_option('nt_loads')}")
+               f"_rr{sol.get_option('pcg_reg_rows')}_rl{sol.get_option('pcg_lds_rows')}_nt{sol.get_option('nt_loads')}")
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
         if tr:
             out["roofline"]["traffic"] = tr["hbm_traffic_bytes_per_launch"]

@@ -109,8 +109,12 @@ int mpcg_pcg_solve_ref(mpcg_handle *h,
 int mpcg_bt_spmv(mpcg_handle *h, const float *d_M, const float *d_x, float *d_y,
                  uint32_t batch, int cols, void *stream);
 
-/* Launch-configuration knobs (tuning / experiments; defaults are chosen by mpcg_create):
- * key "pcg_waves" (8 or 16 wavefronts per trajectory workgroup), "nt_loads" (0/1). */
+/* Launch-configuration knobs (tuning / experiments; defaults are chosen by mpcg_create from
+ * knot_points): "pcg_waves" (4, 8 or 16 wavefronts per trajectory workgroup), "pcg_reg_rows" (block
+ * rows per matrix per wave kept in registers for the whole solve; only compiled (waves, rows) pairs
+ * are accepted at launch), "pcg_lds_rows" (rows per matrix per wave cached in LDS, -1 = what fits),
+ * "nt_loads" (0/1 non-temporal hint on the matrix stream), "pcg_max_wg_per_cu", "spmv_blocks_per_cu".
+ * None of them changes results: all variants are bitwise identical (tested). */
 int mpcg_set_option(mpcg_handle *h, const char *key, int value);
 int mpcg_get_option(const mpcg_handle *h, const char *key, int *value);
 

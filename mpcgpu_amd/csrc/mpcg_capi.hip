@@ -78,6 +78,13 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     if (!h) return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: out of host memory");
     h->device = device; h->n = state_size; h->N = knot_points; h->max_batch = max_batch;
     h->num_cus = prop.multiProcessorCount;
+    // Launch defaults from the round-1 sweeps on MI355X (gpurun_out/tune6.txt, tune8.txt):
+    // keep as many block rows as possible in registers/LDS, one workgroup per CU.
+    if (knot_points <= 64) {            // <= 4 rows per wave and matrix: half or all of them in registers
+        h->pcg_waves = 16; h->reg_rows = 2; h->lds_rows = knot_points <= 32 ? 0 : -1; h->nt_loads = 0;
+    } else {                            // 8 fat waves: 6 rows/matrix in 256 VGPRs, LDS takes what fits
+        h->pcg_waves = 8; h->reg_rows = 6; h->lds_rows = -1; h->nt_loads = knot_points >= 384 ? 1 : 0;
+    }
     *out = h;
     return MPCG_OK;
 }

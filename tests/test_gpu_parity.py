@@ -42,8 +42,10 @@ def solve(P, N, S, Pinv, gamma, lam0, max_iter, tol, precond="ss", waves=None):
     PcgSolver, pcg_config = P
     B = S.shape[0]
     sol = PcgSolver(N, max_batch=B)
-    if waves:
+    if waves:          # explicit wave count = the pure streaming variant; waves=None = mpcg_create's default
         sol.set_option("pcg_waves", waves)
+        sol.set_option("pcg_reg_rows", 0)
+        sol.set_option("pcg_lds_rows", 0)
     lam = dev(lam0, torch.float32)
     it, ex = sol.solve(dev(S), dev(Pinv), dev(gamma), lam,
                        pcg_config(pcg_exit_tol=tol, pcg_max_iter=max_iter), precond)
