@@ -93,6 +93,42 @@ def cpu_baseline(N, S_host, g_host, mean_iters, budget_s=12.0):
 P_HOST = None
 
 
+def latency_config2(dev, reps=200):
+    """BASELINE config 2: IIWA-14 N=32, ONE trajectory, block-Jacobi, max_iter 173 (settings.cuh:127),
+    exit_tol 5e-6 (track_iiwa_pcg.cu:49), through the reference-shaped 12-argument entry.  Timed the way
+    the reference times a linsolve (include/pcg/sqp.cuh:224-241): host monotonic clock around launch + the two
+    D2H copies of (iters, exit), device-synchronised on both sides; plus the bare kernel by HIP events."""
+    N = 32
+    k = synth.make_kkt(N, 1, 1)
+    S, P, g = synth.form_schur(k, precond="jacobi", poison_unused=True)
+    sol = PcgSolver(N, max_batch=1, device=dev.index)
+    d_S, d_P, d_g = (torch.from_numpy(a[0]).to(dev) for a in (S, P, g))
+    d_lam = torch.zeros(14 * N, device=dev)
+    d_it = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_ex = torch.zeros(1, dtype=torch.uint8, device=dev)
+    cfg = pcg_config(pcg_exit_tol=5e-6, pcg_max_iter=synth.pcg_max_iter(N))
+    wall, kern = [], []
+    for i in range(reps + 10):
+        d_lam.zero_()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        sol.solve(d_S.view(1, -1), d_P.view(1, -1), d_g.view(1, -1), d_lam.view(1, -1), cfg, "jacobi", iters=d_it, exits=d_ex)
+        e1.record()
+        it = int(d_it.cpu().item())
+        ex = int(d_ex.cpu().item())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if i >= 10:
+            wall.append((t1 - t0) * 1e6)
+            kern.append(e0.elapsed_time(e1) * 1e3)
+    return {"workload": "IIWA-14 N=32, 1 trajectory, block-Jacobi, max_iter 173, exit_tol 5e-6 (BASELINE config 2)",
+            "pcg_iters": it, "max_iter_exit": ex, "us_per_linsolve_wall_incl_2_d2h": float(np.median(wall)),
+            "us_per_linsolve_kernel": float(np.median(kern)), "us_per_pcg_iter_kernel": float(np.median(kern)) / max(it, 1),
+            "pcg_waves": sol.get_option("pcg_waves"), "pcg_reg_rows": sol.get_option("pcg_reg_rows")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +146,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spmv", action="store_true", help="also time the stand-alone block-tridiagonal SpMV")
+    ap.add_argument("--latency", action="store_true", help="also time BASELINE config 2 (N=32, one trajectory)")
     args = ap.parse_args()
 
     rank, local_rank, world = D.init()
@@ -230,6 +267,9 @@ def main():
         out["spmv"] = {"kernel": "bt_spmv_kernel", "ms": ms, "achieved": b / (ms * 1e-3) / 1e9, "unit": "GB/s",
                        "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b,
                        "trajectory_spmv_per_sec": B / (ms * 1e-3)}
+
+    if rank == 0 and world == 1 and args.latency:
+        out["config2_latency"] = latency_config2(dev)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, S_h, g_h, float(it_host.mean()), args.cpu_seconds)

@@ -109,6 +109,28 @@ int mpcg_pcg_solve_ref(mpcg_handle *h,
 int mpcg_bt_spmv(mpcg_handle *h, const float *d_M, const float *d_x, float *d_y,
                  uint32_t batch, int cols, void *stream);
 
+/* ---- the steps either side of the solve, same layouts as the reference ----
+ *
+ * mpcg_form_schur replaces form_schur_system<T>(state_size, control_size, knot_points, d_G_dense,
+ * d_C_dense, d_g, d_c, d_S, d_Pinv, d_gamma, rho) (include/pcg/linsys_setup.cuh:620-656), batched:
+ *   d_G_dense [batch][(n^2+m^2)N - m^2]  in: Q_0,R_0,...,Q_{N-1} (column-major blocks);  out: their
+ *             inverses with rho added (the reference's in-place side effect, :371-380, consumed by dz)
+ *   d_C_dense [batch][(n^2+nm)(N-1)]     -A_k, -B_k (already negated, include/common/kkt.cuh:115-116)
+ *   d_g [batch][(n+m)N - m], d_c [batch][nN]
+ *   d_S, d_Pinv, d_gamma                 outputs in the layouts mpcg_pcg_solve consumes
+ * precond = MPCG_PRECOND_JACOBI skips the symmetric-stair completion (:9-137): the off-diagonal
+ * blocks of d_Pinv are then left untouched.  The first call allocates a handle-owned staging buffer
+ * of max_batch * sizeof(G) (hipMalloc — not stream-ordered); later calls are purely stream-ordered.
+ *
+ * mpcg_compute_dz replaces compute_dz(state_size, control_size, knot_points, d_Ginv_dense, d_C_dense,
+ * d_g, d_lambda, d_dz) (include/common/dz.cuh:124-136), batched; d_dz [batch][(n+m)N - m]. */
+int mpcg_form_schur(mpcg_handle *h, uint32_t control_size, float *d_G_dense, const float *d_C_dense,
+                    const float *d_g, const float *d_c, float *d_S, float *d_Pinv, float *d_gamma,
+                    float rho, uint32_t batch, mpcg_precond precond, void *stream);
+int mpcg_compute_dz(mpcg_handle *h, uint32_t control_size, const float *d_Ginv_dense,
+                    const float *d_C_dense, const float *d_g, const float *d_lambda, float *d_dz,
+                    uint32_t batch, void *stream);
+
 /* Launch-configuration knobs (tuning / experiments; defaults are chosen by mpcg_create from
  * knot_points): "pcg_waves" (4, 8 or 16 wavefronts per trajectory workgroup), "pcg_reg_rows" (block
  * rows per matrix per wave kept in registers for the whole solve; only compiled (waves, rows) pairs

@@ -9,6 +9,7 @@
 
 #include "../../include/mpcg.h"
 #include "pcg_kernels.hip.h"
+#include "schur_kernels.hip.h"
 
 using namespace mpcg;
 
@@ -22,6 +23,8 @@ struct mpcg_handle {
     int lds_rows = -1;        // RL: rows per matrix per wave cached in LDS; -1 = as many as fit when reg_rows > 0, else 0
     int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
     int spmv_blocks_per_cu = 8;
+    float* ginv_scratch = nullptr;   // staging for the in-place G <- G^-1 of mpcg_form_schur
+    size_t ginv_scratch_floats = 0;
     std::string err;
 };
 
@@ -90,6 +93,10 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
 }
 
 int mpcg_destroy(mpcg_handle* h) {
+    if (h && h->ginv_scratch) {
+        (void)hipSetDevice(h->device);
+        (void)hipFree(h->ginv_scratch);
+    }
     delete h;
     return MPCG_OK;
 }
@@ -278,6 +285,61 @@ int mpcg_bt_spmv(mpcg_handle* h, const float* d_M, const float* d_x, float* d_y,
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (h->nt_loads) hipLaunchKernelGGL((bt_spmv_kernel<NW, true>), dim3((unsigned)blocks), dim3(NW * 64), 0, st, a);
     else hipLaunchKernelGGL((bt_spmv_kernel<NW, false>), dim3((unsigned)blocks), dim3(NW * 64), 0, st, a);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
+
+
+int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, const float* d_C_dense, const float* d_g,
+                    const float* d_c, float* d_S, float* d_Pinv, float* d_gamma, float rho, uint32_t batch,
+                    mpcg_precond precond, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_G_dense || !d_C_dense || !d_g || !d_c || !d_S || !d_Pinv || !d_gamma)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: null device pointer");
+    if (control_size != 7) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur: control_size must be 7 (IIWA-14)");
+    if (precond != MPCG_PRECOND_JACOBI && precond != MPCG_PRECOND_SS)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: bad preconditioner");
+    if (batch == 0) return MPCG_OK;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: batch exceeds max_batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = (int)h->n, m = (int)control_size, N = (int)h->N;
+    const size_t Gsz = (size_t)(n * n + m * m) * N - m * m;
+    const size_t need = Gsz * h->max_batch;
+    if (h->ginv_scratch_floats < need) {          // first call only (not stream-ordered: hipMalloc)
+        if (h->ginv_scratch) HIP_TRY(h, hipFree(h->ginv_scratch));
+        h->ginv_scratch = nullptr; h->ginv_scratch_floats = 0;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->ginv_scratch), need * sizeof(float)));
+        h->ginv_scratch_floats = need;
+    }
+    SchurArgs a;
+    a.G = d_G_dense; a.C = d_C_dense; a.g = d_g; a.c = d_c; a.S = d_S; a.Pinv = d_Pinv; a.gamma = d_gamma;
+    a.Ginv_scratch = h->ginv_scratch; a.Ginv_out = d_G_dense;
+    a.rho = rho; a.n = n; a.m = m; a.N = N; a.batch = (int)batch; a.ss = precond == MPCG_PRECOND_SS;
+    long blocks = (long)batch * N;
+    const long cap = (long)h->num_cus * 64;
+    if (blocks > cap) blocks = cap;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(form_schur_kernel, dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(complete_ss_kernel, dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
+
+int mpcg_compute_dz(mpcg_handle* h, uint32_t control_size, const float* d_Ginv_dense, const float* d_C_dense,
+                    const float* d_g, const float* d_lambda, float* d_dz, uint32_t batch, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_Ginv_dense || !d_C_dense || !d_g || !d_lambda || !d_dz)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_compute_dz: null device pointer");
+    if (control_size != 7) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_compute_dz: control_size must be 7 (IIWA-14)");
+    if (batch == 0) return MPCG_OK;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_compute_dz: batch exceeds max_batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    DzArgs a{d_Ginv_dense, d_C_dense, d_g, d_lambda, d_dz, (int)h->n, (int)control_size, (int)h->N, (int)batch};
+    long blocks = (long)batch * h->N;
+    const long cap = (long)h->num_cus * 64;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(compute_dz_kernel, dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRY(h, hipGetLastError());
     return MPCG_OK;
 }

@@ -1,0 +1,247 @@
+// schur_kernels.hip.h — the steps either side of the PCG, gfx950 HIP:
+//   form_schur_kernel  + complete_ss_kernel : (G, C, g, c, rho) -> (S, Pinv, gamma), G <- G^-1
+//        replaces form_S_gamma_Pinv_kernel / form_schur_system (include/pcg/linsys_setup.cuh:565-656)
+//   compute_dz_kernel : dz = G^-1 (g - C^T lambda)      replaces compute_dz (include/common/dz.cuh:3-136)
+//
+// One wavefront (64 threads) per knot point; batch x N workgroups.  The reference runs both halves
+// of the Schur formation in one cooperative kernel with a grid sync between them (:600); a kernel
+// boundary (~1.5 us on this chip) is cheaper than any grid barrier, so they are two launches here.
+// The reference also overwrites G with its block inverses while other blocks may still be reading
+// the raw blocks (row k writes slot k-1 which row k-1 reads, :321 vs :372 — a benign race there);
+// here the first kernel writes the inverses to a scratch buffer and the second copies them into G.
+//
+// Arithmetic follows the reference operation for operation and is written with contraction OFF and
+// sequential inner products, so that it is BIT-IDENTICAL to the C oracle (oracle/mpcg_oracle_impl.inc,
+// built with -ffp-contract=off) — the parity test compares bits, not tolerances.  These kernels move
+// ~2.5 KB and ~20 kflop per knot: they are latency/launch bound and nowhere near any roofline.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mpcg {
+
+constexpr int SCH_THREADS = 64;
+
+#pragma clang fp contract(off)
+
+// C[m x k] = A[m x n] * B[n x k] (column-major); transB: B stored k x n.  Sequential over n.
+__device__ __forceinline__ void w_gemm(int m, int n, int k, const float* A, const float* B, float* C, bool transB) {
+    for (int e = threadIdx.x; e < m * k; e += SCH_THREADS) {
+        const int row = e % m, col = e / m;
+        float acc = 0.f;
+        for (int t = 0; t < n; ++t) acc += A[row + t * m] * (transB ? B[col + t * k] : B[t + col * n]);
+        C[e] = acc;
+    }
+}
+__device__ __forceinline__ void w_matvec(int rows, int cols, const float* M, const float* v, float* out) {
+    for (int r = threadIdx.x; r < rows; r += SCH_THREADS) {
+        float acc = 0.f;
+        for (int c = 0; c < cols; ++c) acc += M[r + c * rows] * v[c];
+        out[r] = acc;
+    }
+}
+// Gauss-Jordan on [A | I] without pivoting (include/utils/matrix.cuh:120-238): A destroyed, Ainv out.
+// scr: 3n floats (pivot row of A, pivot row of Ainv, pivot column).
+__device__ void w_invert(int n, float* A, float* Ainv, float* scr) {
+    for (int e = threadIdx.x; e < n * n; e += SCH_THREADS) Ainv[e] = (float)((e % n) == (e / n));
+    __syncthreads();
+    float* prowA = scr;
+    float* prowI = scr + n;
+    float* pcol = scr + 2 * n;
+    for (int piv = 0; piv < n; ++piv) {
+        const float pinv = 1.0f / A[piv + piv * n];
+        for (int c = threadIdx.x; c < n; c += SCH_THREADS) {
+            prowA[c] = A[piv + c * n] * pinv;
+            prowI[c] = Ainv[piv + c * n] * pinv;
+            pcol[c] = A[c + piv * n];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n * n; e += SCH_THREADS) {
+            const int r = e % n, c = e / n;
+            if (r == piv) { A[e] = prowA[c]; Ainv[e] = prowI[c]; }
+            else { A[e] -= pcol[r] * prowA[c]; Ainv[e] -= pcol[r] * prowI[c]; }
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void w_copy(int cnt, const float* src, float* dst, float mult = 1.f) {
+    for (int e = threadIdx.x; e < cnt; e += SCH_THREADS) dst[e] = src[e] * mult;
+}
+
+struct SchurArgs {
+    const float* G; const float* C; const float* g; const float* c;
+    float* S; float* Pinv; float* gamma; float* Ginv_scratch; float* Ginv_out;
+    float rho; int n; int m; int N; int batch; int ss;
+};
+
+// block row k of trajectory b: S[k,0], S[k,1], S[k-1,2], Pinv[k,1], gamma[k]; inverses -> scratch
+__global__ __launch_bounds__(SCH_THREADS) void form_schur_kernel(SchurArgs a) {
+    __shared__ float sm[12 * 196 + 2 * 49 + 98 + 8 * 14 + 64];
+    const int n = a.n, m = a.m, N = a.N, nn = n * n, mm = m * m, nm = n * m;
+    const int Gset = nn + mm, Cset = nn + nm, gset = n + m;
+    const size_t Gsz = (size_t)Gset * N - mm, Csz = (size_t)Cset * (N - 1), gsz = (size_t)gset * N - m;
+    float *Qk = sm, *Qki = Qk + nn, *Qp = Qki + nn, *Qpi = Qp + nn, *Ak = Qpi + nn, *phi = Ak + nn, *theta = phi + nn,
+          *thetaInv = theta + nn, *t1 = thetaInv + nn, *t2 = t1 + nn, *phiT = t2 + nn, *BR = phiT + nn /* n x m */,
+          *Bk = BR + nn, *Rk = Bk + nm, *Rki = Rk + mm, *gam = Rki + mm, *v1 = gam + n, *v2 = v1 + n, *qk = v2 + n,
+          *qp = qk + n, *rk = qp + n, *scr = rk + n;
+
+    for (long item = blockIdx.x; item < (long)a.batch * N; item += gridDim.x) {
+        const int b = (int)(item / N), k = (int)(item % N);
+        const float* G = a.G + (size_t)b * Gsz;
+        const float* C = a.C + (size_t)b * Csz;
+        const float* g = a.g + (size_t)b * gsz;
+        const float* c = a.c + (size_t)b * n * N;
+        float* S = a.S + (size_t)b * 3 * nn * N;
+        float* P = a.Pinv + (size_t)b * 3 * nn * N;
+        float* gamma = a.gamma + (size_t)b * n * N;
+        float* Gs = a.Ginv_scratch + (size_t)b * Gsz;
+        __syncthreads();
+        if (k == 0) {                                                    // linsys_setup.cuh:152-277
+            w_copy(nn, G, Qk);
+            w_copy(n, g, qk);
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += SCH_THREADS) Qk[i + i * n] += a.rho;
+            __syncthreads();
+            w_copy(nn, Qk, P + nn, -1.f);                                // Pinv[0,1] = -(Q0 + rho I)
+            __syncthreads();
+            w_invert(n, Qk, Qki, scr);
+            w_copy(nn, Qki, S + nn, -1.f);                               // S[0,1] = -Q0^-1
+            w_matvec(n, n, Qki, qk, v1);
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += SCH_THREADS) gamma[i] = -v1[i];
+            continue;
+        }
+        w_copy(nn, C + (size_t)(k - 1) * Cset, Ak);                      // :318-325
+        w_copy(nm, C + (size_t)(k - 1) * Cset + nn, Bk);
+        w_copy(nn, G + (size_t)(k - 1) * Gset, Qk);
+        w_copy(mm, G + (size_t)(k - 1) * Gset + nn, Rk);
+        w_copy(nn, G + (size_t)k * Gset, Qp);
+        w_copy(n, g + (size_t)(k - 1) * gset, qk);
+        w_copy(m, g + (size_t)(k - 1) * gset + n, rk);
+        w_copy(n, g + (size_t)k * gset, qp);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += SCH_THREADS) { Qk[i + i * n] += a.rho; Qp[i + i * n] += a.rho; }
+        for (int i = threadIdx.x; i < m; i += SCH_THREADS) Rk[i + i * m] += a.rho;
+        __syncthreads();
+        w_invert(n, Qk, Qki, scr);                                       // :356-368
+        w_invert(n, Qp, Qpi, scr);
+        w_invert(m, Rk, Rki, scr);
+        w_gemm(n, n, n, Ak, Qki, phi, false);                            // phi = Abar Qi          :397-398
+        w_gemm(n, m, m, Bk, Rki, BR, false);                             // Bbar Ri                :405-406
+        w_matvec(n, n, Qpi, qp, gam);                                    // :410-415
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += SCH_THREADS) gam[i] -= c[(size_t)k * n + i];   // :416-418
+        w_matvec(n, n, phi, qk, v1);                                     // :421-426
+        w_matvec(n, m, BR, rk, v2);                                      // :431-436
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += SCH_THREADS) gam[i] += v2[i] + v1[i];          // :441-443
+        w_gemm(n, n, n, phi, Ak, theta, true);                           // phi Abar^T             :446-455
+        w_gemm(n, m, n, BR, Bk, t1, true);                               // (Bbar Ri) Bbar^T       :472-481
+        __syncthreads();
+        for (int e = threadIdx.x; e < nn; e += SCH_THREADS) { theta[e] += Qpi[e]; theta[e] += t1[e]; }   // :466-468, 485-487
+        __syncthreads();
+        w_copy(nn, phi, S + (size_t)k * 3 * nn, -1.f);                   // S[k,0]                 :490-497
+        w_copy(nn, theta, S + (size_t)k * 3 * nn + nn, -1.f);            // S[k,1]                 :500-507
+        w_copy(nn, theta, t2);
+        for (int e = threadIdx.x; e < nn; e += SCH_THREADS) { const int i = e % n, j = e / n; phiT[i + j * n] = phi[j + i * n]; }
+        __syncthreads();
+        w_copy(nn, phiT, S + (size_t)(k - 1) * 3 * nn + 2 * nn, -1.f);   // S[k-1,2] = -phi^T      :536-557
+        w_invert(n, t2, thetaInv, scr);                                  // :510-514
+        w_copy(nn, thetaInv, P + (size_t)k * 3 * nn + nn, -1.f);         // Pinv[k,1]              :517-524
+        for (int i = threadIdx.x; i < n; i += SCH_THREADS) gamma[(size_t)k * n + i] = -gam[i];   // :528-532
+        w_copy(nn, Qki, Gs + (size_t)(k - 1) * Gset);                    // G <- G^-1 (via scratch) :371-380
+        w_copy(mm, Rki, Gs + (size_t)(k - 1) * Gset + nn);
+        if (k == N - 1) w_copy(nn, Qpi, Gs + (size_t)k * Gset);
+    }
+}
+
+// symmetric-stair completion (linsys_setup.cuh:9-137) + publication of G^-1
+__global__ __launch_bounds__(SCH_THREADS) void complete_ss_kernel(SchurArgs a) {
+    __shared__ float sm[7 * 196];
+    const int n = a.n, m = a.m, N = a.N, nn = n * n, mm = m * m;
+    const int Gset = nn + mm;
+    const size_t Gsz = (size_t)Gset * N - mm;
+    float *Dk = sm, *Dm = Dk + nn, *Dp = Dm + nn, *L = Dp + nn, *Rt = L + nn, *t1 = Rt + nn, *t2 = t1 + nn;
+    for (long item = blockIdx.x; item < (long)a.batch * N; item += gridDim.x) {
+        const int b = (int)(item / N), k = (int)(item % N);
+        const float* S = a.S + (size_t)b * 3 * nn * N;
+        float* P = a.Pinv + (size_t)b * 3 * nn * N;
+        const int cnt = (k < N - 1) ? Gset : nn;
+        w_copy(cnt, a.Ginv_scratch + (size_t)b * Gsz + (size_t)k * Gset, a.Ginv_out + (size_t)b * Gsz + (size_t)k * Gset);
+        if (!a.ss) continue;
+        __syncthreads();
+        w_copy(nn, P + (size_t)k * 3 * nn + nn, Dk);
+        if (k > 0) {
+            w_copy(nn, S + (size_t)k * 3 * nn, L);
+            w_copy(nn, P + (size_t)(k - 1) * 3 * nn + nn, Dm);
+        }
+        if (k < N - 1) {
+            const float* Sn = S + (size_t)(k + 1) * 3 * nn;                 // phi_{k+1}, transposed on load (:36-43)
+            for (int e = threadIdx.x; e < nn; e += SCH_THREADS) { const int i = e % n, j = e / n; Rt[j + i * n] = Sn[e]; }
+            w_copy(nn, P + (size_t)(k + 1) * 3 * nn + nn, Dp);
+        }
+        __syncthreads();
+        if (k > 0) {
+            w_gemm(n, n, n, Dk, L, t1, false);                             // :100
+            __syncthreads();
+            w_gemm(n, n, n, t1, Dm, t2, false);                            // :102
+            __syncthreads();
+            w_copy(nn, t2, P + (size_t)k * 3 * nn, -1.f);                  // Pinv[k,0]  :106-113
+            __syncthreads();
+        }
+        if (k < N - 1) {
+            w_gemm(n, n, n, Dk, Rt, t1, false);                            // :121
+            __syncthreads();
+            w_gemm(n, n, n, t1, Dp, t2, false);                            // :123
+            __syncthreads();
+            w_copy(nn, t2, P + (size_t)k * 3 * nn + 2 * nn, -1.f);         // Pinv[k,2]  :127-134
+        }
+    }
+}
+
+struct DzArgs { const float* Ginv; const float* C; const float* g; const float* lambda; float* dz; int n; int m; int N; int batch; };
+
+// include/common/dz.cuh:3-121: dz_x = Qi (q - lambda_k - Abar^T lambda_{k+1}), dz_u = Ri (r - Bbar^T lambda_{k+1})
+__global__ __launch_bounds__(SCH_THREADS) void compute_dz_kernel(DzArgs a) {
+    __shared__ float sm[64];
+    const int n = a.n, m = a.m, N = a.N, nn = n * n, mm = m * m, nm = n * m;
+    const size_t Gsz = (size_t)(nn + mm) * N - mm, Csz = (size_t)(nn + nm) * (N - 1), gsz = (size_t)(n + m) * N - m;
+    float* tx = sm;          // n
+    float* tu = sm + 16;     // m
+    for (long item = blockIdx.x; item < (long)a.batch * N; item += gridDim.x) {
+        const int b = (int)(item / N), k = (int)(item % N);
+        const float* Qi = a.Ginv + (size_t)b * Gsz + (size_t)k * (nn + mm);
+        const float* Ck = a.C + (size_t)b * Csz + (size_t)k * (nn + nm);
+        const float* gk = a.g + (size_t)b * gsz + (size_t)k * (n + m);
+        const float* lam = a.lambda + (size_t)b * n * N;
+        float* dz = a.dz + (size_t)b * gsz + (size_t)k * (n + m);
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < n) {                                                      // gato_ATx, matrix.cuh:10-25
+            float acc = 0.f;
+            if (k != N - 1)
+                for (int i = 0; i < n; ++i) acc += Ck[t * n + i] * lam[(size_t)(k + 1) * n + i];
+            tx[t] = gk[t] - (lam[(size_t)k * n + t] + acc);
+        } else if (t >= 32 && t < 32 + m && k != N - 1) {
+            const int j = t - 32;
+            float acc = 0.f;
+            for (int i = 0; i < n; ++i) acc += Ck[nn + j * n + i] * lam[(size_t)(k + 1) * n + i];
+            tu[j] = gk[n + j] - acc;
+        }
+        __syncthreads();
+        if (t < n) {
+            float acc = 0.f;
+            for (int c = 0; c < n; ++c) acc += Qi[t + c * n] * tx[c];
+            dz[t] = acc;
+        } else if (t >= 32 && t < 32 + m && k != N - 1) {
+            const int j = t - 32;
+            float acc = 0.f;
+            for (int c = 0; c < m; ++c) acc += Qi[nn + j + c * m] * tu[c];
+            dz[n + j] = acc;
+        }
+    }
+}
+
+#pragma clang fp contract(fast)
+
+}  // namespace mpcg

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from .synth import STATE_SIZE, pcg_max_iter
+from .synth import CONTROL_SIZE, STATE_SIZE, pcg_max_iter
 
 PCG_NUM_THREADS = 128   # include/common/settings.cuh:111-113 (reference launch shape; informational)
 
@@ -116,6 +116,35 @@ class PcgSolver:
                                                 _ptr(d_r), _ptr(d_p), _ptr(d_v_temp), _ptr(d_eta_new_temp),
                                                 _ptr(d_pcg_iters), _ptr(d_pcg_exit),
                                                 int(pcg_max_iter), float(pcg_exit_tol), _stream()))
+
+    def form_schur(self, G_dense, C_dense, g, c, rho: float, precond: str = "ss", S=None, Pinv=None, gamma=None,
+                   control_size: int = CONTROL_SIZE):
+        """form_schur_system (include/pcg/linsys_setup.cuh:620-656), batched.  G_dense is overwritten by
+        its block inverses (the reference's side effect).  Returns (S, Pinv, gamma) device tensors."""
+        B = c.shape[0] if c.dim() > 1 else 1
+        n, m, N = self.n, control_size, self.N
+        self._chk(G_dense, B * ((n * n + m * m) * N - m * m), torch.float32, "G_dense")
+        self._chk(C_dense, B * (n * n + n * m) * (N - 1), torch.float32, "C_dense")
+        self._chk(g, B * ((n + m) * N - m), torch.float32, "g")
+        self._chk(c, B * n * N, torch.float32, "c")
+        dev = c.device
+        S = torch.empty(B, 3 * n * n * N, device=dev) if S is None else S
+        Pinv = torch.empty(B, 3 * n * n * N, device=dev) if Pinv is None else Pinv
+        gamma = torch.empty(B, n * N, device=dev) if gamma is None else gamma
+        pc = _lib.MPCG_PRECOND_SS if precond == "ss" else _lib.MPCG_PRECOND_JACOBI
+        self._check(self.lib.mpcg_form_schur(self._h, m, _ptr(G_dense), _ptr(C_dense), _ptr(g), _ptr(c), _ptr(S),
+                                             _ptr(Pinv), _ptr(gamma), float(rho), B, pc, _stream()))
+        return S, Pinv, gamma
+
+    def compute_dz(self, Ginv_dense, C_dense, g, lam, dz=None, control_size: int = CONTROL_SIZE):
+        """compute_dz (include/common/dz.cuh:124-136), batched."""
+        B = lam.shape[0] if lam.dim() > 1 else 1
+        n, m, N = self.n, control_size, self.N
+        if dz is None:
+            dz = torch.empty(B, (n + m) * N - m, device=lam.device)
+        self._check(self.lib.mpcg_compute_dz(self._h, m, _ptr(Ginv_dense), _ptr(C_dense), _ptr(g), _ptr(lam), _ptr(dz),
+                                             B, _stream()))
+        return dz
 
     def bt_spmv(self, M, x, y=None, cols: int = 3):
         B = x.shape[0] if x.dim() > 1 else 1

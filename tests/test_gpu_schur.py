@@ -1,0 +1,107 @@
+"""GPU: the steps either side of the PCG through the C ABI:
+mpcg_form_schur == the oracle's knot-by-knot restatement of include/pcg/linsys_setup.cuh BIT FOR BIT
+(same operation order, contraction off on both sides), mpcg_compute_dz likewise vs include/common/dz.cuh;
+plus the whole chain KKT blocks -> Schur -> PCG -> dz against a float64 KKT solve."""
+import numpy as np
+import pytest
+import torch
+
+from mpcgpu_amd import synth
+from util import relinf
+
+pytestmark = pytest.mark.gpu
+n, m = 14, 7
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("N", [2, 3, 8, 33, 128])
+@pytest.mark.parametrize("precond", ["ss", "jacobi"])
+def test_form_schur_bit_exact_vs_oracle(orc, N, precond):
+    from mpcgpu_amd import PcgSolver
+    B = 3
+    k = synth.make_kkt(N, B, 555 + N)
+    G, C, g, c = synth.pack_kkt_dense(k, np.float32)
+    sol = PcgSolver(N, max_batch=B)
+    dG = dev(G)
+    poison = float("nan")
+    S = torch.full((B, 3 * n * n * N), poison, device="cuda")
+    P = torch.full((B, 3 * n * n * N), poison, device="cuda")
+    gam = torch.full((B, n * N), poison, device="cuda")
+    sol.form_schur(dG, dev(C), dev(g), dev(c), 1e-3, precond, S=S, Pinv=P, gamma=gam)
+    torch.cuda.synchronize()
+    S, P, gam, Ginv = S.cpu().numpy(), P.cpu().numpy(), gam.cpu().numpy(), dG.cpu().numpy()
+    for b in range(B):
+        So, Po, go, Go = orc.form_schur(G[b], C[b], g[b], c[b], N, np.float32(1e-3), ss=(precond == "ss"))
+        # identical bits, including WHICH slots are left unwritten (NaN poison on both sides)
+        np.testing.assert_array_equal(S[b], So)
+        np.testing.assert_array_equal(P[b], Po)
+        np.testing.assert_array_equal(gam[b], go)
+        np.testing.assert_array_equal(Ginv[b], Go)
+    # and close to the float64 numpy builder
+    Sn, Pn, gn = synth.form_schur(k, precond=precond, dtype=np.float64)
+    mS = ~np.isnan(S)
+    assert relinf(S[mS], Sn[mS]) < 2e-3 and relinf(gam, gn) < 2e-3
+    mP = ~np.isnan(P)
+    assert relinf(P[mP], Pn[mP]) < 2e-3
+
+
+@pytest.mark.parametrize("N", [2, 9, 128])
+def test_compute_dz_bit_exact_vs_oracle(orc, N):
+    from mpcgpu_amd import PcgSolver
+    B = 2
+    k = synth.make_kkt(N, B, 77 + N)
+    G, C, g, c = synth.pack_kkt_dense(k, np.float32)
+    lam = np.random.default_rng(N).normal(size=(B, n * N)).astype(np.float32)
+    sol = PcgSolver(N, max_batch=B)
+    dG = dev(G)
+    sol.form_schur(dG, dev(C), dev(g), dev(c), 1e-3)
+    dz = sol.compute_dz(dG, dev(C), dev(g), dev(lam))
+    torch.cuda.synchronize()
+    dz = dz.cpu().numpy()
+    Ginv = dG.cpu().numpy()
+    for b in range(B):
+        np.testing.assert_array_equal(dz[b], orc.compute_dz(Ginv[b], C[b], g[b], lam[b], N))
+
+
+def test_kkt_to_step_pipeline_vs_float64_kkt_solve(orc):
+    """KKT blocks -> mpcg_form_schur -> mpcg_pcg_solve -> mpcg_compute_dz, all on the GPU, against the
+    primal step of a dense float64 solve of the regularised KKT system  [G C^T; C 0][dz; lam] = [g; c]
+    (sign conventions of include/common/dz.cuh / linsys_setup.cuh: dz = G^-1 (g - C^T lam))."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, B, rho = 16, 2, 1e-1
+    k = synth.make_kkt(N, B, 31337)
+    G, C, g, c = synth.pack_kkt_dense(k, np.float32)
+    sol = PcgSolver(N, max_batch=B)
+    dG, dC, dg, dc = dev(G), dev(C), dev(g), dev(c)
+    S, P, gam = sol.form_schur(dG, dC, dg, dc, rho, "ss")
+    lam = torch.zeros(B, n * N, device="cuda")
+    it, ex = sol.solve(S, P, gam, lam, pcg_config(pcg_exit_tol=1e-9, pcg_max_iter=2000), "ss")
+    dz = sol.compute_dz(dG, dC, dg, lam)
+    torch.cuda.synchronize()
+    assert (ex.cpu().numpy() == 0).all()
+    dz, lam = dz.cpu().numpy(), lam.cpu().numpy()
+    nz = (n + m) * N - m
+    for b in range(B):
+        Cm, Gm, gz = np.zeros((n * N, nz)), np.zeros((nz, nz)), np.zeros(nz)
+        Cm[:n, :n] = np.eye(n)
+        for kk in range(N):
+            o = kk * (n + m)
+            Gm[o:o + n, o:o + n] = k.Q[b, kk] + rho * np.eye(n)
+            gz[o:o + n] = k.q[b, kk]
+            if kk < N - 1:
+                Gm[o + n:o + n + m, o + n:o + n + m] = k.R[b, kk] + rho * np.eye(m)
+                gz[o + n:o + n + m] = k.r[b, kk]
+            if kk > 0:
+                po = (kk - 1) * (n + m)
+                Cm[kk * n:(kk + 1) * n, po:po + n] = -k.A[b, kk - 1]
+                Cm[kk * n:(kk + 1) * n, po + n:po + n + m] = -k.Bm[b, kk - 1]
+                Cm[kk * n:(kk + 1) * n, o:o + n] = np.eye(n)
+        K = np.block([[Gm, Cm.T], [Cm, np.zeros((n * N, n * N))]])
+        sol64 = np.linalg.solve(K, np.concatenate([gz, k.c[b].reshape(-1)]))
+        assert relinf(lam[b], sol64[nz:]) < 5e-3
+        assert relinf(dz[b], sol64[:nz]) < 5e-3
+        # the step satisfies the linearised constraints C dz = c
+        assert np.abs(Cm @ dz[b].astype(np.float64) - k.c[b].reshape(-1)).max() < 5e-3
