@@ -173,18 +173,32 @@ struct PcgArgs {
     int lds_rows;                          // RL: block rows per matrix per wave cached in LDS
 };
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov0(float v) {     // lanes whose source is outside the row read 0
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
 // sum over the 8 consecutive lanes of each group; valid in the group's lane 0.
 // Order: ((g0+g4)+(g2+g6)) + ((g1+g5)+(g3+g7)), g7 == 0.
+// Twelve v_add_f32 with a DPP row_shl operand (lane i adds lane i+n of its 16-lane row; lanes whose
+// source falls outside the row add 0).  Written as ONE asm statement because hipcc otherwise emits
+// v_mov_b32_dpp + v_pk_add_f32 pairs (VOP3P cannot carry DPP) — 18 instructions + hazard nops.
+// Hazards (a VALU write followed by a DPP read of the same VGPR needs 2 wait states): the leading
+// s_nop covers values written just before the statement; inside, every DPP read is 4 instructions
+// behind its producer.
 __device__ __forceinline__ f4 reduce_g(f4 a) {
-    constexpr int SHL = 0x100;                            // DPP row_shl:n — lane i reads lane i+n
-    a.x += dpp_mov0<SHL + 4>(a.x); a.y += dpp_mov0<SHL + 4>(a.y); a.z += dpp_mov0<SHL + 4>(a.z); a.w += dpp_mov0<SHL + 4>(a.w);
-    a.x += dpp_mov0<SHL + 2>(a.x); a.y += dpp_mov0<SHL + 2>(a.y); a.z += dpp_mov0<SHL + 2>(a.z); a.w += dpp_mov0<SHL + 2>(a.w);
-    a.x += dpp_mov0<SHL + 1>(a.x); a.y += dpp_mov0<SHL + 1>(a.y); a.z += dpp_mov0<SHL + 1>(a.z); a.w += dpp_mov0<SHL + 1>(a.w);
-    return a;
+    float x = a.x, y = a.y, z = a.z, w = a.w;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(x), "+v"(y), "+v"(z), "+v"(w));
+    return f4{x, y, z, w};
 }
 
 // RR = block rows per matrix per wave held in REGISTERS for the whole solve (loaded once), then
@@ -219,8 +233,9 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
     const bool active = lr < 7 && lg < 7;
     const int f_idx = active ? 7 * lg + lr : 0;        // which float4 of a block this lane owns
     const uint32_t lane_off = active ? (uint32_t)f_idx * 16u : OOB_OFF;
-    const int g2 = active ? 2 * lg : 0;                // first column of the lane's column pair
-    const bool a01 = lr <= 3, a23 = lr <= 2;           // accumulators 0,1 / 2,3 multiply column a (else b)
+    // accumulators 0,1 multiply column 2g (residues r <= 3) or 2g+1; accumulators 2,3 column 2g (r <= 2) or 2g+1
+    const int c01 = active ? 2 * lg + (lr <= 3 ? 0 : 1) : 0;
+    const int c23 = active ? 2 * lg + (lr <= 2 ? 0 : 1) : 0;
     const bool head = lg == 0 && lr < 4;               // lanes 0, 8, 16, 24 end up with rows 4r..4r+3
 
     // Block rows owned by this wave: k = w + NW*t, t < T.
@@ -277,9 +292,8 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
 
     // acc += block * x for this lane's float4; xk = the 14-vector the block multiplies
     auto fma_blk = [&](f4& acc, const f4 m, const float* xk) {
-        const f2 x = *reinterpret_cast<const f2*>(xk + g2);      // 56k + 8g bytes: 8-byte aligned
-        const float x01 = a01 ? x.x : x.y;
-        const float x23 = a23 ? x.x : x.y;
+        const float x01 = xk[c01];
+        const float x23 = xk[c23];
         acc.x = fmaf(m.x, x01, acc.x);
         acc.y = fmaf(m.y, x01, acc.y);
         acc.z = fmaf(m.z, x23, acc.z);

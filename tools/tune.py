@@ -19,8 +19,8 @@ ap.add_argument("--nts", default="0,1")
 ap.add_argument("--regs", default="0", help="comma list of waves:reg_rows[:lds_rows] variants, e.g. 8:6:-1,4:12:-1")
 args = ap.parse_args()
 N, B = args.knots, args.batch
-S, P, g = bench.build_inputs(N, B, 0, args.precond)
-dS, dP, dg = (torch.from_numpy(a).cuda() for a in (S, P, g))
+sol0 = PcgSolver(N, max_batch=B)
+dS, dP, dg = bench.build_inputs(sol0, N, B, 0, args.precond, torch.device("cuda", 0))
 lam = torch.zeros(B, 14 * N, device="cuda")
 cfg = pcg_config(pcg_exit_tol=1e-4, pcg_max_iter=synth.pcg_max_iter(N))
 bytes_it = synth.algorithmic_bytes(N, precond=args.precond)["pcg_iter"]
