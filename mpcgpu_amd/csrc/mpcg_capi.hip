@@ -86,7 +86,7 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     if (knot_points <= 64) {            // <= 4 rows per wave and matrix: half or all of them in registers
         h->pcg_waves = 16; h->reg_rows = 2; h->lds_rows = knot_points <= 32 ? 0 : -1; h->nt_loads = 0;
     } else {                            // 8 fat waves: 6 rows/matrix in 256 VGPRs, LDS takes what fits
-        h->pcg_waves = 8; h->reg_rows = 6; h->lds_rows = -1; h->nt_loads = knot_points >= 384 ? 1 : 0;
+        h->pcg_waves = 8; h->reg_rows = 5; h->lds_rows = -1; h->nt_loads = knot_points >= 384 ? 1 : 0;
     }
     *out = h;
     return MPCG_OK;
@@ -192,7 +192,7 @@ static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
 }
 
 // Compiled (waves, register rows) variants.  X(NW, RR)
-#define MPCG_PCG_VARIANTS(X) X(16, 0) X(8, 0) X(4, 0) X(16, 2) X(8, 4) X(8, 6) X(8, 7) X(4, 8) X(4, 12) X(4, 16)
+#define MPCG_PCG_VARIANTS(X) X(16, 0) X(8, 0) X(4, 0) X(16, 2) X(8, 4) X(8, 5) X(8, 6) X(4, 8) X(4, 12)
 
 static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
     HIP_TRY(h, hipSetDevice(h->device));

@@ -205,7 +205,7 @@ __device__ __forceinline__ f4 reduce_g(f4 a) {
 // a.lds_rows rows per matrix per wave held in LDS, the remaining rows streamed every iteration.
 // Wave w owns rows k = w + NW*t; t < RR: registers, RR <= t < RR+RL: LDS, t >= RR+RL: stream.
 template <int NW, int RR, bool NT>
-__global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kernel(PcgArgs a) {
+__global__ __launch_bounds__(NW * 64, (RR == 0 ? 4 : NW / 4)) void pcg_traj_kernel(PcgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int N = a.N;
     const int tid = threadIdx.x;
@@ -242,9 +242,9 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
     const int T = max(0, (N - w + NW - 1) / NW);
     const int RL = a.lds_rows;
     const int t0s = min(T, RR + RL);                 // first streamed row index
-    // streamed step count, padded to even so the two register buffers (rowA/rowB) keep fixed roles
-    // across passes; a padded step has k >= N, loads nothing (OOB) and computes nothing.
-    const int TS = ((T - t0s) + 1) & ~1;
+    // streamed step count, padded to a multiple of 4 so the four register buffers (rowA..rowD) keep
+    // fixed roles across passes; a padded step has k >= N, loads nothing (OOB) and computes nothing.
+    const int TS = ((T - t0s) + 3) & ~3;
 
     // ---- resident rows: registers ----
     Rows regS[RR > 0 ? RR : 1], regP[RR > 0 ? RR : 1];
@@ -276,8 +276,9 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
         if (++st_t >= TS) { st_t = 0; st_pass ^= 1; }
         return R;
     };
-    Rows rowA, rowB;
+    Rows rowA, rowB, rowC, rowD;           // the stream runs two block rows (one pair) ahead of use
     rowA = load_next();                    // (a wave with no streamed rows gets zeros from the OOB path)
+    rowB = load_next();
 
     // ---- stage vectors: xp <- lambda0 (operand of the setup SpMV), lam <- lambda0, xr <- gamma ----
     for (int e = tid; e < (N + 2) * NS; e += NTHR) { xp[e] = 0.f; xr[e] = 0.f; }
@@ -299,49 +300,94 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 8 : NW / 4)) void pcg_traj_kern
         acc.z = fmaf(m.z, x23, acc.z);
         acc.w = fmaf(m.w, x23, acc.w);
     };
-    // one block row: tmp[k] (28 slots) = M[k,:] * x ;  part += d[k] . (M[k,:] x)
-    auto step = [&](const Rows& use, int t, const float* xv, const float* dv, float& part) {
+    // One block row in two halves so that two rows can be in flight per wave (their dependency chains
+    // LDS read -> FMA -> DPP -> bpermute -> LDS write are ~600 cycles each and otherwise serialise):
+    //   begin : x reads, 12 FMAs, DPP reduction over g, issue of the 4 bpermutes, d reads  (branch-free)
+    //   finish: halves a+b, tmp[k] = M[k,:] x, part += d[k] . (M[k,:] x)
+    struct Pend { f4 h; float b0, b1, b2, b3; f2 da, db; int k; bool valid; };
+    auto begin = [&](const Rows& use, int t, const float* xv, const float* dv) -> Pend {
+        Pend q;
         const int k = w + NW * t;
-        if (k < N) {
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
-            fma_blk(acc, use.m0, xv + (k + 0) * NS);
-            fma_blk(acc, use.m1, xv + (k + 1) * NS);
-            fma_blk(acc, use.m2, xv + (k + 2) * NS);
-            const f4 h = reduce_g(acc);
-            f4 y;                                                             // slot e + slot e+14
-            y.x = h.x + __shfl_down(h.z, 24);
-            y.y = h.y + __shfl_down(h.w, 24);
-            y.z = h.z + __shfl_down(h.x, 32);
-            y.w = h.w + __shfl_down(h.y, 32);
-            if (head) {
-                if (lr == 3) { y.z = 0.f; y.w = 0.f; }                       // rows 14, 15 do not exist
-                f2* out = reinterpret_cast<f2*>(tmp + k * NS + 4 * lr);       // 56k + 16r bytes
-                const f2* d2 = reinterpret_cast<const f2*>(dv + (k + 1) * NS + 4 * lr);
-                const f2 da = d2[0];
-                const f2 db = d2[1];      // lane 24 reads rows 14,15 = next knot's 0,1 (padded array): times 0
-                out[0] = f2{y.x, y.y};
-                if (lr < 3) out[1] = f2{y.z, y.w};
-                part += fmaf(y.w, db.y, fmaf(y.z, db.x, fmaf(y.y, da.y, y.x * da.x)));
-            }
+        q.valid = k < N;
+        q.k = q.valid ? k : 0;                          // rows beyond N are all-zero (OOB loads): any knot will do
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        fma_blk(acc, use.m0, xv + (q.k + 0) * NS);
+        fma_blk(acc, use.m1, xv + (q.k + 1) * NS);
+        fma_blk(acc, use.m2, xv + (q.k + 2) * NS);
+        const f2* d2 = reinterpret_cast<const f2*>(dv + (q.k + 1) * NS + 4 * (lr & 3));
+        q.da = d2[0];
+        q.db = d2[1];        // lane 24 reads rows 14,15 = next knot's 0,1 (padded array): multiplied by 0 below
+        q.h = reduce_g(acc);
+        q.b0 = __shfl_down(q.h.z, 24);                  // slot e+14 of slots e = 4r, 4r+1
+        q.b1 = __shfl_down(q.h.w, 24);
+        q.b2 = __shfl_down(q.h.x, 32);                  // ... of slots 4r+2, 4r+3
+        q.b3 = __shfl_down(q.h.y, 32);
+        return q;
+    };
+    auto finish = [&](const Pend& q, float& part) {
+        if (head && q.valid) {
+            f4 y = {q.h.x + q.b0, q.h.y + q.b1, q.h.z + q.b2, q.h.w + q.b3};
+            if (lr == 3) { y.z = 0.f; y.w = 0.f; }                           // rows 14, 15 do not exist
+            f2* out = reinterpret_cast<f2*>(tmp + q.k * NS + 4 * lr);         // 56k + 16r bytes
+            out[0] = f2{y.x, y.y};
+            if (lr < 3) out[1] = f2{y.z, y.w};
+            part += fmaf(y.w, q.db.y, fmaf(y.z, q.db.x, fmaf(y.y, q.da.y, y.x * q.da.x)));
         }
+    };
+    auto lds_row = [&](int mat, int j) -> Rows {
+        Rows R;
+        const f4* src = mc + (size_t)((mat * RL + j) * 3) * BLK4 + f_idx;
+        R.m0 = src[0]; R.m1 = src[BLK4]; R.m2 = src[2 * BLK4];
+        if (!active) { const f4 z = {0.f, 0.f, 0.f, 0.f}; R.m0 = z; R.m1 = z; R.m2 = z; }
+        return R;
     };
     auto pass = [&](auto which, const float* xv, const float* dv) -> float {
         constexpr int MAT = decltype(which)::value;       // 0: S, 1: Pinv (must alternate, S first)
         float part = 0.f;
+        // registers
 #pragma unroll
-        for (int t = 0; t < RR; ++t) step(MAT ? regP[t] : regS[t], t, xv, dv, part);
-        for (int j = 0; j < RL; ++j) {
-            Rows R;
-            const f4* src = mc + (size_t)((MAT * RL + j) * 3) * BLK4 + f_idx;
-            R.m0 = src[0]; R.m1 = src[BLK4]; R.m2 = src[2 * BLK4];
-            if (!active) { const f4 z = {0.f, 0.f, 0.f, 0.f}; R.m0 = z; R.m1 = z; R.m2 = z; }
-            step(R, RR + j, xv, dv, part);
+        for (int t = 0; t + 1 < RR; t += 2) {
+            const Pend p0 = begin(MAT ? regP[t] : regS[t], t, xv, dv);
+            const Pend p1 = begin(MAT ? regP[t + 1] : regS[t + 1], t + 1, xv, dv);
+            finish(p0, part);
+            finish(p1, part);
         }
-        for (int t = 0; t < TS; t += 2) {
-            rowB = load_next();
-            step(rowA, t0s + t, xv, dv, part);
+        if constexpr (RR & 1) {
+            const Pend p0 = begin(MAT ? regP[RR - 1] : regS[RR - 1], RR - 1, xv, dv);
+            finish(p0, part);
+        }
+        // LDS cache
+        int j = 0;
+        for (; j + 1 < RL; j += 2) {
+            const Rows r0 = lds_row(MAT, j), r1 = lds_row(MAT, j + 1);
+            const Pend p0 = begin(r0, RR + j, xv, dv);
+            const Pend p1 = begin(r1, RR + j + 1, xv, dv);
+            finish(p0, part);
+            finish(p1, part);
+        }
+        if (j < RL) {
+            const Rows r0 = lds_row(MAT, j);
+            const Pend p0 = begin(r0, RR + j, xv, dv);
+            finish(p0, part);
+        }
+        // stream: pair (A,B) is consumed while (C,D) is in flight, and vice versa
+        for (int t = 0; t < TS; t += 4) {
+            rowC = load_next();
+            rowD = load_next();
+            {
+                const Pend p0 = begin(rowA, t0s + t, xv, dv);
+                const Pend p1 = begin(rowB, t0s + t + 1, xv, dv);
+                finish(p0, part);
+                finish(p1, part);
+            }
             rowA = load_next();
-            step(rowB, t0s + t + 1, xv, dv, part);
+            rowB = load_next();
+            {
+                const Pend p0 = begin(rowC, t0s + t + 2, xv, dv);
+                const Pend p1 = begin(rowD, t0s + t + 3, xv, dv);
+                finish(p0, part);
+                finish(p1, part);
+            }
         }
         // heads sit in lanes 0, 8, 16, 24: fold them into lane 0 (once per pass): (r0+r2)+(r1+r3)
         part += __shfl_down(part, 16);

@@ -302,7 +302,7 @@ def test_cpp_callsite_over_shim_headers():
     assert out["smem"] == 4 * ((32 + 2) * 14 * 2 + 32 * 14 * 2 + 32)
 
 
-@pytest.mark.parametrize("waves,reg_rows,lds_rows", [(16, 2, -1), (8, 4, 0), (8, 6, -1), (8, 6, 2), (4, 8, -1), (4, 12, -1), (4, 16, 3)])
+@pytest.mark.parametrize("waves,reg_rows,lds_rows", [(16, 2, -1), (8, 4, 0), (8, 5, 1), (8, 6, -1), (8, 6, 2), (4, 8, -1), (4, 12, 3)])
 @pytest.mark.parametrize("N", [5, 32, 128, 200])
 def test_resident_row_variants_bitwise_equal_streaming(P, N, waves, reg_rows, lds_rows):
     """Keeping block rows in registers / LDS across iterations changes where the matrix bytes come from,
