@@ -19,8 +19,9 @@ struct mpcg_handle {
     int num_cus = 0;
     int pcg_waves = 16;       // wavefronts per trajectory workgroup (8 or 16)
     int nt_loads = 1;         // non-temporal hint on the matrix stream
-    int reg_rows = 0;         // RR: block rows per matrix per wave kept in registers (compiled variants only)
-    int lds_rows = -1;        // RL: rows per matrix per wave cached in LDS; -1 = as many as fit when reg_rows > 0, else 0
+    int reg_rows = 0;         // RT: TRIPLES of block rows per matrix per wave kept in registers (compiled variants only)
+    int lds_rows = -1;        // LT: triples per matrix per wave cached in LDS; -1 = as many as fit when reg_rows > 0, else 0
+    int stream_bufs = -1;     // SB: -1 auto, else 0/1/2 register buffers for the streamed triples
     int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
     int spmv_blocks_per_cu = 8;
     float* ginv_scratch = nullptr;   // staging for the in-place G <- G^-1 of mpcg_form_schur
@@ -81,13 +82,16 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     if (!h) return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: out of host memory");
     h->device = device; h->n = state_size; h->N = knot_points; h->max_batch = max_batch;
     h->num_cus = prop.multiProcessorCount;
-    // Launch defaults from the round-1 sweeps on MI355X (gpurun_out/tune6.txt, tune8.txt):
-    // keep as many block rows as possible in registers/LDS, one workgroup per CU.
-    if (knot_points <= 64) {            // <= 4 rows per wave and matrix: half or all of them in registers
-        h->pcg_waves = 16; h->reg_rows = 2; h->lds_rows = knot_points <= 32 ? 0 : -1; h->nt_loads = 0;
-    } else {                            // 8 fat waves: 6 rows/matrix in 256 VGPRs, LDS takes what fits
-        h->pcg_waves = 8; h->reg_rows = 5; h->lds_rows = -1; h->nt_loads = knot_points >= 384 ? 1 : 0;
+    // Launch defaults: keep as many block rows as possible in registers/LDS, one workgroup per CU
+    // (round-1 sweeps on MI355X: gpurun_out/tune11.txt, tune12.txt)
+    if (knot_points <= 48) {            // <= 16 triples: two per wave and matrix, everything in registers
+        h->pcg_waves = 8; h->reg_rows = 2; h->lds_rows = 0;
+    } else if (knot_points <= 96) {     // <= 32 triples: three in registers + one in LDS per wave and matrix
+        h->pcg_waves = 8; h->reg_rows = 3; h->lds_rows = -1;
+    } else {                            // 4 fat waves (512 registers each): 7 triples per matrix in registers
+        h->pcg_waves = 4; h->reg_rows = 7; h->lds_rows = -1;
     }
+    h->nt_loads = 0;                    // strided float2 stream: partial lines must stay cacheable
     *out = h;
     return MPCG_OK;
 }
@@ -112,6 +116,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "nt_loads")) { h->nt_loads = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "pcg_reg_rows")) { h->reg_rows = value; return MPCG_OK; }     // validated at launch
     if (!strcmp(key, "pcg_lds_rows")) { h->lds_rows = value; return MPCG_OK; }
+    if (!strcmp(key, "pcg_stream_bufs")) { h->stream_bufs = value; return MPCG_OK; }
     if (!strcmp(key, "pcg_max_wg_per_cu")) {
         if (value < 0 || value > 8) return fail(h, MPCG_ERR_INVALID, "pcg_max_wg_per_cu out of range");
         h->max_wg_per_cu = value; return MPCG_OK;
@@ -130,6 +135,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "pcg_max_wg_per_cu")) { *value = h->max_wg_per_cu; return MPCG_OK; }
     if (!strcmp(key, "pcg_reg_rows")) { *value = h->reg_rows; return MPCG_OK; }
     if (!strcmp(key, "pcg_lds_rows")) { *value = h->lds_rows; return MPCG_OK; }
+    if (!strcmp(key, "pcg_stream_bufs")) { *value = h->stream_bufs; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "num_cus")) { *value = h->num_cus; return MPCG_OK; }
     return MPCG_ERR_INVALID;
@@ -138,19 +144,20 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
 }  // extern "C"
 
 // ---- launch helpers -----------------------------------------------------------------------------
-// Rows per matrix per wave cached in LDS for this launch configuration.
+// Triples (3 block rows) per matrix per wave cached in LDS for this launch configuration.
 static int lds_rows_for(const mpcg_handle* h, int nw) {
     const size_t base = lds_bytes_for(h->N, nw);
-    const int T = ((int)h->N + nw - 1) / nw;                      // rows per matrix of wave 0
-    const int want_max = T > h->reg_rows ? T - h->reg_rows : 0;
-    int rl = h->lds_rows;
-    if (rl < 0) {
+    const int ntr = ((int)h->N + 2) / 3;
+    const int TT = (ntr + nw - 1) / nw;                           // triples per matrix of wave 0
+    const int want_max = TT > h->reg_rows ? TT - h->reg_rows : 0;
+    int lt = h->lds_rows;
+    if (lt < 0) {
         if (h->reg_rows <= 0) return 0;
-        const size_t per_row_pair = pcg_lds_cache_floats(nw, 1) * sizeof(float);
-        rl = base < kLdsMax ? (int)((kLdsMax - base) / per_row_pair) : 0;
+        const size_t per_pair = pcg_lds_cache_floats(nw, 1) * sizeof(float);
+        lt = base < kLdsMax ? (int)((kLdsMax - base) / per_pair) : 0;
     }
-    if (rl > want_max) rl = want_max;
-    return rl;
+    if (lt > want_max) lt = want_max;
+    return lt;
 }
 
 // LDS bytes requested at launch: vectors + matrix cache, raised to floor(160 KiB / k) when the handle
@@ -165,12 +172,12 @@ static size_t lds_request(const mpcg_handle* h, int nw) {
     return need;
 }
 
-template <int NW, int RR, bool NT>
+template <int NW, int RT, int SB, bool NT>
 static int launch_pcg_t(mpcg_handle* h, PcgArgs a, uint32_t batch, hipStream_t st) {
     const size_t lds = lds_request(h, NW);
     if (lds > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
     a.lds_rows = lds_rows_for(h, NW);
-    auto kern = pcg_traj_kernel<NW, RR, NT>;
+    auto kern = pcg_traj_kernel<NW, RT, SB, NT>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -179,11 +186,11 @@ static int launch_pcg_t(mpcg_handle* h, PcgArgs a, uint32_t batch, hipStream_t s
     return MPCG_OK;
 }
 
-template <int NW, int RR, bool NT>
+template <int NW, int RT, int SB, bool NT>
 static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
     const size_t lds = lds_request(h, NW);
     if (lds > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
-    auto kern = pcg_traj_kernel<NW, RR, NT>;
+    auto kern = pcg_traj_kernel<NW, RT, SB, NT>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -191,26 +198,48 @@ static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
     return MPCG_OK;
 }
 
-// Compiled (waves, register rows) variants.  X(NW, RR)
-#define MPCG_PCG_VARIANTS(X) X(16, 0) X(8, 0) X(4, 0) X(16, 2) X(8, 4) X(8, 5) X(8, 6) X(4, 8) X(4, 12)
+// Compiled (waves, register triples, stream buffers) variants.  X(NW, RT, SB)
+#define MPCG_PCG_VARIANTS(X)                                                              \
+    X(16, 0, 2) X(8, 0, 2) X(4, 0, 2)                                                     \
+    X(16, 1, 0) X(16, 1, 1) X(16, 2, 1)                                                   \
+    X(8, 2, 2) X(8, 2, 1) X(8, 3, 1) X(8, 3, 0) X(8, 4, 0)                                \
+    X(4, 4, 2) X(4, 6, 1) X(4, 7, 1) X(4, 7, 0)
+
+// stream buffers actually needed: 0 when every triple of every wave is resident
+static int stream_bufs_for(const mpcg_handle* h, int nw) {
+    const int ntr = ((int)h->N + 2) / 3;
+    const int TT = (ntr + nw - 1) / nw;
+    const bool all_resident = TT <= h->reg_rows + lds_rows_for(h, nw);
+    if (h->stream_bufs >= 0) return (h->stream_bufs == 0 && !all_resident) ? 1 : h->stream_bufs;
+    return all_resident ? 0 : -1;       // -1: any compiled SB > 0 (1 preferred)
+}
 
 static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
     HIP_TRY(h, hipSetDevice(h->device));
     const bool nt = h->nt_loads != 0;
-#define X(NW_, RR_)                                                                            \
-    if (h->pcg_waves == NW_ && h->reg_rows == RR_)                                             \
-        return nt ? launch_pcg_t<NW_, RR_, true>(h, a, batch, st) : launch_pcg_t<NW_, RR_, false>(h, a, batch, st);
-    MPCG_PCG_VARIANTS(X)
+    const int sb = stream_bufs_for(h, h->pcg_waves);
+    for (int want : {sb, sb == 0 ? 1 : -2, sb <= 0 ? 2 : -2}) {     // exact, then fall back to a streaming build
+        if (want == -2) continue;
+#define X(NW_, RT_, SB_)                                                                       \
+        if (h->pcg_waves == NW_ && h->reg_rows == RT_ && (want == SB_ || (want == -1 && SB_ > 0)))   \
+            return nt ? launch_pcg_t<NW_, RT_, SB_, true>(h, a, batch, st) : launch_pcg_t<NW_, RT_, SB_, false>(h, a, batch, st);
+        MPCG_PCG_VARIANTS(X)
 #undef X
-    return fail(h, MPCG_ERR_UNSUPPORTED, "no compiled kernel variant for this (pcg_waves, pcg_reg_rows)");
+    }
+    return fail(h, MPCG_ERR_UNSUPPORTED, "no compiled kernel variant for this (pcg_waves, pcg_reg_rows, pcg_stream_bufs)");
 }
 
 static int occupancy(mpcg_handle* h, int* per_cu) {
-#define X(NW_, RR_) \
-    if (h->pcg_waves == NW_ && h->reg_rows == RR_) return occupancy_t<NW_, RR_, true>(h, per_cu);
-    MPCG_PCG_VARIANTS(X)
+    const int sb = stream_bufs_for(h, h->pcg_waves);
+    for (int want : {sb, sb == 0 ? 1 : -2, sb <= 0 ? 2 : -2}) {
+        if (want == -2) continue;
+#define X(NW_, RT_, SB_) \
+        if (h->pcg_waves == NW_ && h->reg_rows == RT_ && (want == SB_ || (want == -1 && SB_ > 0))) \
+            return occupancy_t<NW_, RT_, SB_, true>(h, per_cu);
+        MPCG_PCG_VARIANTS(X)
 #undef X
-    return fail(h, MPCG_ERR_UNSUPPORTED, "no compiled kernel variant for this (pcg_waves, pcg_reg_rows)");
+    }
+    return fail(h, MPCG_ERR_UNSUPPORTED, "no compiled kernel variant for this (pcg_waves, pcg_reg_rows, pcg_stream_bufs)");
 }
 
 extern "C" {

@@ -137,22 +137,26 @@ __device__ __forceinline__ float dot4(f4 a, f4 b) {
 // ------------------------------------------------------------------------------------------------
 // Persistent per-trajectory PCG.  grid = batch, block = NW*64.
 //
-// Lane mapping of THIS kernel (differs from the SpMV kernel's in where r and g sit in the lane id):
-// lane = 8*r + g, r = float4 residue (0..6), g = column pair (0..6); lanes with r == 7 or g == 7
-// idle (their loads go to the SRD's out-of-bounds path and return 0).  Lane (r,g) still loads
-// float4 #(7g + r) of every block, so a wave instruction still covers one contiguous 784-byte
-// block.  With g in the low 3 bits the sum over g is a reduction inside groups of 8 consecutive
-// lanes = three v_add_f32 with DPP row_shl:4/2/1 — pure VALU, no LDS crossbar in that part.
-// Lane 8r then holds the 4 "slots" e = 4r..4r+3 (e < 28); row i of the result is slot i + slot i+14
-// (the two column-parity halves), fetched from lanes 8(r+3) / 8(r+4) with one round of 4
-// ds_bpermute.  The summation tree is the same as the SpMV kernel's:
-// ((g0+g4)+(g2+g6)) + ((g1+g5)+g3), then half a + half b.
-// Forming the rows BEFORE the inner products matters numerically: the halves cancel, and dotting
-// the un-combined slots (tried) made fp32 CG drift ~10x faster.
+// Lane mapping of THIS kernel (the SpMV kernel above keeps the float4 mapping, which is the better
+// one for a pure HBM stream).  A wave step handles a TRIPLE of consecutive block rows k0, k0+1, k0+2
+// (k0 = 3*tr).  lane = 21*s + 7*rho + q:
+//     s   = block column (0 left, 1 diagonal, 2 right),  rho = row of the triple,  q = row pair;
+// lane (s,rho,q) owns rows 2q, 2q+1 of block (k0+rho, s): fourteen float2, one per column
+// (element (2q, u) is at 56u + 8q bytes of the block: 8-byte aligned).  63 of 64 lanes work, a block
+// row costs 9.33 VGPRs instead of 12, and per triple the arithmetic is 14 packed FMAs (sequential
+// over the block's columns, like the textbook loop), two bpermute rounds to add the three blocks of
+// a row (s = 0,1,2 sit 21 lanes apart), and 2 FMAs for the inner product: ~9 VALU instructions per
+// block row instead of ~40 with the float4 mapping, whose 4-row-slices need a 7-lane reduction and
+// a second pass to merge column parities.  The price is a strided wave-level load (nine 56-byte
+// segments per instruction), paid only by the block rows that are streamed.
+//
+// Residency: wave w owns triples tr = w + NW*j.  j < RT: held in REGISTERS for the whole solve;
+// RT <= j < RT+LT: held in LDS (lane-private, 112 B per lane and triple); the rest is re-read every
+// iteration through two register buffers that run one triple ahead, also across the barriers.
 //
 // LDS (floats, each region rounded to 4): xp[(N+2)*14] p with a zero knot either side |
 //   xr[(N+2)*14] r likewise | lam[N*14] | tmp[N*14] upsilon, then r~ | red[2*NW] |
-//   matrix cache: per wave, per matrix, RL rows x 3 blocks x 49 float4.
+//   matrix cache: per wave, per matrix, LT triples x 64 lanes x 14 float2.
 // All vector accesses are 8-byte (float2): 14 floats = 56 B keeps every knot 8-byte aligned.
 // ------------------------------------------------------------------------------------------------
 
@@ -160,9 +164,9 @@ __host__ __device__ constexpr size_t r4(size_t x) { return (x + 3) & ~(size_t)3;
 __host__ __device__ constexpr size_t pcg_lds_floats(int N, int NW) {
     return 2 * r4((size_t)(N + 2) * NS) + 2 * r4((size_t)N * NS) + r4(2 * (size_t)NW);
 }
-// LDS matrix cache: per wave, per matrix, RL rows of 3 blocks of 49 lane-private float4
-__host__ __device__ constexpr size_t pcg_lds_cache_floats(int NW, int RL) {
-    return (size_t)NW * 2 * RL * 3 * BLK4 * 4;
+// LDS matrix cache: per wave, per matrix, LT triples of 64 lanes x 14 float2
+__host__ __device__ constexpr size_t pcg_lds_cache_floats(int NW, int LT) {
+    return (size_t)NW * 2 * LT * 64 * 28;
 }
 
 struct PcgArgs {
@@ -170,42 +174,24 @@ struct PcgArgs {
     float* r_out; float* p_out;            // optional [batch][N][n] (may be null)
     uint32_t* iters; uint8_t* max_iter_exit;
     int N; int max_iter; float exit_tol; int pcols;   // pcols: 3 = SS, 1 = block-Jacobi
-    int lds_rows;                          // RL: block rows per matrix per wave cached in LDS
+    int lds_rows;                          // LT: triples per matrix per wave cached in LDS
 };
 
-// sum over the 8 consecutive lanes of each group; valid in the group's lane 0.
-// Order: ((g0+g4)+(g2+g6)) + ((g1+g5)+(g3+g7)), g7 == 0.
-// Twelve v_add_f32 with a DPP row_shl operand (lane i adds lane i+n of its 16-lane row; lanes whose
-// source falls outside the row add 0).  Written as ONE asm statement because hipcc otherwise emits
-// v_mov_b32_dpp + v_pk_add_f32 pairs (VOP3P cannot carry DPP) — 18 instructions + hazard nops.
-// Hazards (a VALU write followed by a DPP read of the same VGPR needs 2 wait states): the leading
-// s_nop covers values written just before the statement; inside, every DPP read is 4 instructions
-// behind its producer.
-__device__ __forceinline__ f4 reduce_g(f4 a) {
-    float x = a.x, y = a.y, z = a.z, w = a.w;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "+v"(x), "+v"(y), "+v"(z), "+v"(w));
-    return f4{x, y, z, w};
+struct Trip { f2 m[NS]; };                 // this lane's two rows of its block: one float2 per column
+
+template <bool NT>
+__device__ __forceinline__ f2 buf_load2(rsrc_t r, uint32_t voff) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, NT ? 2 : 0);
+    return __builtin_bit_cast(f2, v);
 }
 
-// RR = block rows per matrix per wave held in REGISTERS for the whole solve (loaded once), then
-// a.lds_rows rows per matrix per wave held in LDS, the remaining rows streamed every iteration.
-// Wave w owns rows k = w + NW*t; t < RR: registers, RR <= t < RR+RL: LDS, t >= RR+RL: stream.
-template <int NW, int RR, bool NT>
-__global__ __launch_bounds__(NW * 64, (RR == 0 ? 4 : NW / 4)) void pcg_traj_kernel(PcgArgs a) {
+// RT = triples per matrix per wave held in registers.  SB = register buffers of the stream:
+// 2 = ping-pong (one triple ahead), 1 = single buffer refilled as soon as it has been consumed
+// (28 VGPRs cheaper: one more resident triple), 0 = no stream at all (launcher guarantees that every
+// triple is resident).
+template <int NW, int RT, int SB, bool NT>
+__global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kernel(PcgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int N = a.N;
     const int tid = threadIdx.x;
@@ -229,56 +215,81 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 4 : NW / 4)) void pcg_traj_kern
     float* lam_g = a.lambda + (size_t)b * vstride;
 
     // ---- lane roles ----
-    const int lr = lane >> 3, lg = lane & 7;
-    const bool active = lr < 7 && lg < 7;
-    const int f_idx = active ? 7 * lg + lr : 0;        // which float4 of a block this lane owns
-    const uint32_t lane_off = active ? (uint32_t)f_idx * 16u : OOB_OFF;
-    // accumulators 0,1 multiply column 2g (residues r <= 3) or 2g+1; accumulators 2,3 column 2g (r <= 2) or 2g+1
-    const int c01 = active ? 2 * lg + (lr <= 3 ? 0 : 1) : 0;
-    const int c23 = active ? 2 * lg + (lr <= 2 ? 0 : 1) : 0;
-    const bool head = lg == 0 && lr < 4;               // lanes 0, 8, 16, 24 end up with rows 4r..4r+3
+    const bool active = lane < 63;
+    const int ls = active ? lane / 21 : 0;             // block column
+    const int lrem = active ? lane - 21 * ls : 0;
+    const int lrho = lrem / 7;                         // row within the triple
+    const int lq = lrem - 7 * lrho;                    // row pair
+    const bool head = lane < 21;                       // s == 0 lanes receive the finished rows
+    const uint32_t lane_byte = (uint32_t)(ls * 784 + lq * 8);   // inside the block row
 
-    // Block rows owned by this wave: k = w + NW*t, t < T.
-    const int T = max(0, (N - w + NW - 1) / NW);
-    const int RL = a.lds_rows;
-    const int t0s = min(T, RR + RL);                 // first streamed row index
-    // streamed step count, padded to a multiple of 4 so the four register buffers (rowA..rowD) keep
-    // fixed roles across passes; a padded step has k >= N, loads nothing (OOB) and computes nothing.
-    const int TS = ((T - t0s) + 3) & ~3;
+    // triples owned by this wave: tr = w + NW*j, j < TT
+    const int NTR = (N + 2) / 3;
+    const int TT = max(0, (NTR - w + NW - 1) / NW);
+    const int LT = a.lds_rows;
+    const int j0s = min(TT, RT + LT);                  // first streamed triple
+    const int TS = SB == 2 ? (((TT - j0s) + 1) & ~1) : (TT - j0s);   // streamed steps (even for A/B roles)
 
-    // ---- resident rows: registers ----
-    Rows regS[RR > 0 ? RR : 1], regP[RR > 0 ? RR : 1];
+    // byte offset of this lane's (row, block) in the trajectory's matrix, or OOB_OFF when that block
+    // must not be read: rows >= N, the never-written blocks (0,left) and (N-1,right), the
+    // off-diagonal blocks in block-Jacobi mode, lane 63.
+    auto trip_off = [&](int j, int cols) -> uint32_t {
+        const int k = 3 * (w + NW * j) + lrho;
+        const bool ok = active && j < TT && k < N && !(ls == 0 && k == 0) && !(ls == 2 && k == N - 1) && (cols == 3 || ls == 1);
+        return ok ? (uint32_t)k * (ROWF * 4u) + lane_byte : OOB_OFF;
+    };
+    auto load_trip = [&](rsrc_t M, int j, int cols) -> Trip {
+        const uint32_t off = trip_off(j, cols);
+        Trip t;
 #pragma unroll
-    for (int t = 0; t < RR; ++t) {
-        regS[t] = load_rows<NT>(rS, w + NW * t, N, 3, lane_off);
-        regP[t] = load_rows<NT>(rP, w + NW * t, N, a.pcols, lane_off);
+        for (int u = 0; u < NS; ++u) t.m[u] = buf_load2<NT>(M, off + 56u * u);
+        return t;
+    };
+
+    // ---- resident triples: registers ----
+    Trip regS[RT > 0 ? RT : 1], regP[RT > 0 ? RT : 1];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+        regS[j] = load_trip(rS, j, 3);
+        regP[j] = load_trip(rP, j, a.pcols);
     }
-    // ---- resident rows: LDS cache (lane-private float4 slots, filled once) ----
-    f4* mc = mc_base + (size_t)w * 2 * RL * 3 * BLK4;
-    for (int j = 0; j < RL; ++j) {
-        const int k = w + NW * (RR + j);
-        const Rows a0 = load_rows<NT>(rS, k, N, 3, lane_off);
-        const Rows a1 = load_rows<NT>(rP, k, N, a.pcols, lane_off);
-        if (active) {
-            f4* d0 = mc + (size_t)(j * 3) * BLK4 + f_idx;
-            f4* d1 = mc + (size_t)((RL + j) * 3) * BLK4 + f_idx;
-            d0[0] = a0.m0; d0[BLK4] = a0.m1; d0[2 * BLK4] = a0.m2;
-            d1[0] = a1.m0; d1[BLK4] = a1.m1; d1[2 * BLK4] = a1.m2;
+    // ---- resident triples: LDS cache, lane-private 112-byte records ----
+    f4* mc = mc_base + (size_t)w * 2 * LT * 64 * 7;
+    for (int j = 0; j < LT; ++j) {
+        const Trip t0 = load_trip(rS, RT + j, 3);
+        const Trip t1 = load_trip(rP, RT + j, a.pcols);
+        f4* d0 = mc + ((size_t)j * 64 + lane) * 7;
+        f4* d1 = mc + ((size_t)(LT + j) * 64 + lane) * 7;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            d0[u] = f4{t0.m[2 * u].x, t0.m[2 * u].y, t0.m[2 * u + 1].x, t0.m[2 * u + 1].y};
+            d1[u] = f4{t1.m[2 * u].x, t1.m[2 * u].y, t1.m[2 * u + 1].x, t1.m[2 * u + 1].y};
         }
     }
-
-    // ---- matrix stream: S rows, Pinv rows, S rows, ... always one block row ahead of use, and
-    //      NOT drained at workgroup barriers (lds_barrier) ----
-    int st_t = 0, st_pass = 0;             // position of the NEXT row to load
-    auto load_next = [&]() -> Rows {
-        const int k = w + NW * (t0s + st_t);
-        Rows R = st_pass ? load_rows<NT>(rP, k, N, a.pcols, lane_off) : load_rows<NT>(rS, k, N, 3, lane_off);
-        if (++st_t >= TS) { st_t = 0; st_pass ^= 1; }
-        return R;
+    auto lds_trip = [&](int mat, int j) -> Trip {
+        const f4* src = mc + ((size_t)(mat * LT + j) * 64 + lane) * 7;
+        Trip t;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const f4 v = src[u];
+            t.m[2 * u] = f2{v.x, v.y};
+            t.m[2 * u + 1] = f2{v.z, v.w};
+        }
+        return t;
     };
-    Rows rowA, rowB, rowC, rowD;           // the stream runs two block rows (one pair) ahead of use
-    rowA = load_next();                    // (a wave with no streamed rows gets zeros from the OOB path)
-    rowB = load_next();
+
+    // ---- matrix stream: S triples, Pinv triples, S triples, ... one triple ahead of use, and NOT
+    //      drained at workgroup barriers (lds_barrier) ----
+    int st_j = 0, st_pass = 0;             // position of the NEXT triple to load
+    auto load_next = [&]() -> Trip {
+        const Trip t = st_pass ? load_trip(rP, j0s + st_j, a.pcols) : load_trip(rS, j0s + st_j, 3);
+        if (++st_j >= TS) { st_j = 0; st_pass ^= 1; }
+        return t;
+    };
+    Trip bufA, bufB;
+    if constexpr (SB > 0) {
+        if (SB == 2 || TS > 0) bufA = load_next();     // (nothing to stream: zeros from the OOB path)
+    }
 
     // ---- stage vectors: xp <- lambda0 (operand of the setup SpMV), lam <- lambda0, xr <- gamma ----
     for (int e = tid; e < (N + 2) * NS; e += NTHR) { xp[e] = 0.f; xr[e] = 0.f; }
@@ -291,107 +302,87 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 4 : NW / 4)) void pcg_traj_kern
     }
     lds_barrier();
 
-    // acc += block * x for this lane's float4; xk = the 14-vector the block multiplies
-    auto fma_blk = [&](f4& acc, const f4 m, const float* xk) {
-        const float x01 = xk[c01];
-        const float x23 = xk[c23];
-        acc.x = fmaf(m.x, x01, acc.x);
-        acc.y = fmaf(m.y, x01, acc.y);
-        acc.z = fmaf(m.z, x23, acc.z);
-        acc.w = fmaf(m.w, x23, acc.w);
-    };
-    // One block row in two halves so that two rows can be in flight per wave (their dependency chains
-    // LDS read -> FMA -> DPP -> bpermute -> LDS write are ~600 cycles each and otherwise serialise):
-    //   begin : x reads, 12 FMAs, DPP reduction over g, issue of the 4 bpermutes, d reads  (branch-free)
-    //   finish: halves a+b, tmp[k] = M[k,:] x, part += d[k] . (M[k,:] x)
-    struct Pend { f4 h; float b0, b1, b2, b3; f2 da, db; int k; bool valid; };
-    auto begin = [&](const Rows& use, int t, const float* xv, const float* dv) -> Pend {
+    // One triple in two halves so that two can be in flight per wave:
+    //   begin : 14 x values, 14 packed FMAs, issue of the bpermutes that bring blocks 1 and 2 to the
+    //           block-0 lanes, d read                                                   (branch-free)
+    //   finish: left + diagonal + right, tmp[k] = M[k,:] x, part += d[k] . (M[k,:] x)
+    struct Pend { f2 a0, a1, a2, d; int k; bool valid; };
+    auto begin = [&](const Trip& t, int j, const float* xv, const float* dv) -> Pend {
         Pend q;
-        const int k = w + NW * t;
+        const int k = 3 * (w + NW * j) + lrho;
         q.valid = k < N;
         q.k = q.valid ? k : 0;                          // rows beyond N are all-zero (OOB loads): any knot will do
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
-        fma_blk(acc, use.m0, xv + (q.k + 0) * NS);
-        fma_blk(acc, use.m1, xv + (q.k + 1) * NS);
-        fma_blk(acc, use.m2, xv + (q.k + 2) * NS);
-        const f2* d2 = reinterpret_cast<const f2*>(dv + (q.k + 1) * NS + 4 * (lr & 3));
-        q.da = d2[0];
-        q.db = d2[1];        // lane 24 reads rows 14,15 = next knot's 0,1 (padded array): multiplied by 0 below
-        q.h = reduce_g(acc);
-        q.b0 = __shfl_down(q.h.z, 24);                  // slot e+14 of slots e = 4r, 4r+1
-        q.b1 = __shfl_down(q.h.w, 24);
-        q.b2 = __shfl_down(q.h.x, 32);                  // ... of slots 4r+2, 4r+3
-        q.b3 = __shfl_down(q.h.y, 32);
+        const f2* x2 = reinterpret_cast<const f2*>(xv + (q.k + ls) * NS);   // knot k-1+s of the padded vector
+        f2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const f2 x = x2[u];
+            acc.x = fmaf(t.m[2 * u].x, x.x, acc.x);
+            acc.y = fmaf(t.m[2 * u].y, x.x, acc.y);
+            acc.x = fmaf(t.m[2 * u + 1].x, x.y, acc.x);
+            acc.y = fmaf(t.m[2 * u + 1].y, x.y, acc.y);
+        }
+        q.d = *reinterpret_cast<const f2*>(dv + (q.k + 1) * NS + 2 * lq);
+        q.a0 = acc;
+        q.a1.x = __shfl_down(acc.x, 21);
+        q.a1.y = __shfl_down(acc.y, 21);
+        q.a2.x = __shfl_down(acc.x, 42);
+        q.a2.y = __shfl_down(acc.y, 42);
         return q;
     };
     auto finish = [&](const Pend& q, float& part) {
         if (head && q.valid) {
-            f4 y = {q.h.x + q.b0, q.h.y + q.b1, q.h.z + q.b2, q.h.w + q.b3};
-            if (lr == 3) { y.z = 0.f; y.w = 0.f; }                           // rows 14, 15 do not exist
-            f2* out = reinterpret_cast<f2*>(tmp + q.k * NS + 4 * lr);         // 56k + 16r bytes
-            out[0] = f2{y.x, y.y};
-            if (lr < 3) out[1] = f2{y.z, y.w};
-            part += fmaf(y.w, q.db.y, fmaf(y.z, q.db.x, fmaf(y.y, q.da.y, y.x * q.da.x)));
+            const f2 y = (q.a0 + q.a1) + q.a2;
+            *reinterpret_cast<f2*>(tmp + q.k * NS + 2 * lq) = y;             // 56k + 8q bytes
+            part += fmaf(y.y, q.d.y, y.x * q.d.x);
         }
-    };
-    auto lds_row = [&](int mat, int j) -> Rows {
-        Rows R;
-        const f4* src = mc + (size_t)((mat * RL + j) * 3) * BLK4 + f_idx;
-        R.m0 = src[0]; R.m1 = src[BLK4]; R.m2 = src[2 * BLK4];
-        if (!active) { const f4 z = {0.f, 0.f, 0.f, 0.f}; R.m0 = z; R.m1 = z; R.m2 = z; }
-        return R;
     };
     auto pass = [&](auto which, const float* xv, const float* dv) -> float {
         constexpr int MAT = decltype(which)::value;       // 0: S, 1: Pinv (must alternate, S first)
         float part = 0.f;
         // registers
 #pragma unroll
-        for (int t = 0; t + 1 < RR; t += 2) {
-            const Pend p0 = begin(MAT ? regP[t] : regS[t], t, xv, dv);
-            const Pend p1 = begin(MAT ? regP[t + 1] : regS[t + 1], t + 1, xv, dv);
+        for (int j = 0; j + 1 < RT; j += 2) {
+            const Pend p0 = begin(MAT ? regP[j] : regS[j], j, xv, dv);
+            const Pend p1 = begin(MAT ? regP[j + 1] : regS[j + 1], j + 1, xv, dv);
             finish(p0, part);
             finish(p1, part);
         }
-        if constexpr (RR & 1) {
-            const Pend p0 = begin(MAT ? regP[RR - 1] : regS[RR - 1], RR - 1, xv, dv);
+        if constexpr (RT & 1) {
+            const Pend p0 = begin(MAT ? regP[RT - 1] : regS[RT - 1], RT - 1, xv, dv);
             finish(p0, part);
         }
         // LDS cache
-        int j = 0;
-        for (; j + 1 < RL; j += 2) {
-            const Rows r0 = lds_row(MAT, j), r1 = lds_row(MAT, j + 1);
-            const Pend p0 = begin(r0, RR + j, xv, dv);
-            const Pend p1 = begin(r1, RR + j + 1, xv, dv);
-            finish(p0, part);
-            finish(p1, part);
-        }
-        if (j < RL) {
-            const Rows r0 = lds_row(MAT, j);
-            const Pend p0 = begin(r0, RR + j, xv, dv);
+        for (int j = 0; j < LT; ++j) {
+            const Trip t0 = lds_trip(MAT, j);
+            const Pend p0 = begin(t0, RT + j, xv, dv);
             finish(p0, part);
         }
-        // stream: pair (A,B) is consumed while (C,D) is in flight, and vice versa
-        for (int t = 0; t < TS; t += 4) {
-            rowC = load_next();
-            rowD = load_next();
-            {
-                const Pend p0 = begin(rowA, t0s + t, xv, dv);
-                const Pend p1 = begin(rowB, t0s + t + 1, xv, dv);
+        if constexpr (SB == 2) {
+            // stream: A is consumed while B is in flight, and vice versa
+            for (int j = 0; j < TS; j += 2) {
+                bufB = load_next();
+                const Pend p0 = begin(bufA, j0s + j, xv, dv);
+                bufA = load_next();
+                const Pend p1 = begin(bufB, j0s + j + 1, xv, dv);
                 finish(p0, part);
                 finish(p1, part);
             }
-            rowA = load_next();
-            rowB = load_next();
-            {
-                const Pend p0 = begin(rowC, t0s + t + 2, xv, dv);
-                const Pend p1 = begin(rowD, t0s + t + 3, xv, dv);
+        } else if constexpr (SB == 1) {
+            // stream through one buffer: the refill is issued the moment the FMAs have read it and
+            // flies during finish + the next resident work (and the other waves' turns)
+            for (int j = 0; j < TS; ++j) {
+                const Pend p0 = begin(bufA, j0s + j, xv, dv);
+                bufA = load_next();
                 finish(p0, part);
-                finish(p1, part);
             }
         }
-        // heads sit in lanes 0, 8, 16, 24: fold them into lane 0 (once per pass): (r0+r2)+(r1+r3)
-        part += __shfl_down(part, 16);
+        // heads are lanes 0..20 (others hold 0): fold into lane 0 (once per pass)
+        part += __shfl_down(part, 16);      // lanes 0..15 += 16..31 (16..20 live)
         part += __shfl_down(part, 8);
+        part += __shfl_down(part, 4);
+        part += __shfl_down(part, 2);
+        part += __shfl_down(part, 1);
         return part;                        // lane 0
     };
     using MatS = std::integral_constant<int, 0>;
@@ -408,12 +399,11 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 4 : NW / 4)) void pcg_traj_kern
     f2* xr2 = reinterpret_cast<f2*>(xr + NS);
     f2* lam2 = reinterpret_cast<f2*>(lam);
     const f2* tmp2 = reinterpret_cast<const f2*>(tmp);
-    auto tmp_row = [&](int e) -> f2 { return tmp2[e]; };
 
     // ---- setup: r = gamma - S lambda0 ; r~ = Pinv r ; p = r~ ; eta = r . r~ ----
     (void)pass(MatS{}, xp, xp);
     lds_barrier();
-    for (int e = tid; e < NV2; e += NTHR) xr2[e] = xr2[e] - tmp_row(e);
+    for (int e = tid; e < NV2; e += NTHR) xr2[e] = xr2[e] - tmp2[e];
     lds_barrier();
     {
         const float part = pass(MatP{}, xr, xr);
@@ -421,7 +411,7 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 4 : NW / 4)) void pcg_traj_kern
     }
     lds_barrier();
     float eta = block_sum(red_e);
-    for (int e = tid; e < NV2; e += NTHR) xp2[e] = tmp_row(e);
+    for (int e = tid; e < NV2; e += NTHR) xp2[e] = tmp2[e];
     lds_barrier();
 
     uint32_t iters = 0;
@@ -440,7 +430,7 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 4 : NW / 4)) void pcg_traj_kern
             // lambda += alpha p ; r -= alpha upsilon
             for (int e = tid; e < NV2; e += NTHR) {
                 lam2[e] = lam2[e] + alpha * xp2[e];
-                xr2[e] = xr2[e] - alpha * tmp_row(e);
+                xr2[e] = xr2[e] - alpha * tmp2[e];
             }
             lds_barrier();
             // r~ = Pinv r ; eta' = r . r~
@@ -454,7 +444,7 @@ __global__ __launch_bounds__(NW * 64, (RR == 0 ? 4 : NW / 4)) void pcg_traj_kern
             if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
             const float beta = eta_new / eta;
             // p = r~ + beta p
-            for (int e = tid; e < NV2; e += NTHR) xp2[e] = tmp_row(e) + beta * xp2[e];
+            for (int e = tid; e < NV2; e += NTHR) xp2[e] = tmp2[e] + beta * xp2[e];
             eta = eta_new;
             lds_barrier();
         }

@@ -41,3 +41,21 @@ def fp32_band(orc, S, Pinv, g, lam0, N, K, pc, ref64, trials=4):
         gp = (g.astype(np.float64) * (1 + 6e-8 * rng.standard_normal(g.shape))).astype(np.float32)
         band = max(band, relinf(orc.pcg(Sp, P, gp, lam0, N, K, 0.0, pc)["lam"], ref64))
     return band
+
+
+def fp32_iters_band(orc, S, Pinv, g, lam0, N, max_iter, tol, pc, trials=8):
+    """(lo, hi) of the iteration count the CPU float32 restatement needs on the same and on
+    1-ulp-perturbed inputs.  With a tolerance exit the crossing iteration of fp32 CG is erratic
+    (measured on the N=32 golden system: 174..201 against 172 in float64), so a fixed +-10 % around
+    one run would be a coin toss; a correct fp32 kernel must land within this band (+-7 %)."""
+    S = np.nan_to_num(np.asarray(S, np.float32))
+    P = np.nan_to_num(np.asarray(Pinv, np.float32))
+    g = np.asarray(g, np.float32)
+    lam0 = np.asarray(lam0, np.float32)
+    its = [orc.pcg(S, P, g, lam0, N, max_iter, tol, pc)["iters"]]
+    rng = np.random.default_rng(N + max_iter)
+    for _ in range(trials):
+        Sp = (S.astype(np.float64) * (1 + 6e-8 * rng.standard_normal(S.shape))).astype(np.float32)
+        gp = (g.astype(np.float64) * (1 + 6e-8 * rng.standard_normal(g.shape))).astype(np.float32)
+        its.append(orc.pcg(Sp, P, gp, lam0, N, max_iter, tol, pc)["iters"])
+    return min(its), max(its)
