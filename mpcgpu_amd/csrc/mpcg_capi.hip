@@ -83,7 +83,7 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     h->device = device; h->n = state_size; h->N = knot_points; h->max_batch = max_batch;
     h->num_cus = prop.multiProcessorCount;
     // Launch defaults: keep as many block rows as possible in registers/LDS, one workgroup per CU
-    // (round-1 sweeps on MI355X: gpurun_out/tune11.txt, tune12.txt)
+    // (round-1 sweeps on MI355X: profiles/r01_tune11.txt, r01_tune12.txt)
     if (knot_points <= 48) {            // <= 16 triples: two per wave and matrix, everything in registers
         h->pcg_waves = 8; h->reg_rows = 2; h->lds_rows = 0;
     } else if (knot_points <= 96) {     // <= 32 triples: three in registers + one in LDS per wave and matrix

@@ -1,11 +1,15 @@
 // pcg_kernels.hip.h — hand-written CDNA4 (gfx950) kernels for the block-tridiagonal PCG.
 //
-// Design: ONE workgroup solves ONE trajectory, start to finish, inside one
-// launch.  There is no inter-workgroup communication, hence no grid barrier (the reference's
-// structure — one block per knot + cooperative grid sync, include/pcg/sqp.cuh:230 — costs 26-100 us
-// per sync on this chip).  The iterate vectors live in LDS for the whole solve; S and Pinv are
-// streamed from HBM/L2 every iteration with fully coalesced 16-byte loads; wavefront shuffles do
-// the per-block-row reductions and the PCG inner products.
+// Two kernels, two lane mappings:
+//   pcg_traj_kernel  — the solver.  ONE workgroup solves ONE trajectory, start to finish, inside one
+//       launch: no inter-workgroup communication, hence no grid barrier (the reference's structure —
+//       one block per knot + cooperative grid sync, include/pcg/sqp.cuh:230 — costs 26-100 us per sync
+//       on this chip).  Iterate vectors live in LDS; as much of S and Pinv as fits lives in registers
+//       and LDS for the whole solve, the rest is re-read every iteration.  Row-pair x block mapping,
+//       three block rows per wave step (described at the kernel).
+//   bt_spmv_kernel   — stand-alone batched SpMV, a pure HBM stream.  float4 mapping described next
+//       (it was also the PCG kernel's first mapping; the solver moved away from it because its
+//       7-lane reduction + parity merge cost ~40 VALU instructions per block row).
 //
 // Lane mapping for a 14x14 column-major block (196 floats = 49 float4, 16-byte aligned because
 // 196*4 = 49*16): float4 #f of a block covers flat elements 4f..4f+3; since lcm(4,14) = 28 the
