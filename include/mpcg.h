@@ -109,6 +109,20 @@ int mpcg_pcg_solve_ref(mpcg_handle *h,
 int mpcg_bt_spmv(mpcg_handle *h, const float *d_M, const float *d_x, float *d_y,
                  uint32_t batch, int cols, void *stream);
 
+/* ---- reduced-precision matrix storage (BASELINE config 5's fp16 sweep) ----
+ * S and Pinv may be kept in IEEE half precision (same bd layout, 2-byte elements): half the bytes,
+ * so twice as much of a trajectory stays resident in registers/LDS.  All arithmetic, gamma and lambda
+ * stay fp32 (v_fma_mix_f32).  The solve is then exactly the fp32 PCG of the ROUNDED matrices: its
+ * answer differs from the fp32-storage answer by the storage rounding (relative 2^-11 per entry), not
+ * by anything iteration-dependent; entries must be within the half range (|x| < 65504).
+ * mpcg_convert_f32_to_f16: round-to-nearest-even copy of `count` elements (any bd-layout buffer).
+ * mpcg_pcg_solve_f16: mpcg_pcg_solve with d_S16 / d_Pinv16 produced by the conversion. */
+int mpcg_convert_f32_to_f16(mpcg_handle *h, const float *d_src, uint16_t *d_dst, size_t count, void *stream);
+int mpcg_pcg_solve_f16(mpcg_handle *h,
+                       const uint16_t *d_S16, const uint16_t *d_Pinv16, const float *d_gamma, float *d_lambda,
+                       uint32_t batch, uint32_t max_iter, float exit_tol, mpcg_precond precond,
+                       uint32_t *d_iters, uint8_t *d_max_iter_exit, void *stream);
+
 /* ---- the steps either side of the solve, same layouts as the reference ----
  *
  * mpcg_form_schur replaces form_schur_system<T>(state_size, control_size, knot_points, d_G_dense,
@@ -135,7 +149,8 @@ int mpcg_compute_dz(mpcg_handle *h, uint32_t control_size, const float *d_Ginv_d
  * knot_points): "pcg_waves" (4, 8 or 16 wavefronts per trajectory workgroup), "pcg_reg_rows" (block
  * rows per matrix per wave kept in registers for the whole solve; only compiled (waves, rows) pairs
  * are accepted at launch), "pcg_lds_rows" (rows per matrix per wave cached in LDS, -1 = what fits),
- * "nt_loads" (0/1 non-temporal hint on the matrix stream), "pcg_max_wg_per_cu", "spmv_blocks_per_cu".
+ * "pcg_stream_bufs", "nt_loads" (SpMV kernel), "pcg_max_wg_per_cu", "spmv_blocks_per_cu"; "pcg16_*" = the
+ * same for fp16 storage.  reg/lds rows count TRIPLES of block rows per matrix per wave.
  * None of them changes results: all variants are bitwise identical (tested). */
 int mpcg_set_option(mpcg_handle *h, const char *key, int value);
 int mpcg_get_option(const mpcg_handle *h, const char *key, int *value);

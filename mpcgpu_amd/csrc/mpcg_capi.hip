@@ -21,6 +21,7 @@ struct mpcg_handle {
     int nt_loads = 1;         // non-temporal hint on the matrix stream
     int reg_rows = 0;         // RT: TRIPLES of block rows per matrix per wave kept in registers (compiled variants only)
     int lds_rows = -1;        // LT: triples per matrix per wave cached in LDS; -1 = as many as fit when reg_rows > 0, else 0
+    int pcg_waves16 = 8, reg_rows16 = 6, lds_rows16 = -1;   // the same knobs for fp16 matrix storage
     int stream_bufs = -1;     // SB: -1 auto, else 0/1/2 register buffers for the streamed triples
     int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
     int spmv_blocks_per_cu = 8;
@@ -91,7 +92,10 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     } else {                            // 4 fat waves (512 registers each): 7 triples per matrix in registers
         h->pcg_waves = 4; h->reg_rows = 7; h->lds_rows = -1;
     }
-    h->nt_loads = 0;                    // strided float2 stream: partial lines must stay cacheable
+    h->nt_loads = 0;                    // (SpMV kernel only; the PCG kernel's strided stream must stay cacheable)
+    if (knot_points <= 144) { h->pcg_waves16 = 8; h->reg_rows16 = 6; }      // fp16 storage: <= 48 triples all in registers
+    else { h->pcg_waves16 = 4; h->reg_rows16 = 12; }
+    h->lds_rows16 = -1;
     *out = h;
     return MPCG_OK;
 }
@@ -117,6 +121,9 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "pcg_reg_rows")) { h->reg_rows = value; return MPCG_OK; }     // validated at launch
     if (!strcmp(key, "pcg_lds_rows")) { h->lds_rows = value; return MPCG_OK; }
     if (!strcmp(key, "pcg_stream_bufs")) { h->stream_bufs = value; return MPCG_OK; }
+    if (!strcmp(key, "pcg16_waves")) { h->pcg_waves16 = value; return MPCG_OK; }
+    if (!strcmp(key, "pcg16_reg_rows")) { h->reg_rows16 = value; return MPCG_OK; }
+    if (!strcmp(key, "pcg16_lds_rows")) { h->lds_rows16 = value; return MPCG_OK; }
     if (!strcmp(key, "pcg_max_wg_per_cu")) {
         if (value < 0 || value > 8) return fail(h, MPCG_ERR_INVALID, "pcg_max_wg_per_cu out of range");
         h->max_wg_per_cu = value; return MPCG_OK;
@@ -136,6 +143,9 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "pcg_reg_rows")) { *value = h->reg_rows; return MPCG_OK; }
     if (!strcmp(key, "pcg_lds_rows")) { *value = h->lds_rows; return MPCG_OK; }
     if (!strcmp(key, "pcg_stream_bufs")) { *value = h->stream_bufs; return MPCG_OK; }
+    if (!strcmp(key, "pcg16_waves")) { *value = h->pcg_waves16; return MPCG_OK; }
+    if (!strcmp(key, "pcg16_reg_rows")) { *value = h->reg_rows16; return MPCG_OK; }
+    if (!strcmp(key, "pcg16_lds_rows")) { *value = h->lds_rows16; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "num_cus")) { *value = h->num_cus; return MPCG_OK; }
     return MPCG_ERR_INVALID;
@@ -145,15 +155,16 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
 
 // ---- launch helpers -----------------------------------------------------------------------------
 // Triples (3 block rows) per matrix per wave cached in LDS for this launch configuration.
-static int lds_rows_for(const mpcg_handle* h, int nw) {
+static int lds_rows_for(const mpcg_handle* h, int nw, int esz) {
     const size_t base = lds_bytes_for(h->N, nw);
     const int ntr = ((int)h->N + 2) / 3;
     const int TT = (ntr + nw - 1) / nw;                           // triples per matrix of wave 0
-    const int want_max = TT > h->reg_rows ? TT - h->reg_rows : 0;
-    int lt = h->lds_rows;
+    const int rt = esz == 2 ? h->reg_rows16 : h->reg_rows;
+    const int want_max = TT > rt ? TT - rt : 0;
+    int lt = esz == 2 ? h->lds_rows16 : h->lds_rows;
     if (lt < 0) {
-        if (h->reg_rows <= 0) return 0;
-        const size_t per_pair = pcg_lds_cache_floats(nw, 1) * sizeof(float);
+        if (rt <= 0) return 0;
+        const size_t per_pair = pcg_lds_cache_floats(nw, 1, esz) * sizeof(float);
         lt = base < kLdsMax ? (int)((kLdsMax - base) / per_pair) : 0;
     }
     if (lt > want_max) lt = want_max;
@@ -161,10 +172,9 @@ static int lds_rows_for(const mpcg_handle* h, int nw) {
 }
 
 // LDS bytes requested at launch: vectors + matrix cache, raised to floor(160 KiB / k) when the handle
-// limits residency to k workgroups per CU (fewer resident trajectories = smaller re-read set = more
-// of it stays in the 256 MiB Infinity Cache between PCG iterations).
-static size_t lds_request(const mpcg_handle* h, int nw) {
-    size_t need = lds_bytes_for(h->N, nw) + pcg_lds_cache_floats(nw, lds_rows_for(h, nw)) * sizeof(float);
+// limits residency to k workgroups per CU.
+static size_t lds_request(const mpcg_handle* h, int nw, int esz) {
+    size_t need = lds_bytes_for(h->N, nw) + pcg_lds_cache_floats(nw, lds_rows_for(h, nw, esz), esz) * sizeof(float);
     if (h->max_wg_per_cu > 0) {
         size_t pad = (kLdsMax / (size_t)h->max_wg_per_cu) & ~(size_t)15;
         if (pad > need) need = pad;
@@ -172,12 +182,12 @@ static size_t lds_request(const mpcg_handle* h, int nw) {
     return need;
 }
 
-template <int NW, int RT, int SB, bool NT>
+template <int NW, int RT, int SB, typename MT>
 static int launch_pcg_t(mpcg_handle* h, PcgArgs a, uint32_t batch, hipStream_t st) {
-    const size_t lds = lds_request(h, NW);
+    const size_t lds = lds_request(h, NW, (int)sizeof(MT));
     if (lds > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
-    a.lds_rows = lds_rows_for(h, NW);
-    auto kern = pcg_traj_kernel<NW, RT, SB, NT>;
+    a.lds_rows = lds_rows_for(h, NW, (int)sizeof(MT));
+    auto kern = pcg_traj_kernel<NW, RT, SB, MT>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -186,11 +196,11 @@ static int launch_pcg_t(mpcg_handle* h, PcgArgs a, uint32_t batch, hipStream_t s
     return MPCG_OK;
 }
 
-template <int NW, int RT, int SB, bool NT>
+template <int NW, int RT, int SB, typename MT>
 static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
-    const size_t lds = lds_request(h, NW);
+    const size_t lds = lds_request(h, NW, (int)sizeof(MT));
     if (lds > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
-    auto kern = pcg_traj_kernel<NW, RT, SB, NT>;
+    auto kern = pcg_traj_kernel<NW, RT, SB, MT>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -204,38 +214,53 @@ static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
     X(16, 1, 0) X(16, 1, 1) X(16, 2, 1)                                                   \
     X(8, 2, 2) X(8, 2, 1) X(8, 3, 1) X(8, 3, 0) X(8, 4, 0)                                \
     X(4, 4, 2) X(4, 6, 1) X(4, 7, 1) X(4, 7, 0)
+// fp16 matrix storage: a triple costs 14 registers instead of 28
+#define MPCG_PCG_VARIANTS16(X)                                                            \
+    X(16, 0, 2) X(8, 0, 2)                                                                \
+    X(8, 4, 1) X(8, 5, 1) X(8, 6, 0)                                                      \
+    X(4, 10, 1) X(4, 12, 1) X(4, 12, 0)
 
 // stream buffers actually needed: 0 when every triple of every wave is resident
-static int stream_bufs_for(const mpcg_handle* h, int nw) {
+static int stream_bufs_for(const mpcg_handle* h, int nw, int esz) {
     const int ntr = ((int)h->N + 2) / 3;
     const int TT = (ntr + nw - 1) / nw;
-    const bool all_resident = TT <= h->reg_rows + lds_rows_for(h, nw);
+    const int rt = esz == 2 ? h->reg_rows16 : h->reg_rows;
+    const bool all_resident = TT <= rt + lds_rows_for(h, nw, esz);
     if (h->stream_bufs >= 0) return (h->stream_bufs == 0 && !all_resident) ? 1 : h->stream_bufs;
     return all_resident ? 0 : -1;       // -1: any compiled SB > 0 (1 preferred)
 }
 
-static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
     HIP_TRY(h, hipSetDevice(h->device));
-    const bool nt = h->nt_loads != 0;
-    const int sb = stream_bufs_for(h, h->pcg_waves);
+    const int waves = esz == 2 ? h->pcg_waves16 : h->pcg_waves;
+    const int rt = esz == 2 ? h->reg_rows16 : h->reg_rows;
+    const int sb = stream_bufs_for(h, waves, esz);
     for (int want : {sb, sb == 0 ? 1 : -2, sb <= 0 ? 2 : -2}) {     // exact, then fall back to a streaming build
         if (want == -2) continue;
+        if (esz == 4) {
 #define X(NW_, RT_, SB_)                                                                       \
-        if (h->pcg_waves == NW_ && h->reg_rows == RT_ && (want == SB_ || (want == -1 && SB_ > 0)))   \
-            return nt ? launch_pcg_t<NW_, RT_, SB_, true>(h, a, batch, st) : launch_pcg_t<NW_, RT_, SB_, false>(h, a, batch, st);
-        MPCG_PCG_VARIANTS(X)
+            if (waves == NW_ && rt == RT_ && (want == SB_ || (want == -1 && SB_ > 0)))             \
+                return launch_pcg_t<NW_, RT_, SB_, float>(h, a, batch, st);
+            MPCG_PCG_VARIANTS(X)
 #undef X
+        } else {
+#define X(NW_, RT_, SB_)                                                                       \
+            if (waves == NW_ && rt == RT_ && (want == SB_ || (want == -1 && SB_ > 0)))             \
+                return launch_pcg_t<NW_, RT_, SB_, _Float16>(h, a, batch, st);
+            MPCG_PCG_VARIANTS16(X)
+#undef X
+        }
     }
     return fail(h, MPCG_ERR_UNSUPPORTED, "no compiled kernel variant for this (pcg_waves, pcg_reg_rows, pcg_stream_bufs)");
 }
 
 static int occupancy(mpcg_handle* h, int* per_cu) {
-    const int sb = stream_bufs_for(h, h->pcg_waves);
+    const int sb = stream_bufs_for(h, h->pcg_waves, 4);
     for (int want : {sb, sb == 0 ? 1 : -2, sb <= 0 ? 2 : -2}) {
         if (want == -2) continue;
 #define X(NW_, RT_, SB_) \
         if (h->pcg_waves == NW_ && h->reg_rows == RT_ && (want == SB_ || (want == -1 && SB_ > 0))) \
-            return occupancy_t<NW_, RT_, SB_, true>(h, per_cu);
+            return occupancy_t<NW_, RT_, SB_, float>(h, per_cu);
         MPCG_PCG_VARIANTS(X)
 #undef X
     }
@@ -273,7 +298,7 @@ int mpcg_pcg_solve(mpcg_handle* h, const float* d_S, const float* d_Pinv, const 
     a.r_out = nullptr; a.p_out = nullptr;
     a.iters = d_iters; a.max_iter_exit = d_max_iter_exit;
     a.N = (int)h->N; a.max_iter = (int)max_iter; a.exit_tol = exit_tol; a.pcols = (int)precond; a.lds_rows = 0;
-    return launch_pcg(h, a, batch, static_cast<hipStream_t>(stream));
+    return launch_pcg(h, a, batch, static_cast<hipStream_t>(stream), 4);
 }
 
 int mpcg_pcg_solve_ref(mpcg_handle* h, float* d_S, float* d_Pinv, float* d_gamma, float* d_lambda,
@@ -292,7 +317,7 @@ int mpcg_pcg_solve_ref(mpcg_handle* h, float* d_S, float* d_Pinv, float* d_gamma
     a.r_out = d_r; a.p_out = d_p;
     a.iters = d_pcg_iters; a.max_iter_exit = d_pcg_exit;
     a.N = (int)h->N; a.max_iter = (int)pcg_max_iter; a.exit_tol = pcg_exit_tol; a.pcols = 3; a.lds_rows = 0;
-    return launch_pcg(h, a, 1, static_cast<hipStream_t>(stream));
+    return launch_pcg(h, a, 1, static_cast<hipStream_t>(stream), 4);
 }
 
 int mpcg_bt_spmv(mpcg_handle* h, const float* d_M, const float* d_x, float* d_y, uint32_t batch, int cols, void* stream) {
@@ -318,6 +343,41 @@ int mpcg_bt_spmv(mpcg_handle* h, const float* d_M, const float* d_x, float* d_y,
     return MPCG_OK;
 }
 
+
+int mpcg_convert_f32_to_f16(mpcg_handle* h, const float* d_src, uint16_t* d_dst, size_t count, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_src || !d_dst) return fail(h, MPCG_ERR_INVALID, "mpcg_convert_f32_to_f16: null device pointer");
+    if ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(d_dst)) & 15u)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_convert_f32_to_f16: pointers must be 16-byte aligned");
+    if (count == 0) return MPCG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t blocks = (count + 2047) / 2048;
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_src,
+                       reinterpret_cast<_Float16*>(d_dst), count);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
+
+int mpcg_pcg_solve_f16(mpcg_handle* h, const uint16_t* d_S16, const uint16_t* d_Pinv16, const float* d_gamma,
+                       float* d_lambda, uint32_t batch, uint32_t max_iter, float exit_tol, mpcg_precond precond,
+                       uint32_t* d_iters, uint8_t* d_max_iter_exit, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_S16 || !d_Pinv16 || !d_gamma || !d_lambda || !d_iters || !d_max_iter_exit)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_f16: null device pointer");
+    if (batch == 0) return MPCG_OK;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_f16: batch exceeds max_batch");
+    if (precond != MPCG_PRECOND_JACOBI && precond != MPCG_PRECOND_SS)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_f16: bad preconditioner");
+    if (max_iter > 0x7fffffffu) return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_f16: max_iter too large");
+    if ((reinterpret_cast<uintptr_t>(d_S16) | reinterpret_cast<uintptr_t>(d_Pinv16)) & 3u)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_f16: d_S16 / d_Pinv16 must be 4-byte aligned");
+    PcgArgs a;
+    a.S = d_S16; a.Pinv = d_Pinv16; a.gamma = d_gamma; a.lambda = d_lambda;
+    a.r_out = nullptr; a.p_out = nullptr;
+    a.iters = d_iters; a.max_iter_exit = d_max_iter_exit;
+    a.N = (int)h->N; a.max_iter = (int)max_iter; a.exit_tol = exit_tol; a.pcols = (int)precond; a.lds_rows = 0;
+    return launch_pcg(h, a, batch, static_cast<hipStream_t>(stream), 2);
+}
 
 int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, const float* d_C_dense, const float* d_g,
                     const float* d_c, float* d_S, float* d_Pinv, float* d_gamma, float rho, uint32_t batch,

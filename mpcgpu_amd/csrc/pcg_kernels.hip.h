@@ -168,34 +168,63 @@ __host__ __device__ constexpr size_t r4(size_t x) { return (x + 3) & ~(size_t)3;
 __host__ __device__ constexpr size_t pcg_lds_floats(int N, int NW) {
     return 2 * r4((size_t)(N + 2) * NS) + 2 * r4((size_t)N * NS) + r4(2 * (size_t)NW);
 }
-// LDS matrix cache: per wave, per matrix, LT triples of 64 lanes x 14 float2
-__host__ __device__ constexpr size_t pcg_lds_cache_floats(int NW, int LT) {
-    return (size_t)NW * 2 * LT * 64 * 28;
+// LDS matrix cache: per wave, per matrix, LT triples of 64 lanes x 14 element pairs (esz = 4 or 2)
+__host__ __device__ constexpr size_t pcg_lds_cache_floats(int NW, int LT, int esz = 4) {
+    return (size_t)NW * 2 * LT * 64 * (7 * esz);
 }
 
 struct PcgArgs {
-    const float* S; const float* Pinv; const float* gamma; float* lambda;
+    const void* S; const void* Pinv;       // bd layout, element type = the kernel's MT (float or _Float16)
+    const float* gamma; float* lambda;
     float* r_out; float* p_out;            // optional [batch][N][n] (may be null)
     uint32_t* iters; uint8_t* max_iter_exit;
     int N; int max_iter; float exit_tol; int pcols;   // pcols: 3 = SS, 1 = block-Jacobi
     int lds_rows;                          // LT: triples per matrix per wave cached in LDS
 };
 
-struct Trip { f2 m[NS]; };                 // this lane's two rows of its block: one float2 per column
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
-template <bool NT>
-__device__ __forceinline__ f2 buf_load2(rsrc_t r, uint32_t voff) {
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, NT ? 2 : 0);
-    return __builtin_bit_cast(f2, v);
-}
+// Matrix storage type MT: float (the reference's layout, bit for bit) or _Float16 (same bd layout with
+// 2-byte elements, produced by f32_to_f16_kernel; arithmetic stays fp32 — v_fma_mix_f32).
+template <typename MT> struct MatT;
+template <> struct MatT<float> {
+    typedef f2 pair;                                  // two consecutive rows of one column
+    typedef f4 chunk;                                 // LDS cache granule = two columns
+    static __device__ __forceinline__ pair load(rsrc_t r, uint32_t voff) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(f2, (u2)__builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0));
+    }
+    // acc.{x,y} += m.{x,y} * x
+    static __device__ __forceinline__ void fma(f2& acc, pair m, float x) {
+        acc.x = fmaf(m.x, x, acc.x);
+        acc.y = fmaf(m.y, x, acc.y);
+    }
+};
+template <> struct MatT<_Float16> {
+    typedef unsigned pair;                            // two halves kept PACKED in one VGPR for the whole solve
+    typedef f2 chunk;
+    static __device__ __forceinline__ pair load(rsrc_t r, uint32_t voff) {
+        return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0);
+    }
+    // v_fma_mix_f32: f16 source half selected by op_sel, f32 multiplicand and accumulator.  Written as asm
+    // because hipcc otherwise hoists the f16->f32 conversions of the loop-invariant resident triples out of
+    // the PCG loop and keeps them as floats: twice the registers, the whole point lost.
+    static __device__ __forceinline__ void fma(f2& acc, pair m, float x) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc.x) : "v"(m), "v"(x));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc.y) : "v"(m), "v"(x));
+    }
+};
 
 // RT = triples per matrix per wave held in registers.  SB = register buffers of the stream:
 // 2 = ping-pong (one triple ahead), 1 = single buffer refilled as soon as it has been consumed
 // (28 VGPRs cheaper: one more resident triple), 0 = no stream at all (launcher guarantees that every
 // triple is resident).
-template <int NW, int RT, int SB, bool NT>
+template <int NW, int RT, int SB, typename MT>
 __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kernel(PcgArgs a) {
+    typedef typename MatT<MT>::pair mpair;
+    typedef typename MatT<MT>::chunk mchunk;
+    struct Trip { mpair m[NS]; };                      // this lane's two rows of its block, one pair per column
+    constexpr uint32_t ESZ = sizeof(MT);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int N = a.N;
     const int tid = threadIdx.x;
@@ -210,11 +239,11 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
     float* tmp = lam + r4((size_t)N * NS);             // knot j at tmp + j*NS
     float* red_v = tmp + r4((size_t)N * NS);
     float* red_e = red_v + NW;
-    f4* mc_base = reinterpret_cast<f4*>(red_v + r4(2 * (size_t)NW));
+    mchunk* mc_base = reinterpret_cast<mchunk*>(red_v + r4(2 * (size_t)NW));
 
     const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;
-    const rsrc_t rS = make_rsrc(a.S + (size_t)b * mstride, (uint32_t)(mstride * sizeof(float)));
-    const rsrc_t rP = make_rsrc(a.Pinv + (size_t)b * mstride, (uint32_t)(mstride * sizeof(float)));
+    const rsrc_t rS = make_rsrc(static_cast<const MT*>(a.S) + (size_t)b * mstride, (uint32_t)(mstride * ESZ));
+    const rsrc_t rP = make_rsrc(static_cast<const MT*>(a.Pinv) + (size_t)b * mstride, (uint32_t)(mstride * ESZ));
     const float* gam = a.gamma + (size_t)b * vstride;
     float* lam_g = a.lambda + (size_t)b * vstride;
 
@@ -225,7 +254,7 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
     const int lrho = lrem / 7;                         // row within the triple
     const int lq = lrem - 7 * lrho;                    // row pair
     const bool head = lane < 21;                       // s == 0 lanes receive the finished rows
-    const uint32_t lane_byte = (uint32_t)(ls * 784 + lq * 8);   // inside the block row
+    const uint32_t lane_byte = (uint32_t)(ls * 196 + lq * 2) * ESZ;   // inside the block row
 
     // triples owned by this wave: tr = w + NW*j, j < TT
     const int NTR = (N + 2) / 3;
@@ -240,13 +269,13 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
     auto trip_off = [&](int j, int cols) -> uint32_t {
         const int k = 3 * (w + NW * j) + lrho;
         const bool ok = active && j < TT && k < N && !(ls == 0 && k == 0) && !(ls == 2 && k == N - 1) && (cols == 3 || ls == 1);
-        return ok ? (uint32_t)k * (ROWF * 4u) + lane_byte : OOB_OFF;
+        return ok ? (uint32_t)k * (ROWF * ESZ) + lane_byte : OOB_OFF;
     };
     auto load_trip = [&](rsrc_t M, int j, int cols) -> Trip {
         const uint32_t off = trip_off(j, cols);
         Trip t;
 #pragma unroll
-        for (int u = 0; u < NS; ++u) t.m[u] = buf_load2<NT>(M, off + 56u * u);
+        for (int u = 0; u < NS; ++u) t.m[u] = MatT<MT>::load(M, off + (NS * ESZ) * u);
         return t;
     };
 
@@ -257,27 +286,39 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
         regS[j] = load_trip(rS, j, 3);
         regP[j] = load_trip(rP, j, a.pcols);
     }
-    // ---- resident triples: LDS cache, lane-private 112-byte records ----
-    f4* mc = mc_base + (size_t)w * 2 * LT * 64 * 7;
+    // ---- resident triples: LDS cache, lane-private records of 7 chunks (chunk = two columns) ----
+    mchunk* mc = mc_base + (size_t)w * 2 * LT * 64 * 7;
+    auto pack2 = [](mpair lo, mpair hi) -> mchunk {
+        if constexpr (sizeof(MT) == 4) return mchunk{lo.x, lo.y, hi.x, hi.y};
+        else return mchunk{__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi)};   // (bit pattern only)
+    };
     for (int j = 0; j < LT; ++j) {
         const Trip t0 = load_trip(rS, RT + j, 3);
         const Trip t1 = load_trip(rP, RT + j, a.pcols);
-        f4* d0 = mc + ((size_t)j * 64 + lane) * 7;
-        f4* d1 = mc + ((size_t)(LT + j) * 64 + lane) * 7;
+        mchunk* d0 = mc + ((size_t)j * 64 + lane) * 7;
+        mchunk* d1 = mc + ((size_t)(LT + j) * 64 + lane) * 7;
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
-            d0[u] = f4{t0.m[2 * u].x, t0.m[2 * u].y, t0.m[2 * u + 1].x, t0.m[2 * u + 1].y};
-            d1[u] = f4{t1.m[2 * u].x, t1.m[2 * u].y, t1.m[2 * u + 1].x, t1.m[2 * u + 1].y};
+            d0[u] = pack2(t0.m[2 * u], t0.m[2 * u + 1]);
+            d1[u] = pack2(t1.m[2 * u], t1.m[2 * u + 1]);
         }
     }
     auto lds_trip = [&](int mat, int j) -> Trip {
-        const f4* src = mc + ((size_t)(mat * LT + j) * 64 + lane) * 7;
+        const mchunk* src = mc + ((size_t)(mat * LT + j) * 64 + lane) * 7;
         Trip t;
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
-            const f4 v = src[u];
-            t.m[2 * u] = f2{v.x, v.y};
-            t.m[2 * u + 1] = f2{v.z, v.w};
+            const mchunk v = src[u];
+            if constexpr (sizeof(MT) == 4) {
+                t.m[2 * u] = mpair{v.x, v.y};
+                t.m[2 * u + 1] = mpair{v.z, v.w};
+            } else {
+                // (scalar temporaries on purpose: __builtin_bit_cast applied directly to the vector
+                //  element lvalue v.y read element 0 with this compiler)
+                const float c0 = v.x, c1 = v.y;
+                t.m[2 * u] = __builtin_bit_cast(mpair, c0);
+                t.m[2 * u + 1] = __builtin_bit_cast(mpair, c1);
+            }
         }
         return t;
     };
@@ -321,10 +362,8 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             const f2 x = x2[u];
-            acc.x = fmaf(t.m[2 * u].x, x.x, acc.x);
-            acc.y = fmaf(t.m[2 * u].y, x.x, acc.y);
-            acc.x = fmaf(t.m[2 * u + 1].x, x.y, acc.x);
-            acc.y = fmaf(t.m[2 * u + 1].y, x.y, acc.y);
+            MatT<MT>::fma(acc, t.m[2 * u], x.x);
+            MatT<MT>::fma(acc, t.m[2 * u + 1], x.y);
         }
         q.d = *reinterpret_cast<const f2*>(dv + (q.k + 1) * NS + 2 * lq);
         q.a0 = acc;
@@ -463,6 +502,19 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
     if (tid == 0) {
         a.iters[b] = iters;
         a.max_iter_exit[b] = (uint8_t)max_iter_exit;
+    }
+}
+
+// fp32 -> fp16 copy of a bd-layout matrix (round to nearest even), 8 elements per thread.
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t count) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= count) {
+        const f4 a = *reinterpret_cast<const f4*>(src + i), b = *reinterpret_cast<const f4*>(src + i + 4);
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 o = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+        *reinterpret_cast<h8*>(dst + i) = o;
+    } else {
+        for (size_t e = i; e < count; ++e) dst[e] = (_Float16)src[e];
     }
 }
 

@@ -109,6 +109,35 @@ class PcgSolver:
                                             _ptr(iters), _ptr(exits), _stream()))
         return iters, exits
 
+    def to_f16(self, M: torch.Tensor) -> torch.Tensor:
+        """Round a bd-layout fp32 matrix buffer to half precision on the device (mpcg_convert_f32_to_f16)."""
+        self._chk(M, M.numel(), torch.float32, "M")
+        out = torch.empty(M.shape, dtype=torch.float16, device=M.device)
+        self._check(self.lib.mpcg_convert_f32_to_f16(self._h, _ptr(M), _ptr(out), M.numel(), _stream()))
+        return out
+
+    def solve_f16(self, S16, Pinv16, gamma, lam, config: pcg_config | None = None, precond: str = "ss",
+                  iters: torch.Tensor | None = None, exits: torch.Tensor | None = None):
+        """`solve` with S / Pinv stored in half precision (arithmetic stays fp32)."""
+        cfg = config or pcg_config(pcg_max_iter=pcg_max_iter(self.N))
+        B = lam.shape[0] if lam.dim() > 1 else 1
+        n, N = self.n, self.N
+        self._chk(S16, B * 3 * n * n * N, torch.float16, "S16")
+        self._chk(Pinv16, B * 3 * n * n * N, torch.float16, "Pinv16")
+        self._chk(gamma, B * n * N, torch.float32, "gamma")
+        self._chk(lam, B * n * N, torch.float32, "lambda")
+        if iters is None:
+            iters = torch.empty(B, dtype=torch.int32, device=lam.device)
+        if exits is None:
+            exits = torch.empty(B, dtype=torch.uint8, device=lam.device)
+        if precond not in ("ss", "jacobi"):
+            raise ValueError("precond must be 'ss' or 'jacobi'")
+        pc = _lib.MPCG_PRECOND_SS if precond == "ss" else _lib.MPCG_PRECOND_JACOBI
+        self._check(self.lib.mpcg_pcg_solve_f16(self._h, _ptr(S16), _ptr(Pinv16), _ptr(gamma), _ptr(lam), B,
+                                                int(cfg.pcg_max_iter), float(cfg.pcg_exit_tol), pc,
+                                                _ptr(iters), _ptr(exits), _stream()))
+        return iters, exits
+
     def solve_ref(self, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp,
                   d_pcg_iters, d_pcg_exit, pcg_max_iter: int, pcg_exit_tol: float):
         """The reference kernel's argument list, in order (include/pcg/sqp.cuh:137-150)."""
