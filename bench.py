@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spmv", action="store_true", help="also time the stand-alone block-tridiagonal SpMV")
     ap.add_argument("--latency", action="store_true", help="also time BASELINE config 2 (N=32, one trajectory)")
+    ap.add_argument("--storage", default="f32", choices=["f32", "f16"],
+                    help="matrix storage of S/Pinv; f16 = BASELINE config 5's reduced-precision experiment (arithmetic stays fp32)")
     args = ap.parse_args()
 
     rank, local_rank, world = D.init()
@@ -183,9 +185,18 @@ def main():
     if args.lds_rows >= -1:
         sol.set_option("pcg_lds_rows", args.lds_rows)
 
+    if args.storage == "f16":
+        d_S16, d_P16 = sol.to_f16(d_S), sol.to_f16(d_P)
+
+        def run_solve():
+            sol.solve_f16(d_S16, d_P16, d_g, d_lam, cfg, args.precond, iters=d_it, exits=d_ex)
+    else:
+        def run_solve():
+            sol.solve(d_S, d_P, d_g, d_lam, cfg, args.precond, iters=d_it, exits=d_ex)
+
     def step():
         d_lam.zero_()                       # every step is the same cold-start solve
-        sol.solve(d_S, d_P, d_g, d_lam, cfg, args.precond, iters=d_it, exits=d_ex)
+        run_solve()
 
     for _ in range(args.warmup):
         step()
@@ -199,7 +210,7 @@ def main():
     for i in range(args.steps):
         d_lam.zero_()
         ev[i][0].record()                   # HIP events on the stream the kernel is launched on
-        sol.solve(d_S, d_P, d_g, d_lam, cfg, args.precond, iters=d_it, exits=d_ex)
+        run_solve()
         ev[i][1].record()
     torch.cuda.synchronize()
     D.barrier()
@@ -215,13 +226,14 @@ def main():
 
     ms_per_step = 1e3 * t_all / args.steps
     value = iters_step_all / (t_all / args.steps)
-    bytes_iter = synth.algorithmic_bytes(N, precond=args.precond)["pcg_iter"]
+    bytes_iter = synth.algorithmic_bytes(N, precond=args.precond)["pcg_iter"]     # fp32-storage model
     achieved = iters_step_local * bytes_iter / (kern_ms * 1e-3) / 1e9     # GB/s, this rank's kernel
 
     out = {
         "metric": "pcg_iterations_per_sec", "value": value, "unit": "iter/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.storage == "f32" else "f32 arithmetic, f16 matrix storage",
+        "data": "synthetic",
         "config": {"workload": f"IIWA-14 (n=14) N={N} knots, {args.precond} preconditioner, batch {B} trajectories/GPU "
                                f"(BASELINE config 4's batch, HBM-resident 616 MB > 256 MiB MALL), lambda0=0, "
                                f"max_iter={max_iter}, exit_tol={args.exit_tol:g}",
@@ -244,8 +256,10 @@ def main():
 
     # HBM traffic of this exact workload from the committed PMC passes (bench cannot run rocprofv3 on itself)
     try:
-        key = (f"N{N}_B{B}_{args.precond}_it{max_iter}_tol{args.exit_tol:g}_w{sol.get_option('pcg_waves')}"
-               f"_rr{sol.get_option('pcg_reg_rows')}_rl{sol.get_option('pcg_lds_rows')}_nt{sol.get_option('nt_loads')}")
+        pre = "pcg" if args.storage == "f32" else "pcg16"
+        key = (f"N{N}_B{B}_{args.precond}_it{max_iter}_tol{args.exit_tol:g}_w{sol.get_option(pre + '_waves')}"
+               f"_rr{sol.get_option(pre + '_reg_rows')}_rl{sol.get_option(pre + '_lds_rows')}_nt{sol.get_option('nt_loads')}"
+               + ("" if args.storage == "f32" else "_f16"))
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
         if tr:
             out["roofline"]["traffic"] = tr["hbm_traffic_bytes_per_launch"]
@@ -268,6 +282,21 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         b = synth.algorithmic_bytes(N)["spmv"] * B
+        sol.set_option("spmv_mfma", 1)           # config 5's MFMA block-GEMV experiment, same launch shape
+        for _ in range(3):
+            sol.bt_spmv(d_S, x, y)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            sol.bt_spmv(d_S, x, y)
+        e1.record()
+        torch.cuda.synchronize()
+        sol.set_option("spmv_mfma", 0)
+        ms_mfma = e0.elapsed_time(e1) / reps
+        out["spmv_mfma_experiment"] = {"kernel": "bt_spmv_mfma_kernel", "ms": ms_mfma, "achieved": b / (ms_mfma * 1e-3) / 1e9,
+                                       "unit": "GB/s", "frac": b / (ms_mfma * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "mfma_flops_issued_per_launch": 2 * 16 * 16 * 4 * 12 * B * N,
+                                       "useful_flops_per_launch": 2 * (3 * N - 2) * 196 * B}
         out["spmv"] = {"kernel": "bt_spmv_kernel", "ms": ms, "achieved": b / (ms * 1e-3) / 1e9, "unit": "GB/s",
                        "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b,
                        "trajectory_spmv_per_sec": B / (ms * 1e-3)}

@@ -25,6 +25,7 @@ struct mpcg_handle {
     int stream_bufs = -1;     // SB: -1 auto, else 0/1/2 register buffers for the streamed triples
     int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
     int spmv_blocks_per_cu = 8;
+    int spmv_mfma = 0;        // 1 = the MFMA experiment kernel for mpcg_bt_spmv
     float* ginv_scratch = nullptr;   // staging for the in-place G <- G^-1 of mpcg_form_schur
     size_t ginv_scratch_floats = 0;
     std::string err;
@@ -128,6 +129,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
         if (value < 0 || value > 8) return fail(h, MPCG_ERR_INVALID, "pcg_max_wg_per_cu out of range");
         h->max_wg_per_cu = value; return MPCG_OK;
     }
+    if (!strcmp(key, "spmv_mfma")) { h->spmv_mfma = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) {
         if (value < 1 || value > 64) return fail(h, MPCG_ERR_INVALID, "spmv_blocks_per_cu out of range");
         h->spmv_blocks_per_cu = value; return MPCG_OK;
@@ -147,6 +149,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "pcg16_reg_rows")) { *value = h->reg_rows16; return MPCG_OK; }
     if (!strcmp(key, "pcg16_lds_rows")) { *value = h->lds_rows16; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
+    if (!strcmp(key, "spmv_mfma")) { *value = h->spmv_mfma; return MPCG_OK; }
     if (!strcmp(key, "num_cus")) { *value = h->num_cus; return MPCG_OK; }
     return MPCG_ERR_INVALID;
 }
@@ -337,7 +340,8 @@ int mpcg_bt_spmv(mpcg_handle* h, const float* d_M, const float* d_x, float* d_y,
     const long cap = (long)h->num_cus * h->spmv_blocks_per_cu;
     if (blocks > cap) blocks = cap;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (h->nt_loads) hipLaunchKernelGGL((bt_spmv_kernel<NW, true>), dim3((unsigned)blocks), dim3(NW * 64), 0, st, a);
+    if (h->spmv_mfma) hipLaunchKernelGGL((bt_spmv_mfma_kernel<NW>), dim3((unsigned)blocks), dim3(NW * 64), 0, st, a);
+    else if (h->nt_loads) hipLaunchKernelGGL((bt_spmv_kernel<NW, true>), dim3((unsigned)blocks), dim3(NW * 64), 0, st, a);
     else hipLaunchKernelGGL((bt_spmv_kernel<NW, false>), dim3((unsigned)blocks), dim3(NW * 64), 0, st, a);
     HIP_TRY(h, hipGetLastError());
     return MPCG_OK;

@@ -575,4 +575,54 @@ __global__ __launch_bounds__(NW * 64) void bt_spmv_kernel(SpmvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA variant of the batched SpMV (BASELINE config 5: "MFMA per-knot block GEMV on") — an EXPERIMENT
+// kept for measurement, not the default.  One wave per block row; every 14x14 block is padded to 16x16
+// in registers and multiplied as four v_mfma_f32_16x16x4_f32 (A = 16 rows x 4 columns of the block,
+// B = the 4 matching x entries in column 0 of a 4x16 operand, zeros elsewhere), the 12 MFMAs of a block
+// row accumulating into one 16x16 tile of which only column 0 is the result.  15/16 of every MFMA is
+// wasted by construction (one right-hand side per matrix), and fp32-input MFMA runs at the vector FMA
+// rate on gfx950, so this cannot beat the VALU kernel; the numbers are in DESIGN.md §3.4.
+// A-operand loads: lane l reads element (row l&15, column 4c + (l>>4)): four 56-byte column segments
+// per instruction; rows 14, 15 / columns 14, 15 / missing blocks go to the SRD's out-of-bounds path.
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void bt_spmv_mfma_kernel(SpmvArgs a) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = a.N;
+    const long total = (long)a.batch * N;
+    const long gw = (long)blockIdx.x * NW + w, GW = (long)gridDim.x * NW;
+    const int li = lane & 15, lk = lane >> 4;
+    const size_t mstride = (size_t)N * ROWF;
+    for (long q = gw; q < total; q += GW) {
+        const int bt = (int)(q / N), k = (int)(q - (long)bt * N);
+        const rsrc_t r = make_rsrc(a.M + (size_t)bt * mstride, (uint32_t)(mstride * sizeof(float)));
+        const float* xk = a.x + (size_t)q * NS;
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const bool blk = (a.cols == 3 || s == 1) && !(s == 0 && k == 0) && !(s == 2 && k == N - 1);
+            const float* xs = xk + (s - 1) * NS;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = 4 * c + lk;
+                const bool ok = blk && li < NS && j < NS;
+                const uint32_t off = ok ? (uint32_t)(k * ROWF + s * 196 + j * NS + li) * 4u : OOB_OFF;
+                typedef unsigned u1;
+                const float av = __builtin_bit_cast(float, (u1)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+                const float bv = (blk && li == 0 && j < NS) ? xs[j] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+        }
+        // column 0 of the tile: lanes 0, 16, 32, 48 hold rows 4*(lane>>4) .. +3
+        if (li == 0) {
+            float* yk = a.y + (size_t)q * NS + 4 * lk;
+            *reinterpret_cast<f2*>(yk) = f2{acc.x, acc.y};
+            if (lk < 3) *reinterpret_cast<f2*>(yk + 2) = f2{acc.z, acc.w};
+        }
+    }
+}
+
 }  // namespace mpcg

@@ -334,3 +334,20 @@ def test_resident_row_variants_bitwise_equal_streaming(P, N, waves, reg_rows, ld
         np.testing.assert_array_equal(a[1], b[1])
         np.testing.assert_array_equal(a[2], b[2])
     assert np.isfinite(outs[0][0]).all()
+
+
+@pytest.mark.parametrize("cols", [3, 1])
+def test_spmv_mfma_experiment_matches_valu_kernel(P, orc, cols):
+    """BASELINE config 5's MFMA block-GEMV (v_mfma_f32_16x16x4_f32, blocks padded 14->16 in registers):
+    same result as the VALU kernel up to fp32 summation order, unwritten blocks never read."""
+    N, B = 37, 5
+    k = synth.make_kkt(N, B, 9)
+    S, _, _ = synth.form_schur(k, poison_unused=True)
+    x = np.random.default_rng(3).normal(size=(B, n * N)).astype(np.float32)
+    sol = P[0](N, max_batch=B)
+    y0 = sol.bt_spmv(dev(S), dev(x), cols=cols).cpu().numpy()
+    sol.set_option("spmv_mfma", 1)
+    y1 = sol.bt_spmv(dev(S), dev(x), cols=cols).cpu().numpy()
+    assert np.isfinite(y1).all() and relinf(y1, y0) < 5e-6
+    for b in (0, 4):
+        assert relinf(y1[b], orc.bt_spmv(np.nan_to_num(S[b]).astype(np.float64), x[b], N, cols=cols)) < 5e-6
