@@ -420,13 +420,22 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
                 finish(p0, part);
             }
         }
-        // heads are lanes 0..20 (others hold 0): fold into lane 0 (once per pass)
-        part += __shfl_down(part, 16);      // lanes 0..15 += 16..31 (16..20 live)
-        part += __shfl_down(part, 8);
-        part += __shfl_down(part, 4);
-        part += __shfl_down(part, 2);
-        part += __shfl_down(part, 1);
-        return part;                        // lane 0
+        // heads are lanes 0..20 (others hold 0): fold into lane 0, once per pass.  Four DPP adds inside
+        // each 16-lane row (VALU latency) + one readlane, instead of five dependent ds_bpermute round
+        // trips (~100 cycles each, on the critical path of every barrier phase).
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1"
+            : "+v"(part));
+        const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
+        return part + hi;                   // valid in lane 0: (lanes 0..15) + (lanes 16..20)
     };
     using MatS = std::integral_constant<int, 0>;
     using MatP = std::integral_constant<int, 1>;

@@ -159,7 +159,8 @@ def test_pcg_max_iter_flag_and_warm_start(P, orc):
     lam, it, ex = solve(P, N, *args, np.zeros((1, n * N), np.float32), 7, 1e-4)
     assert it[0] == 7 and ex[0] == 1                      # ran out of iterations (mpcsim.cuh:382-387)
     lam, it, ex = solve(P, N, *args, G["lam_warm"].reshape(1, -1), 20, 0.0)
-    assert relinf(lam[0], G["lam_warm_ss_K20"]) < 1e-3    # lambda is in/out: warm start honoured
+    band = fp32_band(orc, G["S"], G["Pinv"], G["gamma"], G["lam_warm"], N, 20, "ss", G["lam_warm_ss_K20"])
+    assert relinf(lam[0], G["lam_warm_ss_K20"]) <= max(1e-3, 4 * band)    # lambda is in/out: warm start honoured
     # already converged: no update, flag cleared, lambda untouched bit for bit
     lam0 = G["lam_direct"].astype(np.float32).reshape(1, -1)
     lam, it, ex = solve(P, N, *args, lam0, 50, 1e-2)
@@ -237,7 +238,8 @@ def test_solve_ref_twelve_argument_entry(P, orc):
     r64 = orc.pcg(G["S"].astype(np.float64), G["Pinv"].astype(np.float64), G["gamma"].astype(np.float64),
                   np.zeros(n * N), N, 20, 0.0, "ss")
     assert int(d_iters.item()) == 20 and bool(d_exit.item()) is True
-    assert relinf(d_lambda.cpu().numpy(), G["lam_ss_K20"]) < 1e-3
+    band = fp32_band(orc, G["S"], G["Pinv"], G["gamma"], np.zeros(n * N), N, 20, "ss", G["lam_ss_K20"])
+    assert relinf(d_lambda.cpu().numpy(), G["lam_ss_K20"]) <= max(1e-3, 4 * band)
     assert relinf(d_r.cpu().numpy(), r64["r"]) < 5e-2 and relinf(d_p.cpu().numpy(), r64["p"]) < 5e-2
     assert (d_v_temp == 3.0).all() and (d_eta_new_temp == 3.0).all()       # accepted, untouched
     # inputs are not modified
@@ -274,7 +276,7 @@ def test_error_behaviour(P):
         P[0](1024)                                    # vectors do not fit LDS -> unsupported, loudly
 
 
-def test_runs_on_non_default_stream(P):
+def test_runs_on_non_default_stream(P, orc):
     G = golden(8)
     N = 8
     sol = P[0](N)
@@ -285,7 +287,8 @@ def test_runs_on_non_default_stream(P):
     with torch.cuda.stream(s):
         it, ex = sol.solve(dS, dP, dg, lam, P[1](pcg_exit_tol=0.0, pcg_max_iter=20))
     s.synchronize()
-    assert relinf(lam.cpu().numpy()[0], G["lam_ss_K20"]) < 1e-3
+    band = fp32_band(orc, G["S"], G["Pinv"], G["gamma"], np.zeros(n * N), N, 20, "ss", G["lam_ss_K20"])
+    assert relinf(lam.cpu().numpy()[0], G["lam_ss_K20"]) <= max(1e-3, 4 * band)
 
 
 def test_cpp_callsite_over_shim_headers():
