@@ -358,13 +358,15 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
         q.valid = k < N;
         q.k = q.valid ? k : 0;                          // rows beyond N are all-zero (OOB loads): any knot will do
         const f2* x2 = reinterpret_cast<const f2*>(xv + (q.k + ls) * NS);   // knot k-1+s of the padded vector
-        f2 acc = {0.f, 0.f};
+        // two accumulator pairs (even / odd columns) halve the dependent FMA chain: 7 deep instead of 14
+        f2 acc = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             const f2 x = x2[u];
             MatT<MT>::fma(acc, t.m[2 * u], x.x);
-            MatT<MT>::fma(acc, t.m[2 * u + 1], x.y);
+            MatT<MT>::fma(acc1, t.m[2 * u + 1], x.y);
         }
+        acc += acc1;
         q.d = *reinterpret_cast<const f2*>(dv + (q.k + 1) * NS + 2 * lq);
         q.a0 = acc;
         q.a1.x = __shfl_down(acc.x, 21);
@@ -439,10 +441,13 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
     };
     using MatS = std::integral_constant<int, 0>;
     using MatP = std::integral_constant<int, 1>;
-    auto block_sum = [&](const float* red) -> float {
+    auto block_sum = [&](const float* red) -> float {      // same order in every thread: deterministic
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) s += red[i];
+        for (int i = 0; i < NW; i += 4) {
+            const f4 v = *reinterpret_cast<const f4*>(red + i);
+            s += v.x; s += v.y; s += v.z; s += v.w;
+        }
         return s;
     };
     // vector items: float2 #e of an [N][14] vector
