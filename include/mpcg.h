@@ -145,6 +145,18 @@ int mpcg_compute_dz(mpcg_handle *h, uint32_t control_size, const float *d_Ginv_d
                     const float *d_C_dense, const float *d_g, const float *d_lambda, float *d_dz,
                     uint32_t batch, void *stream);
 
+/* ---- CSR side of the reference's QDLDL twin (LINSYS_SOLVE == 0) ----
+ * mpcg_prep_csr replaces prep_csr<<<N,64>>>(state_size, knot_points, d_col_ptr, d_row_ind)
+ * (include/utils/csr.cuh:40-73; called once per SQP solve at include/qdldl/sqp.cuh:164): pattern of the lower
+ * triangle, d_col_ptr [nN+1], d_row_ind [nnz], nnz = (N-1)n^2 + N n(n+1)/2 (include/qdldl/sqp.cuh:148).
+ * mpcg_bd_to_csr_lowertri gathers the values form_schur_system_qdldl leaves in d_val
+ * (include/qdldl/linsys_setup.cuh:339-351) from a bd-layout S: per trajectory [nnz] floats = mult * (left
+ * block, then lower triangle of the diagonal block, row by row).  With the S of mpcg_form_schur (already
+ * negated) mult = +1 reproduces the reference's numbers; gamma is shared by both paths.  The CPU LDL^T itself
+ * stays the reference's (qdldl); this library only feeds it. */
+int mpcg_prep_csr(mpcg_handle *h, int32_t *d_col_ptr, int32_t *d_row_ind, void *stream);
+int mpcg_bd_to_csr_lowertri(mpcg_handle *h, const float *d_S, float *d_val, float mult, uint32_t batch, void *stream);
+
 /* Launch-configuration knobs (tuning / experiments; defaults are chosen by mpcg_create from
  * knot_points): "pcg_waves" (4, 8 or 16 wavefronts per trajectory workgroup), "pcg_reg_rows" (block
  * rows per matrix per wave kept in registers for the whole solve; only compiled (waves, rows) pairs

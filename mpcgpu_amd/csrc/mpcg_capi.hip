@@ -437,4 +437,30 @@ int mpcg_compute_dz(mpcg_handle* h, uint32_t control_size, const float* d_Ginv_d
     return MPCG_OK;
 }
 
+
+int mpcg_prep_csr(mpcg_handle* h, int32_t* d_col_ptr, int32_t* d_row_ind, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_col_ptr || !d_row_ind) return fail(h, MPCG_ERR_INVALID, "mpcg_prep_csr: null device pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(prep_csr_kernel, dim3(h->N), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), (int)h->n, (int)h->N,
+                       d_col_ptr, d_row_ind);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
+
+int mpcg_bd_to_csr_lowertri(mpcg_handle* h, const float* d_S, float* d_val, float mult, uint32_t batch, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_S || !d_val) return fail(h, MPCG_ERR_INVALID, "mpcg_bd_to_csr_lowertri: null device pointer");
+    if (batch == 0) return MPCG_OK;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_bd_to_csr_lowertri: batch exceeds max_batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    CsrArgs a{d_S, d_val, mult, (int)h->n, (int)h->N, (int)batch};
+    long blocks = (long)batch * h->N;
+    const long cap = (long)h->num_cus * 64;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(bd_to_csr_kernel, dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
+
 }  // extern "C"

@@ -196,8 +196,7 @@ template <> struct MatT<float> {
     }
     // acc.{x,y} += m.{x,y} * x
     static __device__ __forceinline__ void fma(f2& acc, pair m, float x) {
-        acc.x = fmaf(m.x, x, acc.x);
-        acc.y = fmaf(m.y, x, acc.y);
+        acc = __builtin_elementwise_fma(m, f2{x, x}, acc);      // one v_pk_fma_f32 (x broadcast by op_sel)
     }
 };
 template <> struct MatT<_Float16> {

@@ -242,6 +242,44 @@ __global__ __launch_bounds__(SCH_THREADS) void compute_dz_kernel(DzArgs a) {
     }
 }
 
+// ---- CSR side of the QDLDL twin ----
+// prep_csr_kernel: pattern of the lower triangle of a symmetric block-tridiagonal matrix, exactly
+// include/utils/csr.cuh:40-73 (row (k,i) holds (k>0)*n + i+1 entries, first column (k>0)*(k-1)*n).
+__global__ __launch_bounds__(SCH_THREADS) void prep_csr_kernel(int n, int N, int* col_ptr, int* row_ind) {
+    const int brow = n * n + (n * (n + 1)) / 2;
+    for (int k = blockIdx.x; k < N; k += gridDim.x)
+        for (int row = threadIdx.x; row < n; row += SCH_THREADS) {
+            if (k == 0 && row == 0) col_ptr[0] = 0;
+            const int tri = ((row + 1) * row) / 2;
+            const int off = (k > 0) * ((n + 1) * n) / 2 + (k > 0) * (k - 1) * brow + (k > 0) * row * n + tri;
+            const int len = (k > 0) * n + row + 1;
+            col_ptr[k * n + row + 1] = off + len;
+            for (int c = 0; c < len; ++c) row_ind[off + c] = (k > 0) * (k - 1) * n + c;
+        }
+}
+// values: what form_schur_qdl_kernel leaves in d_val (include/qdldl/linsys_setup.cuh:12-336 via
+// store_block_csr_lowertri, include/utils/csr.cuh:9-36), gathered from the bd-layout S that
+// mpcg_form_schur produced: left block S[k,0] then the lower triangle of S[k,1], scaled by mult.
+struct CsrArgs { const float* S; float* val; float mult; int n; int N; int batch; };
+__global__ __launch_bounds__(SCH_THREADS) void bd_to_csr_kernel(CsrArgs a) {
+    const int n = a.n, N = a.N, nn = n * n;
+    const int brow = nn + (n * (n + 1)) / 2;
+    const size_t nnz = (size_t)(N - 1) * nn + (size_t)N * ((n * (n + 1)) / 2);
+    for (long item = blockIdx.x; item < (long)a.batch * N; item += gridDim.x) {
+        const int b = (int)(item / N), k = (int)(item % N);
+        const float* Sk = a.S + ((size_t)b * N + k) * 3 * nn;
+        float* val = a.val + (size_t)b * nnz;
+        const int per_row_max = n + n;
+        for (int e = threadIdx.x; e < n * per_row_max; e += SCH_THREADS) {
+            const int row = e / per_row_max, c = e % per_row_max;
+            const int tri = ((row + 1) * row) / 2;
+            const int off = (k > 0) * ((n + 1) * n) / 2 + (k > 0) * (k - 1) * brow + (k > 0) * row * n + tri;
+            if (k > 0 && c < n) val[off + c] = a.mult * Sk[row + c * n];                               // left block
+            else if (c >= n && c - n <= row) val[off + (k > 0) * n + (c - n)] = a.mult * Sk[nn + row + (c - n) * n];   // diagonal block
+        }
+    }
+}
+
 #pragma clang fp contract(fast)
 
 }  // namespace mpcg

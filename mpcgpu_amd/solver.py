@@ -175,6 +175,27 @@ class PcgSolver:
                                              B, _stream()))
         return dz
 
+    def csr_nnz(self) -> int:
+        """nnz of the lower triangle (include/qdldl/sqp.cuh:148)."""
+        n, N = self.n, self.N
+        return (N - 1) * n * n + N * (n * (n + 1)) // 2
+
+    def prep_csr(self):
+        """prep_csr (include/utils/csr.cuh:40-73): (col_ptr int32 [nN+1], row_ind int32 [nnz]) on the device."""
+        dev = torch.device("cuda", self.device)
+        col_ptr = torch.empty(self.n * self.N + 1, dtype=torch.int32, device=dev)
+        row_ind = torch.empty(self.csr_nnz(), dtype=torch.int32, device=dev)
+        self._check(self.lib.mpcg_prep_csr(self._h, _ptr(col_ptr), _ptr(row_ind), _stream()))
+        return col_ptr, row_ind
+
+    def bd_to_csr_lowertri(self, S, mult: float = 1.0):
+        """Values of the QDLDL path's d_val from a bd-layout S, batched: [B, nnz]."""
+        B = S.shape[0] if S.dim() > 1 else 1
+        self._chk(S, B * 3 * self.n * self.n * self.N, torch.float32, "S")
+        val = torch.empty(B, self.csr_nnz(), device=S.device)
+        self._check(self.lib.mpcg_bd_to_csr_lowertri(self._h, _ptr(S), _ptr(val), float(mult), B, _stream()))
+        return val
+
     def bt_spmv(self, M, x, y=None, cols: int = 3):
         B = x.shape[0] if x.dim() > 1 else 1
         n, N = self.n, self.N

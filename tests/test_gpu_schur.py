@@ -105,3 +105,29 @@ def test_kkt_to_step_pipeline_vs_float64_kkt_solve(orc):
         assert relinf(dz[b], sol64[:nz]) < 5e-3
         # the step satisfies the linearised constraints C dz = c
         assert np.abs(Cm @ dz[b].astype(np.float64) - k.c[b].reshape(-1)).max() < 5e-3
+
+
+@pytest.mark.parametrize("N", [2, 5, 32, 128])
+def test_csr_emitter_matches_reference_pattern_and_oracle(orc, N):
+    """QDLDL twin (include/utils/csr.cuh, include/qdldl/linsys_setup.cuh): pattern and values emitted on the
+    GPU equal the oracle's restatement bit for bit, and the oracle's QDLDL-style LDL^T solves the system
+    from them (config 1 of BASELINE.json, with the GPU as producer)."""
+    from mpcgpu_amd import PcgSolver
+    B = 3
+    k = synth.make_kkt(N, B, 4000 + N)
+    G, C, g, c = synth.pack_kkt_dense(k, np.float32)
+    sol = PcgSolver(N, max_batch=B)
+    S, P, gam = sol.form_schur(dev(G), dev(C), dev(g), dev(c), 1e-3)
+    col_ptr, row_ind = sol.prep_csr()
+    val = sol.bd_to_csr_lowertri(S)
+    torch.cuda.synchronize()
+    Ap, Ai = orc.prep_csr(N)
+    np.testing.assert_array_equal(col_ptr.cpu().numpy(), Ap)
+    np.testing.assert_array_equal(row_ind.cpu().numpy(), Ai)
+    Sh, vh, gh = S.cpu().numpy(), val.cpu().numpy(), gam.cpu().numpy()
+    assert vh.shape[1] == sol.csr_nnz() == len(Ai)
+    L = orc.LdlSolver(N, np.float32)
+    for b in range(B):
+        np.testing.assert_array_equal(vh[b], orc.bd_to_csr_lowertri(np.nan_to_num(Sh[b]), N))
+        x = L.solve(vh[b], gh[b])
+        assert relinf(x, orc.direct_solve(Sh[b], gh[b], N)) < 5e-2      # float LDL^T at cond ~1e5
