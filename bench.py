@@ -88,7 +88,7 @@ def cpu_baseline(N, S_host, g_host, mean_iters, budget_s=12.0):
         "equiv_pcg_iters_per_sec": solves_per_s * mean_iters,
         "cpu_pcg_port_iters_per_sec": it_cpu / dt_pcg,
         "sample": f"{cnt} QDLDL-style float32 LDL^T factor+solve calls over the first {ns} trajectories of the "
-                  f"workload ({dt:.1f} s, 1 thread, nnz={len(vals[0])}, dim={14 * N}); last rel. residual {resid:.1e}; "
+                  f"workload ({dt:.1f} s, 1 thread, nnz={len(vals[0])}, dim={14 * N}); rel. residual of the last float LDL^T solution against the fp32-built S {resid:.1e}; "
                   f"reference also pays D2H(values,gamma)+H2D(lambda) per solve (include/qdldl/sqp.cuh:261-282), not included",
         "host_cpus": os.cpu_count(),
     }
@@ -160,6 +160,8 @@ def main():
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (the product has no CPU path)"
+    if os.environ.get("MPCG_FORCE_DEVICE"):          # dry-run of the N>1 flow on a 1-GPU box (with MPCG_DIST_BACKEND=gloo)
+        local_rank = int(os.environ["MPCG_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -235,7 +237,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.storage == "f32" else "f32 arithmetic, f16 matrix storage",
         "data": "synthetic",
         "config": {"workload": f"IIWA-14 (n=14) N={N} knots, {args.precond} preconditioner, batch {B} trajectories/GPU "
-                               f"(BASELINE config 4's batch, HBM-resident 616 MB > 256 MiB MALL), lambda0=0, "
+                               f"(BASELINE config 4's batch is 1024; S+Pinv = {2 * B * 3 * 196 * N * 4 / 1e6:.0f} MB in HBM), lambda0=0, "
                                f"max_iter={max_iter}, exit_tol={args.exit_tol:g}",
                    "knot_points": N, "state_size": 14, "batch_per_gpu": B, "global_batch": B * world,
                    "precond": args.precond, "pcg_max_iter": max_iter, "pcg_exit_tol": args.exit_tol,

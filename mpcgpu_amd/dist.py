@@ -26,8 +26,8 @@ def init(backend: str | None = None) -> tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:      # MPCG_DIST_BACKEND=gloo: dry-run the N>1 flow where only one GPU exists
+            backend = os.environ.get("MPCG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
@@ -41,15 +41,20 @@ def barrier():
         dist.barrier()
 
 
+def _coll_device(device):
+    """Collectives run on the GPU with nccl (RCCL), on the host with gloo."""
+    return device if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu"
+
+
 def max_over_ranks(value: float, device="cpu") -> float:
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def sum_over_ranks(value: float, device="cpu") -> float:
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
