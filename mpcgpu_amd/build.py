@@ -34,6 +34,24 @@ EXAMPLE_SRC = os.path.join(_ROOT, "examples", "sqp_pcg_callsite.cpp")
 EXAMPLE_BIN = os.path.join(_ROOT, "examples", "sqp_pcg_callsite")
 
 
+CHAIN_SRC = os.path.join(_ROOT, "examples", "sqp_linsys_chain.cpp")
+CHAIN_BIN = os.path.join(_ROOT, "examples", "sqp_linsys_chain")
+
+
+def build_chain_example(force: bool = False, verbose: bool = False) -> str:
+    """C++ host program: form_schur_system -> pcg -> compute_dz as include/pcg/sqp.cuh:207-259 writes them."""
+    deps = [CHAIN_SRC, LIB_PATH, os.path.join(_ROOT, "include", "gbd_pcg_compat", "gpu_pcg.cuh"),
+            os.path.join(_ROOT, "include", "mpcgpu_compat", "linsys_steps.cuh")]
+    if force or not os.path.exists(CHAIN_BIN) or any(os.path.getmtime(d) > os.path.getmtime(CHAIN_BIN) for d in deps):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(_ROOT, "include", "gbd_pcg_compat"),
+               "-I" + os.path.join(_ROOT, "include", "mpcgpu_compat"), CHAIN_SRC, "-L" + _HERE, "-lmpcg_hip",
+               "-Wl,-rpath,$ORIGIN/../mpcgpu_amd", "-o", CHAIN_BIN]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return CHAIN_BIN
+
+
 def build_example(force: bool = False, verbose: bool = False) -> str:
     """C++ host program: the reference's PCG call site over the shim headers + the C ABI."""
     deps = [EXAMPLE_SRC, LIB_PATH, os.path.join(_ROOT, "include", "gbd_pcg_compat", "gpu_pcg.cuh")]
@@ -49,3 +67,4 @@ def build_example(force: bool = False, verbose: bool = False) -> str:
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_example(force="--force" in sys.argv, verbose=True))
+    print(build_chain_example(force="--force" in sys.argv, verbose=True))

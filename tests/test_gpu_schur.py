@@ -131,3 +131,18 @@ def test_csr_emitter_matches_reference_pattern_and_oracle(orc, N):
         np.testing.assert_array_equal(vh[b], orc.bd_to_csr_lowertri(np.nan_to_num(Sh[b]), N))
         x = L.solve(vh[b], gh[b])
         assert relinf(x, orc.direct_solve(Sh[b], gh[b], N)) < 5e-2      # float LDL^T at cond ~1e5
+
+
+def test_cpp_sqp_linsys_chain_over_shim_headers():
+    """examples/sqp_linsys_chain.cpp: form_schur_system -> PCG launch -> compute_dz with the reference's own
+    names/signatures (include/pcg/sqp.cuh:207-259) over include/mpcgpu_compat + include/gbd_pcg_compat; the
+    program verifies the KKT conditions of the resulting step on the CPU."""
+    import json
+    import os
+    import subprocess
+    from mpcgpu_amd import build
+    exe = build.CHAIN_BIN if os.path.exists(build.CHAIN_BIN) else build.build_chain_example()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["pcg_exit"] == 0 and out["constraint_err"] < 1e-3 and out["stationarity_err"] < 1e-3
