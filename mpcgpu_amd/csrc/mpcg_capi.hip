@@ -22,6 +22,7 @@ struct mpcg_handle {
     int reg_rows = 0;         // RT: TRIPLES of block rows per matrix per wave kept in registers (compiled variants only)
     int lds_rows = -1;        // LT: triples per matrix per wave cached in LDS; -1 = as many as fit when reg_rows > 0, else 0
     int pcg_waves16 = 8, reg_rows16 = 6, lds_rows16 = -1;   // the same knobs for fp16 matrix storage
+    bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any pcg_* set_option clears this)
     int stream_bufs = -1;     // SB: -1 auto, else 0/1/2 register buffers for the streamed triples
     int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
     int spmv_blocks_per_cu = 8;
@@ -114,6 +115,7 @@ const char* mpcg_last_error(const mpcg_handle* h) { return h ? h->err.c_str() : 
 
 int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!h || !key) return MPCG_ERR_INVALID;
+    if (!strncmp(key, "pcg_", 4)) h->auto_cfg = false;
     if (!strcmp(key, "pcg_waves")) {
         if (value != 4 && value != 8 && value != 16) return fail(h, MPCG_ERR_INVALID, "pcg_waves must be 4, 8 or 16");
         h->pcg_waves = value; return MPCG_OK;
@@ -235,6 +237,14 @@ static int stream_bufs_for(const mpcg_handle* h, int nw, int esz) {
 
 static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->auto_cfg && esz == 4 && h->N > 96) {
+        // long horizons: with fewer trajectories than CUs the call is a latency problem -> 8 waves (two per
+        // SIMD) hide more of it (N=128, batch 1: 1.02 ms vs 1.23 ms); with the GPU full, 4 fat waves keep more
+        // of S and Pinv resident (batch 1024: 4.63 ms vs 4.85 ms).  profiles/r01_tune_latency.txt
+        if (batch < (uint32_t)h->num_cus) { h->pcg_waves = 8; h->reg_rows = 3; }
+        else { h->pcg_waves = 4; h->reg_rows = 7; }
+        h->lds_rows = -1;
+    }
     const int waves = esz == 2 ? h->pcg_waves16 : h->pcg_waves;
     const int rt = esz == 2 ? h->reg_rows16 : h->reg_rows;
     const int sb = stream_bufs_for(h, waves, esz);
