@@ -422,9 +422,9 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
     const long cap = (long)h->num_cus * 64;
     if (blocks > cap) blocks = cap;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(form_schur_kernel, dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
+    hipLaunchKernelGGL((form_schur_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
     HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL(complete_ss_kernel, dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
+    hipLaunchKernelGGL((complete_ss_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
     HIP_TRY(h, hipGetLastError());
     return MPCG_OK;
 }
@@ -442,7 +442,7 @@ int mpcg_compute_dz(mpcg_handle* h, uint32_t control_size, const float* d_Ginv_d
     long blocks = (long)batch * h->N;
     const long cap = (long)h->num_cus * 64;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(compute_dz_kernel, dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL((compute_dz_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRY(h, hipGetLastError());
     return MPCG_OK;
 }

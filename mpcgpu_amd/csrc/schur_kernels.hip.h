@@ -42,7 +42,7 @@ __device__ __forceinline__ void w_matvec(int rows, int cols, const float* M, con
 }
 // Gauss-Jordan on [A | I] without pivoting (include/utils/matrix.cuh:120-238): A destroyed, Ainv out.
 // scr: 3n floats (pivot row of A, pivot row of Ainv, pivot column).
-__device__ void w_invert(int n, float* A, float* Ainv, float* scr) {
+__device__ __forceinline__ void w_invert(int n, float* A, float* Ainv, float* scr) {
     for (int e = threadIdx.x; e < n * n; e += SCH_THREADS) Ainv[e] = (float)((e % n) == (e / n));
     __syncthreads();
     float* prowA = scr;
@@ -64,6 +64,49 @@ __device__ void w_invert(int n, float* A, float* Ainv, float* scr) {
         __syncthreads();
     }
 }
+// Three independent Gauss-Jordan inversions advanced in lock-step (the reference inverts Q_k, Q_{k+1}, R_k
+// together too: invertMatrix<T>(dimA, dimB, dimC, ...), include/utils/matrix.cuh): same arithmetic per element
+// as three w_invert calls, a third of the barriers.  n3 <= n1 == n2.  scr: 3*(n1+n2+n3) floats.
+__device__ __forceinline__ void w_invert3(int n1, float* A1, float* I1, int n2, float* A2, float* I2, int n3, float* A3, float* I3, float* scr) {
+    const int e1 = n1 * n1, e2 = n2 * n2, e3 = n3 * n3;
+    for (int e = threadIdx.x; e < e1 + e2 + e3; e += SCH_THREADS) {
+        if (e < e1) I1[e] = (float)((e % n1) == (e / n1));
+        else if (e < e1 + e2) { const int f = e - e1; I2[f] = (float)((f % n2) == (f / n2)); }
+        else { const int f = e - e1 - e2; I3[f] = (float)((f % n3) == (f / n3)); }
+    }
+    __syncthreads();
+    float* s1 = scr;
+    float* s2 = s1 + 3 * n1;
+    float* s3 = s2 + 3 * n2;
+    const int nmax = n1 > n2 ? n1 : n2;
+    for (int piv = 0; piv < nmax; ++piv) {
+        for (int c = threadIdx.x; c < n1 + n2 + n3; c += SCH_THREADS) {
+            int n, cc; float *A, *I, *sc;
+            if (c < n1) { n = n1; cc = c; A = A1; I = I1; sc = s1; }
+            else if (c < n1 + n2) { n = n2; cc = c - n1; A = A2; I = I2; sc = s2; }
+            else { n = n3; cc = c - n1 - n2; A = A3; I = I3; sc = s3; }
+            if (piv < n) {
+                const float pinv = 1.0f / A[piv + piv * n];
+                sc[cc] = A[piv + cc * n] * pinv;
+                sc[n + cc] = I[piv + cc * n] * pinv;
+                sc[2 * n + cc] = A[cc + piv * n];
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < e1 + e2 + e3; e += SCH_THREADS) {
+            int n, f; float *A, *I, *sc;
+            if (e < e1) { n = n1; f = e; A = A1; I = I1; sc = s1; }
+            else if (e < e1 + e2) { n = n2; f = e - e1; A = A2; I = I2; sc = s2; }
+            else { n = n3; f = e - e1 - e2; A = A3; I = I3; sc = s3; }
+            if (piv < n) {
+                const int r = f % n, c = f / n;
+                if (r == piv) { A[f] = sc[c]; I[f] = sc[n + c]; }
+                else { A[f] -= sc[2 * n + r] * sc[c]; I[f] -= sc[2 * n + r] * sc[n + c]; }
+            }
+        }
+        __syncthreads();
+    }
+}
 __device__ __forceinline__ void w_copy(int cnt, const float* src, float* dst, float mult = 1.f) {
     for (int e = threadIdx.x; e < cnt; e += SCH_THREADS) dst[e] = src[e] * mult;
 }
@@ -75,10 +118,15 @@ struct SchurArgs {
 };
 
 // block row k of trajectory b: S[k,0], S[k,1], S[k-1,2], Pinv[k,1], gamma[k]; inverses -> scratch
+// (n, m are compile-time: the small loops unroll and the index arithmetic folds — 3x fewer instructions
+//  than the runtime-dimension version, which was issue-bound at ~16k instructions per knot)
+template <int NN_, int MM_>
 __global__ __launch_bounds__(SCH_THREADS) void form_schur_kernel(SchurArgs a) {
-    __shared__ float sm[12 * 196 + 2 * 49 + 98 + 8 * 14 + 64];
-    const int n = a.n, m = a.m, N = a.N, nn = n * n, mm = m * m, nm = n * m;
-    const int Gset = nn + mm, Cset = nn + nm, gset = n + m;
+    __shared__ float sm[12 * 196 + 2 * 49 + 98 + 8 * 14 + 112];
+    constexpr int n = NN_, m = MM_;
+    const int N = a.N;
+    constexpr int nn = n * n, mm = m * m, nm = n * m;
+    constexpr int Gset = nn + mm, Cset = nn + nm, gset = n + m;
     const size_t Gsz = (size_t)Gset * N - mm, Csz = (size_t)Cset * (N - 1), gsz = (size_t)gset * N - m;
     float *Qk = sm, *Qki = Qk + nn, *Qp = Qki + nn, *Qpi = Qp + nn, *Ak = Qpi + nn, *phi = Ak + nn, *theta = phi + nn,
           *thetaInv = theta + nn, *t1 = thetaInv + nn, *t2 = t1 + nn, *phiT = t2 + nn, *BR = phiT + nn /* n x m */,
@@ -123,9 +171,7 @@ __global__ __launch_bounds__(SCH_THREADS) void form_schur_kernel(SchurArgs a) {
         for (int i = threadIdx.x; i < n; i += SCH_THREADS) { Qk[i + i * n] += a.rho; Qp[i + i * n] += a.rho; }
         for (int i = threadIdx.x; i < m; i += SCH_THREADS) Rk[i + i * m] += a.rho;
         __syncthreads();
-        w_invert(n, Qk, Qki, scr);                                       // :356-368
-        w_invert(n, Qp, Qpi, scr);
-        w_invert(m, Rk, Rki, scr);
+        w_invert3(n, Qk, Qki, n, Qp, Qpi, m, Rk, Rki, scr);              // :356-368
         w_gemm(n, n, n, Ak, Qki, phi, false);                            // phi = Abar Qi          :397-398
         w_gemm(n, m, m, Bk, Rki, BR, false);                             // Bbar Ri                :405-406
         w_matvec(n, n, Qpi, qp, gam);                                    // :410-415
@@ -156,10 +202,12 @@ __global__ __launch_bounds__(SCH_THREADS) void form_schur_kernel(SchurArgs a) {
 }
 
 // symmetric-stair completion (linsys_setup.cuh:9-137) + publication of G^-1
+template <int NN_, int MM_>
 __global__ __launch_bounds__(SCH_THREADS) void complete_ss_kernel(SchurArgs a) {
     __shared__ float sm[7 * 196];
-    const int n = a.n, m = a.m, N = a.N, nn = n * n, mm = m * m;
-    const int Gset = nn + mm;
+    constexpr int n = NN_, m = MM_, nn = n * n, mm = m * m;
+    const int N = a.N;
+    constexpr int Gset = nn + mm;
     const size_t Gsz = (size_t)Gset * N - mm;
     float *Dk = sm, *Dm = Dk + nn, *Dp = Dm + nn, *L = Dp + nn, *Rt = L + nn, *t1 = Rt + nn, *t2 = t1 + nn;
     for (long item = blockIdx.x; item < (long)a.batch * N; item += gridDim.x) {
@@ -202,9 +250,11 @@ __global__ __launch_bounds__(SCH_THREADS) void complete_ss_kernel(SchurArgs a) {
 struct DzArgs { const float* Ginv; const float* C; const float* g; const float* lambda; float* dz; int n; int m; int N; int batch; };
 
 // include/common/dz.cuh:3-121: dz_x = Qi (q - lambda_k - Abar^T lambda_{k+1}), dz_u = Ri (r - Bbar^T lambda_{k+1})
+template <int NN_, int MM_>
 __global__ __launch_bounds__(SCH_THREADS) void compute_dz_kernel(DzArgs a) {
     __shared__ float sm[64];
-    const int n = a.n, m = a.m, N = a.N, nn = n * n, mm = m * m, nm = n * m;
+    constexpr int n = NN_, m = MM_, nn = n * n, mm = m * m, nm = n * m;
+    const int N = a.N;
     const size_t Gsz = (size_t)(nn + mm) * N - mm, Csz = (size_t)(nn + nm) * (N - 1), gsz = (size_t)(n + m) * N - m;
     float* tx = sm;          // n
     float* tu = sm + 16;     // m

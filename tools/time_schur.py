@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Time mpcg_form_schur / mpcg_compute_dz on 128 trajectories x N=128."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mpcgpu_amd import PcgSolver, synth
+N, B = 128, 128
+sol = PcgSolver(N, max_batch=B)
+k = synth.make_kkt(N, B, 1)
+G, C, g, c = (torch.from_numpy(a).cuda() for a in synth.pack_kkt_dense(k, np.float32))
+G0 = G.clone(); S = torch.empty(B, 3 * 196 * N, device="cuda"); P = torch.empty_like(S); gm = torch.empty(B, 14 * N, device="cuda")
+lam = torch.randn(B, 14 * N, device="cuda")
+def t(fn, reps=6):
+    ts = []
+    for i in range(reps):
+        G.copy_(G0); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts[1:])) * 1e3
+print("form_schur (ss)   128 traj x 128 knots: %.1f us" % t(lambda: sol.form_schur(G, C, g, c, 1e-3, "ss", S=S, Pinv=P, gamma=gm)))
+print("form_schur (jac)  128 traj x 128 knots: %.1f us" % t(lambda: sol.form_schur(G, C, g, c, 1e-3, "jacobi", S=S, Pinv=P, gamma=gm)))
+sol.form_schur(G, C, g, c, 1e-3, "ss", S=S, Pinv=P, gamma=gm)
+print("compute_dz        128 traj x 128 knots: %.1f us" % t(lambda: sol.compute_dz(G, C, g, lam)))
