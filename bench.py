@@ -341,6 +341,24 @@ def main():
 
     if rank == 0 and world == 1 and args.latency:
         out["config2_latency"] = latency_config2(dev)
+        # the headline horizon as ONE trajectory (the reference's own mode of use): ms per SQP-linsolve
+        sol1 = PcgSolver(N, max_batch=1, device=local_rank)
+        l1 = torch.zeros(1, 14 * N, device=dev)
+        i1 = torch.zeros(1, dtype=torch.int32, device=dev)
+        x1 = torch.zeros(1, dtype=torch.uint8, device=dev)
+        ts = []
+        for i in range(30):
+            l1.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            sol1.solve(d_S[:1], d_P[:1], d_g[:1], l1, cfg, args.precond, iters=i1, exits=x1)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        out["single_trajectory_latency"] = {"workload": f"N={N}, {args.precond}, ONE trajectory, max_iter={max_iter}",
+                                            "pcg_iters": int(i1.item()), "ms_per_linsolve": float(np.median(ts[5:])),
+                                            "us_per_pcg_iter": float(np.median(ts[5:])) * 1e3 / max(int(i1.item()), 1),
+                                            "pcg_waves": sol1.get_option("pcg_waves"), "pcg_reg_rows": sol1.get_option("pcg_reg_rows")}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, S_h, g_h, float(it_host.mean()), args.cpu_seconds)
