@@ -25,7 +25,7 @@ struct mpcg_handle {
     bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any pcg_* set_option clears this)
     int stream_bufs = -1;     // SB: -1 auto, else 0/1/2 register buffers for the streamed triples
     int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
-    int spmv_blocks_per_cu = 8;
+    int spmv_blocks_per_cu = 32;   // (sweep: profiles/r01_tune_spmv.txt)
     int spmv_mfma = 0;        // 1 = the MFMA experiment kernel for mpcg_bt_spmv
     float* ginv_scratch = nullptr;   // staging for the in-place G <- G^-1 of mpcg_form_schur
     size_t ginv_scratch_floats = 0;
