@@ -164,8 +164,13 @@ int mpcg_bd_to_csr_lowertri(mpcg_handle *h, const float *d_S, float *d_val, floa
  * rows per matrix per wave kept in registers for the whole solve; only compiled (waves, rows) pairs
  * are accepted at launch), "pcg_lds_rows" (rows per matrix per wave cached in LDS, -1 = what fits),
  * "pcg_stream_bufs", "nt_loads" (SpMV kernel), "pcg_max_wg_per_cu", "spmv_blocks_per_cu"; "pcg16_*" = the
- * same for fp16 storage.  reg/lds rows count TRIPLES of block rows per matrix per wave.
- * None of them changes results: all variants are bitwise identical (tested). */
+ * same for fp16 storage.  reg/lds rows count TRIPLES of block rows per matrix per wave.  "cluster": workgroups
+ * (= CUs) per trajectory for the cluster kernel that long horizons use (-1 auto, 0 off, G forced); it exchanges
+ * halo knots and inner-product partials between workgroups through global memory and therefore needs
+ * batch * G <= #CUs per launch (larger batches are chunked).  A cluster that cannot make progress gives up after a
+ * bounded spin: d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for that trajectory.
+ * None of the residency knobs changes results (bitwise identical, tested); the cluster kernel sums the inner
+ * products per workgroup first, so it agrees with the single-workgroup kernel to fp32 round-off. */
 int mpcg_set_option(mpcg_handle *h, const char *key, int value);
 int mpcg_get_option(const mpcg_handle *h, const char *key, int *value);
 

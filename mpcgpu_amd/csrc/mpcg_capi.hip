@@ -22,6 +22,8 @@ struct mpcg_handle {
     int reg_rows = 0;         // RT: TRIPLES of block rows per matrix per wave kept in registers (compiled variants only)
     int lds_rows = -1;        // LT: triples per matrix per wave cached in LDS; -1 = as many as fit when reg_rows > 0, else 0
     int pcg_waves16 = 8, reg_rows16 = 6, lds_rows16 = -1;   // the same knobs for fp16 matrix storage
+    int cluster = -1;         // workgroups per trajectory for the cluster kernel: 0 off, -1 auto, G > 0 forced
+    unsigned long long* cluster_scratch = nullptr;
     bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any pcg_* set_option clears this)
     int stream_bufs = -1;     // SB: -1 auto, else 0/1/2 register buffers for the streamed triples
     int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
@@ -103,9 +105,10 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
 }
 
 int mpcg_destroy(mpcg_handle* h) {
-    if (h && h->ginv_scratch) {
+    if (h && (h->ginv_scratch || h->cluster_scratch)) {
         (void)hipSetDevice(h->device);
-        (void)hipFree(h->ginv_scratch);
+        if (h->ginv_scratch) (void)hipFree(h->ginv_scratch);
+        if (h->cluster_scratch) (void)hipFree(h->cluster_scratch);
     }
     delete h;
     return MPCG_OK;
@@ -124,6 +127,10 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "pcg_reg_rows")) { h->reg_rows = value; return MPCG_OK; }     // validated at launch
     if (!strcmp(key, "pcg_lds_rows")) { h->lds_rows = value; return MPCG_OK; }
     if (!strcmp(key, "pcg_stream_bufs")) { h->stream_bufs = value; return MPCG_OK; }
+    if (!strcmp(key, "cluster")) {
+        if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");
+        h->cluster = value; return MPCG_OK;
+    }
     if (!strcmp(key, "pcg16_waves")) { h->pcg_waves16 = value; return MPCG_OK; }
     if (!strcmp(key, "pcg16_reg_rows")) { h->reg_rows16 = value; return MPCG_OK; }
     if (!strcmp(key, "pcg16_lds_rows")) { h->lds_rows16 = value; return MPCG_OK; }
@@ -147,6 +154,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "pcg_reg_rows")) { *value = h->reg_rows; return MPCG_OK; }
     if (!strcmp(key, "pcg_lds_rows")) { *value = h->lds_rows; return MPCG_OK; }
     if (!strcmp(key, "pcg_stream_bufs")) { *value = h->stream_bufs; return MPCG_OK; }
+    if (!strcmp(key, "cluster")) { *value = h->cluster; return MPCG_OK; }
     if (!strcmp(key, "pcg16_waves")) { *value = h->pcg_waves16; return MPCG_OK; }
     if (!strcmp(key, "pcg16_reg_rows")) { *value = h->reg_rows16; return MPCG_OK; }
     if (!strcmp(key, "pcg16_lds_rows")) { *value = h->lds_rows16; return MPCG_OK; }
@@ -235,8 +243,73 @@ static int stream_bufs_for(const mpcg_handle* h, int nw, int esz) {
     return all_resident ? 0 : -1;       // -1: any compiled SB > 0 (1 preferred)
 }
 
+// ---- cluster kernel: G workgroups per trajectory, everything resident, batch*G <= #CUs ----
+#define MPCG_CLUSTER_VARIANTS(X) X(8, 3) X(8, 2) X(16, 1)
+
+template <int NW, int RT>
+static int launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, int G, int lt, hipStream_t st) {
+    const size_t lds = pcg_cluster_lds_floats((int)h->N, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
+    ClusterArgs ca;
+    ca.p = a; ca.p.lds_rows = lt; ca.scratch = h->cluster_scratch; ca.G = G;
+    auto kern = pcg_cluster_kernel<NW, RT>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(h, hipMemsetAsync(h->cluster_scratch, 0, (size_t)batch * G * CL_WG_WORDS * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(kern, dim3(batch * (unsigned)G), dim3(NW * 64), lds, st, ca);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
+
+// returns 1 when the cluster kernel does not apply.
+// Auto policy (profiles/r01_latency_cluster.txt): G = ceil(#triples / 24) workgroups of 8 waves x 3 register
+// triples hold a whole trajectory.  N >= 384: always (even at full batch it beats the single-workgroup kernel,
+// 4.3 M vs 3.0 M it/s at N=512), in chunks of floor(#CUs / G) trajectories per launch because every member
+// of a cluster must be resident; 192 <= N < 384: only when the whole batch fits one launch (latency regime).
+static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
+    if (h->cluster == 0 || esz != 4) return 1;
+    constexpr int NW = 8, RT = 3;
+    const int ntr = ((int)h->N + 2) / 3;
+    int G = h->cluster;
+    const bool forced = G > 0;
+    if (!forced) {
+        if (h->N < 192) return 1;
+        G = (ntr + NW * RT - 1) / (NW * RT);
+    }
+    if (G < 2 || G > ntr || G > h->num_cus) return 1;
+    const uint32_t chunk = (uint32_t)(h->num_cus / G);
+    if (batch > chunk && (forced || h->N < 384)) return 1;
+    const int per_wg = (ntr + G - 1) / G;                // triples of the largest member
+    const int TT = (per_wg + NW - 1) / NW;
+    const int lt = TT > RT ? TT - RT : 0;
+    const size_t lds = pcg_cluster_lds_floats((int)h->N, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
+    if (lds > kLdsMax) return 1;
+    if (!h->cluster_scratch)                             // first use only (hipMalloc is not stream-ordered)
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->cluster_scratch), (size_t)h->num_cus * CL_WG_WORDS * sizeof(unsigned long long)));
+    const size_t mstride = (size_t)h->N * ROWF, vstride = (size_t)h->N * NS;
+    for (uint32_t lo = 0; lo < batch; lo += chunk) {
+        const uint32_t nb = batch - lo < chunk ? batch - lo : chunk;
+        PcgArgs c = a;
+        c.S = static_cast<const float*>(a.S) + lo * mstride;
+        c.Pinv = static_cast<const float*>(a.Pinv) + lo * mstride;
+        c.gamma = a.gamma + lo * vstride;
+        c.lambda = a.lambda + lo * vstride;
+        if (a.r_out) c.r_out = a.r_out + lo * vstride;
+        if (a.p_out) c.p_out = a.p_out + lo * vstride;
+        c.iters = a.iters + lo;
+        c.max_iter_exit = a.max_iter_exit + lo;
+        const int rc = launch_cluster_t<NW, RT>(h, c, nb, G, lt, st);
+        if (rc != MPCG_OK) return rc;
+    }
+    return MPCG_OK;
+}
+
 static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
     HIP_TRY(h, hipSetDevice(h->device));
+    {
+        const int rc = try_launch_cluster(h, a, batch, st, esz);
+        if (rc != 1) return rc;
+    }
     if (h->auto_cfg && esz == 4 && h->N > 96) {
         // long horizons: with fewer trajectories than CUs the call is a latency problem -> 8 waves (two per
         // SIMD) hide more of it (N=128, batch 1: 1.02 ms vs 1.23 ms); with the GPU full, 4 fat waves keep more

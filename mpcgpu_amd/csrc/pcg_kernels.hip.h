@@ -518,6 +518,328 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cluster variant: G workgroups (on G CUs) solve ONE trajectory together — for long horizons whose S
+// and Pinv do not fit one CU, at batches small enough for all batch*G workgroups to be co-resident
+// (the launcher enforces batch*G <= #CUs: every spin below waits for a RESIDENT peer).
+// Workgroup g owns a contiguous range of triples (all of it register/LDS resident, no stream) and
+// keeps full-length iterate vectors in LDS of which it maintains its own knots plus one halo knot
+// either side.  Per PCG iteration the workgroups exchange, through global memory:
+//   2 inner-product partials (all-to-all among the G workgroups) and 2 x 2 halo knots (neighbours).
+// Hand-off = the R2 recipe of cdna_hip_programming.md §6 G16: 8-byte {epoch, value} granules written with
+// ONE relaxed agent-scope atomic store each (sc1, write-through) and polled with relaxed agent-scope
+// loads — the tag is the flag, no fences; epochs increase by one per exchange and never repeat, the
+// scratch words are zeroed by a memset node before every launch.  Every spin is bounded: on timeout
+// the trajectory is abandoned with iters = 0xFFFFFFFF, exit flag 2.
+// The partials are summed in workgroup order by every workgroup, so all of them take the same
+// decisions, and the result is deterministic.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+constexpr int CL_WG_WORDS = 64;          // u64 words of scratch per workgroup: 2x2x14 halo + 2 partials (+pad)
+constexpr unsigned CL_SPIN_LIMIT = 1u << 22;
+
+__host__ __device__ constexpr size_t pcg_cluster_lds_floats(int N, int NW) {
+    return 2 * r4((size_t)(N + 2) * NS) + 2 * r4((size_t)N * NS) + r4(2 * (size_t)NW + 4);
+}
+
+struct ClusterArgs {
+    PcgArgs p;
+    unsigned long long* scratch;         // [batch*G][CL_WG_WORDS], zeroed before the launch
+    int G;
+};
+
+template <int NW, int RT>
+__global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArgs ca) {
+    typedef float MT;
+    typedef typename MatT<MT>::pair mpair;
+    typedef typename MatT<MT>::chunk mchunk;
+    struct Trip { mpair m[NS]; };
+    constexpr uint32_t ESZ = sizeof(MT);
+    const PcgArgs& a = ca.p;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int N = a.N;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = ca.G;
+    const int b = blockIdx.x / G;                       // trajectory
+    const int g = blockIdx.x - b * G;                   // member of its cluster
+    constexpr int NTHR = NW * 64;
+
+    float* xp = lds;
+    float* xr = xp + r4((size_t)(N + 2) * NS);
+    float* lam = xr + r4((size_t)(N + 2) * NS);
+    float* tmp = lam + r4((size_t)N * NS);
+    float* red_v = tmp + r4((size_t)N * NS);            // [NW] wave partials of v
+    float* red_e = red_v + NW;                          // [NW] wave partials of eta
+    float* bc = red_v + 2 * NW;                         // [4] broadcast cell: total, timeout flag
+    mchunk* mc_base = reinterpret_cast<mchunk*>(red_v + r4(2 * (size_t)NW + 4));
+
+    const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;
+    const rsrc_t rS = make_rsrc(static_cast<const MT*>(a.S) + (size_t)b * mstride, (uint32_t)(mstride * ESZ));
+    const rsrc_t rP = make_rsrc(static_cast<const MT*>(a.Pinv) + (size_t)b * mstride, (uint32_t)(mstride * ESZ));
+    const float* gam = a.gamma + (size_t)b * vstride;
+    float* lam_g = a.lambda + (size_t)b * vstride;
+    gu64* my_words = (gu64*)ca.scratch + (size_t)blockIdx.x * CL_WG_WORDS;
+    gu64* cl_words = (gu64*)ca.scratch + (size_t)b * G * CL_WG_WORDS;      // the cluster's block
+
+    const bool active = lane < 63;
+    const int ls = active ? lane / 21 : 0;
+    const int lrem = active ? lane - 21 * ls : 0;
+    const int lrho = lrem / 7;
+    const int lq = lrem - 7 * lrho;
+    const bool head = lane < 21;
+    const uint32_t lane_byte = (uint32_t)(ls * 196 + lq * 2) * ESZ;
+
+    // this workgroup's triples [t0, t1) and knots [k0, k1)
+    const int NTR = (N + 2) / 3;
+    const int t0 = (int)(((long)g * NTR) / G), t1 = (int)(((long)(g + 1) * NTR) / G);
+    const int k0 = 3 * t0, k1 = min(3 * t1, N);
+    const int TT = max(0, (t1 - t0 - w + NW - 1) / NW);   // this wave's triples: tr = t0 + w + NW*j  (launcher: TT <= RT + LT)
+    const int LT = a.lds_rows;
+
+    auto trip_off = [&](int j, int cols) -> uint32_t {
+        const int k = 3 * (t0 + w + NW * j) + lrho;
+        const bool ok = active && j < TT && k < N && !(ls == 0 && k == 0) && !(ls == 2 && k == N - 1) && (cols == 3 || ls == 1);
+        return ok ? (uint32_t)k * (ROWF * ESZ) + lane_byte : OOB_OFF;
+    };
+    auto load_trip = [&](rsrc_t M, int j, int cols) -> Trip {
+        const uint32_t off = trip_off(j, cols);
+        Trip t;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) t.m[u] = MatT<MT>::load(M, off + (NS * ESZ) * u);
+        return t;
+    };
+    Trip regS[RT > 0 ? RT : 1], regP[RT > 0 ? RT : 1];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+        regS[j] = load_trip(rS, j, 3);
+        regP[j] = load_trip(rP, j, a.pcols);
+    }
+    mchunk* mc = mc_base + (size_t)w * 2 * LT * 64 * 7;
+    for (int j = 0; j < LT; ++j) {
+        const Trip ta = load_trip(rS, RT + j, 3);
+        const Trip tb = load_trip(rP, RT + j, a.pcols);
+        mchunk* d0 = mc + ((size_t)j * 64 + lane) * 7;
+        mchunk* d1 = mc + ((size_t)(LT + j) * 64 + lane) * 7;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            d0[u] = mchunk{ta.m[2 * u].x, ta.m[2 * u].y, ta.m[2 * u + 1].x, ta.m[2 * u + 1].y};
+            d1[u] = mchunk{tb.m[2 * u].x, tb.m[2 * u].y, tb.m[2 * u + 1].x, tb.m[2 * u + 1].y};
+        }
+    }
+    auto lds_trip = [&](int mat, int j) -> Trip {
+        const mchunk* src = mc + ((size_t)(mat * LT + j) * 64 + lane) * 7;
+        Trip t;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const mchunk v = src[u];
+            t.m[2 * u] = mpair{v.x, v.y};
+            t.m[2 * u + 1] = mpair{v.z, v.w};
+        }
+        return t;
+    };
+
+    // ---- stage FULL vectors (every member reads all of lambda0 / gamma: no exchange needed for the setup SpMV) ----
+    for (int e = tid; e < (N + 2) * NS; e += NTHR) { xp[e] = 0.f; xr[e] = 0.f; }
+    lds_barrier();
+    for (int e = tid; e < N * NS; e += NTHR) {
+        const float l0 = lam_g[e];
+        xp[NS + e] = l0;
+        lam[e] = l0;
+        xr[NS + e] = gam[e];
+    }
+    lds_barrier();
+
+    struct Pend { f2 a0, a1, a2, d; int k; bool valid; };
+    auto begin = [&](const Trip& t, int j, const float* xv, const float* dv) -> Pend {
+        Pend q;
+        const int k = 3 * (t0 + w + NW * j) + lrho;
+        q.valid = j < TT && k < N;
+        q.k = q.valid ? k : 0;
+        const f2* x2 = reinterpret_cast<const f2*>(xv + (q.k + ls) * NS);
+        f2 acc = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const f2 x = x2[u];
+            MatT<MT>::fma(acc, t.m[2 * u], x.x);
+            MatT<MT>::fma(acc1, t.m[2 * u + 1], x.y);
+        }
+        acc += acc1;
+        q.d = *reinterpret_cast<const f2*>(dv + (q.k + 1) * NS + 2 * lq);
+        q.a0 = acc;
+        q.a1.x = __shfl_down(acc.x, 21);
+        q.a1.y = __shfl_down(acc.y, 21);
+        q.a2.x = __shfl_down(acc.x, 42);
+        q.a2.y = __shfl_down(acc.y, 42);
+        return q;
+    };
+    auto finish = [&](const Pend& q, float& part) {
+        if (head && q.valid) {
+            const f2 y = (q.a0 + q.a1) + q.a2;
+            *reinterpret_cast<f2*>(tmp + q.k * NS + 2 * lq) = y;
+            part += fmaf(y.y, q.d.y, y.x * q.d.x);
+        }
+    };
+    auto pass = [&](auto which, const float* xv, const float* dv) -> float {
+        constexpr int MAT = decltype(which)::value;
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < RT; ++j) { const Pend q = begin(MAT ? regP[j] : regS[j], j, xv, dv); finish(q, part); }
+        for (int j = 0; j < LT; ++j) { const Trip tt = lds_trip(MAT, j); const Pend q = begin(tt, RT + j, xv, dv); finish(q, part); }
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1"
+            : "+v"(part));
+        const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
+        return part + hi;
+    };
+    using MatS = std::integral_constant<int, 0>;
+    using MatP = std::integral_constant<int, 1>;
+
+    unsigned epoch = 0;
+    bool failed = false;                               // uniform across the workgroup (published through LDS)
+    // all-to-all sum of one float per member, in member order; called by all threads, result uniform.
+    // slot: 0 / 1 (two words so that consecutive reductions never share a word)
+    auto cluster_sum = [&](float* red, int slot) -> float {
+        lds_barrier();                                  // wave partials red[0..NW) are in LDS
+        ++epoch;
+        if (w == 0) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) s += red[i];
+            if (lane == 0)
+                __hip_atomic_store(my_words + 56 + slot, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, s),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long x = 0;
+            unsigned spins = 0;
+            bool ok;
+            do {
+                ok = true;
+                if (lane < G) {
+                    x = __hip_atomic_load(cl_words + (size_t)lane * CL_WG_WORDS + 56 + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (unsigned)(x >> 32) == epoch;
+                }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+            } while (++spins < CL_SPIN_LIMIT);
+            float tot = 0.f;
+            const int bits = (int)(unsigned)x;
+            for (int i = 0; i < G; ++i) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, i));
+            if (lane == 0) { bc[0] = tot; bc[1] = (spins >= CL_SPIN_LIMIT) ? 1.f : 0.f; }
+        }
+        lds_barrier();
+        if (bc[1] != 0.f) failed = true;
+        return bc[0];
+    };
+    // publish this member's first / last knot of `v` (padded vector) and fetch the neighbours' into the halo knots
+    auto halo_exchange = [&](float* v, int which) {
+        lds_barrier();                                  // own knots of v are written
+        ++epoch;
+        if (w == 0) {
+            if (lane < 28) {                            // lanes 0..13: first knot (side 0), 14..27: last knot (side 1)
+                const int side = lane / NS, i = lane - side * NS;
+                const int k = side ? k1 - 1 : k0;
+                const float val = v[(k + 1) * NS + i];
+                __hip_atomic_store(my_words + which * 28 + lane, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, val),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // lanes 0..13: left neighbour's LAST knot -> knot k0-1 ; lanes 14..27: right neighbour's FIRST knot -> knot k1
+            const int side = lane / NS, i = lane - side * NS;
+            const bool want = lane < 28 && (side ? g < G - 1 : g > 0) && k1 > k0;
+            const gu64* src = cl_words + (size_t)(side ? g + 1 : g - 1) * CL_WG_WORDS + which * 28 + (side ? 0 : NS) + i;
+            unsigned long long x = 0;
+            unsigned spins = 0;
+            bool ok;
+            do {
+                ok = true;
+                if (want) {
+                    x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (unsigned)(x >> 32) == epoch;
+                }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+            } while (++spins < CL_SPIN_LIMIT);
+            if (want) v[((side ? k1 : k0 - 1) + 1) * NS + i] = __builtin_bit_cast(float, (unsigned)x);
+            if (lane == 0) bc[1] = (spins >= CL_SPIN_LIMIT) ? 1.f : 0.f;
+        }
+        lds_barrier();
+        if (bc[1] != 0.f) failed = true;
+    };
+
+    // own vector items: float2 #e, e in [7*k0, 7*k1)
+    const int e_lo = (NS / 2) * k0, e_hi = (NS / 2) * k1;
+    f2* xp2 = reinterpret_cast<f2*>(xp + NS);
+    f2* xr2 = reinterpret_cast<f2*>(xr + NS);
+    f2* lam2 = reinterpret_cast<f2*>(lam);
+    const f2* tmp2 = reinterpret_cast<const f2*>(tmp);
+
+    // ---- setup: r = gamma - S lambda0 (own knots) ; halo r ; r~ = Pinv r ; eta ; p = r~ ; halo p ----
+    (void)pass(MatS{}, xp, xp);
+    lds_barrier();
+    for (int e = e_lo + tid; e < e_hi; e += NTHR) xr2[e] = xr2[e] - tmp2[e];
+    halo_exchange(xr, 1);
+    {
+        const float part = pass(MatP{}, xr, xr);
+        if (lane == 0) red_e[w] = part;
+    }
+    float eta = cluster_sum(red_e, 1);
+    for (int e = e_lo + tid; e < e_hi; e += NTHR) xp2[e] = tmp2[e];
+    halo_exchange(xp, 0);
+
+    uint32_t iters = 0;
+    uint32_t max_iter_exit = 1;
+    if (failed) {
+        iters = 0xFFFFFFFFu; max_iter_exit = 2;
+    } else if (fabsf(eta) < a.exit_tol) {
+        max_iter_exit = 0;
+    } else {
+        for (int it = 0; it < a.max_iter; ++it) {
+            {
+                const float part = pass(MatS{}, xp, xp);
+                if (lane == 0) red_v[w] = part;
+            }
+            const float alpha = eta / cluster_sum(red_v, 0);
+            for (int e = e_lo + tid; e < e_hi; e += NTHR) {
+                lam2[e] = lam2[e] + alpha * xp2[e];
+                xr2[e] = xr2[e] - alpha * tmp2[e];
+            }
+            halo_exchange(xr, 1);
+            {
+                const float part = pass(MatP{}, xr, xr);
+                if (lane == 0) red_e[w] = part;
+            }
+            const float eta_new = cluster_sum(red_e, 1);
+            if (failed) { iters = 0xFFFFFFFFu; max_iter_exit = 2; break; }
+            iters = (uint32_t)(it + 1);
+            if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
+            const float beta = eta_new / eta;
+            for (int e = e_lo + tid; e < e_hi; e += NTHR) xp2[e] = tmp2[e] + beta * xp2[e];
+            eta = eta_new;
+            halo_exchange(xp, 0);
+            if (failed) { iters = 0xFFFFFFFFu; max_iter_exit = 2; break; }
+        }
+    }
+
+    // ---- write back own knots ----
+    for (int e = NS * k0 + tid; e < NS * k1; e += NTHR) {
+        lam_g[e] = lam[e];
+        if (a.r_out) a.r_out[(size_t)b * vstride + e] = xr[NS + e];
+        if (a.p_out) a.p_out[(size_t)b * vstride + e] = xp[NS + e];
+    }
+    if (tid == 0 && g == 0) {
+        a.iters[b] = iters;
+        a.max_iter_exit[b] = (uint8_t)max_iter_exit;
+    }
+}
+
 // fp32 -> fp16 copy of a bd-layout matrix (round to nearest even), 8 elements per thread.
 __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t count) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
