@@ -263,9 +263,12 @@ static int launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, in
 
 // returns 1 when the cluster kernel does not apply.
 // Auto policy (profiles/r01_latency_cluster.txt): G = ceil(#triples / 24) workgroups of 8 waves x 3 register
-// triples hold a whole trajectory.  N >= 384: always (even at full batch it beats the single-workgroup kernel,
-// 4.3 M vs 3.0 M it/s at N=512), in chunks of floor(#CUs / G) trajectories per launch because every member
-// of a cluster must be resident; 192 <= N < 384: only when the whole batch fits one launch (latency regime).
+// triples hold a whole trajectory; used for every horizon one workgroup cannot hold (N > 96).
+//   N >= 256: always — even at full batch it beats the single-workgroup kernel (N=512: 5.1 M vs 3.0 M it/s,
+//             N=256: 11.0 M vs 9.7 M) — in chunks of floor(#CUs / G) trajectories per launch, because every
+//             member of a cluster must be resident;
+//   96 < N < 256: when the whole batch fits one launch, batch * G <= #CUs (N=128, batch 1: 0.70 ms vs 1.02 ms;
+//             batch 128: 23.6 M vs 20.0 M it/s); larger batches run the single-workgroup kernel (36 M it/s).
 static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
     if (h->cluster == 0 || esz != 4) return 1;
     constexpr int NW = 8, RT = 3;
@@ -273,12 +276,12 @@ static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
     int G = h->cluster;
     const bool forced = G > 0;
     if (!forced) {
-        if (h->N < 192) return 1;
+        if (h->N <= 96) return 1;
         G = (ntr + NW * RT - 1) / (NW * RT);
     }
     if (G < 2 || G > ntr || G > h->num_cus) return 1;
     const uint32_t chunk = (uint32_t)(h->num_cus / G);
-    if (batch > chunk && (forced || h->N < 384)) return 1;
+    if (batch > chunk && (forced || h->N < 256)) return 1;
     const int per_wg = (ntr + G - 1) / G;                // triples of the largest member
     const int TT = (per_wg + NW - 1) / NW;
     const int lt = TT > RT ? TT - RT : 0;

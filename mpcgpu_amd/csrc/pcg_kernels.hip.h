@@ -525,7 +525,9 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
 // Workgroup g owns a contiguous range of triples (all of it register/LDS resident, no stream) and
 // keeps full-length iterate vectors in LDS of which it maintains its own knots plus one halo knot
 // either side.  Per PCG iteration the workgroups exchange, through global memory:
-//   2 inner-product partials (all-to-all among the G workgroups) and 2 x 2 halo knots (neighbours).
+//   2 inner-product partials (all-to-all among the G workgroups; the only two cluster-wide waits) and 2 x 2
+//   halo knots (neighbours; published right after the vector update, fetched inside the next pass by the one
+//   wave that needs them, so their latency hides behind the interior block rows).
 // Hand-off = the R2 recipe of cdna_hip_programming.md §6 G16: 8-byte {epoch, value} granules written with
 // ONE relaxed agent-scope atomic store each (sc1, write-through) and polled with relaxed agent-scope
 // loads — the tag is the flag, no fences; epochs increase by one per exchange and never repeat, the
@@ -681,12 +683,40 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
             part += fmaf(y.y, q.d.y, y.x * q.d.x);
         }
     };
-    auto pass = [&](auto which, const float* xv, const float* dv) -> float {
+    // The halo knots of the operand arrive DURING the pass: the wave that owns the first (last) triple of this
+    // member polls the left (right) neighbour's granules just before that triple and drops them into the halo
+    // knot of its LDS vector — only that wave reads them, and LDS operations of one wave execute in order, so no
+    // workgroup barrier is involved.  Triple j = 0 is processed last so that the left halo has had time to land.
+    auto fetch_halo = [&](float* v, int which, int side, unsigned ep) {
+        const int i = lane;                             // lanes 0..13: the 14 entries of the neighbour's boundary knot
+        const gu64* src = cl_words + (size_t)(side ? g + 1 : g - 1) * CL_WG_WORDS + which * 28 + (side ? 0 : NS) + (i < NS ? i : 0);
+        unsigned long long x = 0;
+        unsigned spins = 0;
+        bool ok;
+        do {
+            ok = true;
+            if (i < NS) {
+                x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (unsigned)(x >> 32) == ep;
+            }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+        } while (++spins < CL_SPIN_LIMIT);
+        if (i < NS) v[((side ? k1 : k0 - 1) + 1) * NS + i] = __builtin_bit_cast(float, (unsigned)x);
+        if (spins >= CL_SPIN_LIMIT && lane == 0) bc[1] = 1.f;          // sticky timeout flag
+    };
+    auto pass = [&](auto which, float* xv, const float* dv, unsigned ep) -> float {
         constexpr int MAT = decltype(which)::value;
         float part = 0.f;
+        auto halos_for = [&](int j) {                   // wave-uniform
+            const int tr = t0 + w + NW * j;
+            if (j < TT && tr == t1 - 1 && g < G - 1) fetch_halo(xv, MAT, 1, ep);
+            if (j < TT && tr == t0 && g > 0) fetch_halo(xv, MAT, 0, ep);
+        };
 #pragma unroll
-        for (int j = 0; j < RT; ++j) { const Pend q = begin(MAT ? regP[j] : regS[j], j, xv, dv); finish(q, part); }
-        for (int j = 0; j < LT; ++j) { const Trip tt = lds_trip(MAT, j); const Pend q = begin(tt, RT + j, xv, dv); finish(q, part); }
+        for (int j = 1; j < RT; ++j) { halos_for(j); const Pend q = begin(MAT ? regP[j] : regS[j], j, xv, dv); finish(q, part); }
+        for (int j = 0; j < LT; ++j) { halos_for(RT + j); const Trip tt = lds_trip(MAT, j); const Pend q = begin(tt, RT + j, xv, dv); finish(q, part); }
+        if constexpr (RT > 0) { halos_for(0); const Pend q = begin(MAT ? regP[0] : regS[0], 0, xv, dv); finish(q, part); }
         asm volatile(
             "s_nop 1\n\t"
             "v_add_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -733,45 +763,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
             float tot = 0.f;
             const int bits = (int)(unsigned)x;
             for (int i = 0; i < G; ++i) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, i));
-            if (lane == 0) { bc[0] = tot; bc[1] = (spins >= CL_SPIN_LIMIT) ? 1.f : 0.f; }
+            if (lane == 0) { bc[0] = tot; if (spins >= CL_SPIN_LIMIT) bc[1] = 1.f; }
         }
         lds_barrier();
         if (bc[1] != 0.f) failed = true;
         return bc[0];
     };
-    // publish this member's first / last knot of `v` (padded vector) and fetch the neighbours' into the halo knots
-    auto halo_exchange = [&](float* v, int which) {
+    // publish this member's first / last knot of `v` (padded vector) for the neighbours; returns the epoch the
+    // consumers must wait for.  Called by all threads right after the element-wise update of the own knots.
+    auto publish_halo = [&](const float* v, int which) -> unsigned {
         lds_barrier();                                  // own knots of v are written
         ++epoch;
-        if (w == 0) {
-            if (lane < 28) {                            // lanes 0..13: first knot (side 0), 14..27: last knot (side 1)
-                const int side = lane / NS, i = lane - side * NS;
-                const int k = side ? k1 - 1 : k0;
-                const float val = v[(k + 1) * NS + i];
-                __hip_atomic_store(my_words + which * 28 + lane, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, val),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            // lanes 0..13: left neighbour's LAST knot -> knot k0-1 ; lanes 14..27: right neighbour's FIRST knot -> knot k1
+        if (w == 0 && lane < 28) {                      // lanes 0..13: first knot (side 0), 14..27: last knot (side 1)
             const int side = lane / NS, i = lane - side * NS;
-            const bool want = lane < 28 && (side ? g < G - 1 : g > 0) && k1 > k0;
-            const gu64* src = cl_words + (size_t)(side ? g + 1 : g - 1) * CL_WG_WORDS + which * 28 + (side ? 0 : NS) + i;
-            unsigned long long x = 0;
-            unsigned spins = 0;
-            bool ok;
-            do {
-                ok = true;
-                if (want) {
-                    x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = (unsigned)(x >> 32) == epoch;
-                }
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(1);
-            } while (++spins < CL_SPIN_LIMIT);
-            if (want) v[((side ? k1 : k0 - 1) + 1) * NS + i] = __builtin_bit_cast(float, (unsigned)x);
-            if (lane == 0) bc[1] = (spins >= CL_SPIN_LIMIT) ? 1.f : 0.f;
+            const int k = side ? k1 - 1 : k0;
+            const float val = v[(k + 1) * NS + i];
+            __hip_atomic_store(my_words + which * 28 + lane, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, val),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        lds_barrier();
-        if (bc[1] != 0.f) failed = true;
+        return epoch;
     };
 
     // own vector items: float2 #e, e in [7*k0, 7*k1)
@@ -781,18 +791,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
     f2* lam2 = reinterpret_cast<f2*>(lam);
     const f2* tmp2 = reinterpret_cast<const f2*>(tmp);
 
-    // ---- setup: r = gamma - S lambda0 (own knots) ; halo r ; r~ = Pinv r ; eta ; p = r~ ; halo p ----
-    (void)pass(MatS{}, xp, xp);
+    // ---- setup: r = gamma - S lambda0 (own knots) ; r~ = Pinv r ; eta ; p = r~ ----
+    if (tid == 0) bc[1] = 0.f;
+    {   // the setup SpMV has its operand (lambda0) complete in every member: no halo to wait for (epoch 0 never matches,
+        // so make the fetch a no-op by pretending to be a single-member cluster for this pass)
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < RT; ++j) { const Pend q = begin(regS[j], j, xp, xp); finish(q, part); }
+        for (int j = 0; j < LT; ++j) { const Trip tt = lds_trip(0, j); const Pend q = begin(tt, RT + j, xp, xp); finish(q, part); }
+    }
     lds_barrier();
     for (int e = e_lo + tid; e < e_hi; e += NTHR) xr2[e] = xr2[e] - tmp2[e];
-    halo_exchange(xr, 1);
+    unsigned ep_r = publish_halo(xr, 1);
     {
-        const float part = pass(MatP{}, xr, xr);
+        const float part = pass(MatP{}, xr, xr, ep_r);
         if (lane == 0) red_e[w] = part;
     }
     float eta = cluster_sum(red_e, 1);
     for (int e = e_lo + tid; e < e_hi; e += NTHR) xp2[e] = tmp2[e];
-    halo_exchange(xp, 0);
+    unsigned ep_p = publish_halo(xp, 0);
 
     uint32_t iters = 0;
     uint32_t max_iter_exit = 1;
@@ -803,7 +820,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
     } else {
         for (int it = 0; it < a.max_iter; ++it) {
             {
-                const float part = pass(MatS{}, xp, xp);
+                const float part = pass(MatS{}, xp, xp, ep_p);
                 if (lane == 0) red_v[w] = part;
             }
             const float alpha = eta / cluster_sum(red_v, 0);
@@ -811,9 +828,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
                 lam2[e] = lam2[e] + alpha * xp2[e];
                 xr2[e] = xr2[e] - alpha * tmp2[e];
             }
-            halo_exchange(xr, 1);
+            ep_r = publish_halo(xr, 1);
             {
-                const float part = pass(MatP{}, xr, xr);
+                const float part = pass(MatP{}, xr, xr, ep_r);
                 if (lane == 0) red_e[w] = part;
             }
             const float eta_new = cluster_sum(red_e, 1);
@@ -823,8 +840,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
             const float beta = eta_new / eta;
             for (int e = e_lo + tid; e < e_hi; e += NTHR) xp2[e] = tmp2[e] + beta * xp2[e];
             eta = eta_new;
-            halo_exchange(xp, 0);
-            if (failed) { iters = 0xFFFFFFFFu; max_iter_exit = 2; break; }
+            ep_p = publish_halo(xp, 0);
         }
     }
 
