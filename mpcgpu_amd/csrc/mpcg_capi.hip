@@ -57,7 +57,7 @@ extern "C" {
 int mpcg_abi_version(void) { return MPCG_ABI_VERSION; }
 
 const char* mpcg_build_info(void) {
-    return "libmpcg_hip gfx950 fp32 n=14 (persistent per-trajectory PCG, wave64 7x7 float4 block mapping)";
+    return "libmpcg_hip gfx950 fp32 n=14 (persistent per-trajectory and clustered PCG, wave64 row-triple mapping)";
 }
 
 size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
@@ -100,6 +100,13 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     if (knot_points <= 144) { h->pcg_waves16 = 8; h->reg_rows16 = 6; }      // fp16 storage: <= 48 triples all in registers
     else { h->pcg_waves16 = 4; h->reg_rows16 = 12; }
     h->lds_rows16 = -1;
+    // hand-off cells of the cluster kernel (512 B per CU), allocated here so that every solve is pure stream work
+    // and can be captured into a hipGraph
+    if (hipSetDevice(device) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&h->cluster_scratch), (size_t)h->num_cus * CL_WG_WORDS * sizeof(unsigned long long)) != hipSuccess) {
+        delete h;
+        return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the cluster scratch");
+    }
     *out = h;
     return MPCG_OK;
 }
@@ -287,8 +294,6 @@ static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
     const int lt = TT > RT ? TT - RT : 0;
     const size_t lds = pcg_cluster_lds_floats((int)h->N, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
     if (lds > kLdsMax) return 1;
-    if (!h->cluster_scratch)                             // first use only (hipMalloc is not stream-ordered)
-        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->cluster_scratch), (size_t)h->num_cus * CL_WG_WORDS * sizeof(unsigned long long)));
     const size_t mstride = (size_t)h->N * ROWF, vstride = (size_t)h->N * NS;
     for (uint32_t lo = 0; lo < batch; lo += chunk) {
         const uint32_t nb = batch - lo < chunk ? batch - lo : chunk;
