@@ -83,25 +83,10 @@ def cpu_baseline(N, S_host, g_host, mean_iters, budget_s=12.0):
     dt_pcg = time.perf_counter() - t1
     solves_per_s = cnt / dt
     # the same port batch-parallel over every host core: one solver workspace per thread, trajectories
-    # dealt round-robin; ctypes drops the GIL inside the C call
-    import threading
+    # dealt round-robin (POSIX threads inside oracle/mpcg_oracle.c)
     ncore = os.cpu_count() or 1
-    stop_at = time.perf_counter() + min(4.0, budget_s)
-    counts = [0] * ncore
-
-    def work(tid):
-        Lt = orc.LdlSolver(N, np.float32)
-        b = tid % ns
-        while time.perf_counter() < stop_at:
-            Lt.solve(vals[b], g_host[b])
-            counts[tid] += 1
-            b = (b + ncore) % ns
-
-    t3 = time.perf_counter()
-    th = [threading.Thread(target=work, args=(i,)) for i in range(ncore)]
-    [t.start() for t in th]
-    [t.join() for t in th]
-    mt_solves_per_s = sum(counts) / (time.perf_counter() - t3)
+    mt_cnt, mt_el = L.throughput(np.stack(vals), np.ascontiguousarray(g_host[:ns], np.float32), ncore, min(4.0, budget_s))
+    mt_solves_per_s = mt_cnt / mt_el
     # BASELINE config 1: the reference's own CPU-runnable case, N=32 (include/common/settings.cuh:5-7 default)
     k32 = synth.make_kkt(32, 8, 32)
     S32, _, g32 = synth.form_schur(k32)

@@ -134,3 +134,81 @@ int orc_bt_direct_solve_f64(int n, int N, const double *S, const double *b, doub
     free(Dk);
     return rc;
 }
+
+/* Batch-parallel timing harness for bench.py's cpu_baseline "all_cores" leg: `nthreads`
+ * POSIX threads, each with its own QDLDL-style workspace, run numeric factor + solve (the per-linsolve work of
+ * include/qdldl/sqp.cuh:22-49) over the `ns` given systems round-robin for `seconds`.  Returns the number of
+ * completed solves (negative on a zero pivot / allocation failure).  Same arithmetic as
+ * orc_ldl_solve_schur_f32 — this only adds the threads. */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+    int An, nnz, ns, tid, nthreads, sumLnz;
+    const int *Ap, *Ai, *Lnz, *etree;
+    const float *vals, *bs;
+    double seconds;
+    long done;
+} orc_mt_job;
+
+static double orc_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *orc_mt_worker(void *arg)
+{
+    orc_mt_job *j = (orc_mt_job *)arg;
+    const int An = j->An;
+    int *Lp = malloc(sizeof(int) * (size_t)(An + 1)), *Li = malloc(sizeof(int) * (size_t)(j->sumLnz + 1));
+    int *iwork = malloc(sizeof(int) * 3 * (size_t)An);
+    float *Lx = malloc(sizeof(float) * (size_t)(j->sumLnz + 1)), *D = malloc(sizeof(float) * (size_t)An);
+    float *Dinv = malloc(sizeof(float) * (size_t)An), *fwork = malloc(sizeof(float) * (size_t)An);
+    float *x = malloc(sizeof(float) * (size_t)An);
+    unsigned char *bwork = malloc((size_t)An);
+    j->done = -1;
+    if (Lp && Li && iwork && Lx && D && Dinv && fwork && x && bwork) {
+        long cnt = 0;
+        int b = j->tid % j->ns;
+        const double t_end = orc_now() + j->seconds;
+        while (orc_now() < t_end) {
+            int rc = orc_ldl_solve_schur_f32(An, j->Ap, j->Ai, j->vals + (size_t)b * j->nnz, j->bs + (size_t)b * An, x,
+                                             Lp, Li, Lx, D, Dinv, j->Lnz, j->etree, bwork, iwork, fwork);
+            if (rc < 0) { cnt = -1; break; }
+            ++cnt;
+            b = (b + j->nthreads) % j->ns;
+        }
+        j->done = cnt;
+    }
+    free(Lp); free(Li); free(iwork); free(Lx); free(D); free(Dinv); free(fwork); free(x); free(bwork);
+    return NULL;
+}
+
+long orc_ldl_throughput_f32(int An, const int *Ap, const int *Ai, const int *Lnz, const int *etree, int sumLnz,
+                            const float *vals, const float *bs, int ns, int nthreads, double seconds,
+                            double *elapsed_out)
+{
+    if (nthreads < 1 || ns < 1) return -1;
+    pthread_t *th = malloc(sizeof(pthread_t) * (size_t)nthreads);
+    orc_mt_job *jobs = malloc(sizeof(orc_mt_job) * (size_t)nthreads);
+    if (!th || !jobs) { free(th); free(jobs); return -1; }
+    const double t0 = orc_now();
+    int started = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        orc_mt_job j = { An, Ap[An], ns, t, nthreads, sumLnz, Ap, Ai, Lnz, etree, vals, bs, seconds, 0 };
+        jobs[t] = j;
+        if (pthread_create(&th[t], NULL, orc_mt_worker, &jobs[t]) != 0) break;
+        ++started;
+    }
+    long total = 0;
+    for (int t = 0; t < started; ++t) {
+        pthread_join(th[t], NULL);
+        if (jobs[t].done < 0) total = -1;
+        else if (total >= 0) total += jobs[t].done;
+    }
+    if (elapsed_out) *elapsed_out = orc_now() - t0;
+    free(th); free(jobs);
+    return started == nthreads ? total : -1;
+}

@@ -34,6 +34,9 @@ ORC_DECL(double, f64)
 int  orc_ldl_etree(int n, const int *Ap, const int *Ai, int *work, int *Lnz, int *etree);
 void orc_prep_csr(int n, int N, int *col_ptr, int *row_ind);
 int  orc_bt_direct_solve_f64(int n, int N, const double *S, const double *b, double *x);
+long orc_ldl_throughput_f32(int An, const int *Ap, const int *Ai, const int *Lnz, const int *etree, int sumLnz,
+                            const float *vals, const float *bs, int ns, int nthreads, double seconds,
+                            double *elapsed_out);
 
 #ifdef __cplusplus
 }

@@ -169,3 +169,19 @@ class LdlSolver:
             raise FloatingPointError("zero pivot in LDL^T")
         self.positive_D = rc
         return x
+
+    def throughput(self, vals, bs, nthreads, seconds):
+        """(solves, elapsed s) of `nthreads` POSIX threads doing factor+solve over the given systems
+        (float32 only; bench.py cpu_baseline all-cores leg)."""
+        assert self.dtype == np.float32
+        vals = np.ascontiguousarray(vals, np.float32)
+        bs = np.ascontiguousarray(bs, np.float32)
+        f = lib().orc_ldl_throughput_f32
+        f.restype = C.c_long
+        el = C.c_double(0)
+        cnt = f(self.An, _p(self.Ap, C.c_int), _p(self.Ai, C.c_int), _p(self.Lnz, C.c_int), _p(self.etree, C.c_int),
+                C.c_int(int(self.sumLnz)), _p(vals, C.c_float), _p(bs, C.c_float), C.c_int(vals.shape[0]),
+                C.c_int(int(nthreads)), C.c_double(float(seconds)), C.byref(el))
+        if cnt < 0:
+            raise RuntimeError("orc_ldl_throughput_f32 failed")
+        return int(cnt), el.value

@@ -176,3 +176,14 @@ def test_bd_helpers_roundtrip(orc):
     out = np.zeros(n * n, np.float32)
     lib.orc_load_block_bd_f32(n, N, bd.ctypes.data_as(f32p), out.ctypes.data_as(f32p), 2, 1, 1)
     np.testing.assert_array_equal(out.reshape(n, n), -blk.reshape(n, n).T)
+
+
+def test_ldl_throughput_harness_runs_threads(orc):
+    """bench.py's all-cores cpu_baseline leg: the pthread harness completes solves on every thread."""
+    N = 8
+    k = synth.make_kkt(N, 3, 99)
+    S, P, g = synth.form_schur(k, dtype=np.float32)
+    L = orc.LdlSolver(N, np.float32)
+    vals = np.stack([orc.bd_to_csr_lowertri(S[b], N) for b in range(3)])
+    cnt, el = L.throughput(vals, g, 2, 0.2)
+    assert cnt >= 2 and 0.15 < el < 5.0
