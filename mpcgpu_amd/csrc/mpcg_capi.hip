@@ -554,4 +554,13 @@ int mpcg_bd_to_csr_lowertri(mpcg_handle* h, const float* d_S, float* d_val, floa
     return MPCG_OK;
 }
 
+#ifdef MPCG_PROF
+// diagnostic build only (tools/prof_phases.py): the s_memtime stamps of workgroup 0
+int mpcg_debug_read_prof(long long* out, int count) {
+    if (!out || count < 0 || count > 16 * 32) return MPCG_ERR_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return MPCG_ERR_HIP;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mpcg::g_pcg_prof), sizeof(long long) * (size_t)count) == hipSuccess ? MPCG_OK : MPCG_ERR_HIP;
+}
+#endif
+
 }  // extern "C"

@@ -214,6 +214,22 @@ template <> struct MatT<_Float16> {
     }
 };
 
+// Phase timing for tools/prof_phases.py (diagnostic build only, -DMPCG_PROF): workgroup 0 stamps s_memtime at
+// the phase boundaries of one iteration, one row of 32 stamps per wave.
+#ifdef MPCG_PROF
+__device__ long long g_pcg_prof[16 * 32];
+#define MPCG_STAMP(i)                                                                                   \
+    do {                                                                                                \
+        if (prof_on) {                                                                                  \
+            long long t_;                                                                               \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            if (lane == 0) g_pcg_prof[w * 32 + (i)] = t_;                                               \
+        }                                                                                               \
+    } while (0)
+#else
+#define MPCG_STAMP(i) do {} while (0)
+#endif
+
 // RT = triples per matrix per wave held in registers.  SB = register buffers of the stream:
 // 2 = ping-pong (one triple ahead), 1 = single buffer refilled as soon as it has been consumed
 // (28 VGPRs cheaper: one more resident triple), 0 = no stream at all (launcher guarantees that every
@@ -351,6 +367,9 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
     //           block-0 lanes, d read                                                   (branch-free)
     //   finish: left + diagonal + right, tmp[k] = M[k,:] x, part += d[k] . (M[k,:] x)
     struct Pend { f2 a0, a1, a2, d; int k; bool valid; };
+#ifdef MPCG_PROF
+    bool prof_on = false;
+#endif
     auto begin = [&](const Trip& t, int j, const float* xv, const float* dv) -> Pend {
         Pend q;
         const int k = 3 * (w + NW * j) + lrho;
@@ -384,6 +403,7 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
     auto pass = [&](auto which, const float* xv, const float* dv) -> float {
         constexpr int MAT = decltype(which)::value;       // 0: S, 1: Pinv (must alternate, S first)
         float part = 0.f;
+        MPCG_STAMP(MAT * 8 + 0);
         // registers
 #pragma unroll
         for (int j = 0; j + 1 < RT; j += 2) {
@@ -396,12 +416,14 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
             const Pend p0 = begin(MAT ? regP[RT - 1] : regS[RT - 1], RT - 1, xv, dv);
             finish(p0, part);
         }
+        MPCG_STAMP(MAT * 8 + 1);
         // LDS cache
         for (int j = 0; j < LT; ++j) {
             const Trip t0 = lds_trip(MAT, j);
             const Pend p0 = begin(t0, RT + j, xv, dv);
             finish(p0, part);
         }
+        MPCG_STAMP(MAT * 8 + 2);
         if constexpr (SB == 2) {
             // stream: A is consumed while B is in flight, and vice versa
             for (int j = 0; j < TS; j += 2) {
@@ -421,6 +443,7 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
                 finish(p0, part);
             }
         }
+        MPCG_STAMP(MAT * 8 + 3);
         // heads are lanes 0..20 (others hold 0): fold into lane 0, once per pass.  Four DPP adds inside
         // each 16-lane row (VALU latency) + one readlane, instead of five dependent ds_bpermute round
         // trips (~100 cycles each, on the critical path of every barrier phase).
@@ -436,6 +459,7 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
             "s_nop 1"
             : "+v"(part));
         const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
+        MPCG_STAMP(MAT * 8 + 4);
         return part + hi;                   // valid in lane 0: (lanes 0..15) + (lanes 16..20)
     };
     using MatS = std::integral_constant<int, 0>;
@@ -476,25 +500,32 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
         max_iter_exit = 0;
     } else {
         for (int it = 0; it < a.max_iter; ++it) {
+#ifdef MPCG_PROF
+            prof_on = b == 0 && it == 20;
+#endif
             // upsilon = S p ; v = p . upsilon
             {
                 const float part = pass(MatS{}, xp, xp);
                 if (lane == 0) red_v[w] = part;
             }
             lds_barrier();
+            MPCG_STAMP(5);
             const float alpha = eta / block_sum(red_v);
             // lambda += alpha p ; r -= alpha upsilon
             for (int e = tid; e < NV2; e += NTHR) {
                 lam2[e] = lam2[e] + alpha * xp2[e];
                 xr2[e] = xr2[e] - alpha * tmp2[e];
             }
+            MPCG_STAMP(6);
             lds_barrier();
+            MPCG_STAMP(7);
             // r~ = Pinv r ; eta' = r . r~
             {
                 const float part = pass(MatP{}, xr, xr);
                 if (lane == 0) red_e[w] = part;
             }
             lds_barrier();
+            MPCG_STAMP(13);
             const float eta_new = block_sum(red_e);
             iters = (uint32_t)(it + 1);
             if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
@@ -502,7 +533,9 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
             // p = r~ + beta p
             for (int e = tid; e < NV2; e += NTHR) xp2[e] = tmp2[e] + beta * xp2[e];
             eta = eta_new;
+            MPCG_STAMP(14);
             lds_barrier();
+            MPCG_STAMP(15);
         }
     }
 
