@@ -393,6 +393,46 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
         q.a2.y = __shfl_down(acc.y, 42);
         return q;
     };
+    // LEAN: 256-register waves whose resident triples + stream buffer leave fewer than ~60 working registers
+    // (<8,3,1>: 168 + 28).  One triple in flight instead of two (the second wave of the SIMD fills the latencies),
+    // and an LDS-cached triple is consumed chunk by chunk instead of being copied to 28 registers first.
+    // Otherwise the compiler spills resident matrix rows and reloads them from scratch in every S pass, in
+    // order behind the in-flight stream load: measured 2700 of 17200 cycles per iteration (profiles/
+    // r01e_phases_N128.txt).  Same FMA order as the other path: results are bit-identical.
+    constexpr bool LEAN = NW >= 8 && (2 * RT + (SB > 0 ? SB : 0)) * 28 > 190;
+    auto begin_lds = [&](int mat, int jl, const float* xv, const float* dv) -> Pend {
+        Pend q;
+        const int k = 3 * (w + NW * (RT + jl)) + lrho;
+        q.valid = k < N;
+        q.k = q.valid ? k : 0;
+        const f2* x2 = reinterpret_cast<const f2*>(xv + (q.k + ls) * NS);
+        const mchunk* src = mc + ((size_t)(mat * LT + jl) * 64 + lane) * 7;
+        f2 acc = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const mchunk v = src[u];
+            const f2 x = x2[u];
+            mpair m0, m1;
+            if constexpr (sizeof(MT) == 4) {
+                m0 = mpair{v.x, v.y};
+                m1 = mpair{v.z, v.w};
+            } else {
+                const float c0 = v.x, c1 = v.y;
+                m0 = __builtin_bit_cast(mpair, c0);
+                m1 = __builtin_bit_cast(mpair, c1);
+            }
+            MatT<MT>::fma(acc, m0, x.x);
+            MatT<MT>::fma(acc1, m1, x.y);
+        }
+        acc += acc1;
+        q.d = *reinterpret_cast<const f2*>(dv + (q.k + 1) * NS + 2 * lq);
+        q.a0 = acc;
+        q.a1.x = __shfl_down(acc.x, 21);
+        q.a1.y = __shfl_down(acc.y, 21);
+        q.a2.x = __shfl_down(acc.x, 42);
+        q.a2.y = __shfl_down(acc.y, 42);
+        return q;
+    };
     auto finish = [&](const Pend& q, float& part) {
         if (head && q.valid) {
             const f2 y = (q.a0 + q.a1) + q.a2;
@@ -404,24 +444,37 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
         constexpr int MAT = decltype(which)::value;       // 0: S, 1: Pinv (must alternate, S first)
         float part = 0.f;
         MPCG_STAMP(MAT * 8 + 0);
-        // registers
+        // registers: two triples in flight per wave, unless the register budget is tight (LEAN)
+        if constexpr (LEAN) {
 #pragma unroll
-        for (int j = 0; j + 1 < RT; j += 2) {
-            const Pend p0 = begin(MAT ? regP[j] : regS[j], j, xv, dv);
-            const Pend p1 = begin(MAT ? regP[j + 1] : regS[j + 1], j + 1, xv, dv);
-            finish(p0, part);
-            finish(p1, part);
-        }
-        if constexpr (RT & 1) {
-            const Pend p0 = begin(MAT ? regP[RT - 1] : regS[RT - 1], RT - 1, xv, dv);
-            finish(p0, part);
+            for (int j = 0; j < RT; ++j) {
+                const Pend p0 = begin(MAT ? regP[j] : regS[j], j, xv, dv);
+                finish(p0, part);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j + 1 < RT; j += 2) {
+                const Pend p0 = begin(MAT ? regP[j] : regS[j], j, xv, dv);
+                const Pend p1 = begin(MAT ? regP[j + 1] : regS[j + 1], j + 1, xv, dv);
+                finish(p0, part);
+                finish(p1, part);
+            }
+            if constexpr (RT & 1) {
+                const Pend p0 = begin(MAT ? regP[RT - 1] : regS[RT - 1], RT - 1, xv, dv);
+                finish(p0, part);
+            }
         }
         MPCG_STAMP(MAT * 8 + 1);
         // LDS cache
         for (int j = 0; j < LT; ++j) {
-            const Trip t0 = lds_trip(MAT, j);
-            const Pend p0 = begin(t0, RT + j, xv, dv);
-            finish(p0, part);
+            if constexpr (LEAN) {
+                const Pend p0 = begin_lds(MAT, j, xv, dv);
+                finish(p0, part);
+            } else {
+                const Trip t0 = lds_trip(MAT, j);
+                const Pend p0 = begin(t0, RT + j, xv, dv);
+                finish(p0, part);
+            }
         }
         MPCG_STAMP(MAT * 8 + 2);
         if constexpr (SB == 2) {
