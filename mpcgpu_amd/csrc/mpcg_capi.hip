@@ -93,6 +93,8 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
         h->pcg_waves = 8; h->reg_rows = 2; h->lds_rows = 0;
     } else if (knot_points <= 96) {     // <= 32 triples: three in registers + one in LDS per wave and matrix
         h->pcg_waves = 8; h->reg_rows = 3; h->lds_rows = -1;
+    } else if (knot_points < 256) {     // the same, the rest streamed every iteration
+        h->pcg_waves = 8; h->reg_rows = 3; h->lds_rows = -1;
     } else {                            // 4 fat waves (512 registers each): 7 triples per matrix in registers
         h->pcg_waves = 4; h->reg_rows = 7; h->lds_rows = -1;
     }
@@ -319,10 +321,11 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
         if (rc != 1) return rc;
     }
     if (h->auto_cfg && esz == 4 && h->N > 96) {
-        // long horizons: with fewer trajectories than CUs the call is a latency problem -> 8 waves (two per
-        // SIMD) hide more of it (N=128, batch 1: 1.02 ms vs 1.23 ms); with the GPU full, 4 fat waves keep more
-        // of S and Pinv resident (batch 1024: 4.63 ms vs 4.85 ms).  profiles/r01_tune_latency.txt
-        if (batch < (uint32_t)h->num_cus) { h->pcg_waves = 8; h->reg_rows = 3; }
+        // long horizons: 8 waves (two per SIMD) with 3 register triples + 1 LDS triple per wave and matrix beat
+        // 4 fat waves with 7 + 2 since <8,3,1> runs spill-free (N=128, batch 1024: 4.06 ms vs 5.23 ms,
+        // profiles/r01e_tune_nsweep.txt, r01e_phases_N128.txt); beyond N=256 (reached only with the cluster
+        // kernel switched off) the fat waves' larger resident share wins again (profiles/r01_tune12.txt)
+        if (h->N < 256 || batch < (uint32_t)h->num_cus) { h->pcg_waves = 8; h->reg_rows = 3; }
         else { h->pcg_waves = 4; h->reg_rows = 7; }
         h->lds_rows = -1;
     }

@@ -394,12 +394,12 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
         return q;
     };
     // LEAN: 256-register waves whose resident triples + stream buffer leave fewer than ~60 working registers
-    // (<8,3,1>: 168 + 28).  One triple in flight instead of two (the second wave of the SIMD fills the latencies),
+    // (<8,3,1,float>: 168 + 28).  One triple in flight instead of two (the second wave of the SIMD fills the latencies),
     // and an LDS-cached triple is consumed chunk by chunk instead of being copied to 28 registers first.
     // Otherwise the compiler spills resident matrix rows and reloads them from scratch in every S pass, in
     // order behind the in-flight stream load: measured 2700 of 17200 cycles per iteration (profiles/
     // r01e_phases_N128.txt).  Same FMA order as the other path: results are bit-identical.
-    constexpr bool LEAN = NW >= 8 && (2 * RT + (SB > 0 ? SB : 0)) * 28 > 190;
+    constexpr bool LEAN = NW >= 8 && (2 * RT + (SB > 0 ? SB : 0)) * 7 * (int)sizeof(MT) > 190;
     auto begin_lds = [&](int mat, int jl, const float* xv, const float* dv) -> Pend {
         Pend q;
         const int k = 3 * (w + NW * (RT + jl)) + lrho;
