@@ -52,6 +52,8 @@ static bool shape_supported(uint32_t n, uint32_t N) { return n == (uint32_t)NS &
 static size_t lds_bytes_for(uint32_t N, int nw) { return pcg_lds_floats((int)N, nw) * sizeof(float); }
 static constexpr size_t kLdsMax = 160 * 1024;
 
+static int stream_bufs_for(const mpcg_handle* h, int nw, int esz);
+
 extern "C" {
 
 int mpcg_abi_version(void) { return MPCG_ABI_VERSION; }
@@ -163,6 +165,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "pcg_reg_rows")) { *value = h->reg_rows; return MPCG_OK; }
     if (!strcmp(key, "pcg_lds_rows")) { *value = h->lds_rows; return MPCG_OK; }
     if (!strcmp(key, "pcg_stream_bufs")) { *value = h->stream_bufs; return MPCG_OK; }
+    if (!strcmp(key, "pcg_resident")) { *value = stream_bufs_for(h, h->pcg_waves, 4) == 0; return MPCG_OK; }   // 1: nothing is streamed
     if (!strcmp(key, "cluster")) { *value = h->cluster; return MPCG_OK; }
     if (!strcmp(key, "pcg16_waves")) { *value = h->pcg_waves16; return MPCG_OK; }
     if (!strcmp(key, "pcg16_reg_rows")) { *value = h->reg_rows16; return MPCG_OK; }
@@ -234,7 +237,7 @@ static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
 #define MPCG_PCG_VARIANTS(X)                                                              \
     X(16, 0, 2) X(8, 0, 2) X(4, 0, 2)                                                     \
     X(16, 1, 0) X(16, 1, 1) X(16, 2, 1)                                                   \
-    X(8, 2, 2) X(8, 2, 1) X(8, 3, 1) X(8, 3, 0) X(8, 4, 0)                                \
+    X(8, 2, 2) X(8, 2, 1) X(8, 2, 0) X(8, 3, 1) X(8, 3, 0) X(8, 4, 0)                                \
     X(4, 4, 2) X(4, 6, 1) X(4, 7, 1) X(4, 7, 0)
 // fp16 matrix storage: a triple costs 14 registers instead of 28
 #define MPCG_PCG_VARIANTS16(X)                                                            \

@@ -214,6 +214,17 @@ template <> struct MatT<_Float16> {
     }
 };
 
+// DPP wave shift: lane i receives the value of lane i+1 (0 beyond lane 63).  VALU-only neighbour exchange —
+// no LDS crossbar trip (ds_bpermute) on the critical path of every triple.
+__device__ __forceinline__ f2 wave_shl1(f2 v) {
+    constexpr int DPP_WAVE_SHL1 = 0x130;
+    const float vx = v.x, vy = v.y;     // (scalar temporaries: __builtin_bit_cast on a vector element lvalue reads element 0)
+    f2 o;
+    o.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, vx), DPP_WAVE_SHL1, 0xf, 0xf, true));
+    o.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, vy), DPP_WAVE_SHL1, 0xf, 0xf, true));
+    return o;
+}
+
 // Phase timing for tools/prof_phases.py (diagnostic build only, -DMPCG_PROF): workgroup 0 stamps s_memtime at
 // the phase boundaries of one iteration, one row of 32 stamps per wave.
 #ifdef MPCG_PROF
@@ -264,11 +275,20 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
 
     // ---- lane roles ----
     const bool active = lane < 63;
-    const int ls = active ? lane / 21 : 0;             // block column
-    const int lrem = active ? lane - 21 * ls : 0;
-    const int lrho = lrem / 7;                         // row within the triple
-    const int lq = lrem - 7 * lrho;                    // row pair
-    const bool head = lane < 21;                       // s == 0 lanes receive the finished rows
+    // Two lane orders:
+    //   streaming kernels (SB > 0): lane = 21 s + 7 rho + q — the seven row pairs of a block column are adjacent
+    //       lanes, so each streamed load instruction reads 56 contiguous bytes per block; the three blocks of a row
+    //       sit 21 lanes apart and are merged with two ds_bpermute rounds;
+    //   all-resident kernels (SB == 0, nothing is loaded inside the PCG loop): lane = 3 (7 rho + q) + s — the
+    //       three blocks of a row are ADJACENT lanes and are merged with two DPP wave shifts (VALU only): no LDS
+    //       crossbar round trip on the critical path of every triple (N=64: 108 -> 127 M it/s; the same order
+    //       makes a streamed triple 1.7x slower, hence the split).
+    constexpr bool ADJ = SB == 0;
+    const int lg = active ? (ADJ ? lane / 3 : lane % 21) : 0;          // 7*rho + q
+    const int ls = active ? (ADJ ? lane - 3 * lg : lane / 21) : 0;     // block column
+    const int lrho = lg / 7;                           // row within the triple
+    const int lq = lg - 7 * lrho;                      // row pair
+    const bool head = active && ls == 0;               // s == 0 lanes receive the finished rows
     const uint32_t lane_byte = (uint32_t)(ls * 196 + lq * 2) * ESZ;   // inside the block row
 
     // triples owned by this wave: tr = w + NW*j, j < TT
@@ -387,10 +407,15 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
         acc += acc1;
         q.d = *reinterpret_cast<const f2*>(dv + (q.k + 1) * NS + 2 * lq);
         q.a0 = acc;
-        q.a1.x = __shfl_down(acc.x, 21);
-        q.a1.y = __shfl_down(acc.y, 21);
-        q.a2.x = __shfl_down(acc.x, 42);
-        q.a2.y = __shfl_down(acc.y, 42);
+        if constexpr (ADJ) {
+            q.a1 = wave_shl1(acc);                       // block 1's partial, from lane + 1
+            q.a2 = wave_shl1(q.a1);                      // block 2's partial, from lane + 2
+        } else {
+            q.a1.x = __shfl_down(acc.x, 21);
+            q.a1.y = __shfl_down(acc.y, 21);
+            q.a2.x = __shfl_down(acc.x, 42);
+            q.a2.y = __shfl_down(acc.y, 42);
+        }
         return q;
     };
     // LEAN: 256-register waves whose resident triples + stream buffer leave fewer than ~60 working registers
@@ -427,10 +452,15 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
         acc += acc1;
         q.d = *reinterpret_cast<const f2*>(dv + (q.k + 1) * NS + 2 * lq);
         q.a0 = acc;
-        q.a1.x = __shfl_down(acc.x, 21);
-        q.a1.y = __shfl_down(acc.y, 21);
-        q.a2.x = __shfl_down(acc.x, 42);
-        q.a2.y = __shfl_down(acc.y, 42);
+        if constexpr (ADJ) {
+            q.a1 = wave_shl1(acc);                       // block 1's partial, from lane + 1
+            q.a2 = wave_shl1(q.a1);                      // block 2's partial, from lane + 2
+        } else {
+            q.a1.x = __shfl_down(acc.x, 21);
+            q.a1.y = __shfl_down(acc.y, 21);
+            q.a2.x = __shfl_down(acc.x, 42);
+            q.a2.y = __shfl_down(acc.y, 42);
+        }
         return q;
     };
     auto finish = [&](const Pend& q, float& part) {
@@ -511,9 +541,16 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
             "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
             "s_nop 1"
             : "+v"(part));
-        const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
+        const int pb = __builtin_bit_cast(int, part);
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 16));
+        if constexpr (ADJ) {                // heads are lanes 0, 3, ..., 60: all four 16-lane rows, in order
+            const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 32));
+            const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 48));
+            MPCG_STAMP(MAT * 8 + 4);
+            return ((part + r1) + r2) + r3;
+        }
         MPCG_STAMP(MAT * 8 + 4);
-        return part + hi;                   // valid in lane 0: (lanes 0..15) + (lanes 16..20)
+        return part + r1;                   // heads are lanes 0..20: (lanes 0..15) + (lanes 16..20); valid in lane 0
     };
     using MatS = std::integral_constant<int, 0>;
     using MatP = std::integral_constant<int, 1>;
@@ -672,11 +709,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
     gu64* cl_words = (gu64*)ca.scratch + (size_t)b * G * CL_WG_WORDS;      // the cluster's block
 
     const bool active = lane < 63;
-    const int ls = active ? lane / 21 : 0;
-    const int lrem = active ? lane - 21 * ls : 0;
-    const int lrho = lrem / 7;
-    const int lq = lrem - 7 * lrho;
-    const bool head = lane < 21;
+    // (the all-resident lane order of pcg_traj_kernel: lane = 3 (7 rho + q) + s, blocks of a row merged by DPP wave shifts)
+    const int lg = active ? lane / 3 : 0;
+    const int ls = active ? lane - 3 * lg : 0;
+    const int lrho = lg / 7;
+    const int lq = lg - 7 * lrho;
+    const bool head = active && ls == 0;
     const uint32_t lane_byte = (uint32_t)(ls * 196 + lq * 2) * ESZ;
 
     // this workgroup's triples [t0, t1) and knots [k0, k1)
@@ -756,10 +794,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
         acc += acc1;
         q.d = *reinterpret_cast<const f2*>(dv + (q.k + 1) * NS + 2 * lq);
         q.a0 = acc;
-        q.a1.x = __shfl_down(acc.x, 21);
-        q.a1.y = __shfl_down(acc.y, 21);
-        q.a2.x = __shfl_down(acc.x, 42);
-        q.a2.y = __shfl_down(acc.y, 42);
+        q.a1 = wave_shl1(acc);
+        q.a2 = wave_shl1(q.a1);
         return q;
     };
     auto finish = [&](const Pend& q, float& part) {
@@ -814,8 +850,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
             "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
             "s_nop 1"
             : "+v"(part));
-        const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
-        return part + hi;
+        const int pb = __builtin_bit_cast(int, part);
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 32));
+        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 48));
+        return ((part + r1) + r2) + r3;
     };
     using MatS = std::integral_constant<int, 0>;
     using MatP = std::integral_constant<int, 1>;
