@@ -25,6 +25,7 @@ struct mpcg_handle {
     int cluster = -1;         // workgroups per trajectory for the cluster kernel: 0 off, -1 auto, G > 0 forced
     unsigned long long* cluster_scratch = nullptr;
     bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any pcg_* set_option clears this)
+    int lds_extra = -1;       // <.,.,1> kernels: single-triple LDS slots beyond the uniform cache (-1 = as many as fit, 0 = none)
     int stream_bufs = -1;     // SB: -1 auto, else 0/1/2 register buffers for the streamed triples
     int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
     int spmv_blocks_per_cu = 32;   // (sweep: profiles/r01_tune_spmv.txt)
@@ -138,6 +139,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "pcg_reg_rows")) { h->reg_rows = value; return MPCG_OK; }     // validated at launch
     if (!strcmp(key, "pcg_lds_rows")) { h->lds_rows = value; return MPCG_OK; }
     if (!strcmp(key, "pcg_stream_bufs")) { h->stream_bufs = value; return MPCG_OK; }
+    if (!strcmp(key, "lds_extra")) { h->lds_extra = value; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
         if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");
         h->cluster = value; return MPCG_OK;
@@ -165,6 +167,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "pcg_reg_rows")) { *value = h->reg_rows; return MPCG_OK; }
     if (!strcmp(key, "pcg_lds_rows")) { *value = h->lds_rows; return MPCG_OK; }
     if (!strcmp(key, "pcg_stream_bufs")) { *value = h->stream_bufs; return MPCG_OK; }
+    if (!strcmp(key, "lds_extra")) { *value = h->lds_extra; return MPCG_OK; }
     if (!strcmp(key, "pcg_resident")) { *value = stream_bufs_for(h, h->pcg_waves, 4) == 0; return MPCG_OK; }   // 1: nothing is streamed
     if (!strcmp(key, "cluster")) { *value = h->cluster; return MPCG_OK; }
     if (!strcmp(key, "pcg16_waves")) { *value = h->pcg_waves16; return MPCG_OK; }
@@ -207,11 +210,30 @@ static size_t lds_request(const mpcg_handle* h, int nw, int esz) {
     return need;
 }
 
+// <.,.,1> kernels: single-triple LDS slots that still fit after the uniform cache, at most two per wave that streams
+static int lds_extra_for(const mpcg_handle* h, int nw, int sb, int esz) {
+    if (sb != 1 || h->lds_extra == 0) return 0;
+    const int rt = esz == 2 ? h->reg_rows16 : h->reg_rows;
+    const int lt = lds_rows_for(h, nw, esz);
+    const int ntr = ((int)h->N + 2) / 3;
+    int streaming_waves = 0;                                   // waves whose triples exceed registers + uniform cache
+    for (int w = 0; w < nw; ++w) streaming_waves += (ntr - w + nw - 1) / nw > rt + lt;
+    const size_t used = lds_bytes_for(h->N, nw) + pcg_lds_cache_floats(nw, lt, esz) * sizeof(float);
+    const size_t slot = pcg_lds_cache_floats(1, 1, esz) * sizeof(float) / 2;      // one wave, one matrix, one triple
+    int e = used < kLdsMax ? (int)((kLdsMax - used) / slot) : 0;
+    if (e > 2 * streaming_waves) e = 2 * streaming_waves;
+    if (h->lds_extra > 0 && e > h->lds_extra) e = h->lds_extra;
+    return e;
+}
+
 template <int NW, int RT, int SB, typename MT>
 static int launch_pcg_t(mpcg_handle* h, PcgArgs a, uint32_t batch, hipStream_t st) {
-    const size_t lds = lds_request(h, NW, (int)sizeof(MT));
-    if (lds > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
     a.lds_rows = lds_rows_for(h, NW, (int)sizeof(MT));
+    a.lds_extra = lds_extra_for(h, NW, SB, (int)sizeof(MT));
+    size_t lds = lds_bytes_for(h->N, NW) + pcg_lds_cache_floats(NW, a.lds_rows, (int)sizeof(MT)) * sizeof(float)
+               + (size_t)a.lds_extra * (pcg_lds_cache_floats(1, 1, (int)sizeof(MT)) * sizeof(float) / 2);
+    if (lds > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
+    { const size_t padded = lds_request(h, NW, (int)sizeof(MT)); if (padded > lds && padded <= kLdsMax) lds = padded; }
     auto kern = pcg_traj_kernel<NW, RT, SB, MT>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -180,6 +180,7 @@ struct PcgArgs {
     uint32_t* iters; uint8_t* max_iter_exit;
     int N; int max_iter; float exit_tol; int pcols;   // pcols: 3 = SS, 1 = block-Jacobi
     int lds_rows;                          // LT: triples per matrix per wave cached in LDS
+    int lds_extra;                         // <.,.,1> kernels: extra single-triple LDS slots, dealt to (wave 0,S),(wave 0,Pinv),(wave 1,S),...
 };
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -295,8 +296,14 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
     const int NTR = (N + 2) / 3;
     const int TT = max(0, (NTR - w + NW - 1) / NW);
     const int LT = a.lds_rows;
-    const int j0s = min(TT, RT + LT);                  // first streamed triple
-    const int TS = SB == 2 ? (((TT - j0s) + 1) & ~1) : (TT - j0s);   // streamed steps (even for A/B roles)
+    // <.,.,1> kernels: the LDS left over after the uniform cache (fewer than 2 NW slots) is handed out one triple
+    // at a time, to (wave 0, S), (wave 0, Pinv), (wave 1, S), ... — the waves that own the most triples
+    const int EX = SB == 1 ? a.lds_extra : 0;
+    const int LTs = LT + (2 * w < EX ? 1 : 0), LTp = LT + (2 * w + 1 < EX ? 1 : 0);
+    const int j0sS = min(TT, RT + LTs), j0sP = min(TT, RT + LTp);   // first streamed triple of S / of Pinv
+    // streamed steps (even for the A/B roles of SB == 2, where LTs == LTp)
+    const int TSs = SB == 2 ? (((TT - j0sS) + 1) & ~1) : (TT - j0sS);
+    const int TSp = SB == 2 ? TSs : (TT - j0sP);
 
     // byte offset of this lane's (row, block) in the trajectory's matrix, or OOB_OFF when that block
     // must not be read: rows >= N, the never-written blocks (0,left) and (N-1,right), the
@@ -323,23 +330,24 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
     }
     // ---- resident triples: LDS cache, lane-private records of 7 chunks (chunk = two columns) ----
     mchunk* mc = mc_base + (size_t)w * 2 * LT * 64 * 7;
+    mchunk* mc_x = mc_base + (size_t)NW * 2 * LT * 64 * 7 + (size_t)(2 * w) * 64 * 7;   // this wave's two extra slots
+    auto slot = [&](int mat, int j) -> mchunk* {
+        return j < LT ? mc + ((size_t)(mat * LT + j) * 64 + lane) * 7 : mc_x + ((size_t)mat * 64 + lane) * 7;
+    };
     auto pack2 = [](mpair lo, mpair hi) -> mchunk {
         if constexpr (sizeof(MT) == 4) return mchunk{lo.x, lo.y, hi.x, hi.y};
         else return mchunk{__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi)};   // (bit pattern only)
     };
-    for (int j = 0; j < LT; ++j) {
-        const Trip t0 = load_trip(rS, RT + j, 3);
-        const Trip t1 = load_trip(rP, RT + j, a.pcols);
-        mchunk* d0 = mc + ((size_t)j * 64 + lane) * 7;
-        mchunk* d1 = mc + ((size_t)(LT + j) * 64 + lane) * 7;
+    for (int j = 0; j < LTs + LTp; ++j) {              // one triple at a time
+        const bool isP = j >= LTs;
+        const int jj = isP ? j - LTs : j;
+        const Trip t0 = isP ? load_trip(rP, RT + jj, a.pcols) : load_trip(rS, RT + jj, 3);
+        mchunk* d0 = slot(isP, jj);
 #pragma unroll
-        for (int u = 0; u < 7; ++u) {
-            d0[u] = pack2(t0.m[2 * u], t0.m[2 * u + 1]);
-            d1[u] = pack2(t1.m[2 * u], t1.m[2 * u + 1]);
-        }
+        for (int u = 0; u < 7; ++u) d0[u] = pack2(t0.m[2 * u], t0.m[2 * u + 1]);
     }
     auto lds_trip = [&](int mat, int j) -> Trip {
-        const mchunk* src = mc + ((size_t)(mat * LT + j) * 64 + lane) * 7;
+        const mchunk* src = slot(mat, j);
         Trip t;
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
@@ -361,14 +369,17 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
     // ---- matrix stream: S triples, Pinv triples, S triples, ... one triple ahead of use, and NOT
     //      drained at workgroup barriers (lds_barrier) ----
     int st_j = 0, st_pass = 0;             // position of the NEXT triple to load
-    auto load_next = [&]() -> Trip {
-        const Trip t = st_pass ? load_trip(rP, j0s + st_j, a.pcols) : load_trip(rS, j0s + st_j, 3);
-        if (++st_j >= TS) { st_j = 0; st_pass ^= 1; }
+    auto load_next = [&]() -> Trip {                   // (SB == 1: only called when TSs + TSp > 0)
+        if constexpr (SB == 1) {
+            if ((st_pass ? TSp : TSs) == 0) st_pass ^= 1;   // this wave streams nothing of that matrix
+        }
+        const Trip t = st_pass ? load_trip(rP, j0sP + st_j, a.pcols) : load_trip(rS, j0sS + st_j, 3);
+        if (++st_j >= (st_pass ? TSp : TSs)) { st_j = 0; st_pass ^= 1; }
         return t;
     };
     Trip bufA, bufB;
     if constexpr (SB > 0) {
-        if (SB == 2 || TS > 0) bufA = load_next();     // (nothing to stream: zeros from the OOB path)
+        if (SB == 2 || TSs + TSp > 0) bufA = load_next();     // (nothing to stream: zeros from the OOB path)
     }
 
     // ---- stage vectors: xp <- lambda0 (operand of the setup SpMV), lam <- lambda0, xr <- gamma ----
@@ -431,7 +442,7 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
         q.valid = k < N;
         q.k = q.valid ? k : 0;
         const f2* x2 = reinterpret_cast<const f2*>(xv + (q.k + ls) * NS);
-        const mchunk* src = mc + ((size_t)(mat * LT + jl) * 64 + lane) * 7;
+        const mchunk* src = slot(mat, jl);
         f2 acc = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
@@ -473,6 +484,7 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
     auto pass = [&](auto which, const float* xv, const float* dv) -> float {
         constexpr int MAT = decltype(which)::value;       // 0: S, 1: Pinv (must alternate, S first)
         float part = 0.f;
+        const int LTm = MAT ? LTp : LTs, j0s = MAT ? j0sP : j0sS, TS = MAT ? TSp : TSs;
         MPCG_STAMP(MAT * 8 + 0);
         // registers: two triples in flight per wave, unless the register budget is tight (LEAN)
         if constexpr (LEAN) {
@@ -496,7 +508,7 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
         }
         MPCG_STAMP(MAT * 8 + 1);
         // LDS cache
-        for (int j = 0; j < LT; ++j) {
+        for (int j = 0; j < LTm; ++j) {
             if constexpr (LEAN) {
                 const Pend p0 = begin_lds(MAT, j, xv, dv);
                 finish(p0, part);
@@ -522,7 +534,7 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kern
             // flies during finish + the next resident work (and the other waves' turns)
             for (int j = 0; j < TS; ++j) {
                 const Pend p0 = begin(bufA, j0s + j, xv, dv);
-                bufA = load_next();
+                if (TSs + TSp > 1 || j + 1 < TS) bufA = load_next();   // (a lone streamed triple stays in its buffer)
                 finish(p0, part);
             }
         }
