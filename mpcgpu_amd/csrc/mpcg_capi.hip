@@ -260,7 +260,7 @@ static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
     X(16, 0, 2) X(8, 0, 2) X(4, 0, 2)                                                     \
     X(16, 1, 0) X(16, 1, 1) X(16, 2, 1)                                                   \
     X(8, 2, 2) X(8, 2, 1) X(8, 2, 0) X(8, 3, 1) X(8, 3, 0) X(8, 4, 0)                                \
-    X(4, 4, 2) X(4, 6, 1) X(4, 7, 1) X(4, 7, 0)
+    X(4, 3, 0) X(4, 4, 2) X(4, 6, 1) X(4, 7, 1) X(4, 7, 0)
 // fp16 matrix storage: a triple costs 14 registers instead of 28
 #define MPCG_PCG_VARIANTS16(X)                                                            \
     X(16, 0, 2) X(8, 0, 2)                                                                \
@@ -344,6 +344,14 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
     {
         const int rc = try_launch_cluster(h, a, batch, st, esz);
         if (rc != 1) return rc;
+    }
+    if (h->auto_cfg && esz == 4 && h->N <= 36) {
+        // short horizons (<= 12 triples): with more trajectories than CUs, 4 waves x 3 register triples need < 256
+        // registers, so TWO trajectories share a CU and fill each other's barrier and reduction latencies
+        // (N=32, batch 2048: 269 vs 171 M it/s); up to one trajectory per CU the 8-wave kernel is the faster solve
+        if (batch > (uint32_t)h->num_cus) { h->pcg_waves = 4; h->reg_rows = 3; }
+        else { h->pcg_waves = 8; h->reg_rows = 2; }
+        h->lds_rows = 0;
     }
     if (h->auto_cfg && esz == 4 && h->N > 96) {
         // long horizons: 8 waves (two per SIMD) with 3 register triples + 1 LDS triple per wave and matrix beat

@@ -247,7 +247,7 @@ __device__ long long g_pcg_prof[16 * 32];
 // (28 VGPRs cheaper: one more resident triple), 0 = no stream at all (launcher guarantees that every
 // triple is resident).
 template <int NW, int RT, int SB, typename MT>
-__global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : NW / 4)) void pcg_traj_kernel(PcgArgs a) {
+__global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : NW / 4))) void pcg_traj_kernel(PcgArgs a) {
     typedef typename MatT<MT>::pair mpair;
     typedef typename MatT<MT>::chunk mchunk;
     struct Trip { mpair m[NS]; };                      // this lane's two rows of its block, one pair per column

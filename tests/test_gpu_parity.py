@@ -368,3 +368,34 @@ def test_spmv_mfma_experiment_matches_valu_kernel(P, orc, cols):
     assert np.isfinite(y1).all() and relinf(y1, y0) < 5e-6
     for b in (0, 4):
         assert relinf(y1[b], orc.bt_spmv(np.nan_to_num(S[b]).astype(np.float64), x[b], N, cols=cols)) < 5e-6
+
+
+def test_short_horizon_batches_run_two_trajectories_per_cu(P, orc):
+    """N <= 36 with more trajectories than CUs: the library switches to <4,3,0> (two workgroups per CU).  Same
+    solve as the 8-wave kernel up to the summation order of the inner products, and inside the oracle's fp32 band."""
+    PcgSolver, pcg_config = P
+    N, B = 32, 300
+    k = synth.make_kkt(N, B, 1234)
+    S, Pinv, g = synth.form_schur(k, poison_unused=True)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    cfg = pcg_config(pcg_exit_tol=1e-5, pcg_max_iter=173)
+    sol = PcgSolver(N, max_batch=B)
+    lam = torch.zeros(B, n * N, device="cuda")
+    it, ex = sol.solve(dS, dP, dg, lam, cfg, "ss")
+    torch.cuda.synchronize()
+    assert sol.get_option("pcg_waves") == 4 and sol.get_option("pcg_reg_rows") == 3
+    assert sol.checkPcgOccupancy() == 2 * sol.get_option("num_cus")
+    sol8 = PcgSolver(N, max_batch=B)
+    sol8.set_option("pcg_waves", 8); sol8.set_option("pcg_reg_rows", 2); sol8.set_option("pcg_lds_rows", 0)
+    lam8 = torch.zeros(B, n * N, device="cuda")
+    it8, ex8 = sol8.solve(dS, dP, dg, lam8, cfg, "ss")
+    torch.cuda.synchronize()
+    it, it8, lam, lam8 = it.cpu().numpy(), it8.cpu().numpy(), lam.cpu().numpy(), lam8.cpu().numpy()
+    assert np.abs(it.astype(int) - it8.astype(int)).max() <= max(3, int(0.05 * it8.max()))
+    for b in (0, 1, 150, 299):
+        Sz, Pz = np.nan_to_num(S[b]), np.nan_to_num(Pinv[b])
+        lo, hi = fp32_iters_band(orc, Sz, Pz, g[b], np.zeros(n * N, np.float32), N, 173, 1e-5, "ss", trials=4)
+        assert 0.93 * lo - 2 <= int(it[b]) <= 1.07 * hi + 2
+        r_hip = rel_residual(S[b], g[b], lam[b], N)
+        r_cpu = rel_residual(S[b], g[b], orc.pcg(Sz, Pz, g[b], np.zeros(n * N, np.float32), N, 173, 1e-5, "ss")["lam"], N)
+        assert r_hip <= 2 * r_cpu + 1e-6
