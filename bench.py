@@ -287,6 +287,9 @@ def main():
         if tr:
             out["roofline"]["traffic"] = tr["hbm_traffic_bytes_per_launch"]
             out["roofline"]["traffic_source"] = tr["source"]
+            # the L2-miss bytes over the live kernel time: what the memory side actually sustains
+            out["roofline"]["traffic_gbs"] = tr["hbm_traffic_bytes_per_launch"] / (out["roofline"]["kernel_ms"] * 1e-3) / 1e9
+            out["roofline"]["traffic_frac"] = out["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
     except (OSError, ValueError):
         pass
 

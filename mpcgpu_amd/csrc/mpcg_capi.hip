@@ -345,13 +345,13 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
         const int rc = try_launch_cluster(h, a, batch, st, esz);
         if (rc != 1) return rc;
     }
-    if (h->auto_cfg && esz == 4 && h->N <= 36) {
-        // short horizons (<= 12 triples): with more trajectories than CUs, 4 waves x 3 register triples need < 256
-        // registers, so TWO trajectories share a CU and fill each other's barrier and reduction latencies
-        // (N=32, batch 2048: 269 vs 171 M it/s); up to one trajectory per CU the 8-wave kernel is the faster solve
-        if (batch > (uint32_t)h->num_cus) { h->pcg_waves = 4; h->reg_rows = 3; }
-        else { h->pcg_waves = 8; h->reg_rows = 2; }
-        h->lds_rows = 0;
+    if (h->auto_cfg && esz == 4 && h->N <= 48) {
+        // short horizons (<= 16 triples): with more trajectories than CUs, 4 waves x 3 register triples (+ 1 in LDS
+        // beyond N=36) need < 256 registers, so TWO trajectories share a CU and fill each other's barrier and
+        // reduction latencies (batch 2048: N=32 269 vs 171 M it/s, N=48 187 vs 166); up to one trajectory per CU
+        // the 8-wave kernel is the faster solve
+        if (batch > (uint32_t)h->num_cus) { h->pcg_waves = 4; h->reg_rows = 3; h->lds_rows = -1; }
+        else { h->pcg_waves = 8; h->reg_rows = 2; h->lds_rows = 0; }
     }
     if (h->auto_cfg && esz == 4 && h->N > 96) {
         // long horizons: 8 waves (two per SIMD) with 3 register triples + 1 LDS triple per wave and matrix beat
