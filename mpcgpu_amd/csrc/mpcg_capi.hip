@@ -22,6 +22,7 @@ struct mpcg_handle {
     int reg_rows = 0;         // RT: TRIPLES of block rows per matrix per wave kept in registers (compiled variants only)
     int lds_rows = -1;        // LT: triples per matrix per wave cached in LDS; -1 = as many as fit when reg_rows > 0, else 0
     int pcg_waves16 = 8, reg_rows16 = 6, lds_rows16 = -1;   // the same knobs for fp16 matrix storage
+    int cluster_adj = 1;      // lane order of the cluster kernel (1: blocks of a row in adjacent lanes)
     int cluster = -1;         // workgroups per trajectory for the cluster kernel: 0 off, -1 auto, G > 0 forced
     unsigned long long* cluster_scratch = nullptr;
     bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any pcg_* set_option clears this)
@@ -140,6 +141,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "pcg_lds_rows")) { h->lds_rows = value; return MPCG_OK; }
     if (!strcmp(key, "pcg_stream_bufs")) { h->stream_bufs = value; return MPCG_OK; }
     if (!strcmp(key, "lds_extra")) { h->lds_extra = value; return MPCG_OK; }
+    if (!strcmp(key, "cluster_adj")) { h->cluster_adj = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
         if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");
         h->cluster = value; return MPCG_OK;
@@ -285,7 +287,7 @@ static int launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, in
     const size_t lds = pcg_cluster_lds_floats((int)h->N, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
     ClusterArgs ca;
     ca.p = a; ca.p.lds_rows = lt; ca.scratch = h->cluster_scratch; ca.G = G;
-    auto kern = pcg_cluster_kernel<NW, RT>;
+    auto kern = h->cluster_adj ? pcg_cluster_kernel<NW, RT, true> : pcg_cluster_kernel<NW, RT, false>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

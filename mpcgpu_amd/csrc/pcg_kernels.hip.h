@@ -685,7 +685,7 @@ struct ClusterArgs {
     int G;
 };
 
-template <int NW, int RT>
+template <int NW, int RT, bool ADJ>
 __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArgs ca) {
     typedef float MT;
     typedef typename MatT<MT>::pair mpair;
@@ -722,8 +722,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
 
     const bool active = lane < 63;
     // (the all-resident lane order of pcg_traj_kernel: lane = 3 (7 rho + q) + s, blocks of a row merged by DPP wave shifts)
-    const int lg = active ? lane / 3 : 0;
-    const int ls = active ? lane - 3 * lg : 0;
+    const int lg = active ? (ADJ ? lane / 3 : lane % 21) : 0;
+    const int ls = active ? (ADJ ? lane - 3 * lg : lane / 21) : 0;
     const int lrho = lg / 7;
     const int lq = lg - 7 * lrho;
     const bool head = active && ls == 0;
@@ -806,8 +806,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
         acc += acc1;
         q.d = *reinterpret_cast<const f2*>(dv + (q.k + 1) * NS + 2 * lq);
         q.a0 = acc;
-        q.a1 = wave_shl1(acc);
-        q.a2 = wave_shl1(q.a1);
+        if constexpr (ADJ) {
+            q.a1 = wave_shl1(acc);
+            q.a2 = wave_shl1(q.a1);
+        } else {
+            q.a1.x = __shfl_down(acc.x, 21);
+            q.a1.y = __shfl_down(acc.y, 21);
+            q.a2.x = __shfl_down(acc.x, 42);
+            q.a2.y = __shfl_down(acc.y, 42);
+        }
         return q;
     };
     auto finish = [&](const Pend& q, float& part) {
@@ -864,6 +871,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
             : "+v"(part));
         const int pb = __builtin_bit_cast(int, part);
         const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 16));
+        if constexpr (!ADJ) return part + r1;
         const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 32));
         const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 48));
         return ((part + r1) + r2) + r3;
