@@ -399,3 +399,31 @@ def test_short_horizon_batches_run_two_trajectories_per_cu(P, orc):
         r_hip = rel_residual(S[b], g[b], lam[b], N)
         r_cpu = rel_residual(S[b], g[b], orc.pcg(Sz, Pz, g[b], np.zeros(n * N, np.float32), N, 173, 1e-5, "ss")["lam"], N)
         assert r_hip <= 2 * r_cpu + 1e-6
+
+
+@pytest.mark.parametrize("N", [2, 7, 36, 37, 48, 49, 96, 97, 129, 200, 255, 256, 300, 729])
+def test_default_configuration_across_horizons(P, orc, N):
+    """Whatever the library picks by itself for a horizon (all-register kernels, LEAN streaming kernel with extra
+    LDS slots, cluster kernel, single-workgroup fallback at the LDS limit N=729) solves the same system: 30 fixed
+    iterations against the float64 oracle inside the fp32 band, for both preconditioners, and deterministically."""
+    PcgSolver, pcg_config = P
+    B, K = 3, 30
+    k = synth.make_kkt(N, B, 7000 + N)
+    S, Pinv, g = synth.form_schur(k, precond="ss", poison_unused=True)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    for pc in ("ss", "jacobi"):
+        outs = []
+        for rep in range(2):
+            sol = PcgSolver(N, max_batch=B)
+            lam = torch.zeros(B, n * N, device="cuda")
+            it, ex = sol.solve(dS, dP, dg, lam, cfg, pc)
+            torch.cuda.synchronize()
+            assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all()
+            outs.append(lam.cpu().numpy())
+        np.testing.assert_array_equal(outs[0], outs[1])
+        for b in range(B):
+            Sz, Pz = np.nan_to_num(S[b]), np.nan_to_num(Pinv[b])
+            r64 = orc.pcg(Sz.astype(np.float64), Pz.astype(np.float64), g[b].astype(np.float64), np.zeros(n * N), N, K, 0.0, pc)
+            band = fp32_band(orc, Sz, Pz, g[b], np.zeros(n * N), N, K, pc, r64["lam"])
+            assert relinf(outs[0][b], r64["lam"]) <= max(1e-3, 4 * band), (N, pc, b, relinf(outs[0][b], r64["lam"]), band)
