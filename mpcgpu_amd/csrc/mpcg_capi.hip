@@ -10,6 +10,7 @@
 #include "../../include/mpcg.h"
 #include "pcg_kernels.hip.h"
 #include "schur_kernels.hip.h"
+#include "schur_dpp.hip.h"
 
 using namespace mpcg;
 
@@ -22,6 +23,7 @@ struct mpcg_handle {
     int reg_rows = 0;         // RT: TRIPLES of block rows per matrix per wave kept in registers (compiled variants only)
     int lds_rows = -1;        // LT: triples per matrix per wave cached in LDS; -1 = as many as fit when reg_rows > 0, else 0
     int pcg_waves16 = 8, reg_rows16 = 6, lds_rows16 = -1;   // the same knobs for fp16 matrix storage
+    int schur_dpp = 1;        // 1: register-resident Schur formation kernels (schur_dpp.hip.h), 0: the LDS versions
     int cluster_adj = 1;      // lane order of the cluster kernel (1: blocks of a row in adjacent lanes)
     int cluster = -1;         // workgroups per trajectory for the cluster kernel: 0 off, -1 auto, G > 0 forced
     unsigned long long* cluster_scratch = nullptr;
@@ -142,6 +144,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "pcg_stream_bufs")) { h->stream_bufs = value; return MPCG_OK; }
     if (!strcmp(key, "lds_extra")) { h->lds_extra = value; return MPCG_OK; }
     if (!strcmp(key, "cluster_adj")) { h->cluster_adj = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "schur_dpp")) { h->schur_dpp = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
         if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");
         h->cluster = value; return MPCG_OK;
@@ -523,6 +526,7 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
         return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: bad preconditioner");
     if (batch == 0) return MPCG_OK;
     if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: batch exceeds max_batch");
+    if ((uint64_t)batch * h->N >= (1ull << 31)) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur: batch * knot_points must stay below 2^31");
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = (int)h->n, m = (int)control_size, N = (int)h->N;
     const size_t Gsz = (size_t)(n * n + m * m) * N - m * m;
@@ -541,10 +545,27 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
     const long cap = (long)h->num_cus * 64;
     if (blocks > cap) blocks = cap;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL((form_schur_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
-    HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL((complete_ss_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
-    HIP_TRY(h, hipGetLastError());
+    a.k0_only = 0;
+    if (h->schur_dpp) {
+        // register-resident kernels, four knots per wave (schur_dpp.hip.h); block row 0 (a different, much
+        // smaller computation) stays with the LDS kernel
+        a.k0_only = 1;
+        hipLaunchKernelGGL((form_schur_kernel<14, 7>), dim3((unsigned)(batch < cap ? batch : cap)), dim3(SCH_THREADS), 0, st, a);
+        HIP_TRY(h, hipGetLastError());
+        long b4 = ((long)batch * (N - 1) + 3) / 4;
+        if (b4 > cap) b4 = cap;
+        hipLaunchKernelGGL(form_schur_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);
+        HIP_TRY(h, hipGetLastError());
+        b4 = ((long)batch * N + 3) / 4;
+        if (b4 > cap) b4 = cap;
+        hipLaunchKernelGGL(complete_ss_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);
+        HIP_TRY(h, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL((form_schur_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL((complete_ss_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
+        HIP_TRY(h, hipGetLastError());
+    }
     return MPCG_OK;
 }
 

@@ -115,6 +115,7 @@ struct SchurArgs {
     const float* G; const float* C; const float* g; const float* c;
     float* S; float* Pinv; float* gamma; float* Ginv_scratch; float* Ginv_out;
     float rho; int n; int m; int N; int batch; int ss;
+    int k0_only;              // form_schur_kernel: block row 0 of every trajectory only (the rest: schur_dpp.hip.h)
 };
 
 // block row k of trajectory b: S[k,0], S[k,1], S[k-1,2], Pinv[k,1], gamma[k]; inverses -> scratch
@@ -133,8 +134,9 @@ __global__ __launch_bounds__(SCH_THREADS) void form_schur_kernel(SchurArgs a) {
           *Bk = BR + nn, *Rk = Bk + nm, *Rki = Rk + mm, *gam = Rki + mm, *v1 = gam + n, *v2 = v1 + n, *qk = v2 + n,
           *qp = qk + n, *rk = qp + n, *scr = rk + n;
 
-    for (long item = blockIdx.x; item < (long)a.batch * N; item += gridDim.x) {
-        const int b = (int)(item / N), k = (int)(item % N);
+    const long total = a.k0_only ? (long)a.batch : (long)a.batch * N;
+    for (long item = blockIdx.x; item < total; item += gridDim.x) {
+        const int b = a.k0_only ? (int)item : (int)(item / N), k = a.k0_only ? 0 : (int)(item % N);
         const float* G = a.G + (size_t)b * Gsz;
         const float* C = a.C + (size_t)b * Csz;
         const float* g = a.g + (size_t)b * gsz;

@@ -18,7 +18,10 @@ def t(fn, reps=6):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return float(np.median(ts[1:])) * 1e3
-print("form_schur (ss)   128 traj x 128 knots: %.1f us" % t(lambda: sol.form_schur(G, C, g, c, 1e-3, "ss", S=S, Pinv=P, gamma=gm)))
-print("form_schur (jac)  128 traj x 128 knots: %.1f us" % t(lambda: sol.form_schur(G, C, g, c, 1e-3, "jacobi", S=S, Pinv=P, gamma=gm)))
+for dpp in (0, 1):
+    sol.set_option("schur_dpp", dpp)
+    tag = "register/DPP kernels" if dpp else "LDS kernels"
+    print("form_schur (ss)   128 traj x 128 knots, %s: %.1f us" % (tag, t(lambda: sol.form_schur(G, C, g, c, 1e-3, "ss", S=S, Pinv=P, gamma=gm))))
+    print("form_schur (jac)  128 traj x 128 knots, %s: %.1f us" % (tag, t(lambda: sol.form_schur(G, C, g, c, 1e-3, "jacobi", S=S, Pinv=P, gamma=gm))))
 sol.form_schur(G, C, g, c, 1e-3, "ss", S=S, Pinv=P, gamma=gm)
 print("compute_dz        128 traj x 128 knots: %.1f us" % t(lambda: sol.compute_dz(G, C, g, lam)))
