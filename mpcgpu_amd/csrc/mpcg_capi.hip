@@ -11,6 +11,7 @@
 #include "pcg_kernels.hip.h"
 #include "schur_kernels.hip.h"
 #include "schur_dpp.hip.h"
+#include "block_solve.hip.h"
 
 using namespace mpcg;
 
@@ -33,6 +34,7 @@ struct mpcg_handle {
     int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
     int spmv_blocks_per_cu = 32;   // (sweep: profiles/r01_tune_spmv.txt)
     int spmv_mfma = 0;        // 1 = the MFMA experiment kernel for mpcg_bt_spmv
+    float* block_scratch = nullptr;  // W_k, z_k of mpcg_block_solve: max_batch x N x 210 floats (first call)
     float* ginv_scratch = nullptr;   // staging for the in-place G <- G^-1 of mpcg_form_schur
     size_t ginv_scratch_floats = 0;
     std::string err;
@@ -120,8 +122,9 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
 }
 
 int mpcg_destroy(mpcg_handle* h) {
-    if (h && (h->ginv_scratch || h->cluster_scratch)) {
+    if (h && (h->ginv_scratch || h->cluster_scratch || h->block_scratch)) {
         (void)hipSetDevice(h->device);
+        if (h->block_scratch) (void)hipFree(h->block_scratch);
         if (h->ginv_scratch) (void)hipFree(h->ginv_scratch);
         if (h->cluster_scratch) (void)hipFree(h->cluster_scratch);
     }
@@ -513,6 +516,22 @@ int mpcg_pcg_solve_f16(mpcg_handle* h, const uint16_t* d_S16, const uint16_t* d_
     a.iters = d_iters; a.max_iter_exit = d_max_iter_exit;
     a.N = (int)h->N; a.max_iter = (int)max_iter; a.exit_tol = exit_tol; a.pcols = (int)precond; a.lds_rows = 0;
     return launch_pcg(h, a, batch, static_cast<hipStream_t>(stream), 2);
+}
+
+int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, float* d_lambda, uint32_t batch, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_S || !d_gamma || !d_lambda) return fail(h, MPCG_ERR_INVALID, "mpcg_block_solve: null device pointer");
+    if (batch == 0) return MPCG_OK;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_block_solve: batch exceeds max_batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->block_scratch)                        // first call only (not stream-ordered: hipMalloc)
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->block_scratch),
+                             (size_t)h->max_batch * h->N * (NS * NS + NS) * sizeof(float)));
+    BlockSolveArgs a;
+    a.S = d_S; a.gamma = d_gamma; a.lambda = d_lambda; a.work = h->block_scratch; a.N = (int)h->N; a.batch = (int)batch;
+    hipLaunchKernelGGL(bt_block_solve_kernel, dim3((batch + 3) / 4), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
 }
 
 int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, const float* d_C_dense, const float* d_g,

@@ -146,6 +146,19 @@ class PcgSolver:
                                                 _ptr(d_pcg_iters), _ptr(d_pcg_exit),
                                                 int(pcg_max_iter), float(pcg_exit_tol), _stream()))
 
+    def block_solve(self, S, gamma, lam=None):
+        """Batched block-tridiagonal direct solve (the GPU counterpart of qdldl_solve_schur,
+        include/qdldl/sqp.cuh:22-49).  S: [B, 3*n*n*N], gamma: [B, n*N]; returns lambda [B, n*N]."""
+        B = gamma.shape[0] if gamma.dim() > 1 else 1
+        n, N = self.n, self.N
+        self._chk(S, B * 3 * n * n * N, torch.float32, "S")
+        self._chk(gamma, B * n * N, torch.float32, "gamma")
+        if lam is None:
+            lam = torch.empty(B, n * N, device=gamma.device)
+        self._chk(lam, B * n * N, torch.float32, "lambda")
+        self._check(self.lib.mpcg_block_solve(self._h, _ptr(S), _ptr(gamma), _ptr(lam), B, _stream()))
+        return lam
+
     def form_schur(self, G_dense, C_dense, g, c, rho: float, precond: str = "ss", S=None, Pinv=None, gamma=None,
                    control_size: int = CONTROL_SIZE):
         """form_schur_system (include/pcg/linsys_setup.cuh:620-656), batched.  G_dense is overwritten by

@@ -23,6 +23,7 @@ int  orc_ldl_factor_##S(int n, const int *Ap, const int *Ai, const REAL *Ax, int
                         REAL *D, REAL *Dinv, const int *Lnz, const int *etree, \
                         unsigned char *bwork, int *iwork, REAL *fwork); \
 void orc_ldl_solve_##S(int n, const int *Lp, const int *Li, const REAL *Lx, const REAL *Dinv, REAL *x); \
+int  orc_bt_block_solve_##S(int n, int N, const REAL *S_, const REAL *gamma, REAL *lambda, REAL *work); \
 int  orc_ldl_solve_schur_##S(int An, const int *Ap, const int *Ai, const REAL *Ax, const REAL *b, REAL *x, \
                              int *Lp, int *Li, REAL *Lx, REAL *D, REAL *Dinv, const int *Lnz, \
                              const int *etree, unsigned char *bwork, int *iwork, REAL *fwork);

@@ -112,6 +112,20 @@ def direct_solve(S, b, N, n=14):
     return x
 
 
+def block_solve(S, gamma, N, n=14):
+    """Block-tridiagonal direct solve in the dtype of S (the operation order of mpcgpu_amd/csrc/block_solve.hip.h)."""
+    ct, suf = _real(S.dtype)
+    S = np.ascontiguousarray(np.nan_to_num(S))
+    gamma = np.ascontiguousarray(gamma, S.dtype)
+    lam = np.zeros(n * N, S.dtype)
+    work = np.zeros(N * (n * n + n), S.dtype)
+    f = getattr(lib(), f"orc_bt_block_solve_{suf}")
+    f.restype = C.c_int
+    rc = f(n, N, _p(S, ct), _p(gamma, ct), _p(lam, ct), _p(work, ct))
+    assert rc == 0
+    return lam
+
+
 def prep_csr(N, n=14):
     nnz = (N - 1) * n * n + N * (n * (n + 1)) // 2      # include/qdldl/sqp.cuh:148
     col_ptr = np.zeros(n * N + 1, np.int32)
