@@ -398,6 +398,29 @@ def main():
                                             "us_per_pcg_iter": float(np.median(ts[5:])) * 1e3 / max(int(i1.item()), 1),
                                             "pcg_waves": sol1.get_option("pcg_waves"), "pcg_reg_rows": sol1.get_option("pcg_reg_rows")}
 
+    if rank == 0 and args.storage == "f32":
+        # the other selectable solver on the same resident systems: batched block-tridiagonal direct solve
+        # (GPU counterpart of the reference's QDLDL path, i.e. of what cpu_baseline times on the host)
+        lam_d = torch.empty(B, 14 * N, device=dev)
+        ts = []
+        for _ in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            sol.block_solve(d_S, d_g, lam_d)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ms_d = float(np.median(ts[1:]))
+        nb = min(4, B)
+        Sd = d_S[:nb].cpu().numpy()
+        gd = d_g[:nb].cpu().numpy()
+        ld = lam_d[:nb].cpu().numpy().astype(np.float64)
+        res = [float(np.linalg.norm(gd[b] - synth.bd_to_dense(np.nan_to_num(Sd[b]), N) @ ld[b]) / np.linalg.norm(gd[b])) for b in range(nb)]
+        out["block_solve"] = {"kernel": "bt_block_solve_kernel (mpcg_block_solve)", "ms_per_batch": ms_d, "batch": B,
+                              "linsolves_per_sec": B / (ms_d * 1e-3), "us_per_linsolve_throughput": ms_d * 1e3 / B,
+                              "true_rel_residual_sample": res,
+                              "note": "fp32 block LU sweep, four trajectories per wavefront; not the headline metric (which counts PCG iterations)"}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, S_h, g_h, float(it_host.mean()), args.cpu_seconds)
         out["cpu_baseline"]["gpu_linsolves_per_sec"] = out["linsolves_per_sec"]
