@@ -566,11 +566,7 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
     hipStream_t st = static_cast<hipStream_t>(stream);
     a.k0_only = 0;
     if (h->schur_dpp) {
-        // register-resident kernels, four knots per wave (schur_dpp.hip.h); block row 0 (a different, much
-        // smaller computation) stays with the LDS kernel
-        a.k0_only = 1;
-        hipLaunchKernelGGL((form_schur_kernel<14, 7>), dim3((unsigned)(batch < cap ? batch : cap)), dim3(SCH_THREADS), 0, st, a);
-        HIP_TRY(h, hipGetLastError());
+        // register-resident kernels, four knots per wave (schur_dpp.hip.h)
         long b4 = ((long)batch * (N - 1) + 3) / 4;
         if (b4 > cap) b4 = cap;
         hipLaunchKernelGGL(form_schur_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);

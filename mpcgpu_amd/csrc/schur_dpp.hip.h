@@ -145,7 +145,7 @@ __device__ __forceinline__ void store_rows(const float (&M)[COLS], float* base, 
 
 }  // namespace sdpp
 
-// Block rows k >= 1 of every trajectory (block row 0 stays with form_schur_kernel, launched with only_k0):
+// Block rows k >= 1 of every trajectory (the k = 1 item also emits block row 0):
 // S[k,0], S[k,1], S[k-1,2], Pinv[k,1], gamma[k]; inverses of Q_{k-1}, R_{k-1} (and Q_{N-1}) -> scratch.
 __global__ __launch_bounds__(64, 2) void form_schur_dpp_kernel(SchurArgs a) {
     using namespace sdpp;
@@ -190,10 +190,21 @@ __global__ __launch_bounds__(64, 2) void form_schur_dpp_kernel(SchurArgs a) {
         for (int i = 0; i < m; ++i) {
             if (lr == i) Rk[i] += a.rho;
         }
+        const bool st14 = live && r14, st7 = live && r7;
+        // block row 0 (linsys_setup.cuh:152-277) needs nothing but Q_0 + rho I, its inverse and q_0 — all of which
+        // the k = 1 item has in hand: Pinv[0,1] = -(Q0 + rho I), S[0,1] = -Q0^-1, gamma_0 = -Q0^-1 q_0
+        if (k == 1) store_rows(Qk, P + nn, n, lr, st14, -1.f);                        // :201-210
         float Qki[n], Qpi[n], Rki[m];
         invert(Qk, Qki, lr);                                                          // :356-368
         invert(Qp, Qpi, lr);
         invert(Rk, Rki, lr);
+        {
+            const float g0 = matvec<n>(Qki, qk);                                      // :259-264
+            if (k == 1) {
+                store_rows(Qki, S + nn, n, lr, st14, -1.f);                           // :248-255
+                if (st14) gamma[lr] = -g0;                                            // :272-276
+            }
+        }
         float phi[n], BR[m];
         gemm_nn<n, n>(Ak, Qki, phi);                                                  // phi = Abar Qi      :397-398
         gemm_nn<m, m>(Bk, Rki, BR);                                                   // Bbar Ri            :405-406
@@ -207,7 +218,6 @@ __global__ __launch_bounds__(64, 2) void form_schur_dpp_kernel(SchurArgs a) {
         gemm_nt<m, n>(BR, Bk, t1);                                                    // (Bbar Ri) Bbar^T   :472-481
 #pragma unroll
         for (int cc = 0; cc < n; ++cc) { theta[cc] += Qpi[cc]; theta[cc] += t1[cc]; } // :466-468, 485-487
-        const bool st14 = live && r14, st7 = live && r7;
         store_rows(phi, S + (size_t)k * 3 * nn, n, lr, st14, -1.f);                   // S[k,0]             :490-497
         store_rows(theta, S + (size_t)k * 3 * nn + nn, n, lr, st14, -1.f);            // S[k,1]             :500-507
         if (st14) {                                                                   // S[k-1,2] = -phi^T  :536-557
