@@ -219,7 +219,8 @@ static size_t lds_request(const mpcg_handle* h, int nw, int esz) {
 }
 
 // <.,.,1> kernels: single-triple LDS slots that still fit after the uniform cache, at most two per wave that streams
-static int lds_extra_for(const mpcg_handle* h, int nw, int sb, int esz) {
+static int lds_extra_for(const mpcg_handle* h, int nw, int sb, int esz, int* streaming_waves_out) {
+    *streaming_waves_out = 0;
     if (sb != 1 || h->lds_extra == 0) return 0;
     const int rt = esz == 2 ? h->reg_rows16 : h->reg_rows;
     const int lt = lds_rows_for(h, nw, esz);
@@ -229,17 +230,27 @@ static int lds_extra_for(const mpcg_handle* h, int nw, int sb, int esz) {
     const size_t used = lds_bytes_for(h->N, nw) + pcg_lds_cache_floats(nw, lt, esz) * sizeof(float);
     const size_t slot = pcg_lds_cache_floats(1, 1, esz) * sizeof(float) / 2;      // one wave, one matrix, one triple
     int e = used < kLdsMax ? (int)((kLdsMax - used) / slot) : 0;
-    if (e > 2 * streaming_waves) e = 2 * streaming_waves;
+    // slot layout [S: nw][Pinv: nw]: a Pinv slot of wave w sits nw + w slots in, so Pinv slots only fit if ...
+    if (e > streaming_waves) {
+        const int room = e - nw;                    // slots available beyond the S bank
+        e = streaming_waves + (room > 0 ? (room < streaming_waves ? room : streaming_waves) : 0);
+    }
     if (h->lds_extra > 0 && e > h->lds_extra) e = h->lds_extra;
+    *streaming_waves_out = streaming_waves;
     return e;
 }
 
 template <int NW, int RT, int SB, typename MT>
 static int launch_pcg_t(mpcg_handle* h, PcgArgs a, uint32_t batch, hipStream_t st) {
     a.lds_rows = lds_rows_for(h, NW, (int)sizeof(MT));
-    a.lds_extra = lds_extra_for(h, NW, SB, (int)sizeof(MT));
+    int streaming_waves = 0;
+    const int extra = lds_extra_for(h, NW, SB, (int)sizeof(MT), &streaming_waves);
+    a.lds_extra_s = extra < streaming_waves ? extra : streaming_waves;             // S first: one pass loses its longest stream
+    a.lds_extra_p = extra - a.lds_extra_s;
+    // (the kernel lays the extra slots out as [S: NW][Pinv: NW]; only the first lds_extra_s / NW + lds_extra_p are touched)
+    const int extra_span = a.lds_extra_p > 0 ? NW + a.lds_extra_p : a.lds_extra_s;
     size_t lds = lds_bytes_for(h->N, NW) + pcg_lds_cache_floats(NW, a.lds_rows, (int)sizeof(MT)) * sizeof(float)
-               + (size_t)a.lds_extra * (pcg_lds_cache_floats(1, 1, (int)sizeof(MT)) * sizeof(float) / 2);
+               + (size_t)extra_span * (pcg_lds_cache_floats(1, 1, (int)sizeof(MT)) * sizeof(float) / 2);
     if (lds > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
     { const size_t padded = lds_request(h, NW, (int)sizeof(MT)); if (padded > lds && padded <= kLdsMax) lds = padded; }
     auto kern = pcg_traj_kernel<NW, RT, SB, MT>;

@@ -168,9 +168,12 @@ __host__ __device__ constexpr size_t r4(size_t x) { return (x + 3) & ~(size_t)3;
 __host__ __device__ constexpr size_t pcg_lds_floats(int N, int NW) {
     return 2 * r4((size_t)(N + 2) * NS) + 2 * r4((size_t)N * NS) + r4(2 * (size_t)NW);
 }
-// LDS matrix cache: per wave, per matrix, LT triples of 64 lanes x 14 element pairs (esz = 4 or 2)
+// LDS matrix cache: per wave, per matrix, LT triples of SLOT_LANES lane records x 14 element pairs (esz = 4 or 2).
+// Only 63 lanes carry data (lane 63 is idle and aliases lane 62's record): 7,056 B per fp32 triple instead of
+// 7,168 — at N=128 the 2 KB this saves over the uniform cache is what lets a third extra slot fit.
+constexpr int SLOT_LANES = 63;
 __host__ __device__ constexpr size_t pcg_lds_cache_floats(int NW, int LT, int esz = 4) {
-    return (size_t)NW * 2 * LT * 64 * (7 * esz);
+    return (size_t)NW * 2 * LT * SLOT_LANES * (7 * esz);
 }
 
 struct PcgArgs {
@@ -180,7 +183,7 @@ struct PcgArgs {
     uint32_t* iters; uint8_t* max_iter_exit;
     int N; int max_iter; float exit_tol; int pcols;   // pcols: 3 = SS, 1 = block-Jacobi
     int lds_rows;                          // LT: triples per matrix per wave cached in LDS
-    int lds_extra;                         // <.,.,1> kernels: extra single-triple LDS slots, dealt to (wave 0,S),(wave 0,Pinv),(wave 1,S),...
+    int lds_extra_s, lds_extra_p;          // <.,.,1> kernels: waves 0..x-1 cache one more triple of S / of Pinv in LDS
 };
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -297,9 +300,9 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : N
     const int TT = max(0, (NTR - w + NW - 1) / NW);
     const int LT = a.lds_rows;
     // <.,.,1> kernels: the LDS left over after the uniform cache (fewer than 2 NW slots) is handed out one triple
-    // at a time, to (wave 0, S), (wave 0, Pinv), (wave 1, S), ... — the waves that own the most triples
-    const int EX = SB == 1 ? a.lds_extra : 0;
-    const int LTs = LT + (2 * w < EX ? 1 : 0), LTp = LT + (2 * w + 1 < EX ? 1 : 0);
+    // at a time, to (wave 0, S), (wave 1, S), ..., then (wave 0, Pinv), ... — the waves that own the most triples
+    // first, and S before Pinv so that at least one of the two passes loses its longest stream
+    const int LTs = LT + (SB == 1 && w < a.lds_extra_s ? 1 : 0), LTp = LT + (SB == 1 && w < a.lds_extra_p ? 1 : 0);
     const int j0sS = min(TT, RT + LTs), j0sP = min(TT, RT + LTp);   // first streamed triple of S / of Pinv
     // streamed steps (even for the A/B roles of SB == 2, where LTs == LTp)
     const int TSs = SB == 2 ? (((TT - j0sS) + 1) & ~1) : (TT - j0sS);
@@ -329,10 +332,12 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : N
         regP[j] = load_trip(rP, j, a.pcols);
     }
     // ---- resident triples: LDS cache, lane-private records of 7 chunks (chunk = two columns) ----
-    mchunk* mc = mc_base + (size_t)w * 2 * LT * 64 * 7;
-    mchunk* mc_x = mc_base + (size_t)NW * 2 * LT * 64 * 7 + (size_t)(2 * w) * 64 * 7;   // this wave's two extra slots
+    const int slane = active ? lane : SLOT_LANES - 1;  // (idle lane 63 reads lane 62's record and writes nothing)
+    mchunk* mc = mc_base + (size_t)w * 2 * LT * SLOT_LANES * 7;
+    mchunk* mc_x = mc_base + (size_t)NW * 2 * LT * SLOT_LANES * 7;             // extra slots: index = wave (S), NW + wave (Pinv)
     auto slot = [&](int mat, int j) -> mchunk* {
-        return j < LT ? mc + ((size_t)(mat * LT + j) * 64 + lane) * 7 : mc_x + ((size_t)mat * 64 + lane) * 7;
+        return j < LT ? mc + ((size_t)(mat * LT + j) * SLOT_LANES + slane) * 7
+                      : mc_x + ((size_t)(mat * NW + w) * SLOT_LANES + slane) * 7;
     };
     auto pack2 = [](mpair lo, mpair hi) -> mchunk {
         if constexpr (sizeof(MT) == 4) return mchunk{lo.x, lo.y, hi.x, hi.y};
@@ -343,8 +348,10 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : N
         const int jj = isP ? j - LTs : j;
         const Trip t0 = isP ? load_trip(rP, RT + jj, a.pcols) : load_trip(rS, RT + jj, 3);
         mchunk* d0 = slot(isP, jj);
+        if (active) {
 #pragma unroll
-        for (int u = 0; u < 7; ++u) d0[u] = pack2(t0.m[2 * u], t0.m[2 * u + 1]);
+            for (int u = 0; u < 7; ++u) d0[u] = pack2(t0.m[2 * u], t0.m[2 * u + 1]);
+        }
     }
     auto lds_trip = [&](int mat, int j) -> Trip {
         const mchunk* src = slot(mat, j);
@@ -754,20 +761,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
         regS[j] = load_trip(rS, j, 3);
         regP[j] = load_trip(rP, j, a.pcols);
     }
-    mchunk* mc = mc_base + (size_t)w * 2 * LT * 64 * 7;
+    const int slane = active ? lane : SLOT_LANES - 1;
+    mchunk* mc = mc_base + (size_t)w * 2 * LT * SLOT_LANES * 7;
     for (int j = 0; j < LT; ++j) {
         const Trip ta = load_trip(rS, RT + j, 3);
         const Trip tb = load_trip(rP, RT + j, a.pcols);
-        mchunk* d0 = mc + ((size_t)j * 64 + lane) * 7;
-        mchunk* d1 = mc + ((size_t)(LT + j) * 64 + lane) * 7;
+        mchunk* d0 = mc + ((size_t)j * SLOT_LANES + slane) * 7;
+        mchunk* d1 = mc + ((size_t)(LT + j) * SLOT_LANES + slane) * 7;
+        if (active) {
 #pragma unroll
-        for (int u = 0; u < 7; ++u) {
-            d0[u] = mchunk{ta.m[2 * u].x, ta.m[2 * u].y, ta.m[2 * u + 1].x, ta.m[2 * u + 1].y};
-            d1[u] = mchunk{tb.m[2 * u].x, tb.m[2 * u].y, tb.m[2 * u + 1].x, tb.m[2 * u + 1].y};
+            for (int u = 0; u < 7; ++u) {
+                d0[u] = mchunk{ta.m[2 * u].x, ta.m[2 * u].y, ta.m[2 * u + 1].x, ta.m[2 * u + 1].y};
+                d1[u] = mchunk{tb.m[2 * u].x, tb.m[2 * u].y, tb.m[2 * u + 1].x, tb.m[2 * u + 1].y};
+            }
         }
     }
     auto lds_trip = [&](int mat, int j) -> Trip {
-        const mchunk* src = mc + ((size_t)(mat * LT + j) * 64 + lane) * 7;
+        const mchunk* src = mc + ((size_t)(mat * LT + j) * SLOT_LANES + slane) * 7;
         Trip t;
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
