@@ -163,10 +163,9 @@ int mpcg_bd_to_csr_lowertri(mpcg_handle *h, const float *d_S, float *d_val, floa
  * linear-system path (LINSYS_SOLVE == 0: qdldl_solve_schur, include/qdldl/sqp.cuh:22-49, called at :261-282 with
  * D2H(values, gamma) + CPU LDL^T + H2D(lambda) inside the timed region).  Reads d_S / d_gamma exactly as
  * mpcg_form_schur (or form_schur_system) left them, writes d_lambda (no warm start: lambda is output only).
- * Block LU without pivoting, pivot blocks inverted by the reference's Gauss-Jordan; four trajectories per wavefront,
- * serial in the knot index — the throughput solver for batches (1/50 of the flops of 167 PCG iterations), while
- * mpcg_pcg_solve is the low-latency solver for one trajectory and for warm starts.  fp32 at cond ~1e5: relative
- * error ~1e-2, as the float QDLDL path.  Scratch (batch x N x 210 floats) is owned by the handle (first call
+ * Block LU without pivoting, pivot blocks eliminated by the reference's Gauss-Jordan scheme; four trajectories per
+ * wavefront, serial in the knot index — the throughput solver for batches (1/50 of the flops of 167 PCG iterations),
+ * while mpcg_pcg_solve keeps warm starts and the tolerance knob.  fp32 at cond ~1e5: relative error ~3e-4.  Scratch (batch x N x 210 floats) is owned by the handle (first call
  * allocates: not capturable into a graph). */
 int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, float* d_lambda, uint32_t batch,
                      void* stream);

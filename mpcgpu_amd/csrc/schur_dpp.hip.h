@@ -123,6 +123,33 @@ __device__ __forceinline__ void invert(float (&A)[NN], float (&I)[NN], int lr) {
     });
 }
 
+// Gauss-Jordan elimination of [A | R] -> [I | A^-1 R] without pivoting, rows in lanes 0..NN-1, NR right-hand
+// columns.  Columns of A at or left of the pivot are not touched (they are unit columns afterwards by construction
+// and nobody reads them): 4 (NN - 1 - p + NR) instructions for pivot p.  A is destroyed.
+template <int NN, int NR>
+__device__ __forceinline__ void solve_aug(float (&A)[NN], float (&R)[NR], int lr) {
+    SFor<0, NN>::run([&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        const float pinv = 1.0f / rbc<P>(A[P]);
+        const float pcol = A[P];
+        const bool is_p = lr == P;
+#pragma unroll
+        for (int c = P + 1; c < NN; ++c) {
+            const float pa = A[c] * pinv;
+            const float ta = pcol * rbc<P>(pa);
+            const float na = A[c] - ta;
+            A[c] = is_p ? pa : na;
+        }
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            const float pr = R[c] * pinv;
+            const float tr = pcol * rbc<P>(pr);
+            const float nr = R[c] - tr;
+            R[c] = is_p ? pr : nr;
+        }
+    });
+}
+
 // row lr of a column-major rows x cols matrix
 // (always loads — from a clamped, in-bounds row — and selects afterwards: a per-row condition around the loads
 //  turns into divergent branches with the whole operand array parked in scratch)
