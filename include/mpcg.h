@@ -165,8 +165,9 @@ int mpcg_bd_to_csr_lowertri(mpcg_handle *h, const float *d_S, float *d_val, floa
  * mpcg_form_schur (or form_schur_system) left them, writes d_lambda (no warm start: lambda is output only).
  * Block LU without pivoting, pivot blocks eliminated by the reference's Gauss-Jordan scheme; four trajectories per
  * wavefront, serial in the knot index — the throughput solver for batches (1/50 of the flops of 167 PCG iterations),
- * while mpcg_pcg_solve keeps warm starts and the tolerance knob.  fp32 at cond ~1e5: relative error ~3e-4.  Scratch (batch x N x 210 floats) is owned by the handle (first call
- * allocates: not capturable into a graph). */
+ * while mpcg_pcg_solve keeps warm starts and the tolerance knob.  fp32 at cond ~1e5: relative error ~3e-4.
+ * Scratch (max_batch x N x 210 floats) is owned by the handle; the first call allocates it, later calls are pure
+ * stream work (capturable into a graph). */
 int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, float* d_lambda, uint32_t batch,
                      void* stream);
 
@@ -180,8 +181,12 @@ int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, flo
  * halo knots and inner-product partials between workgroups through global memory and therefore needs
  * batch * G <= #CUs per launch (larger batches are chunked).  A cluster that cannot make progress gives up after a
  * bounded spin: d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for that trajectory.
- * None of the residency knobs changes results (bitwise identical, tested); the cluster kernel sums the inner
- * products per workgroup first, so it agrees with the single-workgroup kernel to fp32 round-off. */
+ * "lds_extra" (single-triple LDS slots beyond the uniform cache of the <.,.,1> kernels: -1 what fits, 0 none),
+ * "cluster_adj" (lane order of the cluster kernel), "schur_dpp" (1: register/DPP Schur kernels, 0: the LDS versions);
+ * read-only: "num_cus", "pcg_resident" (1 if the current configuration streams nothing inside the PCG loop).
+ * None of the residency knobs changes results within a lane-order family (bitwise identical, tested); kernels that
+ * keep everything resident use the adjacent-lane order and agree with the streaming ones to fp32 round-off of the
+ * inner products, as does the cluster kernel, which sums the inner products per workgroup first. */
 int mpcg_set_option(mpcg_handle *h, const char *key, int value);
 int mpcg_get_option(const mpcg_handle *h, const char *key, int *value);
 

@@ -30,8 +30,9 @@ def test_linsys_chain_replays_from_a_hipgraph(N, B):
         lam = torch.zeros(B, n * N, device="cuda")
         it, ex = sol.solve(S, P, gam, lam, cfg, "ss")
         dz = sol.compute_dz(dG, dC, dg, lam)
+        lam_d = sol.block_solve(S, gam)
         torch.cuda.synchronize()
-        return lam.cpu().numpy(), dz.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy()
+        return lam.cpu().numpy(), dz.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy(), lam_d.cpu().numpy()
 
     want = [eager(*s) for s in sets]            # also the warm-up that sizes the library's scratch
 
@@ -43,6 +44,7 @@ def test_linsys_chain_replays_from_a_hipgraph(N, B):
     gam = torch.empty(B, n * N, device="cuda")
     lam = torch.empty(B, n * N, device="cuda")
     dz = torch.empty(B, (n + m) * N - m, device="cuda")
+    lam_d = torch.empty(B, n * N, device="cuda")
     it = torch.zeros(B, dtype=torch.int32, device="cuda")
     ex = torch.zeros(B, dtype=torch.uint8, device="cuda")
     graph = torch.cuda.CUDAGraph()
@@ -53,12 +55,14 @@ def test_linsys_chain_replays_from_a_hipgraph(N, B):
         sol.form_schur(dG, inC, ing, inc, 1e-3, "ss", S=S, Pinv=P, gamma=gam)
         sol.solve(S, P, gam, lam, cfg, "ss", iters=it, exits=ex)
         sol.compute_dz(dG, inC, ing, lam, dz=dz)
+        sol.block_solve(S, gam, lam_d)                      # the other solver, same graph
     for rep in (0, 1, 2, 1):
         G, C, g, c = sets[rep]
         inG.copy_(dev(G)); inC.copy_(dev(C)); ing.copy_(dev(g)); inc.copy_(dev(c))
         graph.replay()
         torch.cuda.synchronize()
-        wl, wz, wi, we = want[rep]
+        wl, wz, wi, we, wd = want[rep]
+        np.testing.assert_array_equal(lam_d.cpu().numpy(), wd)
         np.testing.assert_array_equal(it.cpu().numpy(), wi)
         np.testing.assert_array_equal(ex.cpu().numpy(), we)
         np.testing.assert_array_equal(lam.cpu().numpy(), wl)
