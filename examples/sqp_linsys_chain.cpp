@@ -5,6 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O2 -Iinclude/gbd_pcg_compat -Iinclude/mpcgpu_compat examples/sqp_linsys_chain.cpp -Lmpcgpu_amd -lmpcg_hip
 #include <cmath>
 #include <cstdio>
+#include <string>
 #include <vector>
 
 #include "gpu_pcg.cuh"
@@ -15,7 +16,8 @@
 #define PCG_NUM_THREADS 128
 typedef float T;
 
-int main() {
+int main(int argc, char** argv) {
+    const bool use_direct = argc > 1 && std::string(argv[1]) == "--direct";   // block_solve_schur instead of pcg<>
     const uint32_t state_size = STATE_SIZE, control_size = 7, knot_points = KNOT_POINTS;
     const int n = 14, m = 7, N = KNOT_POINTS, nn = n * n, mm = m * m, nm = n * m;
     const size_t Gsz = (size_t)(nn + mm) * N - mm, Csz = (size_t)(nn + nm) * (N - 1), gsz = (size_t)(n + m) * N - m;
@@ -76,9 +78,15 @@ int main() {
     // ---- include/pcg/sqp.cuh:207-259 ----
     form_schur_system<T>(state_size, control_size, knot_points, d_G_dense, d_C_dense, d_g, d_c, d_S, d_Pinv, d_gamma, rho);
     gpuErrchk(hipPeekAtLastError());
-    gpuErrchk(mpcgLaunchPcg(pcg_kernel, knot_points, PCG_NUM_THREADS, pcgKernelArgs, ppcg_kernel_smem_size));
-    gpuErrchk(hipMemcpy(&pcg_iters, d_pcg_iters, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    gpuErrchk(hipMemcpy(&pcg_exit, d_pcg_exit, sizeof(bool), hipMemcpyDeviceToHost));
+    if (use_direct) {                                                      // the LINSYS_SOLVE == 0 twin, on the GPU
+        block_solve_schur<T>(state_size, knot_points, d_S, d_gamma, d_lambda);
+        pcg_iters = 0;
+        pcg_exit = false;
+    } else {
+        gpuErrchk(mpcgLaunchPcg(pcg_kernel, knot_points, PCG_NUM_THREADS, pcgKernelArgs, ppcg_kernel_smem_size));
+        gpuErrchk(hipMemcpy(&pcg_iters, d_pcg_iters, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        gpuErrchk(hipMemcpy(&pcg_exit, d_pcg_exit, sizeof(bool), hipMemcpyDeviceToHost));
+    }
     compute_dz(state_size, control_size, knot_points, d_Ginv_dense, d_C_dense, d_g, d_lambda, d_dz);
     gpuErrchk(hipDeviceSynchronize());
 

@@ -31,3 +31,13 @@ void compute_dz(uint32_t state_size, uint32_t control_size, uint32_t knot_points
     if (mpcg_compute_dz(h, control_size, d_G_dense, d_C_dense, d_g_val, d_lambda, d_dz, 1, /*stream*/ nullptr) != MPCG_OK)
         mpcg_compat::die("compute_dz", h);
 }
+
+// The linear solve of the reference's other path (LINSYS_SOLVE == 0) — D2H(values, gamma), qdldl_solve_schur
+// (include/qdldl/sqp.cuh:22-49), H2D(lambda), timed as one region at include/qdldl/sqp.cuh:261-282 — as one GPU call on
+// the bd-layout S and gamma that form_schur_system left on the device: block-tridiagonal direct sweep, no host round trip.
+template <typename T>
+void block_solve_schur(uint32_t state_size, uint32_t knot_points, T* d_S, T* d_gamma, T* d_lambda) {
+    static_assert(std::is_same<T, float>::value, "libmpcg_hip is built for linsys_t = float");
+    mpcg_handle* h = mpcg_compat::handle_for(state_size, knot_points);
+    if (mpcg_block_solve(h, d_S, d_gamma, d_lambda, 1, /*stream*/ nullptr) != MPCG_OK) mpcg_compat::die("block_solve_schur", h);
+}

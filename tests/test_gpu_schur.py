@@ -142,10 +142,11 @@ def test_cpp_sqp_linsys_chain_over_shim_headers():
     import subprocess
     from mpcgpu_amd import build
     exe = build.CHAIN_BIN if os.path.exists(build.CHAIN_BIN) else build.build_chain_example()
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stdout + r.stderr
-    out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["pcg_exit"] == 0 and out["constraint_err"] < 1e-3 and out["stationarity_err"] < 1e-3
+    for args in ([], ["--direct"]):                 # pcg<> launch, then the GPU twin of the QDLDL path
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out["pcg_exit"] == 0 and out["constraint_err"] < 1e-3 and out["stationarity_err"] < 1e-3
 
 
 @pytest.mark.parametrize("N", [2, 3, 9, 32, 128, 300])
