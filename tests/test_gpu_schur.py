@@ -159,10 +159,14 @@ def test_block_solve_bit_exact_vs_oracle_and_close_to_float64(orc, N):
     k = synth.make_kkt(N, B, 6100 + N)
     S, Pinv, g = synth.form_schur(k, poison_unused=True)          # NaN in the two never-written blocks
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("block_solve_wide", 0)            # four trajectories per wavefront
     lam = sol.block_solve(dev(S), dev(g))
+    sol.set_option("block_solve_wide", 1)            # one trajectory per wavefront, columns dealt over the DPP rows
+    lam_w = sol.block_solve(dev(S), dev(g))
     torch.cuda.synchronize()
-    lam = lam.cpu().numpy()
+    lam, lam_w = lam.cpu().numpy(), lam_w.cpu().numpy()
     assert np.isfinite(lam).all()
+    np.testing.assert_array_equal(lam_w, lam)
     for b in range(B):
         np.testing.assert_array_equal(lam[b], orc.block_solve(S[b], g[b], N))
         x64 = orc.direct_solve(S[b], g[b], N)
