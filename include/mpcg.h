@@ -46,6 +46,7 @@ typedef enum mpcg_status {
  * block-Jacobi = only the diagonal blocks Pinv[k,1] are read (:202-210, 510-524);
  * symmetric stair = all three block columns (:97-136). */
 typedef enum mpcg_precond {
+    MPCG_PRECOND_NONE = 0,       /* mpcg_form_schur only: S and gamma, no Pinv at all (for mpcg_block_solve) */
     MPCG_PRECOND_JACOBI = 1,
     MPCG_PRECOND_SS = 3
 } mpcg_precond;
@@ -134,6 +135,8 @@ int mpcg_pcg_solve_f16(mpcg_handle *h,
  *   d_C_dense [batch][(n^2+nm)(N-1)]     -A_k, -B_k (already negated, include/common/kkt.cuh:115-116)
  *   d_g [batch][(n+m)N - m], d_c [batch][nN]
  *   d_S, d_Pinv, d_gamma                 outputs in the layouts mpcg_pcg_solve consumes
+ * precond = MPCG_PRECOND_NONE writes S and gamma only (d_Pinv is not touched and may be NULL): what
+ * mpcg_block_solve needs; it saves the inversion of every diagonal block of S and the completion kernel's products.
  * precond = MPCG_PRECOND_JACOBI skips the symmetric-stair completion (:9-137): the off-diagonal
  * blocks of d_Pinv are then left untouched.  The first call allocates a handle-owned staging buffer
  * of max_batch * sizeof(G) (hipMalloc — not stream-ordered); later calls are purely stream-ordered.

@@ -16,6 +16,7 @@ MPCG_ERR_INVALID = -1
 MPCG_ERR_UNSUPPORTED = -2
 MPCG_ERR_HIP = -3
 MPCG_ERR_NOMEM = -4
+MPCG_PRECOND_NONE = 0
 MPCG_PRECOND_JACOBI = 1
 MPCG_PRECOND_SS = 3
 

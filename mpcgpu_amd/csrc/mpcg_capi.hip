@@ -556,10 +556,10 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
                     const float* d_c, float* d_S, float* d_Pinv, float* d_gamma, float rho, uint32_t batch,
                     mpcg_precond precond, void* stream) {
     if (!h) return MPCG_ERR_INVALID;
-    if (!d_G_dense || !d_C_dense || !d_g || !d_c || !d_S || !d_Pinv || !d_gamma)
+    if (!d_G_dense || !d_C_dense || !d_g || !d_c || !d_S || (!d_Pinv && precond != MPCG_PRECOND_NONE) || !d_gamma)
         return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: null device pointer");
     if (control_size != 7) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur: control_size must be 7 (IIWA-14)");
-    if (precond != MPCG_PRECOND_JACOBI && precond != MPCG_PRECOND_SS)
+    if (precond != MPCG_PRECOND_NONE && precond != MPCG_PRECOND_JACOBI && precond != MPCG_PRECOND_SS)
         return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: bad preconditioner");
     if (batch == 0) return MPCG_OK;
     if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: batch exceeds max_batch");
@@ -577,7 +577,7 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
     SchurArgs a;
     a.G = d_G_dense; a.C = d_C_dense; a.g = d_g; a.c = d_c; a.S = d_S; a.Pinv = d_Pinv; a.gamma = d_gamma;
     a.Ginv_scratch = h->ginv_scratch; a.Ginv_out = d_G_dense;
-    a.rho = rho; a.n = n; a.m = m; a.N = N; a.batch = (int)batch; a.ss = precond == MPCG_PRECOND_SS;
+    a.rho = rho; a.n = n; a.m = m; a.N = N; a.batch = (int)batch; a.ss = precond == MPCG_PRECOND_SS; a.pinv = precond != MPCG_PRECOND_NONE;
     long blocks = (long)batch * N;
     const long cap = (long)h->num_cus * 64;
     if (blocks > cap) blocks = cap;

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64, 2) void form_schur_dpp_kernel(SchurArgs a) {
         const bool st14 = live && r14, st7 = live && r7;
         // block row 0 (linsys_setup.cuh:152-277) needs nothing but Q_0 + rho I, its inverse and q_0 — all of which
         // the k = 1 item has in hand: Pinv[0,1] = -(Q0 + rho I), S[0,1] = -Q0^-1, gamma_0 = -Q0^-1 q_0
-        if (k == 1) store_rows(Qk, P + nn, n, lr, st14, -1.f);                        // :201-210
+        if (k == 1 && a.pinv) store_rows(Qk, P + nn, n, lr, st14, -1.f);              // :201-210
         float Qki[n], Qpi[n], Rki[m];
         invert(Qk, Qki, lr);                                                          // :356-368
         invert(Qp, Qpi, lr);
@@ -252,9 +252,11 @@ __global__ __launch_bounds__(64, 2) void form_schur_dpp_kernel(SchurArgs a) {
 #pragma unroll
             for (int cc = 0; cc < n; ++cc) dst[cc + lr * n] = phi[cc] * -1.f;
         }
-        float thetaInv[n];
-        invert(theta, thetaInv, lr);                                                  // :510-514
-        store_rows(thetaInv, P + (size_t)k * 3 * nn + nn, n, lr, st14, -1.f);         // Pinv[k,1]          :517-524
+        if (a.pinv) {                                                                 // (uniform)
+            float thetaInv[n];
+            invert(theta, thetaInv, lr);                                              // :510-514
+            store_rows(thetaInv, P + (size_t)k * 3 * nn + nn, n, lr, st14, -1.f);     // Pinv[k,1]          :517-524
+        }
         if (st14) gamma[(size_t)k * n + lr] = -gam;                                   // :528-532
         store_rows(Qki, Gs + (size_t)(k - 1) * Gset, n, lr, st14, 1.f);               // G <- G^-1 (via scratch) :371-380
         store_rows(Rki, Gs + (size_t)(k - 1) * Gset + nn, m, lr, st7, 1.f);

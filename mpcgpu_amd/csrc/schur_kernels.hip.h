@@ -115,6 +115,7 @@ struct SchurArgs {
     const float* G; const float* C; const float* g; const float* c;
     float* S; float* Pinv; float* gamma; float* Ginv_scratch; float* Ginv_out;
     float rho; int n; int m; int N; int batch; int ss;
+    int pinv;                 // 0: S and gamma only (no Pinv block is computed or written)
     int k0_only;              // form_schur_kernel: block row 0 of every trajectory only (the rest: schur_dpp.hip.h)
 };
 
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(SCH_THREADS) void form_schur_kernel(SchurArgs a) {
             __syncthreads();
             for (int i = threadIdx.x; i < n; i += SCH_THREADS) Qk[i + i * n] += a.rho;
             __syncthreads();
-            w_copy(nn, Qk, P + nn, -1.f);                                // Pinv[0,1] = -(Q0 + rho I)
+            if (a.pinv) w_copy(nn, Qk, P + nn, -1.f);                    // Pinv[0,1] = -(Q0 + rho I)
             __syncthreads();
             w_invert(n, Qk, Qki, scr);
             w_copy(nn, Qki, S + nn, -1.f);                               // S[0,1] = -Q0^-1
@@ -194,8 +195,10 @@ __global__ __launch_bounds__(SCH_THREADS) void form_schur_kernel(SchurArgs a) {
         for (int e = threadIdx.x; e < nn; e += SCH_THREADS) { const int i = e % n, j = e / n; phiT[i + j * n] = phi[j + i * n]; }
         __syncthreads();
         w_copy(nn, phiT, S + (size_t)(k - 1) * 3 * nn + 2 * nn, -1.f);   // S[k-1,2] = -phi^T      :536-557
-        w_invert(n, t2, thetaInv, scr);                                  // :510-514
-        w_copy(nn, thetaInv, P + (size_t)k * 3 * nn + nn, -1.f);         // Pinv[k,1]              :517-524
+        if (a.pinv) {
+            w_invert(n, t2, thetaInv, scr);                              // :510-514
+            w_copy(nn, thetaInv, P + (size_t)k * 3 * nn + nn, -1.f);     // Pinv[k,1]              :517-524
+        }
         for (int i = threadIdx.x; i < n; i += SCH_THREADS) gamma[(size_t)k * n + i] = -gam[i];   // :528-532
         w_copy(nn, Qki, Gs + (size_t)(k - 1) * Gset);                    // G <- G^-1 (via scratch) :371-380
         w_copy(mm, Rki, Gs + (size_t)(k - 1) * Gset + nn);

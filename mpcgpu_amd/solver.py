@@ -173,7 +173,7 @@ class PcgSolver:
         S = torch.empty(B, 3 * n * n * N, device=dev) if S is None else S
         Pinv = torch.empty(B, 3 * n * n * N, device=dev) if Pinv is None else Pinv
         gamma = torch.empty(B, n * N, device=dev) if gamma is None else gamma
-        pc = _lib.MPCG_PRECOND_SS if precond == "ss" else _lib.MPCG_PRECOND_JACOBI
+        pc = {"ss": _lib.MPCG_PRECOND_SS, "jacobi": _lib.MPCG_PRECOND_JACOBI, "none": _lib.MPCG_PRECOND_NONE}[precond]
         self._check(self.lib.mpcg_form_schur(self._h, m, _ptr(G_dense), _ptr(C_dense), _ptr(g), _ptr(c), _ptr(S),
                                              _ptr(Pinv), _ptr(gamma), float(rho), B, pc, _stream()))
         return S, Pinv, gamma

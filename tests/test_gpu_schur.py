@@ -192,3 +192,28 @@ def test_block_solve_well_conditioned_is_accurate_and_agrees_with_pcg(orc):
     for b in range(B):
         x64 = orc.direct_solve(S[b], g[b], N)
         assert relinf(lam_d[b], x64) < 2e-4 and relinf(lam_p[b], x64) < 2e-4
+
+
+def test_form_schur_without_preconditioner_for_the_direct_solver(orc):
+    """precond='none': the same S, gamma and G^-1 bit for bit, d_Pinv never touched — what mpcg_block_solve needs."""
+    from mpcgpu_amd import PcgSolver
+    N, B = 33, 5
+    k = synth.make_kkt(N, B, 909)
+    G, C, g, c = synth.pack_kkt_dense(k, np.float32)
+    sol = PcgSolver(N, max_batch=B)
+    for dpp in (1, 0):
+        sol.set_option("schur_dpp", dpp)
+        dG = dev(G)
+        S = torch.full((B, 3 * n * n * N), float("nan"), device="cuda")
+        P = torch.full((B, 3 * n * n * N), 123.0, device="cuda")
+        gam = torch.empty(B, n * N, device="cuda")
+        sol.form_schur(dG, dev(C), dev(g), dev(c), 1e-3, "none", S=S, Pinv=P, gamma=gam)
+        lam = sol.block_solve(S, gam)
+        torch.cuda.synchronize()
+        assert (P.cpu().numpy() == 123.0).all()
+        for b in range(B):
+            So, Po, go, Go = orc.form_schur(G[b], C[b], g[b], c[b], N, np.float32(1e-3), ss=False)
+            np.testing.assert_array_equal(S[b].cpu().numpy(), So)
+            np.testing.assert_array_equal(gam[b].cpu().numpy(), go)
+            np.testing.assert_array_equal(dG[b].cpu().numpy(), Go)
+            np.testing.assert_array_equal(lam[b].cpu().numpy(), orc.block_solve(So, go, N))

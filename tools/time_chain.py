@@ -19,7 +19,7 @@ for N, B in ((32, 1024), (128, 128), (128, 1024)):
     cfg = pcg_config(pcg_exit_tol=1e-4, pcg_max_iter=synth.pcg_max_iter(N))
     def chain(direct):
         dG.copy_(G)
-        sol.form_schur(dG, C, g, c, 1e-3, "ss", S=S, Pinv=P, gamma=gam)
+        sol.form_schur(dG, C, g, c, 1e-3, "none" if direct else "ss", S=S, Pinv=P, gamma=gam)
         if direct: sol.block_solve(S, gam, lam)
         else:
             lam.zero_(); sol.solve(S, P, gam, lam, cfg, "ss", iters=it, exits=ex)
