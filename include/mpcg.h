@@ -60,9 +60,12 @@ const char *mpcg_build_info(void);
 /* Handle = per-device solver context for fixed (state_size, knot_points).  Replaces the
  * per-call cudaMalloc of PCG scratch in sqpSolvePcg (include/pcg/sqp.cuh:116-135): the solver
  * needs no global scratch at all (r, p, upsilon live in LDS), the handle only caches launch
- * configuration (and, after the first mpcg_form_schur, one staging buffer).  max_batch bounds `batch` of later
- * calls.  device < 0 = current device.  One handle per (device, knot_points); calls on the same handle must
- * not overlap on the host side (launch knobs are chosen per call), different handles are independent. */
+ * configuration and owns three device buffers: the hand-off cells of the cluster kernel (512 B per CU, allocated
+ * here) and, from their first use on, the staging buffer of mpcg_form_schur and the sweep scratch of
+ * mpcg_block_solve.  max_batch bounds `batch` of later calls.  device < 0 = current device.  One handle per
+ * (device, knot_points) and per concurrently used stream: calls on the same handle must not overlap on the host
+ * side (launch knobs are chosen per call) and their device work must be ordered (one stream, or events) because
+ * they share those buffers; different handles are independent. */
 int mpcg_create(mpcg_handle **out, int device, uint32_t state_size, uint32_t knot_points, uint32_t max_batch);
 int mpcg_destroy(mpcg_handle *h);
 const char *mpcg_last_error(const mpcg_handle *h);   /* h may be NULL: last error of mpcg_create */
