@@ -10,7 +10,8 @@
 //   cudaLaunchCooperativeKernel(pcg_kernel, N, threads, args, smem)   include/pcg/sqp.cuh:230
 //                                                        -> mpcgLaunchPcg(pcg_kernel, N, threads, args, smem)
 //                                                           (the ONE line of sqp.cuh that changes)
-// Only T = float (linsys_t with USE_DOUBLES=0, include/common/settings.cuh:41-49) and STATE_SIZE = 14.
+// T = float (linsys_t with USE_DOUBLES=0, include/common/settings.cuh:41-49) is the tuned path; T = double
+// (USE_DOUBLES=1) is served by the library's functional double-precision kernel.  STATE_SIZE = 14.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -58,13 +59,13 @@ inline mpcg_handle* handle_for(uint32_t state_size, uint32_t knot_points) {
 
 template <typename T>
 size_t pcgSharedMemSize(uint32_t state_size, uint32_t knot_points) {
-    static_assert(std::is_same<T, float>::value, "libmpcg_hip is built for linsys_t = float");
-    return mpcg_pcg_lds_bytes(state_size, knot_points);
+    static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value, "linsys_t is float or double");
+    return mpcg_pcg_lds_bytes(state_size, knot_points) * (sizeof(T) / sizeof(float));
 }
 
 template <typename T>
 bool checkPcgOccupancy(void* /*kernel*/, dim3 /*block*/, uint32_t state_size, uint32_t knot_points) {
-    static_assert(std::is_same<T, float>::value, "libmpcg_hip is built for linsys_t = float");
+    static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value, "linsys_t is float or double");
     uint32_t resident = 0;
     mpcg_handle* h = mpcg_compat::handle_for(state_size, knot_points);
     if (mpcg_check_pcg_occupancy(h, &resident) != MPCG_OK) mpcg_compat::die("checkPcgOccupancy", h);
@@ -75,23 +76,30 @@ bool checkPcgOccupancy(void* /*kernel*/, dim3 /*block*/, uint32_t state_size, ui
 template <typename T, uint32_t STATE_SIZE, uint32_t KNOT_POINTS>
 void pcg(T* d_S, T* d_Pinv, T* d_gamma, T* d_lambda, T* d_r, T* d_p, T* d_v_temp, T* d_eta_new_temp,
          uint32_t* d_iters, bool* d_max_iter_exit, uint32_t max_iter, T exit_tol) {
-    static_assert(std::is_same<T, float>::value, "libmpcg_hip is built for linsys_t = float");
+    static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value, "linsys_t is float or double");
     static_assert(sizeof(bool) == 1, "exit flag is one byte");
     mpcg_handle* h = mpcg_compat::handle_for(STATE_SIZE, KNOT_POINTS);
-    if (mpcg_pcg_solve_ref(h, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp, d_iters,
-                           reinterpret_cast<uint8_t*>(d_max_iter_exit), max_iter, exit_tol, /*stream*/ nullptr) != MPCG_OK)
-        mpcg_compat::die("pcg", h);
+    int rc;
+    if constexpr (std::is_same<T, float>::value)
+        rc = mpcg_pcg_solve_ref(h, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp, d_iters,
+                                reinterpret_cast<uint8_t*>(d_max_iter_exit), max_iter, exit_tol, /*stream*/ nullptr);
+    else
+        rc = mpcg_pcg_solve_ref_f64(h, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp, d_iters,
+                                    reinterpret_cast<uint8_t*>(d_max_iter_exit), max_iter, exit_tol, /*stream*/ nullptr);
+    if (rc != MPCG_OK) mpcg_compat::die("pcg", h);
 }
 
 // Replaces cudaLaunchCooperativeKernel at include/pcg/sqp.cuh:230.  `kernel` is the void* the call
 // site made from pcg<T,n,N>; `args` is its pcgKernelArgs array (addresses of the 12 arguments).
-// Grid/block/smem are accepted and ignored: the launch shape is the library's business.
+// Grid/block/smem are accepted and ignored: the launch shape is the library's business.  T defaults to float; inside
+// sqpSolvePcg<T> write mpcgLaunchPcg<T>(...) if the build may use linsys_t = double.
+template <typename T = float>
 inline hipError_t mpcgLaunchPcg(void* kernel, unsigned /*grid*/, unsigned /*block*/, void** args, size_t /*smem*/) {
-    using F = void (*)(float*, float*, float*, float*, float*, float*, float*, float*, uint32_t*, bool*, uint32_t, float);
+    using F = void (*)(T*, T*, T*, T*, T*, T*, T*, T*, uint32_t*, bool*, uint32_t, T);
     F f = reinterpret_cast<F>(kernel);
-    f(*static_cast<float**>(args[0]), *static_cast<float**>(args[1]), *static_cast<float**>(args[2]),
-      *static_cast<float**>(args[3]), *static_cast<float**>(args[4]), *static_cast<float**>(args[5]),
-      *static_cast<float**>(args[6]), *static_cast<float**>(args[7]), *static_cast<uint32_t**>(args[8]),
-      *static_cast<bool**>(args[9]), *static_cast<uint32_t*>(args[10]), *static_cast<float*>(args[11]));
+    f(*static_cast<T**>(args[0]), *static_cast<T**>(args[1]), *static_cast<T**>(args[2]),
+      *static_cast<T**>(args[3]), *static_cast<T**>(args[4]), *static_cast<T**>(args[5]),
+      *static_cast<T**>(args[6]), *static_cast<T**>(args[7]), *static_cast<uint32_t**>(args[8]),
+      *static_cast<bool**>(args[9]), *static_cast<uint32_t*>(args[10]), *static_cast<T*>(args[11]));
     return hipGetLastError();
 }

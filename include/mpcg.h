@@ -165,6 +165,17 @@ int mpcg_compute_dz(mpcg_handle *h, uint32_t control_size, const float *d_Ginv_d
 int mpcg_prep_csr(mpcg_handle *h, int32_t *d_col_ptr, int32_t *d_row_ind, void *stream);
 int mpcg_bd_to_csr_lowertri(mpcg_handle *h, const float *d_S, float *d_val, float mult, uint32_t batch, void *stream);
 
+/* linsys_t = double (USE_DOUBLES=1, include/common/settings.cuh:41-49): the same solve, same semantics, in double
+ * precision.  A functional path (S and Pinv are streamed every iteration), limited to knot_points <= 350 (iterate
+ * vectors in LDS).  mpcg_pcg_solve_ref_f64 carries the reference kernel's 12 arguments for pcg<double, n, N>. */
+int mpcg_pcg_solve_f64(mpcg_handle *h, const double *d_S, const double *d_Pinv, const double *d_gamma, double *d_lambda,
+                       uint32_t batch, uint32_t max_iter, double exit_tol, mpcg_precond precond,
+                       uint32_t *d_iters, uint8_t *d_max_iter_exit, void *stream);
+int mpcg_pcg_solve_ref_f64(mpcg_handle *h, double *d_S, double *d_Pinv, double *d_gamma, double *d_lambda,
+                           double *d_r, double *d_p, double *d_v_temp, double *d_eta_new_temp,
+                           uint32_t *d_pcg_iters, uint8_t *d_pcg_exit, uint32_t pcg_max_iter, double pcg_exit_tol,
+                           void *stream);
+
 /* Batched block-tridiagonal DIRECT solve of S lambda = gamma — the GPU-native counterpart of the reference's second
  * linear-system path (LINSYS_SOLVE == 0: qdldl_solve_schur, include/qdldl/sqp.cuh:22-49, called at :261-282 with
  * D2H(values, gamma) + CPU LDL^T + H2D(lambda) inside the timed region).  Reads d_S / d_gamma exactly as

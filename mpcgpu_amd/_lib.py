@@ -43,6 +43,9 @@ SYMBOLS = {
     "mpcg_compute_dz": (C.c_int, [C.c_void_p, C.c_uint32, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_void_p]),
     "mpcg_prep_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mpcg_bd_to_csr_lowertri": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_uint32, C.c_void_p]),
+    "mpcg_pcg_solve_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                     C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mpcg_pcg_solve_ref_f64": (C.c_int, [C.c_void_p] * 11 + [C.c_uint32, C.c_double, C.c_void_p]),
     "mpcg_block_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "mpcg_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "mpcg_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),

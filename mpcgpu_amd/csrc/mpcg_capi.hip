@@ -12,6 +12,7 @@
 #include "schur_kernels.hip.h"
 #include "schur_dpp.hip.h"
 #include "block_solve.hip.h"
+#include "pcg_f64.hip.h"
 
 using namespace mpcg;
 
@@ -529,6 +530,49 @@ int mpcg_pcg_solve_f16(mpcg_handle* h, const uint16_t* d_S16, const uint16_t* d_
     a.iters = d_iters; a.max_iter_exit = d_max_iter_exit;
     a.N = (int)h->N; a.max_iter = (int)max_iter; a.exit_tol = exit_tol; a.pcols = (int)precond; a.lds_rows = 0;
     return launch_pcg(h, a, batch, static_cast<hipStream_t>(stream), 2);
+}
+
+static int launch_f64(mpcg_handle* h, PcgArgs64 a, uint32_t batch, void* stream) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t lds = pcg_f64_lds_doubles((int)h->N) * sizeof(double);
+    if (lds > kLdsMax) return fail(h, MPCG_ERR_UNSUPPORTED, "double precision: the iterate vectors do not fit 160 KiB of LDS (knot_points <= 350)");
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_f64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(pcg_f64_kernel, dim3(batch), dim3(F64_THREADS), lds, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
+
+int mpcg_pcg_solve_f64(mpcg_handle* h, const double* d_S, const double* d_Pinv, const double* d_gamma, double* d_lambda,
+                       uint32_t batch, uint32_t max_iter, double exit_tol, mpcg_precond precond,
+                       uint32_t* d_iters, uint8_t* d_max_iter_exit, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_S || !d_Pinv || !d_gamma || !d_lambda || !d_iters || !d_max_iter_exit)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_f64: null device pointer");
+    if (batch == 0) return MPCG_OK;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_f64: batch exceeds max_batch");
+    if (precond != MPCG_PRECOND_JACOBI && precond != MPCG_PRECOND_SS)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_f64: bad preconditioner");
+    if (max_iter > 0x7fffffffu) return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_f64: max_iter too large");
+    PcgArgs64 a;
+    a.S = d_S; a.Pinv = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda; a.r_out = nullptr; a.p_out = nullptr;
+    a.iters = d_iters; a.max_iter_exit = d_max_iter_exit; a.N = (int)h->N; a.max_iter = (int)max_iter;
+    a.exit_tol = exit_tol; a.pcols = precond == MPCG_PRECOND_SS ? 3 : 1;
+    return launch_f64(h, a, batch, stream);
+}
+
+int mpcg_pcg_solve_ref_f64(mpcg_handle* h, double* d_S, double* d_Pinv, double* d_gamma, double* d_lambda,
+                           double* d_r, double* d_p, double* /*d_v_temp*/, double* /*d_eta_new_temp*/,
+                           uint32_t* d_pcg_iters, uint8_t* d_pcg_exit, uint32_t pcg_max_iter, double pcg_exit_tol, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_S || !d_Pinv || !d_gamma || !d_lambda || !d_pcg_iters || !d_pcg_exit)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_ref_f64: null device pointer");
+    if (pcg_max_iter > 0x7fffffffu) return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_ref_f64: max_iter too large");
+    PcgArgs64 a;
+    a.S = d_S; a.Pinv = d_Pinv; a.gamma = d_gamma; a.lambda = d_lambda; a.r_out = d_r; a.p_out = d_p;
+    a.iters = d_pcg_iters; a.max_iter_exit = d_pcg_exit; a.N = (int)h->N; a.max_iter = (int)pcg_max_iter;
+    a.exit_tol = pcg_exit_tol; a.pcols = 3;
+    return launch_f64(h, a, 1, stream);
 }
 
 int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, float* d_lambda, uint32_t batch, void* stream) {

@@ -138,6 +138,26 @@ class PcgSolver:
                                                 _ptr(iters), _ptr(exits), _stream()))
         return iters, exits
 
+    def solve_f64(self, S, Pinv, gamma, lam, config: pcg_config | None = None, precond: str = "ss",
+                  iters: torch.Tensor | None = None, exits: torch.Tensor | None = None):
+        """`solve` in double precision (linsys_t = double, USE_DOUBLES=1 of include/common/settings.cuh:41-49)."""
+        cfg = config or pcg_config(pcg_max_iter=pcg_max_iter(self.N))
+        B = lam.shape[0] if lam.dim() > 1 else 1
+        n, N = self.n, self.N
+        for t, k, nm in ((S, 3 * n * n, "S"), (Pinv, 3 * n * n, "Pinv"), (gamma, n, "gamma"), (lam, n, "lambda")):
+            self._chk(t, B * k * N, torch.float64, nm)
+        if iters is None:
+            iters = torch.empty(B, dtype=torch.int32, device=lam.device)
+        if exits is None:
+            exits = torch.empty(B, dtype=torch.uint8, device=lam.device)
+        if precond not in ("ss", "jacobi"):
+            raise ValueError("precond must be 'ss' or 'jacobi'")
+        pc = _lib.MPCG_PRECOND_SS if precond == "ss" else _lib.MPCG_PRECOND_JACOBI
+        self._check(self.lib.mpcg_pcg_solve_f64(self._h, _ptr(S), _ptr(Pinv), _ptr(gamma), _ptr(lam), B,
+                                                int(cfg.pcg_max_iter), float(cfg.pcg_exit_tol), pc,
+                                                _ptr(iters), _ptr(exits), _stream()))
+        return iters, exits
+
     def solve_ref(self, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp,
                   d_pcg_iters, d_pcg_exit, pcg_max_iter: int, pcg_exit_tol: float):
         """The reference kernel's argument list, in order (include/pcg/sqp.cuh:137-150)."""
