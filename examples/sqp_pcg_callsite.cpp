@@ -13,7 +13,11 @@
 #define STATE_SIZE 14
 #define KNOT_POINTS 32
 #define PCG_NUM_THREADS 128
+#ifdef USE_DOUBLES            // linsys_t = double, include/common/settings.cuh:41-49
+typedef double T;
+#else
 typedef float T;
+#endif
 
 int main() {
     const uint32_t state_size = STATE_SIZE, knot_points = KNOT_POINTS;
@@ -86,7 +90,7 @@ int main() {
     size_t ppcg_kernel_smem_size = pcgSharedMemSize<T>(state_size, knot_points);
 
     // ---- include/pcg/sqp.cuh:230-232 ----
-    gpuErrchk(mpcgLaunchPcg(pcg_kernel, knot_points, PCG_NUM_THREADS, pcgKernelArgs, ppcg_kernel_smem_size));
+    gpuErrchk(mpcgLaunchPcg<T>(pcg_kernel, knot_points, PCG_NUM_THREADS, pcgKernelArgs, ppcg_kernel_smem_size));
     gpuErrchk(hipMemcpy(&pcg_iters, d_pcg_iters, sizeof(uint32_t), hipMemcpyDeviceToHost));
     gpuErrchk(hipMemcpy(&pcg_exit, d_pcg_exit, sizeof(bool), hipMemcpyDeviceToHost));
     gpuErrchk(hipMemcpy(h_lambda.data(), d_lambda, h_lambda.size() * sizeof(T), hipMemcpyDeviceToHost));

@@ -53,6 +53,21 @@ def build_chain_example(force: bool = False, verbose: bool = False) -> str:
     return CHAIN_BIN
 
 
+EXAMPLE_BIN64 = os.path.join(_ROOT, "examples", "sqp_pcg_callsite_f64")
+
+
+def build_example_f64(force: bool = False, verbose: bool = False) -> str:
+    """The same call site compiled with -DUSE_DOUBLES (linsys_t = double): pcg<double, n, N> over the shim."""
+    deps = [EXAMPLE_SRC, LIB_PATH, os.path.join(_ROOT, "include", "gbd_pcg_compat", "gpu_pcg.cuh")]
+    if force or not os.path.exists(EXAMPLE_BIN64) or any(os.path.getmtime(d) > os.path.getmtime(EXAMPLE_BIN64) for d in deps):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-DUSE_DOUBLES", "-I" + os.path.join(_ROOT, "include", "gbd_pcg_compat"),
+               EXAMPLE_SRC, "-L" + _HERE, "-lmpcg_hip", "-Wl,-rpath,$ORIGIN/../mpcgpu_amd", "-o", EXAMPLE_BIN64]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return EXAMPLE_BIN64
+
+
 def build_example(force: bool = False, verbose: bool = False) -> str:
     """C++ host program: the reference's PCG call site over the shim headers + the C ABI."""
     deps = [EXAMPLE_SRC, LIB_PATH, os.path.join(_ROOT, "include", "gbd_pcg_compat", "gpu_pcg.cuh")]

@@ -307,6 +307,12 @@ def test_cpp_callsite_over_shim_headers():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["pcg_exit"] == 0 and 0 < out["pcg_iters"] < 200 and out["rel_residual"] < 1e-4
     assert out["smem"] == 4 * ((32 + 2) * 14 * 2 + 32 * 14 * 2 + 32)
+    # the same source with -DUSE_DOUBLES: pcg<double, n, N>, mpcgLaunchPcg<double>
+    exe64 = build.EXAMPLE_BIN64 if os.path.exists(build.EXAMPLE_BIN64) else build.build_example_f64()
+    r = subprocess.run([exe64], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["pcg_exit"] == 0 and 0 < out["pcg_iters"] < 200 and out["rel_residual"] < 1e-4 and out["smem"] == 8 * ((32 + 2) * 14 * 2 + 32 * 14 * 2 + 32)
 
 
 @pytest.mark.parametrize("waves,reg_rows,lds_rows", [(16, 1, -1), (16, 1, 0), (16, 2, -1), (8, 2, 0), (8, 2, 1), (8, 3, -1), (4, 4, -1), (4, 6, 2), (4, 7, -1)])
