@@ -304,8 +304,10 @@ static int stream_bufs_for(const mpcg_handle* h, int nw, int esz) {
 
 template <int NW, int RT>
 static int launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, int G, int lt, hipStream_t st) {
-    const size_t lds = pcg_cluster_lds_floats((int)h->N, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
+    const int kl_max = 3 * ((((int)h->N + 2) / 3 + G - 1) / G);
+    const size_t lds = pcg_cluster_lds_floats(kl_max, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
     ClusterArgs ca;
+    ca.kl_max = kl_max;
     ca.p = a; ca.p.lds_rows = lt; ca.scratch = h->cluster_scratch; ca.G = G;
     auto kern = h->cluster_adj ? pcg_cluster_kernel<NW, RT, true> : pcg_cluster_kernel<NW, RT, false>;
     if (lds > 48 * 1024)
@@ -341,7 +343,7 @@ static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
     const int per_wg = (ntr + G - 1) / G;                // triples of the largest member
     const int TT = (per_wg + NW - 1) / NW;
     const int lt = TT > RT ? TT - RT : 0;
-    const size_t lds = pcg_cluster_lds_floats((int)h->N, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
+    const size_t lds = pcg_cluster_lds_floats(3 * per_wg, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
     if (lds > kLdsMax) return 1;
     const size_t mstride = (size_t)h->N * ROWF, vstride = (size_t)h->N * NS;
     for (uint32_t lo = 0; lo < batch; lo += chunk) {

@@ -682,11 +682,13 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 constexpr int CL_WG_WORDS = 64;          // u64 words of scratch per workgroup: 2x2x14 halo + 2 partials (+pad)
 constexpr unsigned CL_SPIN_LIMIT = 1u << 22;
 
-__host__ __device__ constexpr size_t pcg_cluster_lds_floats(int N, int NW) {
-    return 2 * r4((size_t)(N + 2) * NS) + 2 * r4((size_t)N * NS) + r4(2 * (size_t)NW + 4);
+// LDS of one cluster member: its own KL knots (+ one halo knot either side for p and r), not the whole horizon
+__host__ __device__ constexpr size_t pcg_cluster_lds_floats(int KL, int NW) {
+    return 2 * r4((size_t)(KL + 2) * NS) + 2 * r4((size_t)KL * NS) + r4(2 * (size_t)NW + 4);
 }
 
 struct ClusterArgs {
+    int kl_max;                              // knots of the largest member: 3 * ceil(#triples / G)
     PcgArgs p;
     unsigned long long* scratch;         // [batch*G][CL_WG_WORDS], zeroed before the launch
     int G;
@@ -710,11 +712,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
     const int g = blockIdx.x - b * G;                   // member of its cluster
     constexpr int NTHR = NW * 64;
 
-    float* xp = lds;
-    float* xr = xp + r4((size_t)(N + 2) * NS);
-    float* lam = xr + r4((size_t)(N + 2) * NS);
-    float* tmp = lam + r4((size_t)N * NS);
-    float* red_v = tmp + r4((size_t)N * NS);            // [NW] wave partials of v
+    // this workgroup's triples [t0, t1) and knots [k0, k1)
+    const int NTR = (N + 2) / 3;
+    const int t0 = (int)(((long)g * NTR) / G), t1 = (int)(((long)(g + 1) * NTR) / G);
+    const int k0 = 3 * t0, k1 = min(3 * t1, N);
+    // The member keeps only ITS knots of the iterate vectors (+ one halo knot either side of p and r): KL = ca.kl_max
+    // knots of LDS per vector.  The pointers are biased by -k0 knots so that the code below keeps indexing with
+    // global knot numbers: knot k of a padded vector is at v + (k + 1) * NS for k in [k0 - 1, k1], of an unpadded
+    // one at v + k * NS for k in [k0, k1).
+    const int KL = ca.kl_max;
+    float* xp_l = lds;
+    float* xr_l = xp_l + r4((size_t)(KL + 2) * NS);
+    float* lam_l = xr_l + r4((size_t)(KL + 2) * NS);
+    float* tmp_l = lam_l + r4((size_t)KL * NS);
+    float* xp = xp_l - (ptrdiff_t)k0 * NS;
+    float* xr = xr_l - (ptrdiff_t)k0 * NS;
+    float* lam = lam_l - (ptrdiff_t)k0 * NS;
+    float* tmp = tmp_l - (ptrdiff_t)k0 * NS;
+    float* red_v = tmp_l + r4((size_t)KL * NS);         // [NW] wave partials of v
     float* red_e = red_v + NW;                          // [NW] wave partials of eta
     float* bc = red_v + 2 * NW;                         // [4] broadcast cell: total, timeout flag
     mchunk* mc_base = reinterpret_cast<mchunk*>(red_v + r4(2 * (size_t)NW + 4));
@@ -736,10 +751,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
     const bool head = active && ls == 0;
     const uint32_t lane_byte = (uint32_t)(ls * 196 + lq * 2) * ESZ;
 
-    // this workgroup's triples [t0, t1) and knots [k0, k1)
-    const int NTR = (N + 2) / 3;
-    const int t0 = (int)(((long)g * NTR) / G), t1 = (int)(((long)(g + 1) * NTR) / G);
-    const int k0 = 3 * t0, k1 = min(3 * t1, N);
     const int TT = max(0, (t1 - t0 - w + NW - 1) / NW);   // this wave's triples: tr = t0 + w + NW*j  (launcher: TT <= RT + LT)
     const int LT = a.lds_rows;
 
@@ -788,14 +799,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
         return t;
     };
 
-    // ---- stage FULL vectors (every member reads all of lambda0 / gamma: no exchange needed for the setup SpMV) ----
-    for (int e = tid; e < (N + 2) * NS; e += NTHR) { xp[e] = 0.f; xr[e] = 0.f; }
+    // ---- stage the member's knots; lambda0 also for the halo knots k0-1 and k1 (it is complete in global memory: the
+    //      setup SpMV needs no exchange); knots outside [0, N) are the zero padding ----
+    for (int e = tid; e < (KL + 2) * NS; e += NTHR) { xp_l[e] = 0.f; xr_l[e] = 0.f; }
     lds_barrier();
-    for (int e = tid; e < N * NS; e += NTHR) {
+    for (int e = NS * (k0 - 1) + tid; e < NS * (k1 + 1); e += NTHR) {
+        const int k = e / NS;                           // (e >= -NS: k0 >= 0; e in [-NS, 0) only for k0 = 0, skipped below)
+        if (e < 0 || k >= N) continue;
         const float l0 = lam_g[e];
         xp[NS + e] = l0;
-        lam[e] = l0;
-        xr[NS + e] = gam[e];
+        if (k >= k0 && k < k1) {
+            lam[e] = l0;
+            xr[NS + e] = gam[e];
+        }
     }
     lds_barrier();
 
@@ -804,7 +820,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArg
         Pend q;
         const int k = 3 * (t0 + w + NW * j) + lrho;
         q.valid = j < TT && k < N;
-        q.k = q.valid ? k : 0;
+        q.k = q.valid ? k : k0;                          // (any knot of this member will do for the zero rows)
         const f2* x2 = reinterpret_cast<const f2*>(xv + (q.k + ls) * NS);
         f2 acc = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
