@@ -199,6 +199,7 @@ int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, flo
  * batch * G <= #CUs per launch (larger batches are chunked).  A cluster that cannot make progress gives up after a
  * bounded spin: d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for that trajectory.
  * "lds_extra" (single-triple LDS slots beyond the uniform cache of the <.,.,1> kernels: -1 what fits, 0 none),
+ * "cluster_waves" (waves per cluster member: 8 = one member per CU, 4 = two per CU, -1 by horizon and batch),
  * "cluster_adj" (lane order of the cluster kernel), "schur_dpp" (1: register/DPP Schur kernels, 0: the LDS versions),
  * "block_solve_wide" (mpcg_block_solve: 1 one trajectory per wavefront, 0 four, -1 by batch size; same bits);
  * read-only: "num_cus", "pcg_resident" (1 if the current configuration streams nothing inside the PCG loop).

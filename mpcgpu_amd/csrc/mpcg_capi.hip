@@ -27,6 +27,7 @@ struct mpcg_handle {
     int pcg_waves16 = 8, reg_rows16 = 6, lds_rows16 = -1;   // the same knobs for fp16 matrix storage
     int block_solve_wide = -1; // mpcg_block_solve: one trajectory per wavefront (1), four (0), by batch size (-1)
     int schur_dpp = 1;        // 1: register-resident Schur formation kernels (schur_dpp.hip.h), 0: the LDS versions
+    int cluster_waves = -1;   // waves per cluster member: 8 (one member per CU), 4 (two per CU), -1 by batch size
     int cluster_adj = 1;      // lane order of the cluster kernel (1: blocks of a row in adjacent lanes)
     int cluster = -1;         // workgroups per trajectory for the cluster kernel: 0 off, -1 auto, G > 0 forced
     unsigned long long* cluster_scratch = nullptr;
@@ -115,7 +116,7 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     // hand-off cells of the cluster kernel (512 B per CU), allocated here so that every solve is pure stream work
     // and can be captured into a hipGraph
     if (hipSetDevice(device) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&h->cluster_scratch), (size_t)h->num_cus * CL_WG_WORDS * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void**>(&h->cluster_scratch), (size_t)2 * h->num_cus * CL_WG_WORDS * sizeof(unsigned long long)) != hipSuccess) {
         delete h;
         return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the cluster scratch");
     }
@@ -149,6 +150,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "pcg_stream_bufs")) { h->stream_bufs = value; return MPCG_OK; }
     if (!strcmp(key, "lds_extra")) { h->lds_extra = value; return MPCG_OK; }
     if (!strcmp(key, "cluster_adj")) { h->cluster_adj = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "cluster_waves")) { h->cluster_waves = value; return MPCG_OK; }
     if (!strcmp(key, "schur_dpp")) { h->schur_dpp = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "block_solve_wide")) { h->block_solve_wide = value; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
@@ -327,24 +329,27 @@ static int launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, in
 //             member of a cluster must be resident;
 //   96 < N < 256: when the whole batch fits one launch, batch * G <= #CUs (N=128, batch 1: 0.70 ms vs 1.02 ms;
 //             batch 128: 23.6 M vs 20.0 M it/s); larger batches run the single-workgroup kernel (36 M it/s).
-static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
-    if (h->cluster == 0 || esz != 4) return 1;
-    constexpr int NW = 8, RT = 3;
+// NW_ = 8: one member per CU (8 waves x 3 register triples).  NW_ = 4: members of 4 waves x (3 register + 1 LDS)
+// triples need < 256 registers and < 80 KiB of LDS, so TWO members — of different clusters, usually — share a CU and
+// compute through each other's cluster-wide waits: the throughput configuration for long horizons.
+template <int NW, int RT>
+static int try_launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int per_cu) {
     const int ntr = ((int)h->N + 2) / 3;
+    const int lt_cap = NW == 4 ? 1 : 0;                  // LDS triples per wave and matrix a member may use by default
     int G = h->cluster;
     const bool forced = G > 0;
     if (!forced) {
         if (h->N <= 96) return 1;
-        G = (ntr + NW * RT - 1) / (NW * RT);
+        G = (ntr + NW * (RT + lt_cap) - 1) / (NW * (RT + lt_cap));
     }
     if (G < 2 || G > ntr || G > h->num_cus) return 1;
-    const uint32_t chunk = (uint32_t)(h->num_cus / G);
+    const uint32_t chunk = (uint32_t)(per_cu * h->num_cus / G);
     if (batch > chunk && (forced || h->N < 256)) return 1;
     const int per_wg = (ntr + G - 1) / G;                // triples of the largest member
     const int TT = (per_wg + NW - 1) / NW;
     const int lt = TT > RT ? TT - RT : 0;
     const size_t lds = pcg_cluster_lds_floats(3 * per_wg, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
-    if (lds > kLdsMax) return 1;
+    if (lds > kLdsMax / (size_t)per_cu) return 1;
     const size_t mstride = (size_t)h->N * ROWF, vstride = (size_t)h->N * NS;
     for (uint32_t lo = 0; lo < batch; lo += chunk) {
         const uint32_t nb = batch - lo < chunk ? batch - lo : chunk;
@@ -361,6 +366,24 @@ static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
         if (rc != MPCG_OK) return rc;
     }
     return MPCG_OK;
+}
+
+static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
+    if (h->cluster == 0 || esz != 4) return 1;
+    // "cluster_waves": 8, 4, or -1 = 4-wave members (two per CU) when the batch needs more than one launch of 8-wave
+    // members anyway, i.e. when the call is about throughput
+    int waves = h->cluster_waves;
+    if (waves < 0) {
+        const int ntr = ((int)h->N + 2) / 3;
+        const int g8 = (ntr + 23) / 24;
+        // (N=512: 6.3 vs 5.3 M it/s at batch 1024; N=256: no gain, the members' passes get too long)
+        waves = (h->N >= 384 && g8 >= 2 && batch > (uint32_t)(h->num_cus / g8)) ? 4 : 8;
+    }
+    if (waves == 4) {
+        const int rc = try_launch_cluster_t<4, 3>(h, a, batch, st, 2);
+        if (rc != 1) return rc;
+    }
+    return try_launch_cluster_t<8, 3>(h, a, batch, st, 1);
 }
 
 static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {

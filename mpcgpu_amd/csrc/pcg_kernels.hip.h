@@ -695,7 +695,7 @@ struct ClusterArgs {
 };
 
 template <int NW, int RT, bool ADJ>
-__global__ __launch_bounds__(NW * 64, NW / 4) void pcg_cluster_kernel(ClusterArgs ca) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 && RT <= 3 ? 2 : NW / 4)) void pcg_cluster_kernel(ClusterArgs ca) {
     typedef float MT;
     typedef typename MatT<MT>::pair mpair;
     typedef typename MatT<MT>::chunk mchunk;

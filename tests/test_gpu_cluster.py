@@ -17,10 +17,14 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("N,G,B", [(128, 2, 3), (200, 3, 2), (256, 4, 2), (512, 8, 2), (512, 16, 1), (64, 2, 1)])
+@pytest.mark.parametrize("N,G,B", [(128, 2, 3), (200, 3, 2), (256, 4, 2), (512, 8, 2), (512, 16, 1), (64, 2, 1),
+                                   (512, -411, 40), (256, -406, 70)])      # G < 0: 4-wave members, -(400 + G), two per CU
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
 def test_cluster_matches_oracle_and_single_workgroup(orc, N, G, B, pc):
     from mpcgpu_amd import PcgSolver, pcg_config
+    waves4 = G < 0
+    if waves4:
+        G = -G - 400
     k = synth.make_kkt(N, B, 7700 + N + G)
     S, Pinv, g = synth.form_schur(k, poison_unused=True)
     lam0 = np.random.default_rng(N).normal(0, 0.2, (B, n * N)).astype(np.float32)
@@ -29,6 +33,7 @@ def test_cluster_matches_oracle_and_single_workgroup(orc, N, G, B, pc):
     for mode in ("cluster", "single"):
         sol = PcgSolver(N, max_batch=B)
         sol.set_option("cluster", G if mode == "cluster" else 0)
+        sol.set_option("cluster_waves", 4 if waves4 else 8)
         for K, tol in ((3, 0.0), (30, 0.0), (400, 1e-3)):
             lam = dev(lam0)
             it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=tol, pcg_max_iter=K), pc)
@@ -42,7 +47,7 @@ def test_cluster_matches_oracle_and_single_workgroup(orc, N, G, B, pc):
     for K in (3, 30):
         c, s1 = out[("cluster", K)], out[("single", K)]
         assert (c[1] == K).all() and (c[2] == 1).all(), (c[1], c[2])          # no timeout (would be 0xFFFFFFFF / 2)
-        for t in range(B):
+        for t in (range(B) if B <= 3 else (0, B // 2, B - 1)):
             r64 = orc.pcg(np.nan_to_num(S[t]).astype(np.float64), np.nan_to_num(Pinv[t]).astype(np.float64),
                           g[t].astype(np.float64), lam0[t].astype(np.float64), N, K, 0.0, pc)
             band = fp32_band(orc, S[t], Pinv[t], g[t], lam0[t], N, K, pc, r64["lam"], trials=2)
