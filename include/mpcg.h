@@ -60,7 +60,7 @@ const char *mpcg_build_info(void);
 /* Handle = per-device solver context for fixed (state_size, knot_points).  Replaces the
  * per-call cudaMalloc of PCG scratch in sqpSolvePcg (include/pcg/sqp.cuh:116-135): the solver
  * needs no global scratch at all (r, p, upsilon live in LDS), the handle only caches launch
- * configuration and owns three device buffers: the hand-off cells of the cluster kernel (512 B per CU, allocated
+ * configuration and owns three device buffers: the hand-off cells of the cluster kernel (1 KiB per CU, allocated
  * here) and, from their first use on, the staging buffer of mpcg_form_schur and the sweep scratch of
  * mpcg_block_solve.  max_batch bounds `batch` of later calls.  device < 0 = current device.  One handle per
  * (device, knot_points) and per concurrently used stream: calls on the same handle must not overlap on the host

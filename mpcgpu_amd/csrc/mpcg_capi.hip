@@ -113,7 +113,7 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     if (knot_points <= 144) { h->pcg_waves16 = 8; h->reg_rows16 = 6; }      // fp16 storage: <= 48 triples all in registers
     else { h->pcg_waves16 = 4; h->reg_rows16 = 12; }
     h->lds_rows16 = -1;
-    // hand-off cells of the cluster kernel (512 B per CU), allocated here so that every solve is pure stream work
+    // hand-off cells of the cluster kernel (512 B per member, up to two members per CU), allocated here so that every solve is pure stream work
     // and can be captured into a hipGraph
     if (hipSetDevice(device) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&h->cluster_scratch), (size_t)2 * h->num_cus * CL_WG_WORDS * sizeof(unsigned long long)) != hipSuccess) {
