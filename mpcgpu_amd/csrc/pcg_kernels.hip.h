@@ -380,8 +380,13 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : N
         if constexpr (SB == 1) {
             if ((st_pass ? TSp : TSs) == 0) st_pass ^= 1;   // this wave streams nothing of that matrix
         }
-        const Trip t = st_pass ? load_trip(rP, j0sP + st_j, a.pcols) : load_trip(rS, j0sS + st_j, 3);
-        if (++st_j >= (st_pass ? TSp : TSs)) { st_j = 0; st_pass ^= 1; }
+        // ONE load sequence through a selected descriptor — `st_pass ? load_trip(rP…) : load_trip(rS…)` compiled to a
+        // speculative first load, a branch and an `s_waitcnt vmcnt(0)` before the other thirteen: every refill was
+        // waited for on the spot, a full memory latency per streamed triple
+        const bool isP = st_pass != 0;
+        const rsrc_t M = isP ? rP : rS;
+        const Trip t = load_trip(M, (isP ? j0sP : j0sS) + st_j, isP ? a.pcols : 3);
+        if (++st_j >= (isP ? TSp : TSs)) { st_j = 0; st_pass ^= 1; }
         return t;
     };
     Trip bufA, bufB;
