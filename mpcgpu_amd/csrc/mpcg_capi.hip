@@ -9,6 +9,7 @@
 
 #include "../../include/mpcg.h"
 #include "pcg_kernels.hip.h"
+#include "pcg_lpb.hip.h"
 #include "schur_kernels.hip.h"
 #include "schur_dpp.hip.h"
 #include "block_solve.hip.h"
@@ -16,25 +17,39 @@
 
 using namespace mpcg;
 
+// Launch knobs of the single-workgroup PCG kernels.  The handle holds the user's (or mpcg_create's) values; every
+// call works on a COPY that the automatic policy may adjust for that call's batch — the handle is never rewritten
+// by a solve (two calls with different batches do not see each other's choices).
+struct PcgKnobs {
+    int waves = 16;           // wavefronts per trajectory workgroup (4, 8 or 16)
+    int reg_rows = 0;         // RT: TRIPLES of block rows per matrix per wave kept in registers (compiled variants only)
+    int lds_rows = -1;        // LT: triples per matrix per wave cached in LDS; -1 = as many as fit when reg_rows > 0, else 0
+    int waves16 = 8, reg_rows16 = 6, lds_rows16 = -1;   // the same knobs for fp16 matrix storage
+    int lds_extra = -1;       // <.,.,1> kernels: single-triple LDS slots beyond the uniform cache (-1 = as many as fit, 0 = none)
+    int stream_bufs = -1;     // SB: -1 auto, else 0/1/2 register buffers for the streamed triples
+    int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
+};
+
+// What the last solve on this handle actually launched (read-only "last_kernel_*" options; tests assert on it).
+enum { FAM_NONE = -1, FAM_TRAJ = 0, FAM_CLUSTER = 1, FAM_LPB = 2 };
+struct LastKernel { int family = FAM_NONE, waves = 0, reg_rows = 0, lds_rows = 0, stream_bufs = 0, cluster = 0, lds_bytes = 0, lds_extra = 0; };
+
 struct mpcg_handle {
     int device = 0;
     uint32_t n = 0, N = 0, max_batch = 0;
     int num_cus = 0;
-    int pcg_waves = 16;       // wavefronts per trajectory workgroup (8 or 16)
+    PcgKnobs k;
+    LastKernel last;
     int nt_loads = 1;         // non-temporal hint on the matrix stream
-    int reg_rows = 0;         // RT: TRIPLES of block rows per matrix per wave kept in registers (compiled variants only)
-    int lds_rows = -1;        // LT: triples per matrix per wave cached in LDS; -1 = as many as fit when reg_rows > 0, else 0
-    int pcg_waves16 = 8, reg_rows16 = 6, lds_rows16 = -1;   // the same knobs for fp16 matrix storage
+    int lpb = -1;             // lane-per-block kernel (pcg_lpb.hip.h): -1 auto (N <= 128, fp32, automatic configuration), 0 off, 1 forced
     int block_solve_wide = -1; // mpcg_block_solve: one trajectory per wavefront (1), four (0), by batch size (-1)
     int schur_dpp = 1;        // 1: register-resident Schur formation kernels (schur_dpp.hip.h), 0: the LDS versions
     int cluster_waves = -1;   // waves per cluster member: 8 (one member per CU), 4 (two per CU), -1 by batch size
     int cluster_adj = 1;      // lane order of the cluster kernel (1: blocks of a row in adjacent lanes)
     int cluster = -1;         // workgroups per trajectory for the cluster kernel: 0 off, -1 auto, G > 0 forced
+    int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
     unsigned long long* cluster_scratch = nullptr;
-    bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any pcg_* set_option clears this)
-    int lds_extra = -1;       // <.,.,1> kernels: single-triple LDS slots beyond the uniform cache (-1 = as many as fit, 0 = none)
-    int stream_bufs = -1;     // SB: -1 auto, else 0/1/2 register buffers for the streamed triples
-    int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
+    bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any valid pcg_* set_option clears this)
     int spmv_blocks_per_cu = 32;   // (sweep: profiles/r01_tune_spmv.txt)
     int spmv_mfma = 0;        // 1 = the MFMA experiment kernel for mpcg_bt_spmv
     float* block_scratch = nullptr;  // W_k, z_k of mpcg_block_solve: max_batch x N x 210 floats (first call)
@@ -60,21 +75,24 @@ static bool shape_supported(uint32_t n, uint32_t N) { return n == (uint32_t)NS &
 
 static size_t lds_bytes_for(uint32_t N, int nw) { return pcg_lds_floats((int)N, nw) * sizeof(float); }
 static constexpr size_t kLdsMax = 160 * 1024;
+static constexpr uint32_t kLpbMaxN = 128;         // one block per lane: 8 waves x 64 lanes hold 2 (2N - 1) blocks
 
-static int stream_bufs_for(const mpcg_handle* h, int nw, int esz);
+static int stream_bufs_for(const mpcg_handle* h, const PcgKnobs& k, int nw, int esz);
+static void choose_auto(const mpcg_handle* h, PcgKnobs& k, uint32_t batch, int esz);
+static size_t default_launch_lds_bytes(uint32_t N, int num_cus);
 
 extern "C" {
 
 int mpcg_abi_version(void) { return MPCG_ABI_VERSION; }
 
 const char* mpcg_build_info(void) {
-    return "libmpcg_hip gfx950 fp32 n=14 (persistent per-trajectory and clustered PCG, wave64 row-triple mapping)";
+    return "libmpcg_hip gfx950 fp32 n=14 (lane-per-block register-resident PCG, clustered PCG for long horizons, wave64 row-triple streaming PCG)";
 }
 
 size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
     if (!shape_supported(state_size, knot_points)) return 0;
-    size_t b = lds_bytes_for(knot_points, 16);
-    return b <= kLdsMax ? b : 0;
+    if (knot_points > kLpbMaxN && lds_bytes_for(knot_points, 16) > kLdsMax) return 0;
+    return default_launch_lds_bytes(knot_points, 256);
 }
 
 int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t knot_points, uint32_t max_batch) {
@@ -98,21 +116,9 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     if (!h) return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: out of host memory");
     h->device = device; h->n = state_size; h->N = knot_points; h->max_batch = max_batch;
     h->num_cus = prop.multiProcessorCount;
-    // Launch defaults: keep as many block rows as possible in registers/LDS, one workgroup per CU
-    // (round-1 sweeps on MI355X: profiles/r01_tune11.txt, r01_tune12.txt)
-    if (knot_points <= 48) {            // <= 16 triples: two per wave and matrix, everything in registers
-        h->pcg_waves = 8; h->reg_rows = 2; h->lds_rows = 0;
-    } else if (knot_points <= 96) {     // <= 32 triples: three in registers + one in LDS per wave and matrix
-        h->pcg_waves = 8; h->reg_rows = 3; h->lds_rows = -1;
-    } else if (knot_points < 256) {     // the same, the rest streamed every iteration
-        h->pcg_waves = 8; h->reg_rows = 3; h->lds_rows = -1;
-    } else {                            // 4 fat waves (512 registers each): 7 triples per matrix in registers
-        h->pcg_waves = 4; h->reg_rows = 7; h->lds_rows = -1;
-    }
     h->nt_loads = 0;                    // (SpMV kernel only; the PCG kernel's strided stream must stay cacheable)
-    if (knot_points <= 144) { h->pcg_waves16 = 8; h->reg_rows16 = 6; }      // fp16 storage: <= 48 triples all in registers
-    else { h->pcg_waves16 = 4; h->reg_rows16 = 12; }
-    h->lds_rows16 = -1;
+    choose_auto(h, h->k, 1, 4);         // knobs of the single-workgroup kernels as a batch-1 call would pick them
+    choose_auto(h, h->k, 1, 2);
     // hand-off cells of the cluster kernel (512 B per member, up to two members per CU), allocated here so that every solve is pure stream work
     // and can be captured into a hipGraph
     if (hipSetDevice(device) != hipSuccess ||
@@ -137,32 +143,45 @@ int mpcg_destroy(mpcg_handle* h) {
 
 const char* mpcg_last_error(const mpcg_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
+// key -> int member of the handle (plain knobs without range checks)
+static int* knob_ptr(mpcg_handle* h, const char* key) {
+    if (!strcmp(key, "pcg_reg_rows")) return &h->k.reg_rows;          // validated at launch
+    if (!strcmp(key, "pcg_lds_rows")) return &h->k.lds_rows;
+    if (!strcmp(key, "pcg_stream_bufs")) return &h->k.stream_bufs;
+    if (!strcmp(key, "lds_extra")) return &h->k.lds_extra;
+    if (!strcmp(key, "cluster_waves")) return &h->cluster_waves;
+    if (!strcmp(key, "block_solve_wide")) return &h->block_solve_wide;
+    if (!strcmp(key, "pcg16_waves")) return &h->k.waves16;
+    if (!strcmp(key, "pcg16_reg_rows")) return &h->k.reg_rows16;
+    if (!strcmp(key, "pcg16_lds_rows")) return &h->k.lds_rows16;
+    return nullptr;
+}
+
 int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!h || !key) return MPCG_ERR_INVALID;
-    if (!strncmp(key, "pcg_", 4)) h->auto_cfg = false;
+    // an explicit pcg_* knob switches the automatic per-call configuration off — once the key has validated
+    const bool is_pcg = !strncmp(key, "pcg_", 4);
     if (!strcmp(key, "pcg_waves")) {
         if (value != 4 && value != 8 && value != 16) return fail(h, MPCG_ERR_INVALID, "pcg_waves must be 4, 8 or 16");
-        h->pcg_waves = value; return MPCG_OK;
+        h->k.waves = value; h->auto_cfg = false; return MPCG_OK;
     }
+    if (!strcmp(key, "pcg_max_wg_per_cu")) {
+        if (value < 0 || value > 8) return fail(h, MPCG_ERR_INVALID, "pcg_max_wg_per_cu out of range");
+        h->k.max_wg_per_cu = value; h->auto_cfg = false; return MPCG_OK;
+    }
+    if (!strcmp(key, "pcg_lpb")) {
+        if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "pcg_lpb must be -1 (auto), 0 (off) or 1 (forced)");
+        if (value == 1 && h->N > kLpbMaxN) return fail(h, MPCG_ERR_UNSUPPORTED, "pcg_lpb: the lane-per-block kernel holds knot_points <= 128");
+        h->lpb = value; return MPCG_OK;                 // (does not touch the knobs of the other kernels)
+    }
+    if (int* p = knob_ptr(h, key)) { *p = value; if (is_pcg) h->auto_cfg = false; return MPCG_OK; }
     if (!strcmp(key, "nt_loads")) { h->nt_loads = value ? 1 : 0; return MPCG_OK; }
-    if (!strcmp(key, "pcg_reg_rows")) { h->reg_rows = value; return MPCG_OK; }     // validated at launch
-    if (!strcmp(key, "pcg_lds_rows")) { h->lds_rows = value; return MPCG_OK; }
-    if (!strcmp(key, "pcg_stream_bufs")) { h->stream_bufs = value; return MPCG_OK; }
-    if (!strcmp(key, "lds_extra")) { h->lds_extra = value; return MPCG_OK; }
     if (!strcmp(key, "cluster_adj")) { h->cluster_adj = value ? 1 : 0; return MPCG_OK; }
-    if (!strcmp(key, "cluster_waves")) { h->cluster_waves = value; return MPCG_OK; }
+    if (!strcmp(key, "cluster_fixup")) { h->cluster_fixup = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "schur_dpp")) { h->schur_dpp = value ? 1 : 0; return MPCG_OK; }
-    if (!strcmp(key, "block_solve_wide")) { h->block_solve_wide = value; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
         if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");
         h->cluster = value; return MPCG_OK;
-    }
-    if (!strcmp(key, "pcg16_waves")) { h->pcg_waves16 = value; return MPCG_OK; }
-    if (!strcmp(key, "pcg16_reg_rows")) { h->reg_rows16 = value; return MPCG_OK; }
-    if (!strcmp(key, "pcg16_lds_rows")) { h->lds_rows16 = value; return MPCG_OK; }
-    if (!strcmp(key, "pcg_max_wg_per_cu")) {
-        if (value < 0 || value > 8) return fail(h, MPCG_ERR_INVALID, "pcg_max_wg_per_cu out of range");
-        h->max_wg_per_cu = value; return MPCG_OK;
     }
     if (!strcmp(key, "spmv_mfma")) { h->spmv_mfma = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) {
@@ -174,21 +193,29 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
 
 int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!h || !key || !value) return MPCG_ERR_INVALID;
-    if (!strcmp(key, "pcg_waves")) { *value = h->pcg_waves; return MPCG_OK; }
+    if (!strcmp(key, "pcg_waves")) { *value = h->k.waves; return MPCG_OK; }
+    if (!strcmp(key, "pcg_max_wg_per_cu")) { *value = h->k.max_wg_per_cu; return MPCG_OK; }
+    if (!strcmp(key, "pcg_lpb")) { *value = h->lpb; return MPCG_OK; }
+    if (const int* p = knob_ptr(const_cast<mpcg_handle*>(h), key)) { *value = *p; return MPCG_OK; }
     if (!strcmp(key, "nt_loads")) { *value = h->nt_loads; return MPCG_OK; }
-    if (!strcmp(key, "pcg_max_wg_per_cu")) { *value = h->max_wg_per_cu; return MPCG_OK; }
-    if (!strcmp(key, "pcg_reg_rows")) { *value = h->reg_rows; return MPCG_OK; }
-    if (!strcmp(key, "pcg_lds_rows")) { *value = h->lds_rows; return MPCG_OK; }
-    if (!strcmp(key, "pcg_stream_bufs")) { *value = h->stream_bufs; return MPCG_OK; }
-    if (!strcmp(key, "lds_extra")) { *value = h->lds_extra; return MPCG_OK; }
-    if (!strcmp(key, "pcg_resident")) { *value = stream_bufs_for(h, h->pcg_waves, 4) == 0; return MPCG_OK; }   // 1: nothing is streamed
+    if (!strcmp(key, "pcg_resident")) { *value = stream_bufs_for(h, h->k, h->k.waves, 4) == 0; return MPCG_OK; }   // 1: the single-workgroup configuration streams nothing
     if (!strcmp(key, "cluster")) { *value = h->cluster; return MPCG_OK; }
-    if (!strcmp(key, "pcg16_waves")) { *value = h->pcg_waves16; return MPCG_OK; }
-    if (!strcmp(key, "pcg16_reg_rows")) { *value = h->reg_rows16; return MPCG_OK; }
-    if (!strcmp(key, "pcg16_lds_rows")) { *value = h->lds_rows16; return MPCG_OK; }
+    if (!strcmp(key, "cluster_adj")) { *value = h->cluster_adj; return MPCG_OK; }
+    if (!strcmp(key, "cluster_fixup")) { *value = h->cluster_fixup; return MPCG_OK; }
+    if (!strcmp(key, "schur_dpp")) { *value = h->schur_dpp; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "spmv_mfma")) { *value = h->spmv_mfma; return MPCG_OK; }
     if (!strcmp(key, "num_cus")) { *value = h->num_cus; return MPCG_OK; }
+    if (!strcmp(key, "auto_cfg")) { *value = h->auto_cfg ? 1 : 0; return MPCG_OK; }
+    // what the last solve on this handle launched
+    if (!strcmp(key, "last_kernel_family")) { *value = h->last.family; return MPCG_OK; }      // 0 single-workgroup, 1 cluster, 2 lane-per-block
+    if (!strcmp(key, "last_kernel_waves")) { *value = h->last.waves; return MPCG_OK; }
+    if (!strcmp(key, "last_kernel_reg_rows")) { *value = h->last.reg_rows; return MPCG_OK; }
+    if (!strcmp(key, "last_kernel_lds_rows")) { *value = h->last.lds_rows; return MPCG_OK; }
+    if (!strcmp(key, "last_kernel_lds_extra")) { *value = h->last.lds_extra; return MPCG_OK; }
+    if (!strcmp(key, "last_kernel_stream_bufs")) { *value = h->last.stream_bufs; return MPCG_OK; }
+    if (!strcmp(key, "last_kernel_cluster")) { *value = h->last.cluster; return MPCG_OK; }
+    if (!strcmp(key, "last_kernel_lds_bytes")) { *value = h->last.lds_bytes; return MPCG_OK; }
     return MPCG_ERR_INVALID;
 }
 
@@ -196,13 +223,13 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
 
 // ---- launch helpers -----------------------------------------------------------------------------
 // Triples (3 block rows) per matrix per wave cached in LDS for this launch configuration.
-static int lds_rows_for(const mpcg_handle* h, int nw, int esz) {
+static int lds_rows_for(const mpcg_handle* h, const PcgKnobs& k, int nw, int esz) {
     const size_t base = lds_bytes_for(h->N, nw);
     const int ntr = ((int)h->N + 2) / 3;
     const int TT = (ntr + nw - 1) / nw;                           // triples per matrix of wave 0
-    const int rt = esz == 2 ? h->reg_rows16 : h->reg_rows;
+    const int rt = esz == 2 ? k.reg_rows16 : k.reg_rows;
     const int want_max = TT > rt ? TT - rt : 0;
-    int lt = esz == 2 ? h->lds_rows16 : h->lds_rows;
+    int lt = esz == 2 ? k.lds_rows16 : k.lds_rows;
     if (lt < 0) {
         if (rt <= 0) return 0;
         const size_t per_pair = pcg_lds_cache_floats(nw, 1, esz) * sizeof(float);
@@ -214,21 +241,21 @@ static int lds_rows_for(const mpcg_handle* h, int nw, int esz) {
 
 // LDS bytes requested at launch: vectors + matrix cache, raised to floor(160 KiB / k) when the handle
 // limits residency to k workgroups per CU.
-static size_t lds_request(const mpcg_handle* h, int nw, int esz) {
-    size_t need = lds_bytes_for(h->N, nw) + pcg_lds_cache_floats(nw, lds_rows_for(h, nw, esz), esz) * sizeof(float);
-    if (h->max_wg_per_cu > 0) {
-        size_t pad = (kLdsMax / (size_t)h->max_wg_per_cu) & ~(size_t)15;
+static size_t lds_request(const mpcg_handle* h, const PcgKnobs& k, int nw, int esz) {
+    size_t need = lds_bytes_for(h->N, nw) + pcg_lds_cache_floats(nw, lds_rows_for(h, k, nw, esz), esz) * sizeof(float);
+    if (k.max_wg_per_cu > 0) {
+        size_t pad = (kLdsMax / (size_t)k.max_wg_per_cu) & ~(size_t)15;
         if (pad > need) need = pad;
     }
     return need;
 }
 
 // <.,.,1> kernels: single-triple LDS slots that still fit after the uniform cache, at most two per wave that streams
-static int lds_extra_for(const mpcg_handle* h, int nw, int sb, int esz, int* streaming_waves_out) {
+static int lds_extra_for(const mpcg_handle* h, const PcgKnobs& k, int nw, int sb, int esz, int* streaming_waves_out) {
     *streaming_waves_out = 0;
-    if (sb != 1 || h->lds_extra == 0) return 0;
-    const int rt = esz == 2 ? h->reg_rows16 : h->reg_rows;
-    const int lt = lds_rows_for(h, nw, esz);
+    if (sb != 1 || k.lds_extra == 0) return 0;
+    const int rt = esz == 2 ? k.reg_rows16 : k.reg_rows;
+    const int lt = lds_rows_for(h, k, nw, esz);
     const int ntr = ((int)h->N + 2) / 3;
     int streaming_waves = 0;                                   // waves whose triples exceed registers + uniform cache
     for (int w = 0; w < nw; ++w) streaming_waves += (ntr - w + nw - 1) / nw > rt + lt;
@@ -240,42 +267,53 @@ static int lds_extra_for(const mpcg_handle* h, int nw, int sb, int esz, int* str
         const int room = e - nw;                    // slots available beyond the S bank
         e = streaming_waves + (room > 0 ? (room < streaming_waves ? room : streaming_waves) : 0);
     }
-    if (h->lds_extra > 0 && e > h->lds_extra) e = h->lds_extra;
+    if (k.lds_extra > 0 && e > k.lds_extra) e = k.lds_extra;
     *streaming_waves_out = streaming_waves;
     return e;
 }
 
-template <int NW, int RT, int SB, typename MT>
-static int launch_pcg_t(mpcg_handle* h, PcgArgs a, uint32_t batch, hipStream_t st) {
-    a.lds_rows = lds_rows_for(h, NW, (int)sizeof(MT));
+// LDS layout of one <NW,RT,SB> launch: (bytes, LT, extra S slots, extra Pinv slots)
+struct TrajLds { size_t bytes; int lt, extra_s, extra_p; };
+static TrajLds traj_lds(const mpcg_handle* h, const PcgKnobs& k, int nw, int sb, int esz) {
+    TrajLds t;
+    t.lt = lds_rows_for(h, k, nw, esz);
     int streaming_waves = 0;
-    const int extra = lds_extra_for(h, NW, SB, (int)sizeof(MT), &streaming_waves);
-    a.lds_extra_s = extra < streaming_waves ? extra : streaming_waves;             // S first: one pass loses its longest stream
-    a.lds_extra_p = extra - a.lds_extra_s;
-    // (the kernel lays the extra slots out as [S: NW][Pinv: NW]; only the first lds_extra_s / NW + lds_extra_p are touched)
-    const int extra_span = a.lds_extra_p > 0 ? NW + a.lds_extra_p : a.lds_extra_s;
-    size_t lds = lds_bytes_for(h->N, NW) + pcg_lds_cache_floats(NW, a.lds_rows, (int)sizeof(MT)) * sizeof(float)
-               + (size_t)extra_span * (pcg_lds_cache_floats(1, 1, (int)sizeof(MT)) * sizeof(float) / 2);
-    if (lds > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
-    { const size_t padded = lds_request(h, NW, (int)sizeof(MT)); if (padded > lds && padded <= kLdsMax) lds = padded; }
+    const int extra = lds_extra_for(h, k, nw, sb, esz, &streaming_waves);
+    t.extra_s = extra < streaming_waves ? extra : streaming_waves;             // S first: one pass loses its longest stream
+    t.extra_p = extra - t.extra_s;
+    // (the kernel lays the extra slots out as [S: NW][Pinv: NW]; only the first extra_s / NW + extra_p are touched)
+    const int extra_span = t.extra_p > 0 ? nw + t.extra_p : t.extra_s;
+    t.bytes = lds_bytes_for(h->N, nw) + pcg_lds_cache_floats(nw, t.lt, esz) * sizeof(float)
+            + (size_t)extra_span * (pcg_lds_cache_floats(1, 1, esz) * sizeof(float) / 2);
+    const size_t padded = lds_request(h, k, nw, esz);
+    if (t.bytes <= kLdsMax && padded > t.bytes && padded <= kLdsMax) t.bytes = padded;
+    return t;
+}
+
+template <int NW, int RT, int SB, typename MT>
+static int launch_pcg_t(mpcg_handle* h, const PcgKnobs& k, PcgArgs a, uint32_t batch, hipStream_t st, bool record) {
+    const TrajLds t = traj_lds(h, k, NW, SB, (int)sizeof(MT));
+    a.lds_rows = t.lt; a.lds_extra_s = t.extra_s; a.lds_extra_p = t.extra_p;
+    if (t.bytes > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
     auto kern = pcg_traj_kernel<NW, RT, SB, MT>;
-    if (lds > 48 * 1024)
+    if (t.bytes > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(batch), dim3(NW * 64), lds, st, a);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.bytes));
+    hipLaunchKernelGGL(kern, dim3(batch), dim3(NW * 64), t.bytes, st, a);
     HIP_TRY(h, hipGetLastError());
+    if (record) h->last = LastKernel{FAM_TRAJ, NW, RT, t.lt, SB, 0, (int)t.bytes, t.extra_s + t.extra_p};
     return MPCG_OK;
 }
 
 template <int NW, int RT, int SB, typename MT>
-static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
-    const size_t lds = lds_request(h, NW, (int)sizeof(MT));
-    if (lds > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
+static int occupancy_t(mpcg_handle* h, const PcgKnobs& k, int* blocks_per_cu) {
+    const TrajLds t = traj_lds(h, k, NW, SB, (int)sizeof(MT));
+    if (t.bytes > kLdsMax) return fail(h, MPCG_ERR_INVALID, "pcg_lds_rows does not fit 160 KiB of LDS");
     auto kern = pcg_traj_kernel<NW, RT, SB, MT>;
-    if (lds > 48 * 1024)
+    if (t.bytes > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kern, NW * 64, lds));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.bytes));
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kern, NW * 64, t.bytes));
     return MPCG_OK;
 }
 
@@ -292,13 +330,62 @@ static int occupancy_t(mpcg_handle* h, int* blocks_per_cu) {
     X(4, 10, 1) X(4, 12, 1) X(4, 12, 0)
 
 // stream buffers actually needed: 0 when every triple of every wave is resident
-static int stream_bufs_for(const mpcg_handle* h, int nw, int esz) {
+static int stream_bufs_for(const mpcg_handle* h, const PcgKnobs& k, int nw, int esz) {
     const int ntr = ((int)h->N + 2) / 3;
     const int TT = (ntr + nw - 1) / nw;
-    const int rt = esz == 2 ? h->reg_rows16 : h->reg_rows;
-    const bool all_resident = TT <= rt + lds_rows_for(h, nw, esz);
-    if (h->stream_bufs >= 0) return (h->stream_bufs == 0 && !all_resident) ? 1 : h->stream_bufs;
+    const int rt = esz == 2 ? k.reg_rows16 : k.reg_rows;
+    const bool all_resident = TT <= rt + lds_rows_for(h, k, nw, esz);
+    if (k.stream_bufs >= 0) return (k.stream_bufs == 0 && !all_resident) ? 1 : k.stream_bufs;
     return all_resident ? 0 : -1;       // -1: any compiled SB > 0 (1 preferred)
+}
+
+// Automatic per-call configuration of the single-workgroup kernels (round-1 sweeps on MI355X: profiles/r01_tune11.txt,
+// r01_tune12.txt, r01e_tune_nsweep.txt).  Writes into the caller's COPY of the knobs.
+static void choose_auto(const mpcg_handle* h, PcgKnobs& k, uint32_t batch, int esz) {
+    const uint32_t N = h->N;
+    if (esz == 2) {     // fp16 storage: <= 48 triples all in registers
+        if (N <= 144) { k.waves16 = 8; k.reg_rows16 = 6; } else { k.waves16 = 4; k.reg_rows16 = 12; }
+        k.lds_rows16 = -1;
+        return;
+    }
+    if (N <= 48) {
+        // short horizons (<= 16 triples): with more trajectories than CUs, 4 waves x 3 register triples (+ 1 in LDS
+        // beyond N=36) need < 256 registers, so TWO trajectories share a CU and fill each other's barrier and
+        // reduction latencies (batch 2048: N=32 269 vs 171 M it/s, N=48 187 vs 166); up to one trajectory per CU
+        // the 8-wave kernel with everything in registers is the faster solve
+        if (batch > (uint32_t)h->num_cus) { k.waves = 4; k.reg_rows = 3; k.lds_rows = -1; }
+        else { k.waves = 8; k.reg_rows = 2; k.lds_rows = 0; }
+    } else if (N <= 96) {   // <= 32 triples: three in registers + one in LDS per wave and matrix
+        k.waves = 8; k.reg_rows = 3; k.lds_rows = -1;
+    } else {
+        // long horizons: 8 waves (two per SIMD) with 3 register triples + 1 LDS triple per wave and matrix, the rest
+        // streamed, beat 4 fat waves with 7 + 2 since <8,3,1> runs spill-free (N=128, batch 1024: 4.06 ms vs 5.23 ms,
+        // profiles/r01e_phases_N128.txt); beyond N=256 (reached only with the cluster kernel switched off) the fat
+        // waves' larger resident share wins again (profiles/r01_tune12.txt)
+        if (N < 256 || batch < (uint32_t)h->num_cus) { k.waves = 8; k.reg_rows = 3; }
+        else { k.waves = 4; k.reg_rows = 7; }
+        k.lds_rows = -1;
+    }
+}
+
+// ---- lane-per-block kernel (pcg_lpb.hip.h): everything register-resident, N <= 128 ----
+template <int NWR>
+static int launch_lpb_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    const size_t lds = pcg_lpb_lds_floats((int)h->N, 4 * NWR) * sizeof(float);
+    auto kern = pcg_lpb_kernel<NWR>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(batch), dim3(NWR * 256), lds, st, a);
+    HIP_TRY(h, hipGetLastError());
+    h->last = LastKernel{FAM_LPB, 4 * NWR, 0, 0, 0, 0, (int)lds, 0};
+    return MPCG_OK;
+}
+static int launch_lpb(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    return h->N <= 64 ? launch_lpb_t<1>(h, a, batch, st) : launch_lpb_t<2>(h, a, batch, st);
+}
+static bool use_lpb(const mpcg_handle* h, int esz) {
+    if (esz != 4 || h->N > kLpbMaxN || h->lpb == 0) return false;
+    return h->lpb == 1 || (h->auto_cfg && h->cluster <= 0);
 }
 
 // ---- cluster kernel: G workgroups per trajectory, everything resident, batch*G <= #CUs ----
@@ -318,20 +405,26 @@ static int launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, in
     HIP_TRY(h, hipMemsetAsync(h->cluster_scratch, 0, (size_t)batch * G * CL_WG_WORDS * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(kern, dim3(batch * (unsigned)G), dim3(NW * 64), lds, st, ca);
     HIP_TRY(h, hipGetLastError());
+    h->last = LastKernel{FAM_CLUSTER, NW, RT, lt, 0, G, (int)lds, 0};
     return MPCG_OK;
 }
 
+static int launch_traj(mpcg_handle* h, const PcgKnobs& k, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz, bool record);
+
 // returns 1 when the cluster kernel does not apply.
 // Auto policy (profiles/r01_latency_cluster.txt): G = ceil(#triples / 24) workgroups of 8 waves x 3 register
-// triples hold a whole trajectory; used for every horizon one workgroup cannot hold (N > 96).
+// triples hold a whole trajectory; used for the horizons the lane-per-block kernel cannot hold (N > 128).
 //   N >= 256: always — even at full batch it beats the single-workgroup kernel (N=512: 5.1 M vs 3.0 M it/s,
 //             N=256: 11.0 M vs 9.7 M) — in chunks of floor(#CUs / G) trajectories per launch, because every
 //             member of a cluster must be resident;
-//   96 < N < 256: when the whole batch fits one launch, batch * G <= #CUs (N=128, batch 1: 0.70 ms vs 1.02 ms;
-//             batch 128: 23.6 M vs 20.0 M it/s); larger batches run the single-workgroup kernel (36 M it/s).
+//   128 < N < 256: when the whole batch fits one launch, batch * G <= #CUs; larger batches run the single-workgroup kernel.
 // NW_ = 8: one member per CU (8 waves x 3 register triples).  NW_ = 4: members of 4 waves x (3 register + 1 LDS)
 // triples need < 256 registers and < 80 KiB of LDS, so TWO members — of different clusters, usually — share a CU and
 // compute through each other's cluster-wide waits: the throughput configuration for long horizons.
+// Fail-safe: members must be co-resident, which a plain launch cannot guarantee when another stream holds CUs.  A member
+// that waits longer than CL_SPIN_TICKS gives up (the cluster's trajectory is flagged in the scratch block); every chunk
+// is followed by a launch of the single-workgroup kernel in which only the flagged trajectories run (the others exit
+// at once), so the caller always gets a solved system — PCG converges from whatever lambda the abandoned attempt left.
 template <int NW, int RT>
 static int try_launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int per_cu) {
     const int ntr = ((int)h->N + 2) / 3;
@@ -339,7 +432,7 @@ static int try_launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch
     int G = h->cluster;
     const bool forced = G > 0;
     if (!forced) {
-        if (h->N <= 96) return 1;
+        if (h->N <= kLpbMaxN) return 1;
         G = (ntr + NW * (RT + lt_cap) - 1) / (NW * (RT + lt_cap));
     }
     if (G < 2 || G > ntr || G > h->num_cus) return 1;
@@ -350,6 +443,10 @@ static int try_launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch
     const int lt = TT > RT ? TT - RT : 0;
     const size_t lds = pcg_cluster_lds_floats(3 * per_wg, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
     if (lds > kLdsMax / (size_t)per_cu) return 1;
+    // single-workgroup configuration of the fix-up launch (only where that kernel can hold the horizon's vectors)
+    PcgKnobs kf = h->k;
+    choose_auto(h, kf, 1, 4);
+    const bool fixup = h->cluster_fixup && lds_bytes_for(h->N, kf.waves) <= kLdsMax;
     const size_t mstride = (size_t)h->N * ROWF, vstride = (size_t)h->N * NS;
     for (uint32_t lo = 0; lo < batch; lo += chunk) {
         const uint32_t nb = batch - lo < chunk ? batch - lo : chunk;
@@ -362,14 +459,21 @@ static int try_launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch
         if (a.p_out) c.p_out = a.p_out + lo * vstride;
         c.iters = a.iters + lo;
         c.max_iter_exit = a.max_iter_exit + lo;
-        const int rc = launch_cluster_t<NW, RT>(h, c, nb, G, lt, st);
+        int rc = launch_cluster_t<NW, RT>(h, c, nb, G, lt, st);
         if (rc != MPCG_OK) return rc;
+        if (fixup) {
+            c.redo_flags = h->cluster_scratch + CL_FAIL_WORD;      // member 0 of trajectory b: word b * G * CL_WG_WORDS + CL_FAIL_WORD
+            c.redo_stride = G * CL_WG_WORDS;
+            rc = launch_traj(h, kf, c, nb, st, 4, /*record=*/false);
+            if (rc != MPCG_OK) return rc;
+        }
     }
     return MPCG_OK;
 }
 
 static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
     if (h->cluster == 0 || esz != 4) return 1;
+    if (h->cluster < 0 && !h->auto_cfg) return 1;       // explicit pcg_* knobs: the caller asked for a single-workgroup variant
     // "cluster_waves": 8, 4, or -1 = 4-wave members (two per CU) when the batch needs more than one launch of 8-wave
     // members anyway, i.e. when the call is about throughput
     int waves = h->cluster_waves;
@@ -386,44 +490,22 @@ static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
     return try_launch_cluster_t<8, 3>(h, a, batch, st, 1);
 }
 
-static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
-    HIP_TRY(h, hipSetDevice(h->device));
-    {
-        const int rc = try_launch_cluster(h, a, batch, st, esz);
-        if (rc != 1) return rc;
-    }
-    if (h->auto_cfg && esz == 4 && h->N <= 48) {
-        // short horizons (<= 16 triples): with more trajectories than CUs, 4 waves x 3 register triples (+ 1 in LDS
-        // beyond N=36) need < 256 registers, so TWO trajectories share a CU and fill each other's barrier and
-        // reduction latencies (batch 2048: N=32 269 vs 171 M it/s, N=48 187 vs 166); up to one trajectory per CU
-        // the 8-wave kernel is the faster solve
-        if (batch > (uint32_t)h->num_cus) { h->pcg_waves = 4; h->reg_rows = 3; h->lds_rows = -1; }
-        else { h->pcg_waves = 8; h->reg_rows = 2; h->lds_rows = 0; }
-    }
-    if (h->auto_cfg && esz == 4 && h->N > 96) {
-        // long horizons: 8 waves (two per SIMD) with 3 register triples + 1 LDS triple per wave and matrix beat
-        // 4 fat waves with 7 + 2 since <8,3,1> runs spill-free (N=128, batch 1024: 4.06 ms vs 5.23 ms,
-        // profiles/r01e_tune_nsweep.txt, r01e_phases_N128.txt); beyond N=256 (reached only with the cluster
-        // kernel switched off) the fat waves' larger resident share wins again (profiles/r01_tune12.txt)
-        if (h->N < 256 || batch < (uint32_t)h->num_cus) { h->pcg_waves = 8; h->reg_rows = 3; }
-        else { h->pcg_waves = 4; h->reg_rows = 7; }
-        h->lds_rows = -1;
-    }
-    const int waves = esz == 2 ? h->pcg_waves16 : h->pcg_waves;
-    const int rt = esz == 2 ? h->reg_rows16 : h->reg_rows;
-    const int sb = stream_bufs_for(h, waves, esz);
+static int launch_traj(mpcg_handle* h, const PcgKnobs& k, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz, bool record) {
+    const int waves = esz == 2 ? k.waves16 : k.waves;
+    const int rt = esz == 2 ? k.reg_rows16 : k.reg_rows;
+    const int sb = stream_bufs_for(h, k, waves, esz);
     for (int want : {sb, sb == 0 ? 1 : -2, sb <= 0 ? 2 : -2}) {     // exact, then fall back to a streaming build
         if (want == -2) continue;
         if (esz == 4) {
 #define X(NW_, RT_, SB_)                                                                       \
             if (waves == NW_ && rt == RT_ && (want == SB_ || (want == -1 && SB_ > 0)))             \
-                return launch_pcg_t<NW_, RT_, SB_, float>(h, a, batch, st);
+                return launch_pcg_t<NW_, RT_, SB_, float>(h, k, a, batch, st, record);
             MPCG_PCG_VARIANTS(X)
 #undef X
         } else {
 #define X(NW_, RT_, SB_)                                                                       \
             if (waves == NW_ && rt == RT_ && (want == SB_ || (want == -1 && SB_ > 0)))             \
-                return launch_pcg_t<NW_, RT_, SB_, _Float16>(h, a, batch, st);
+                return launch_pcg_t<NW_, RT_, SB_, _Float16>(h, k, a, batch, st, record);
             MPCG_PCG_VARIANTS16(X)
 #undef X
         }
@@ -431,27 +513,72 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
     return fail(h, MPCG_ERR_UNSUPPORTED, "no compiled kernel variant for this (pcg_waves, pcg_reg_rows, pcg_stream_bufs)");
 }
 
-static int occupancy(mpcg_handle* h, int* per_cu) {
-    const int sb = stream_bufs_for(h, h->pcg_waves, 4);
+// Kernel selection of one solve:
+//   1. lane-per-block kernel: fp32, N <= 128, automatic configuration (or "pcg_lpb" = 1);
+//   2. cluster kernel: forced ("cluster" = G), or automatic configuration and a horizon one CU cannot hold;
+//   3. single-workgroup kernel <waves, reg_rows, stream_bufs> — the handle's knobs, adjusted per call by the
+//      automatic policy unless the caller set any pcg_* knob.
+static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (use_lpb(h, esz)) return launch_lpb(h, a, batch, st);
+    {
+        const int rc = try_launch_cluster(h, a, batch, st, esz);
+        if (rc != 1) return rc;
+    }
+    PcgKnobs k = h->k;
+    if (h->auto_cfg) choose_auto(h, k, batch, esz);
+    return launch_traj(h, k, a, batch, st, esz, /*record=*/true);
+}
+
+static int occupancy(mpcg_handle* h, const PcgKnobs& k, int* per_cu) {
+    const int sb = stream_bufs_for(h, k, k.waves, 4);
     for (int want : {sb, sb == 0 ? 1 : -2, sb <= 0 ? 2 : -2}) {
         if (want == -2) continue;
 #define X(NW_, RT_, SB_) \
-        if (h->pcg_waves == NW_ && h->reg_rows == RT_ && (want == SB_ || (want == -1 && SB_ > 0))) \
-            return occupancy_t<NW_, RT_, SB_, float>(h, per_cu);
+        if (k.waves == NW_ && k.reg_rows == RT_ && (want == SB_ || (want == -1 && SB_ > 0))) \
+            return occupancy_t<NW_, RT_, SB_, float>(h, k, per_cu);
         MPCG_PCG_VARIANTS(X)
 #undef X
     }
     return fail(h, MPCG_ERR_UNSUPPORTED, "no compiled kernel variant for this (pcg_waves, pcg_reg_rows, pcg_stream_bufs)");
 }
 
+// LDS bytes of the launch a default-configured batch-1 solve makes (what pcgSharedMemSize stands for)
+static size_t default_launch_lds_bytes(uint32_t N, int num_cus) {
+    if (N <= kLpbMaxN) return pcg_lpb_lds_floats((int)N, N <= 64 ? 4 : 8) * sizeof(float);
+    mpcg_handle tmp;
+    tmp.N = N; tmp.n = NS; tmp.num_cus = num_cus;
+    const int ntr = ((int)N + 2) / 3;
+    const int G = (ntr + 23) / 24;                       // 8-wave cluster members, 3 register triples per wave and matrix
+    if (G >= 2 && G <= num_cus) {
+        const int per_wg = (ntr + G - 1) / G;
+        const int TT = (per_wg + 7) / 8;
+        const int lt = TT > 3 ? TT - 3 : 0;
+        const size_t lds = pcg_cluster_lds_floats(3 * per_wg, 8) * sizeof(float) + pcg_lds_cache_floats(8, lt, 4) * sizeof(float);
+        if (lds <= kLdsMax) return lds;
+    }
+    choose_auto(&tmp, tmp.k, 1, 4);
+    const int sb = stream_bufs_for(&tmp, tmp.k, tmp.k.waves, 4);
+    return traj_lds(&tmp, tmp.k, tmp.k.waves, sb == 0 ? 0 : 1, 4).bytes;
+}
+
 extern "C" {
 
+// Resident trajectories of the configuration a throughput-sized call (batch = max_batch) would launch.
 int mpcg_check_pcg_occupancy(mpcg_handle* h, uint32_t* resident_trajectories) {
     if (!h || !resident_trajectories) return MPCG_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     int per_cu = 0;
-    int rc = occupancy(h, &per_cu);
-    if (rc != MPCG_OK) return rc;
+    if (use_lpb(h, 4)) {
+        const size_t lds = pcg_lpb_lds_floats((int)h->N, h->N <= 64 ? 4 : 8) * sizeof(float);
+        if (h->N <= 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpb_kernel<1>, 256, lds));
+        else HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpb_kernel<2>, 512, lds));
+    } else {
+        PcgKnobs k = h->k;
+        if (h->auto_cfg) choose_auto(h, k, h->max_batch, 4);
+        const int rc = occupancy(h, k, &per_cu);
+        if (rc != MPCG_OK) return rc;
+    }
     if (per_cu < 1) return fail(h, MPCG_ERR_UNSUPPORTED, "PCG workgroup does not fit on a CU");
     *resident_trajectories = (uint32_t)per_cu * (uint32_t)h->num_cus;
     return MPCG_OK;

@@ -184,6 +184,9 @@ struct PcgArgs {
     int N; int max_iter; float exit_tol; int pcols;   // pcols: 3 = SS, 1 = block-Jacobi
     int lds_rows;                          // LT: triples per matrix per wave cached in LDS
     int lds_extra_s, lds_extra_p;          // <.,.,1> kernels: waves 0..x-1 cache one more triple of S / of Pinv in LDS
+    // fix-up launches behind the cluster kernel: trajectory b runs only if redo_flags[b * redo_stride] != 0
+    const unsigned long long* redo_flags = nullptr;
+    int redo_stride = 0;
 };
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : N
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     constexpr int NTHR = NW * 64;
+    if (a.redo_flags && a.redo_flags[(size_t)b * a.redo_stride] == 0) return;      // (uniform) nothing to redo for this trajectory
 
     float* xp = lds;                                   // knot j at xp + (j+1)*NS
     float* xr = xp + r4((size_t)(N + 2) * NS);
@@ -684,8 +688,12 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : N
 // decisions, and the result is deterministic.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) unsigned long long gu64;
-constexpr int CL_WG_WORDS = 64;          // u64 words of scratch per workgroup: 2x2x14 halo + 2 partials (+pad)
-constexpr unsigned CL_SPIN_LIMIT = 1u << 22;
+constexpr int CL_WG_WORDS = 64;          // u64 words of scratch per workgroup: 2x2x14 halo + 2 partials + fail word (+pad)
+constexpr int CL_FAIL_WORD = 58;         // word of member 0's block: set by any member of the cluster that gave up
+// A poll is one sc1 load + s_sleep (25-70 ns): 2^16 polls = 1.5-4.5 ms.  Members of a launch are dispatched within a
+// microsecond of each other on a free GPU, so a wait this long means a peer is not resident (another stream holds its
+// CU): the member gives up and the host-side fix-up launch re-solves the trajectory with the single-workgroup kernel.
+constexpr unsigned CL_SPIN_LIMIT = 1u << 16;
 
 // LDS of one cluster member: its own KL knots (+ one halo knot either side for p and r), not the whole horizon
 __host__ __device__ constexpr size_t pcg_cluster_lds_floats(int KL, int NW) {
@@ -1020,11 +1028,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && RT <= 3 ? 2 : NW / 4)) void pc
         }
     }
 
-    // ---- write back own knots ----
-    for (int e = NS * k0 + tid; e < NS * k1; e += NTHR) {
-        lam_g[e] = lam[e];
-        if (a.r_out) a.r_out[(size_t)b * vstride + e] = xr[NS + e];
-        if (a.p_out) a.p_out[(size_t)b * vstride + e] = xp[NS + e];
+    // ---- write back own knots (a member that gave up leaves lambda alone and flags the trajectory for the fix-up launch) ----
+    if (failed) {
+        if (tid == 0) __hip_atomic_store(cl_words + CL_FAIL_WORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        for (int e = NS * k0 + tid; e < NS * k1; e += NTHR) {
+            lam_g[e] = lam[e];
+            if (a.r_out) a.r_out[(size_t)b * vstride + e] = xr[NS + e];
+            if (a.p_out) a.p_out[(size_t)b * vstride + e] = xp[NS + e];
+        }
     }
     if (tid == 0 && g == 0) {
         a.iters[b] = iters;
