@@ -60,7 +60,8 @@ inline mpcg_handle* handle_for(uint32_t state_size, uint32_t knot_points) {
 template <typename T>
 size_t pcgSharedMemSize(uint32_t state_size, uint32_t knot_points) {
     static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value, "linsys_t is float or double");
-    return mpcg_pcg_lds_bytes(state_size, knot_points) * (sizeof(T) / sizeof(float));
+    if constexpr (std::is_same<T, double>::value) return mpcg_pcg_lds_bytes_f64(state_size, knot_points);
+    else return mpcg_pcg_lds_bytes(state_size, knot_points);
 }
 
 template <typename T>

@@ -70,9 +70,13 @@ int mpcg_create(mpcg_handle **out, int device, uint32_t state_size, uint32_t kno
 int mpcg_destroy(mpcg_handle *h);
 const char *mpcg_last_error(const mpcg_handle *h);   /* h may be NULL: last error of mpcg_create */
 
-/* Replaces pcgSharedMemSize<T>(state_size, knot_points) (include/pcg/sqp.cuh:151): dynamic LDS
- * bytes one trajectory's workgroup uses.  0 if the shape is unsupported. */
+/* Replaces pcgSharedMemSize<T>(state_size, knot_points) (include/pcg/sqp.cuh:151): the dynamic LDS bytes of
+ * the launch a default-configured single-trajectory solve makes (the reference passes this value as the launch's
+ * smem argument; here the library launches, the number is informational but exact: it equals the
+ * "last_kernel_lds_bytes" option after such a solve).  0 if the shape is unsupported.  _f64: the same for
+ * linsys_t = double (mpcg_pcg_solve_ref_f64). */
 size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points);
+size_t mpcg_pcg_lds_bytes_f64(uint32_t state_size, uint32_t knot_points);
 
 /* Replaces checkPcgOccupancy<T>(kernel, threads, n, N) (examples/track_iiwa_pcg.cu:24).  The
  * reference aborts when its N cooperative blocks cannot be co-resident; this solver has no

@@ -29,6 +29,7 @@ SYMBOLS = {
     "mpcg_destroy": (C.c_int, [C.c_void_p]),
     "mpcg_last_error": (C.c_char_p, [C.c_void_p]),
     "mpcg_pcg_lds_bytes": (C.c_size_t, [C.c_uint32, C.c_uint32]),
+    "mpcg_pcg_lds_bytes_f64": (C.c_size_t, [C.c_uint32, C.c_uint32]),
     "mpcg_check_pcg_occupancy": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "mpcg_pcg_solve": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.c_float,
                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

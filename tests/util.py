@@ -59,3 +59,19 @@ def fp32_iters_band(orc, S, Pinv, g, lam0, N, max_iter, tol, pc, trials=8):
         gp = (g.astype(np.float64) * (1 + 6e-8 * rng.standard_normal(g.shape))).astype(np.float32)
         its.append(orc.pcg(Sp, P, gp, lam0, N, max_iter, tol, pc)["iters"])
     return min(its), max(its)
+
+
+def exit_iter_bounds(orc, S, Pinv, g, lam0, N, max_iter, tol, pc, trials=8):
+    """Acceptable range of the iteration at which an fp32 PCG leaves on |eta| < tol.  Lower end: 7 % below the
+    earliest exit of the CPU float32 restatement (same / 1-ulp-perturbed inputs) and of the float64 restatement.
+    Upper end: 7 % above the latest of those AND of the first DECISIVE crossing of the float64 eta history
+    (|eta| < tol/4): near the threshold eta hovers (N=32 golden system, block-Jacobi: float64 dips to 0.55 tol at
+    iteration 343 for three iterations, climbs back to 2 tol and only falls below tol/4 at 382), so whether an fp32
+    implementation catches a marginal dip is a coin toss on its summation order — the same final residual either way."""
+    lo, hi = fp32_iters_band(orc, S, Pinv, g, lam0, N, max_iter, tol, pc, trials)
+    S64 = np.nan_to_num(np.asarray(S, np.float64))
+    P64 = np.nan_to_num(np.asarray(Pinv, np.float64))
+    h = np.abs(orc.pcg(S64, P64, np.asarray(g, np.float64), np.asarray(lam0, np.float64), N, max_iter, tol * 1e-3, pc, hist=True)["eta_hist"])
+    first = int(np.argmax(h < tol)) if (h < tol).any() else max_iter
+    decisive = int(np.argmax(h < tol / 4)) if (h < tol / 4).any() else max_iter
+    return int(0.93 * min(lo, first) - 2), int(min(max_iter, 1.07 * max(hi, decisive) + 2))
