@@ -12,9 +12,15 @@ their own `batch` (weak scaling) and the only collectives are the barrier, the m
 the time and the sum of the iteration counts (RCCL).  Inputs are synthetic (mpcgpu_amd.synth),
 built on the host and resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0: value = PCG iterations / second over all GPUs, plus `roofline`
-(HBM, algorithmic bytes of the dominant kernel / its HIP-event duration) and, at N=1,
-`cpu_baseline` (the reference's QDLDL CPU path, restated in oracle/, timed on this host).
+Prints ONE JSON line on rank 0: value = PCG iterations / second over all GPUs, plus
+  roofline               the HBM-bound kernel of the path — the stand-alone block-tridiagonal SpMV (the
+                         >= 60 % target) streamed over 1.2 GB of S (>> the 256 MiB Infinity Cache): frac <= 1 by construction
+  roofline_pcg_streaming the PCG solve with NOTHING resident (every block re-read every iteration): the HBM model of
+                         SURVEY §8d applies to it as written
+  roofline_resident      the kernel `value` is measured on: register-resident, its HBM traffic is one read of the
+                         lower block triangle per solve; bound = fp32 VALU, reported as useful TFLOP/s over 157.3
+  parity_sample          sampled trajectories of the timed workload checked against the CPU oracle after the timed region
+  cpu_baseline           (N=1 only) the reference's QDLDL CPU path, restated in oracle/, timed on this host.
 """
 from __future__ import annotations
 
@@ -33,7 +39,8 @@ sys.path.insert(0, ROOT)
 from mpcgpu_amd import PcgSolver, pcg_config, synth  # noqa: E402
 from mpcgpu_amd import dist as D  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP32_VALU_PEAK_TF = 157.3  # same guide: peak fp32 vector = 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz
 
 
 def build_inputs(sol, N, batch, seed0, precond, dev, chunk=128, rho=synth.RHO_INIT):
@@ -110,14 +117,17 @@ def cpu_baseline(N, S_host, g_host, mean_iters, budget_s=12.0):
         "sample": f"{cnt} QDLDL-style float32 LDL^T factor+solve calls over the first {ns} trajectories of the "
                   f"workload ({dt:.1f} s, 1 thread, nnz={len(vals[0])}, dim={14 * N}); rel. residual of the last float LDL^T solution against the fp32-built S {resid:.1e}; "
                   f"reference also pays D2H(values,gamma)+H2D(lambda) per solve (include/qdldl/sqp.cuh:261-282), not included",
-        "host_cpus": os.cpu_count(),
+        "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+        "rel_residual_float_ldl": resid, "meets_1e-4_residual_gate_of_BASELINE_md_3": bool(resid <= 1e-4),
+        "residual_note": "QDLDL is built with float (Makefile:16 -DQDLDL_FLOAT=true); at cond(S) ~ 1e5 a float LDL^T cannot reach 1e-4 — "
+                         "the port is timed as the reference runs it, the miss is reported, not hidden",
     }
 
 
 P_HOST = None
 
 
-def latency_config2(dev, reps=200):
+def latency_config2(dev, reps=100):
     """BASELINE config 2: IIWA-14 N=32, ONE trajectory, block-Jacobi, max_iter 173 (settings.cuh:127),
     exit_tol 5e-6 (track_iiwa_pcg.cu:49), through the reference-shaped 12-argument entry.  Timed the way
     the reference times a linsolve (include/pcg/sqp.cuh:224-241): host monotonic clock around launch + the two
@@ -150,7 +160,58 @@ def latency_config2(dev, reps=200):
     return {"workload": "IIWA-14 N=32, 1 trajectory, block-Jacobi, max_iter 173, exit_tol 5e-6 (BASELINE config 2)",
             "pcg_iters": it, "max_iter_exit": ex, "us_per_linsolve_wall_incl_2_d2h": float(np.median(wall)),
             "us_per_linsolve_kernel": float(np.median(kern)), "us_per_pcg_iter_kernel": float(np.median(kern)) / max(it, 1),
-            "pcg_waves": sol.get_option("pcg_waves"), "pcg_reg_rows": sol.get_option("pcg_reg_rows")}
+            "kernel_family": sol.get_option("last_kernel_family"), "kernel_waves": sol.get_option("last_kernel_waves")}
+
+
+def fp32_check(orc, S, P, g, lam_gpu, it_gpu, N, pc):
+    """One sampled trajectory against the oracle: the float64 iterate after the SAME number of iterations, the band
+    the CPU float32 restatement reaches on the same inputs (tests/util.py:fp32_band, no perturbation trials here),
+    and the true residuals."""
+    S, P = np.nan_to_num(S), np.nan_to_num(P)
+    z = np.zeros(14 * N)
+    r64 = orc.pcg(S.astype(np.float64), P.astype(np.float64), g.astype(np.float64), z, N, it_gpu, 0.0, pc)["lam"]
+    r32 = orc.pcg(S, P, g, z.astype(np.float32), N, it_gpu, 0.0, pc)["lam"]
+    den = max(np.abs(r64).max(), 1e-300)
+    err, band = float(np.abs(lam_gpu - r64).max() / den), float(np.abs(r32 - r64).max() / den)
+    Sd = synth.bd_to_dense(S, N)
+    res = lambda v: float(np.linalg.norm(g - Sd @ np.asarray(v, np.float64)) / np.linalg.norm(g))
+    return {"iters": int(it_gpu), "rel_err_vs_f64_same_iters": err, "cpu_f32_band": band, "ok": bool(err <= max(1e-3, 4 * band)),
+            "true_residual_gpu": res(lam_gpu), "true_residual_cpu_f32": res(r32)}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def timed(fn, reps, warm=1):
+    """Median HIP-event time (ms) of `fn` over `reps` runs on the current stream (= the stream the kernels are launched on)."""
+    ts = []
+    for i in range(reps + warm):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        if i >= warm:
+            ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def load_traffic(kernel_key):
+    """HBM-side traffic of one launch from this round's committed PMC passes (profiles/traffic.json, written by
+    tools/profile_round.sh from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench command; bench cannot
+    run rocprofv3 on itself)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return t.get("kernels", {}).get(kernel_key), t.get("source")
+    except (OSError, ValueError):
+        return None, None
 
 
 def main():
@@ -159,19 +220,25 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--knots", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=1024, help="trajectories PER GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=1024, help="trajectories per GPU (--scaling weak) or in total (--scaling strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank solves --batch trajectories; strong: --batch trajectories are sharded over the ranks "
+                         "(BASELINE config 4 as written: 1024 over 8 GPUs = 128 each)")
     ap.add_argument("--precond", default="ss", choices=["ss", "jacobi"])
     ap.add_argument("--exit-tol", type=float, default=1e-4)
     ap.add_argument("--max-iter", type=int, default=0, help="0 = reference table (settings.cuh:123-139)")
+    ap.add_argument("--lpb", type=int, default=-1, help="lane-per-block kernel: -1 auto, 0 off (single-workgroup kernels), 1 forced")
     ap.add_argument("--pcg-waves", type=int, default=0)
-    ap.add_argument("--nt", type=int, default=-1)
     ap.add_argument("--reg-rows", type=int, default=-1)
     ap.add_argument("--lds-rows", type=int, default=-2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--spmv", action="store_true", help="also time the stand-alone block-tridiagonal SpMV")
-    ap.add_argument("--warm", action="store_true", help="also run the workload from warm starts (mixed iteration counts)")
-    ap.add_argument("--latency", action="store_true", help="also time BASELINE config 2 (N=32, one trajectory)")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region (no roofline side kernels, parity sample, warm run, latency)")
+    ap.add_argument("--profile-lean", action="store_true",
+                    help="for rocprofv3 passes: only the timed region + the two HBM roofline kernels, so that per-kernel averages are not "
+                         "diluted by the batch-1 latency launches, the 4000-iteration warm-start reference solve and the parity sample")
+    ap.add_argument("--spmv-mfma", action="store_true", help="also time BASELINE config 5's MFMA block-GEMV experiment")
+    ap.add_argument("--spmv-batch", type=int, default=4096, help="trajectories streamed by the SpMV roofline run (S = batch x 301 KB)")
     ap.add_argument("--storage", default="f32", choices=["f32", "f16"],
                     help="matrix storage of S/Pinv; f16 = BASELINE config 5's reduced-precision experiment (arithmetic stays fp32)")
     args = ap.parse_args()
@@ -186,23 +253,29 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    N, B = args.knots, args.batch
+    N = args.knots
+    if args.scaling == "strong":
+        lo, hi = D.shard_range(args.batch, rank, world)
+        B, seed0, B_global = hi - lo, lo, args.batch
+    else:
+        B, seed0, B_global = args.batch, rank * args.batch, args.batch * world
+    assert B > 0, "more ranks than trajectories"
     max_iter = args.max_iter or synth.pcg_max_iter(N)
     cfg = pcg_config(pcg_exit_tol=args.exit_tol, pcg_max_iter=max_iter)
 
     global P_HOST
-    sol = PcgSolver(N, max_batch=B, device=local_rank)
-    d_S, d_P, d_g = build_inputs(sol, N, B, rank * B, args.precond, dev)
+    sol = PcgSolver(N, max_batch=max(B, args.spmv_batch if not args.no_extras else B), device=local_rank)
+    d_S, d_P, d_g = build_inputs(sol, N, B, seed0, args.precond, dev)
     ns = min(32, B)
     S_h, P_h, g_h = (t[:ns].cpu().numpy() for t in (d_S, d_P, d_g))     # host copies of the CPU-baseline sample
     P_HOST = P_h
     d_lam = torch.zeros(B, 14 * N, device=dev)
     d_it = torch.zeros(B, dtype=torch.int32, device=dev)
     d_ex = torch.zeros(B, dtype=torch.uint8, device=dev)
+    if args.lpb != -1:
+        sol.set_option("pcg_lpb", args.lpb)
     if args.pcg_waves:
         sol.set_option("pcg_waves", args.pcg_waves)
-    if args.nt >= 0:
-        sol.set_option("nt_loads", args.nt)
     if args.reg_rows >= 0:
         sol.set_option("pcg_reg_rows", args.reg_rows)
     if args.lds_rows >= -1:
@@ -217,12 +290,9 @@ def main():
         def run_solve():
             sol.solve(d_S, d_P, d_g, d_lam, cfg, args.precond, iters=d_it, exits=d_ex)
 
-    def step():
+    for _ in range(args.warmup):
         d_lam.zero_()                       # every step is the same cold-start solve
         run_solve()
-
-    for _ in range(args.warmup):
-        step()
     torch.cuda.synchronize()
 
     # --- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks ---
@@ -240,177 +310,197 @@ def main():
     t_local = time.perf_counter() - t0
     t_all = D.max_over_ranks(t_local, dev)
 
+    fam = {0: "pcg_traj_kernel", 1: "pcg_cluster_kernel", 2: "pcg_lpb_kernel"}[sol.get_option("last_kernel_family")]
+    kdesc = {"family": fam, **{k: sol.get_option("last_kernel_" + k) for k in ("waves", "reg_rows", "lds_rows", "stream_bufs", "cluster", "lds_bytes")}}
     it_host = d_it.cpu().numpy().astype(np.int64)
     ex_host = d_ex.cpu().numpy()
     iters_step_local = int(it_host.sum())
     iters_step_all = D.sum_over_ranks(iters_step_local, dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     kern_ms_all = D.max_over_ranks(kern_ms, dev)
+    # the only collective of the path: per-trajectory (iters, exit flag) of every shard to every rank (RCCL all-gather)
+    g_it, g_ex = D.gather_results(d_it, d_ex, B_global if args.scaling == "strong" else None)
+    gathered_ok = bool(int(g_it.to(torch.int64).sum().item()) == int(iters_step_all) and g_it.numel() == B_global)
 
     ms_per_step = 1e3 * t_all / args.steps
     value = iters_step_all / (t_all / args.steps)
     bytes_iter = synth.algorithmic_bytes(N, precond=args.precond)["pcg_iter"]     # fp32-storage model
-    achieved = iters_step_local * bytes_iter / (kern_ms * 1e-3) / 1e9     # GB/s, this rank's kernel
+    # useful flops of one PCG iteration of one trajectory: two block-tridiagonal products + 2 inner products + 3 axpys
+    nblk = (3 * N - 2) + ((3 * N - 2) if args.precond == "ss" else N)
+    flops_iter = 2 * 196 * nblk + 10 * 14 * N
 
     out = {
         "metric": "pcg_iterations_per_sec", "value": value, "unit": "iter/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.storage == "f32" else "f32 arithmetic, f16 matrix storage",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32" if args.storage == "f32" else "f32 arithmetic, f16 matrix storage",
         "data": "synthetic",
-        "config": {"workload": f"IIWA-14 (n=14) N={N} knots, {args.precond} preconditioner, batch {B} trajectories/GPU "
-                               f"(BASELINE config 4's batch is 1024; S+Pinv = {2 * B * 3 * 196 * N * 4 / 1e6:.0f} MB in HBM), lambda0=0, "
+        "config": {"workload": f"IIWA-14 (n=14) N={N} knots, {args.precond} preconditioner, batch {B} trajectories on this GPU / {B_global} in total "
+                               f"(BASELINE config 4: 1024 trajectories; S+Pinv = {2 * B * 3 * 196 * N * 4 / 1e6:.0f} MB in HBM per GPU), lambda0=0, "
                                f"max_iter={max_iter}, exit_tol={args.exit_tol:g}",
-                   "knot_points": N, "state_size": 14, "batch_per_gpu": B, "global_batch": B * world,
+                   "knot_points": N, "state_size": 14, "batch_per_gpu": B, "global_batch": B_global,
                    "precond": args.precond, "pcg_max_iter": max_iter, "pcg_exit_tol": args.exit_tol,
-                   "parallelism": f"batch-sharded x{world}", "pcg_waves": sol.get_option("pcg_waves"),
-                   "pcg_reg_rows": sol.get_option("pcg_reg_rows"), "pcg_lds_rows": sol.get_option("pcg_lds_rows"),
-                   "nt_loads": sol.get_option("nt_loads")},
+                   "parallelism": f"batch-sharded x{world} ({args.scaling} scaling, no data-path collective)", "kernel": kdesc},
         "ms_per_linsolve": ms_per_step / B,
-        "linsolves_per_sec": B * world / (ms_per_step * 1e-3),
+        "linsolves_per_sec": B_global / (ms_per_step * 1e-3),
         "mean_pcg_iters": float(it_host.mean()), "max_iter_exit_rate": float(ex_host.mean()),
         "resident_trajectories_per_gpu": sol.checkPcgOccupancy(),
-        "roofline": {"bound": "hbm", "kernel": "pcg_traj_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_all,
-                     "algorithmic_bytes_per_launch": iters_step_local * bytes_iter,
-                     "bytes_per_unit": bytes_iter, "units_per_launch": iters_step_local,
-                     "unit_of_work": "one PCG iteration of one trajectory"},
+        "results_gather": {"collective": "all_gather of (iters, exit) per trajectory", "backend": D.backend_name(),
+                           "trajectories": int(g_it.numel()), "consistent_with_allreduce_sum": gathered_ok},
     }
 
-    # HBM traffic of this exact workload from the committed PMC passes (bench cannot run rocprofv3 on itself)
-    try:
-        pre = "pcg" if args.storage == "f32" else "pcg16"
-        key = (f"N{N}_B{B}_{args.precond}_it{max_iter}_tol{args.exit_tol:g}_w{sol.get_option(pre + '_waves')}"
-               f"_rr{sol.get_option(pre + '_reg_rows')}_rl{sol.get_option(pre + '_lds_rows')}_nt{sol.get_option('nt_loads')}"
-               + ("" if args.storage == "f32" else "_f16"))
-        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+    # ---- the kernel `value` is measured on ----
+    dom = {"kernel": fam, "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_all, "units_per_launch": iters_step_local,
+           "unit_of_work": "one PCG iteration of one trajectory"}
+    if fam == "pcg_traj_kernel" and kdesc["reg_rows"] == 0:
+        # nothing resident: the HBM model applies as written
+        ach = iters_step_local * bytes_iter / (kern_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", **dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "bytes_per_unit": bytes_iter}
+    else:
+        tf = iters_step_local * flops_iter / (kern_ms * 1e-3) / 1e12
+        model_gbs = iters_step_local * bytes_iter / (kern_ms * 1e-3) / 1e9
+        rr = {"bound": "valu", **dom, "achieved": tf, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TF,
+              "flops_per_unit": flops_iter,
+              "why_not_hbm": "S and Pinv stay in registers for the whole solve: HBM sees one read of the lower block triangle per "
+                             "solve, not one per iteration; the streaming-model rate below exceeds the HBM peak and is NOT a roofline fraction",
+              "hbm_streaming_model": {"bytes_per_unit": bytes_iter, "rate_gbs": model_gbs, "speedup_vs_hbm_streaming_ceiling": model_gbs / HBM_PEAK_GBS},
+              "hbm_algorithmic_bytes_per_launch": B * (2 * (2 * N - 1) * 784 + 3 * 14 * N * 4 + 5),
+              "traffic": None}
+        tr, src = load_traffic(f"{fam}|N{N}_B{B}_{args.precond}_it{max_iter}_tol{args.exit_tol:g}")
         if tr:
-            out["roofline"]["traffic"] = tr["hbm_traffic_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = tr["source"]
-            # the L2-miss bytes over the live kernel time: what the memory side actually sustains
-            out["roofline"]["traffic_gbs"] = tr["hbm_traffic_bytes_per_launch"] / (out["roofline"]["kernel_ms"] * 1e-3) / 1e9
-            out["roofline"]["traffic_frac"] = out["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
-    except (OSError, ValueError):
-        pass
+            rr["traffic"] = tr["hbm_traffic_bytes_per_launch"]
+            rr["traffic_source"] = src
+            rr["traffic_gbs"] = tr["hbm_traffic_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
+            rr["traffic_frac_of_hbm_peak"] = rr["traffic_gbs"] / HBM_PEAK_GBS
+        out["roofline_resident"] = rr
 
-    if args.warm and args.storage == "f32":
-        # the reference's operating regime: lambda is warm-started from the previous SQP / MPC step
-        # (include/mpcsim.cuh:186,267,337), so solves leave the loop at different iterations.  Emulated by
-        # starting from a perturbed converged solution; the hardware workgroup scheduler rebalances.
+    extras = not args.no_extras and args.storage == "f32"
+    if extras:
+        # ---- HBM roofline 1: stand-alone block-tridiagonal SpMV, S streamed from HBM (>> L3) ----
+        Bs = max(B, args.spmv_batch)
+        reps = (Bs + B - 1) // B
+        S_big = d_S.repeat(reps, 1)[:Bs].contiguous() if reps > 1 else d_S
+        x = torch.randn(Bs, 14 * N, device=dev)
+        y = torch.empty_like(x)
+        def spmv20():
+            for _ in range(20):
+                sol.bt_spmv(S_big, x, y)
+        ms = timed(spmv20, 3, warm=1) / 20          # 20 back-to-back launches per timing, like the rocprofv3 average
+        b_sp = synth.algorithmic_bytes(N)["spmv"] * Bs
+        sp = {"bound": "hbm", "kernel": "bt_spmv_kernel", "achieved": b_sp / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": b_sp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms, "traffic": None,
+              "algorithmic_bytes_per_launch": b_sp, "bytes_per_unit": synth.algorithmic_bytes(N)["spmv"], "units_per_launch": Bs,
+              "unit_of_work": "one block-tridiagonal SpMV of one trajectory (SURVEY §8d)", "working_set_mb": Bs * 3 * 196 * N * 4 / 1e6,
+              "frac_of_measured_copy_ceiling_6.29TBs": b_sp / (ms * 1e-3) / 1e9 / 6290.0,
+              "trajectory_spmv_per_sec": Bs / (ms * 1e-3)}
+        tr, src = load_traffic(f"bt_spmv_kernel|N{N}_B{Bs}")
+        if tr:
+            sp["traffic"] = tr["hbm_traffic_bytes_per_launch"]
+            sp["traffic_source"] = src
+        if "roofline" not in out:
+            out["roofline"] = sp
+        else:
+            out["roofline_spmv"] = sp
+        if args.spmv_mfma:
+            sol.set_option("spmv_mfma", 1)           # config 5's MFMA block-GEMV experiment, same launch shape
+            ms_mfma = timed(spmv20, 3, warm=1) / 20
+            sol.set_option("spmv_mfma", 0)
+            out["spmv_mfma_experiment"] = {"kernel": "bt_spmv_mfma_kernel", "ms": ms_mfma, "achieved": b_sp / (ms_mfma * 1e-3) / 1e9,
+                                           "unit": "GB/s", "frac": b_sp / (ms_mfma * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "mfma_flops_issued_per_launch": 2 * 16 * 16 * 4 * 12 * Bs * N,
+                                           "useful_flops_per_launch": 2 * (3 * N - 2) * 196 * Bs}
+        del S_big, x, y
+
+        # ---- HBM roofline 2: the PCG solve with nothing resident (every block re-read every iteration) ----
+        if "roofline_resident" in out:
+            Bz = max(B, 2048)                    # S + Pinv = 1.2 GB >> 256 MiB Infinity Cache: re-read from HBM every iteration
+            rz = (Bz + B - 1) // B
+            zS, zP, zg = (t.repeat(rz, 1)[:Bz].contiguous() if rz > 1 else t for t in (d_S, d_P, d_g))
+            ss = PcgSolver(N, max_batch=Bz, device=local_rank)
+            ss.set_option("pcg_waves", 16); ss.set_option("pcg_reg_rows", 0); ss.set_option("pcg_lds_rows", 0)
+            l2 = torch.zeros(Bz, 14 * N, device=dev)
+            i2 = torch.zeros(Bz, dtype=torch.int32, device=dev)
+            x2 = torch.zeros(Bz, dtype=torch.uint8, device=dev)
+
+            def stream_solve():
+                l2.zero_()
+                ss.solve(zS, zP, zg, l2, cfg, args.precond, iters=i2, exits=x2)
+            ms_s = timed(stream_solve, 3, warm=1)
+            ms_z = timed(lambda: l2.zero_(), 3, warm=1)
+            its_s = int(i2.sum().item())
+            ach = its_s * bytes_iter / ((ms_s - ms_z) * 1e-3) / 1e9
+            out["roofline_pcg_streaming"] = {
+                "bound": "hbm", "kernel": "pcg_traj_kernel<16,0,2> (no resident rows)", "kernel_ms": ms_s - ms_z, "achieved": ach,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "bytes_per_unit": bytes_iter, "units_per_launch": its_s,
+                "working_set_mb": 2 * Bz * 3 * 196 * N * 4 / 1e6, "pcg_iterations_per_sec": its_s / ((ms_s - ms_z) * 1e-3),
+                "batch": Bz}
+            tr, src = load_traffic(f"pcg_traj_kernel<16,0,2>|N{N}_B{Bz}_{args.precond}_it{max_iter}_tol{args.exit_tol:g}")
+            if tr:
+                out["roofline_pcg_streaming"]["traffic"] = tr["hbm_traffic_bytes_per_launch"]
+                out["roofline_pcg_streaming"]["traffic_source"] = src
+            assert ss.get_option("last_kernel_family") == 0 and ss.get_option("last_kernel_reg_rows") == 0
+            del ss, l2, zS, zP, zg
+
+    lean = args.profile_lean
+    if extras and rank == 0 and not lean:
+        # ---- parity of the workload that was just timed: sampled trajectories against the CPU oracle ----
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as orc
+        orc.build()
+        lam_h = d_lam.cpu().numpy()
+        idx = sorted({0, B // 3, (2 * B) // 3, B - 1})
+        checks = []
+        for b_ in idx:
+            c = fp32_check(orc, d_S[b_].cpu().numpy(), d_P[b_].cpu().numpy(), d_g[b_].cpu().numpy(), lam_h[b_], int(it_host[b_]), N, args.precond)
+            c["trajectory"] = int(b_)
+            checks.append(c)
+        out["parity_sample"] = {"against": "oracle/ (CPU, float64 iterate after the same number of iterations; tolerance max(1e-3, 4 x CPU float32 band))",
+                                "checked": len(checks), "all_ok": bool(all(c["ok"] for c in checks)), "samples": checks}
+
+    if extras and not lean:
+        # ---- the reference's operating regime: lambda warm-started from the previous SQP / MPC step
+        # (include/mpcsim.cuh:186,267,337), so solves leave the loop at different iterations.  Emulated by starting
+        # from a perturbed converged solution; the hardware workgroup scheduler rebalances.
         lam_star = torch.zeros(B, 14 * N, device=dev)
         sol.solve(d_S, d_P, d_g, lam_star, pcg_config(pcg_exit_tol=1e-9, pcg_max_iter=4000), args.precond)
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         scale = lam_star.abs().amax(dim=1, keepdim=True)
         amp = torch.logspace(-4, -1, B, device=dev)[torch.randperm(B, device=dev, generator=gen)].unsqueeze(1)
         lam_w = lam_star + amp * scale * torch.randn(B, 14 * N, device=dev, generator=gen)
-        ts = []
-        for i in range(4):
+
+        def warm_solve():
             d_lam.copy_(lam_w)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
             run_solve()
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
+        ms_w = timed(warm_solve, 3, warm=1) - timed(lambda: d_lam.copy_(lam_w), 3, warm=1)
         itw = d_it.cpu().numpy().astype(np.int64)
-        ms_w = float(np.median(ts[1:]))
         out["warm_start_run"] = {"lambda0": "converged solution + gaussian noise of relative amplitude 1e-4..1e-1 (log-uniform over the batch)",
                                  "mean_pcg_iters": float(itw.mean()), "min_pcg_iters": int(itw.min()), "max_pcg_iters": int(itw.max()),
                                  "max_iter_exit_rate": float(d_ex.float().mean().item()), "kernel_ms": ms_w,
                                  "pcg_iterations_per_sec": float(itw.sum() / (ms_w * 1e-3)),
                                  "linsolves_per_sec": B / (ms_w * 1e-3)}
 
-    if args.spmv and args.storage == "f32":
-        # the same solve with NOTHING resident (every block row re-read every iteration): the variant that sits
-        # on the HBM roofline, reported next to the default so that frac > 1 above can be read for what it is
-        saved = {k: sol.get_option(k) for k in ("pcg_waves", "pcg_reg_rows", "pcg_lds_rows")}
-        sol.set_option("pcg_waves", 16); sol.set_option("pcg_reg_rows", 0); sol.set_option("pcg_lds_rows", 0)
-        ts = []
-        for i in range(4):
-            d_lam.zero_()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            run_solve()
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        ms_s = float(np.median(ts[1:]))
-        its_s = int(d_it.sum().item())
-        out["streaming_variant"] = {"kernel": "pcg_traj_kernel<16,0,2> (no resident rows)", "kernel_ms": ms_s,
-                                    "achieved": its_s * bytes_iter / (ms_s * 1e-3) / 1e9, "unit": "GB/s",
-                                    "frac": its_s * bytes_iter / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "pcg_iterations_per_sec": its_s / (ms_s * 1e-3)}
-        for k, v in saved.items():
-            sol.set_option(k, v)
-
-    if args.spmv:
-        x = torch.randn(B, 14 * N, device=dev)
-        y = torch.empty_like(x)
-        for _ in range(3):
-            sol.bt_spmv(d_S, x, y)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            sol.bt_spmv(d_S, x, y)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        b = synth.algorithmic_bytes(N)["spmv"] * B
-        sol.set_option("spmv_mfma", 1)           # config 5's MFMA block-GEMV experiment, same launch shape
-        for _ in range(3):
-            sol.bt_spmv(d_S, x, y)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            sol.bt_spmv(d_S, x, y)
-        e1.record()
-        torch.cuda.synchronize()
-        sol.set_option("spmv_mfma", 0)
-        ms_mfma = e0.elapsed_time(e1) / reps
-        out["spmv_mfma_experiment"] = {"kernel": "bt_spmv_mfma_kernel", "ms": ms_mfma, "achieved": b / (ms_mfma * 1e-3) / 1e9,
-                                       "unit": "GB/s", "frac": b / (ms_mfma * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                       "mfma_flops_issued_per_launch": 2 * 16 * 16 * 4 * 12 * B * N,
-                                       "useful_flops_per_launch": 2 * (3 * N - 2) * 196 * B}
-        out["spmv"] = {"kernel": "bt_spmv_kernel", "ms": ms, "achieved": b / (ms * 1e-3) / 1e9, "unit": "GB/s",
-                       "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b,
-                       "trajectory_spmv_per_sec": B / (ms * 1e-3)}
-
-    if rank == 0 and world == 1 and args.latency:
+    if extras and rank == 0 and world == 1 and not lean:
         out["config2_latency"] = latency_config2(dev)
         # the headline horizon as ONE trajectory (the reference's own mode of use): ms per SQP-linsolve
         sol1 = PcgSolver(N, max_batch=1, device=local_rank)
         l1 = torch.zeros(1, 14 * N, device=dev)
         i1 = torch.zeros(1, dtype=torch.int32, device=dev)
         x1 = torch.zeros(1, dtype=torch.uint8, device=dev)
-        ts = []
-        for i in range(30):
-            l1.zero_()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            sol1.solve(d_S[:1], d_P[:1], d_g[:1], l1, cfg, args.precond, iters=i1, exits=x1)
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        out["single_trajectory_latency"] = {"workload": f"N={N}, {args.precond}, ONE trajectory, max_iter={max_iter}",
-                                            "pcg_iters": int(i1.item()), "ms_per_linsolve": float(np.median(ts[5:])),
-                                            "us_per_pcg_iter": float(np.median(ts[5:])) * 1e3 / max(int(i1.item()), 1),
-                                            "pcg_waves": sol1.get_option("pcg_waves"), "pcg_reg_rows": sol1.get_option("pcg_reg_rows")}
 
-    if rank == 0 and args.storage == "f32":
+        def one():
+            l1.zero_()
+            sol1.solve(d_S[:1], d_P[:1], d_g[:1], l1, cfg, args.precond, iters=i1, exits=x1)
+        ms1 = timed(one, 25, warm=5)
+        out["single_trajectory_latency"] = {"workload": f"N={N}, {args.precond}, ONE trajectory, max_iter={max_iter}",
+                                            "pcg_iters": int(i1.item()), "ms_per_linsolve": ms1,
+                                            "us_per_pcg_iter": ms1 * 1e3 / max(int(i1.item()), 1),
+                                            "kernel_family": sol1.get_option("last_kernel_family"), "kernel_waves": sol1.get_option("last_kernel_waves")}
+
+    if extras and rank == 0 and not lean:
         # the other selectable solver on the same resident systems: batched block-tridiagonal direct solve
         # (GPU counterpart of the reference's QDLDL path, i.e. of what cpu_baseline times on the host)
         lam_d = torch.empty(B, 14 * N, device=dev)
-        ts = []
-        for _ in range(6):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            sol.block_solve(d_S, d_g, lam_d)
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        ms_d = float(np.median(ts[1:]))
+        ms_d = timed(lambda: sol.block_solve(d_S, d_g, lam_d), 5, warm=1)
         nb = min(4, B)
         Sd = d_S[:nb].cpu().numpy()
         gd = d_g[:nb].cpu().numpy()
@@ -419,16 +509,22 @@ def main():
         out["block_solve"] = {"kernel": "bt_block_solve_kernel (mpcg_block_solve)", "ms_per_batch": ms_d, "batch": B,
                               "linsolves_per_sec": B / (ms_d * 1e-3), "us_per_linsolve_throughput": ms_d * 1e3 / B,
                               "true_rel_residual_sample": res,
-                              "note": "fp32 block LU sweep, four trajectories per wavefront; not the headline metric (which counts PCG iterations)"}
+                              "note": "fp32 block LU sweep; not the headline metric (which counts PCG iterations)"}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not lean:
         out["cpu_baseline"] = cpu_baseline(N, S_h, g_h, float(it_host.mean()), args.cpu_seconds)
         out["cpu_baseline"]["gpu_linsolves_per_sec"] = out["linsolves_per_sec"]
 
-    if rank == 0:
-        print(json.dumps(out))
+    # the JSON line goes out LAST: RCCL writes a version banner through C stdio when the communicator goes away
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

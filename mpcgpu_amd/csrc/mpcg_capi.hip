@@ -50,7 +50,7 @@ struct mpcg_handle {
     int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
     unsigned long long* cluster_scratch = nullptr;
     bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any valid pcg_* set_option clears this)
-    int spmv_blocks_per_cu = 32;   // (sweep: profiles/r01_tune_spmv.txt)
+    int spmv_blocks_per_cu = 4;    // (sweep at 4096 trajectories = 1.2 GB of S, a true HBM stream: profiles/r02_tune_spmv.txt)
     int spmv_mfma = 0;        // 1 = the MFMA experiment kernel for mpcg_bt_spmv
     float* block_scratch = nullptr;  // W_k, z_k of mpcg_block_solve: max_batch x N x 210 floats (first call)
     float* ginv_scratch = nullptr;   // staging for the in-place G <- G^-1 of mpcg_form_schur
@@ -122,7 +122,7 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     if (!h) return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: out of host memory");
     h->device = device; h->n = state_size; h->N = knot_points; h->max_batch = max_batch;
     h->num_cus = prop.multiProcessorCount;
-    h->nt_loads = 0;                    // (SpMV kernel only; the PCG kernel's strided stream must stay cacheable)
+    h->nt_loads = 1;                    // SpMV kernel only: the matrix is read once — non-temporal loads, +4..9 % (profiles/r02_tune_spmv.txt)
     choose_auto(h, h->k, 1, 4);         // knobs of the single-workgroup kernels as a batch-1 call would pick them
     choose_auto(h, h->k, 1, 2);
     // hand-off cells of the cluster kernel (512 B per member, up to two members per CU), allocated here so that every solve is pure stream work

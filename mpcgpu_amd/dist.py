@@ -23,7 +23,10 @@ def env_world() -> tuple[int, int, int]:
 
 def init(backend: str | None = None) -> tuple[int, int, int]:
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    # MPCG_DIST_FORCE=1: create the process group even at world size 1, so that the RCCL collectives of this module run
+    # (a communicator of one) on a single-GPU box instead of being dead code there
+    force = os.environ.get("MPCG_DIST_FORCE") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:      # MPCG_DIST_BACKEND=gloo: dry-run the N>1 flow where only one GPU exists
@@ -39,6 +42,13 @@ def init(backend: str | None = None) -> tuple[int, int, int]:
 def barrier():
     if dist.is_initialized():
         dist.barrier()
+
+
+def backend_name() -> str:
+    if not dist.is_initialized():
+        return "none (single process)"
+    b = dist.get_backend()
+    return "nccl (RCCL)" if b == "nccl" else b
 
 
 def _coll_device(device):
@@ -60,15 +70,18 @@ def sum_over_ranks(value: float, device="cpu") -> float:
     return float(t.item())
 
 
-def gather_results(iters: torch.Tensor, exits: torch.Tensor, total: int) -> tuple[torch.Tensor, torch.Tensor]:
+def gather_results(iters: torch.Tensor, exits: torch.Tensor, total: int | None) -> tuple[torch.Tensor, torch.Tensor]:
     """All-gather the per-trajectory (iters, max_iter_exit) of every rank's shard into global
-    order.  Shards follow shard_range(total, rank, world); they may be ragged, so each rank pads
-    to the largest shard."""
+    order.  total = N: shards follow shard_range(N, rank, world) and may be ragged, so each rank pads to the
+    largest shard; total = None: every rank holds the same number of trajectories (weak scaling)."""
     if not dist.is_initialized():
         return iters.clone(), exits.clone()
     world = dist.get_world_size()
+    if total is None:
+        total = iters.numel() * world
     cap = max(shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world))
-    buf = torch.zeros(cap, 2, dtype=torch.int32, device=iters.device)
+    cdev = _coll_device(iters.device)
+    buf = torch.zeros(cap, 2, dtype=torch.int32, device=cdev)
     buf[: iters.numel(), 0] = iters.to(torch.int32)
     buf[: exits.numel(), 1] = exits.to(torch.int32)
     out = [torch.empty_like(buf) for _ in range(world)]
@@ -78,4 +91,4 @@ def gather_results(iters: torch.Tensor, exits: torch.Tensor, total: int) -> tupl
         lo, hi = shard_range(total, r, world)
         it.append(out[r][: hi - lo, 0])
         ex.append(out[r][: hi - lo, 1])
-    return torch.cat(it), torch.cat(ex).to(torch.uint8)
+    return torch.cat(it).to(iters.device), torch.cat(ex).to(torch.uint8).to(iters.device)
