@@ -413,7 +413,7 @@ def main():
 
         # ---- HBM roofline 2: the PCG solve with nothing resident (every block re-read every iteration) ----
         if "roofline_resident" in out:
-            Bz = max(B, 2048)                    # S + Pinv = 1.2 GB >> 256 MiB Infinity Cache: re-read from HBM every iteration
+            Bz = max(B, 4096)                    # S + Pinv = 2.5 GB >> 256 MiB Infinity Cache: re-read from HBM every iteration
             rz = (Bz + B - 1) // B
             zS, zP, zg = (t.repeat(rz, 1)[:Bz].contiguous() if rz > 1 else t for t in (d_S, d_P, d_g))
             ss = PcgSolver(N, max_batch=Bz, device=local_rank)

@@ -74,12 +74,14 @@ bool checkPcgOccupancy(void* /*kernel*/, dim3 /*block*/, uint32_t state_size, ui
 }
 
 // Host launcher carrying the reference kernel's parameter list (include/pcg/sqp.cuh:137-150).
-template <typename T, uint32_t STATE_SIZE, uint32_t KNOT_POINTS>
+// (template parameter names differ from the reference's STATE_SIZE / KNOT_POINTS MACROS, include/common/settings.cuh:5-12, which are
+//  defined before this header is included in the reference's translation units)
+template <typename T, uint32_t StateSize, uint32_t KnotPoints>
 void pcg(T* d_S, T* d_Pinv, T* d_gamma, T* d_lambda, T* d_r, T* d_p, T* d_v_temp, T* d_eta_new_temp,
          uint32_t* d_iters, bool* d_max_iter_exit, uint32_t max_iter, T exit_tol) {
     static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value, "linsys_t is float or double");
     static_assert(sizeof(bool) == 1, "exit flag is one byte");
-    mpcg_handle* h = mpcg_compat::handle_for(STATE_SIZE, KNOT_POINTS);
+    mpcg_handle* h = mpcg_compat::handle_for(StateSize, KnotPoints);
     int rc;
     if constexpr (std::is_same<T, float>::value)
         rc = mpcg_pcg_solve_ref(h, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp, d_iters,

@@ -164,8 +164,8 @@ int mpcg_compute_dz(mpcg_handle *h, uint32_t control_size, const float *d_Ginv_d
  * mpcg_bd_to_csr_lowertri gathers the values form_schur_system_qdldl leaves in d_val
  * (include/qdldl/linsys_setup.cuh:339-351) from a bd-layout S: per trajectory [nnz] floats = mult * (left
  * block, then lower triangle of the diagonal block, row by row).  With the S of mpcg_form_schur (already
- * negated) mult = +1 reproduces the reference's numbers; gamma is shared by both paths.  The CPU LDL^T itself
- * stays the reference's (qdldl); this library only feeds it. */
+ * negated) mult = +1 reproduces the reference's numbers; gamma is shared by both paths.  The CPU LDL^T that consumes
+ * them: the reference's own qdldl, or mpcg_ldl_* / mpcg_qdldl_solve_schur below. */
 int mpcg_prep_csr(mpcg_handle *h, int32_t *d_col_ptr, int32_t *d_row_ind, void *stream);
 int mpcg_bd_to_csr_lowertri(mpcg_handle *h, const float *d_S, float *d_val, float mult, uint32_t batch, void *stream);
 
@@ -191,6 +191,27 @@ int mpcg_pcg_solve_ref_f64(mpcg_handle *h, double *d_S, double *d_Pinv, double *
  * stream work (capturable into a graph). */
 int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, float* d_lambda, uint32_t batch,
                      void* stream);
+
+/* ---- LINSYS_SOLVE == 0 as a selectable solver: the reference's CPU LDL^T path ----
+ * The reference's second linear-system path factors the (negated) Schur matrix on the HOST with QDLDL
+ * (include/qdldl/sqp.cuh: pattern prep_csr :164 + QDLDL_etree :193 once per SQP call; per SQP iteration D2H(values,
+ * gamma), qdldl_solve_schur = QDLDL_factor + QDLDL_solve :22-49, H2D(lambda) :261-282).  QDLDL (osqp/qdldl, float /
+ * int32 build, Makefile:16) is an un-vendored submodule of the reference; libmpcg_hip carries its own implementation of
+ * the same published algorithm (elimination tree, up-looking LDL^T without pivoting, triangular solves) so that the
+ * A/B switch of include/mpcsim.cuh:21-25 exists in-tree.  These entry points are a SOLVER THE CALLER SELECTS, never a
+ * fallback: no GPU entry point calls them.  mpcg_ldl_* are pure host code (no device needed).
+ *   mpcg_ldl_create        pattern of the lower triangle in CSR (= include/utils/csr.cuh:40-73, identical to what
+ *                          mpcg_prep_csr writes on the device) + elimination tree + workspace, for (state_size, knot_points)
+ *   mpcg_ldl_pattern       host pointers to col_ptr [nN+1] / row_ind [nnz]; nnz = (N-1)n^2 + N n(n+1)/2 (:148)
+ *   mpcg_ldl_solve         qdldl_solve_schur(:22-49): numeric factorisation of h_val [nnz] + solve; h_lambda may alias h_gamma
+ *   mpcg_qdldl_solve_schur the reference's timed region (:268-273) on device buffers: D2H(d_val as mpcg_bd_to_csr_lowertri
+ *                          / form_schur_system_qdldl left it, d_gamma), factor + solve, H2D(d_lambda); synchronises `stream`. */
+typedef struct mpcg_ldl mpcg_ldl;
+int mpcg_ldl_create(mpcg_ldl **out, uint32_t state_size, uint32_t knot_points);
+int mpcg_ldl_destroy(mpcg_ldl *l);
+int mpcg_ldl_pattern(const mpcg_ldl *l, const int32_t **h_col_ptr, const int32_t **h_row_ind, uint32_t *nnz, uint32_t *sum_lnz);
+int mpcg_ldl_solve(mpcg_ldl *l, const float *h_val, const float *h_gamma, float *h_lambda);
+int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, const float *d_gamma, float *d_lambda, void *stream);
 
 /* Launch-configuration knobs (tuning / experiments; defaults are chosen by mpcg_create from
  * knot_points): "pcg_waves" (4, 8 or 16 wavefronts per trajectory workgroup), "pcg_reg_rows" (block

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libmpcg_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "mpcg_capi.hip")]
-DEPS = SOURCES + [os.path.join(_HERE, "csrc", f) for f in ("pcg_kernels.hip.h", "pcg_lpb.hip.h", "schur_kernels.hip.h", "schur_dpp.hip.h", "block_solve.hip.h", "pcg_f64.hip.h")] + [
+DEPS = SOURCES + [os.path.join(_HERE, "csrc", f) for f in ("pcg_kernels.hip.h", "pcg_lpb.hip.h", "schur_kernels.hip.h", "schur_dpp.hip.h", "block_solve.hip.h", "pcg_f64.hip.h", "ldl_host.hpp")] + [
     os.path.join(_ROOT, "include", "mpcg.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -80,7 +80,44 @@ def build_example(force: bool = False, verbose: bool = False) -> str:
     return EXAMPLE_BIN
 
 
+DEMO_SRC = os.path.join(_ROOT, "examples", "mpcsim_shim_demo.cpp")
+DEMO_BINS = {1: os.path.join(_ROOT, "examples", "mpcsim_shim_demo_pcg"), 0: os.path.join(_ROOT, "examples", "mpcsim_shim_demo_qdldl")}
+
+
+def build_mpcsim_demo(force: bool = False, verbose: bool = False):
+    """simulateMPC -> sqpSolvePcg | sqpSolveQdldl over this repo's include/mpcsim.cuh, include/pcg/sqp.cuh, include/qdldl/sqp.cuh:
+    the same source compiled with -DLINSYS_SOLVE=1 and =0 (the reference's compile-time solver switch, include/mpcsim.cuh:21-25)."""
+    inc = os.path.join(_ROOT, "include")
+    deps = [DEMO_SRC, LIB_PATH] + [os.path.join(inc, f) for f in ("mpcsim.cuh", "pcg/sqp.cuh", "qdldl/sqp.cuh", "mpcgpu_compat/sqp_stages.cuh",
+                                                                  "mpcgpu_compat/linsys_steps.cuh", "gbd_pcg_compat/gpu_pcg.cuh")]
+    for sel, exe in DEMO_BINS.items():
+        if force or not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", f"-DLINSYS_SOLVE={sel}", "-I" + inc, DEMO_SRC, "-L" + _HERE, "-lmpcg_hip",
+                   "-Wl,-rpath,$ORIGIN/../mpcgpu_amd", "-o", exe]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    return DEMO_BINS
+
+
+UTILS_SRC = os.path.join(_ROOT, "examples", "bd_utils_probe.cpp")
+UTILS_BIN = os.path.join(_ROOT, "examples", "bd_utils_probe")
+
+
+def build_utils_probe(force: bool = False, verbose: bool = False) -> str:
+    """Instantiates store_block_bd / load_block_bd / gato_memcpy of include/gbd_pcg_compat/utils.cuh in a kernel."""
+    deps = [UTILS_SRC, os.path.join(_ROOT, "include", "gbd_pcg_compat", "utils.cuh")]
+    if force or not os.path.exists(UTILS_BIN) or any(os.path.getmtime(d) > os.path.getmtime(UTILS_BIN) for d in deps):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(_ROOT, "include", "gbd_pcg_compat"), UTILS_SRC, "-o", UTILS_BIN]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return UTILS_BIN
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_example(force="--force" in sys.argv, verbose=True))
     print(build_chain_example(force="--force" in sys.argv, verbose=True))
+    print(build_mpcsim_demo(force="--force" in sys.argv, verbose=True))
+    print(build_utils_probe(force="--force" in sys.argv, verbose=True))

@@ -40,6 +40,54 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class QdldlSolver:
+    """The reference's LINSYS_SOLVE == 0 path (include/qdldl/sqp.cuh) as a selectable solver: CSR lower-triangle pattern
+    (include/utils/csr.cuh:40-73) + elimination tree once, then numeric LDL^T factor + solve per call on the HOST
+    (libmpcg_hip's own implementation of the QDLDL algorithm; pure host code, works without a GPU)."""
+
+    def __init__(self, knot_points: int, state_size: int = STATE_SIZE):
+        import numpy as np
+        self.lib = _lib.load()
+        self.n, self.N = int(state_size), int(knot_points)
+        h = C.c_void_p()
+        rc = self.lib.mpcg_ldl_create(C.byref(h), self.n, self.N)
+        if rc != _lib.MPCG_OK:
+            raise _lib.MpcgError(rc, "mpcg_ldl_create")
+        self._l = h
+        cp, ri = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        nnz, slnz = C.c_uint32(), C.c_uint32()
+        self.lib.mpcg_ldl_pattern(self._l, C.byref(cp), C.byref(ri), C.byref(nnz), C.byref(slnz))
+        self.nnz, self.sum_lnz = nnz.value, slnz.value
+        self.col_ptr = np.ctypeslib.as_array(cp, shape=(self.n * self.N + 1,)).copy()
+        self.row_ind = np.ctypeslib.as_array(ri, shape=(self.nnz,)).copy()
+
+    def close(self):
+        if getattr(self, "_l", None):
+            self.lib.mpcg_ldl_destroy(self._l)
+            self._l = None
+
+    __del__ = close
+
+    def solve_host(self, val, gamma):
+        """qdldl_solve_schur (include/qdldl/sqp.cuh:22-49) on host arrays: val [nnz] float32, gamma [nN] float32."""
+        import numpy as np
+        val = np.ascontiguousarray(val, np.float32)
+        gamma = np.ascontiguousarray(gamma, np.float32)
+        assert val.size == self.nnz and gamma.size == self.n * self.N
+        lam = np.empty_like(gamma)
+        rc = self.lib.mpcg_ldl_solve(self._l, val.ctypes.data_as(C.c_void_p), gamma.ctypes.data_as(C.c_void_p), lam.ctypes.data_as(C.c_void_p))
+        if rc != _lib.MPCG_OK:
+            raise _lib.MpcgError(rc, "mpcg_ldl_solve: zero pivot")
+        return lam
+
+    def solve_schur(self, sol: "PcgSolver", d_val, d_gamma, d_lambda):
+        """The reference's timed region (include/qdldl/sqp.cuh:268-273): D2H(values, gamma), factor + solve, H2D(lambda)."""
+        rc = self.lib.mpcg_qdldl_solve_schur(sol._h, self._l, _ptr(d_val), _ptr(d_gamma), _ptr(d_lambda), _stream())
+        if rc != _lib.MPCG_OK:
+            raise _lib.MpcgError(rc, self.lib.mpcg_last_error(sol._h).decode())
+        return d_lambda
+
+
 class PcgSolver:
     """One handle per (device, state_size, knot_points).  `solve` is the batched hot path,
     `solve_ref` the reference's single-trajectory 12-argument launch."""

@@ -18,7 +18,7 @@ for name, k in pmc.items():
     elif "bt_spmv_kernel" in name:
         key = f"bt_spmv_kernel|N{N}_B{spB}"
     elif "pcg_traj_kernel<16, 0, 2" in name:
-        key = f"pcg_traj_kernel<16,0,2>|N{N}_B{max(int(B), 2048)}_{pc}_it{mi}_tol{float(tol):g}"
+        key = f"pcg_traj_kernel<16,0,2>|N{N}_B{max(int(B), 4096)}_{pc}_it{mi}_tol{float(tol):g}"
     else:
         continue
     out["kernels"][key] = {"kernel": name, "hbm_traffic_bytes_per_launch": k["hbm_traffic_bytes_per_launch"],
