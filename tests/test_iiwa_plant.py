@@ -1,0 +1,80 @@
+"""CPU: the IIWA-14 producer side (stage A) — mpcgpu_amd/iiwa.py (numpy float64 restatement of
+include/common/kkt.cuh:22-163 + the plant it calls) against the reference's own trajectory fixtures
+(tests/golden/iiwa_traj_0_0.npz = first 200 rows of examples/trajfiles/0_0_traj.csv and 0_0_eepos.traj) and the KKT / Schur
+fixtures tests/make_iiwa_golden.py produced in the build container."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from mpcgpu_amd import iiwa, synth
+
+
+@pytest.fixture(scope="module")
+def M():
+    return iiwa.Model()
+
+
+@pytest.fixture(scope="module")
+def traj():
+    d = np.load(os.path.join(GOLDEN, "iiwa_traj_0_0.npz"))
+    return d["xu"].astype(np.float64), d["eepos"].astype(np.float64)
+
+
+def test_end_effector_kinematics_reproduce_the_reference_fixture(M, traj):
+    """Row t of 0_0_eepos.traj is the end-effector position of row t of 0_0_traj.csv (the reference generated one from the
+    other with its GRiD kinematics): the restated forward kinematics must reproduce all 200 rows (csv precision ~1e-6)."""
+    xu, eep = traj
+    err = max(np.abs(M.ee_pos(xu[t, :7]) - eep[t, :3]).max() for t in range(200))
+    assert err < 2e-5, err
+    # and the Jacobian is the derivative of that map
+    q = xu[17, :7]
+    J = M.ee_jac(q)
+    d = 1e-5 * np.arange(1, 8)
+    assert np.abs(M.ee_pos(q + d) - M.ee_pos(q) - J @ d).max() < 1e-8
+
+
+def test_rigid_body_dynamics_identities(M, traj):
+    xu, _ = traj
+    q, qd, u = xu[40, :7], xu[40, 7:14], xu[40, 14:]
+    Mm = M.mass_matrix(q)
+    assert np.allclose(Mm, Mm.T) and np.linalg.eigvalsh(Mm).min() > 1e-4          # symmetric positive definite
+    qdd, dq, dqd, du = M.forward_dynamics_and_gradient(q, qd, u)
+    assert np.abs(M.rnea(q, qd, qdd) - u).max() < 1e-9                              # ID(FD(u)) = u
+    # the gradient formula -Minv dID/dq|qdd equals the derivative of the forward dynamics itself
+    fd = lambda q_, qd_, u_: M.forward_dynamics_and_gradient(q_, qd_, u_)[0]
+    h = 1e-6
+    for j in (0, 3, 6):
+        e = np.zeros(7)
+        e[j] = h
+        assert np.abs((fd(q + e, qd, u) - fd(q - e, qd, u)) / (2 * h) - dq[:, j]).max() < 1e-4 * max(1.0, np.abs(dq).max())
+        assert np.abs((fd(q, qd + e, u) - fd(q, qd - e, u)) / (2 * h) - dqd[:, j]).max() < 1e-4 * max(1.0, np.abs(dqd).max())
+    assert np.abs(du - np.linalg.inv(Mm)).max() < 1e-10
+    # kinetic energy form: qd^T ID(q, 0, qd_as_acc) = qd^T M qd
+    assert abs(qd @ M.rnea(q, np.zeros(7), qd) - qd @ Mm @ qd) < 1e-10
+
+
+def test_generate_kkt_matches_fixture_and_reference_structure(M, orc):
+    d = np.load(os.path.join(GOLDEN, "iiwa_kkt_N32.npz"))
+    N, n, m = 32, 14, 7
+    for s in range(3):
+        G, C, g, c = iiwa.generate_kkt(M, d[f"s{s}_xu"].astype(np.float64), d[f"s{s}_goals"].astype(np.float64), d[f"s{s}_xs"].astype(np.float64), N)
+        for a, name in ((G, "G"), (C, "C"), (g, "g"), (c, "c")):
+            want = d[f"s{s}_{name}"]
+            assert np.abs(a - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (s, name)       # (inputs were rounded to float32 in the fixture)
+        # structure of include/common/kkt.cuh / iiwa_eepos_plant.cuh:358-368: Q_k = blkdiag(g g^T, QD I), R_k = R_COST I, C = -A, -B
+        Q0 = G[:196].reshape(14, 14).T
+        assert np.linalg.matrix_rank(Q0[:7, :7], tol=1e-12) <= 1 and np.allclose(Q0[7:, 7:], iiwa.QD_COST * np.eye(7)) and np.allclose(Q0[:7, 7:], 0)
+        assert np.allclose(G[196:196 + 49].reshape(7, 7), iiwa.r_cost(N) * np.eye(7))
+        A0 = -C[:196].reshape(14, 14).T
+        assert np.allclose(A0[:7, :7], np.eye(7)) and np.allclose(A0[:7, 7:], iiwa.TIMESTEP * np.eye(7))    # Euler: q+ = q + dt qd
+        B0 = -C[196:196 + 98].reshape(7, 14).T
+        assert np.allclose(B0[:7], 0) and np.linalg.eigvalsh(0.5 * (B0[7:] + B0[7:].T)).min() > 0          # dt Minv
+        # the Schur system the oracle forms from the fixture's blocks is the stored one, and PCG behaves as recorded
+        S, P, gam, _ = orc.form_schur(d[f"s{s}_G"].copy(), d[f"s{s}_C"], d[f"s{s}_g"], d[f"s{s}_c"], N, synth.RHO_INIT, ss=True)
+        np.testing.assert_array_equal(np.nan_to_num(S), d[f"s{s}_S"])
+        np.testing.assert_array_equal(np.nan_to_num(P), d[f"s{s}_Pinv"])
+        r = orc.pcg(d[f"s{s}_S"], d[f"s{s}_Pinv"], d[f"s{s}_gamma"], np.zeros(n * N, np.float32), N, 5000, 1e-4, "ss")
+        assert r["iters"] == int(d[f"s{s}_iters_ss_1e4"]) and r["iters"] <= synth.pcg_max_iter(N)          # inside the reference's cap of 173
+        assert float(d[f"s{s}_cond"]) > 1e4                                                                # real systems are ill-conditioned
