@@ -192,6 +192,31 @@ int mpcg_pcg_solve_ref_f64(mpcg_handle *h, double *d_S, double *d_Pinv, double *
 int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, float* d_lambda, uint32_t batch,
                      void* stream);
 
+/* ---- the producer of the path's inputs: KKT block assembly ----
+ * mpcg_generate_kkt replaces generate_kkt_submatrices<T><<<knot_points, KKT_THREADS, smem>>>(state_size, control_size, knot_points,
+ * d_G_dense, d_C_dense, d_g, d_c, d_dynMem_const, timestep, d_eePos_traj, d_xs, d_xu) (include/common/kkt.cuh:22-163, launched at
+ * include/pcg/sqp.cuh:190-204), batched, with the plant functions it calls (include/dynamics/iiwa/iiwa_eepos_plant.cuh:
+ * forwardDynamicsAndGradient, trackingCostGradientAndHessian(_lastblock)) and the Euler integrator of
+ * include/common/integrator.cuh.  Outputs in the layouts mpcg_form_schur consumes (C holds -A, -B; c_0 = x_0 - x_s).
+ * The reference's d_dynMem_const (GRiD's robotModel) becomes an mpcg_plant: the robot as DATA — a fixed-base serial chain
+ * of revolute joints given by the tables GRiD tabulates (all column-major; *_trig: entry idx = coef * sin(q_j) for j < nj,
+ * coef * cos(q_{j-nj}) otherwise, replacing the constant at idx):
+ *   X_const [nj*36] spatial transforms parent -> link, I_spatial [nj*36] spatial inertias, Xhom_const [nj*16] homogeneous
+ *   transforms link -> parent.  mpcgpu_amd/data/iiwa14_model.json carries the KUKA iiwa 14 in exactly this form.
+ * The cost is the reference's end-effector tracking cost: 1/2 |ee(q_k) - goal_k|^2 (xyz of d_eePos_traj [batch][N][6]) +
+ * 1/2 qd_cost |qd|^2 + 1/2 r_cost |u|^2 with its Gauss-Newton Hessian.  Derivatives of the inverse dynamics are central
+ * differences in float64 on the device (agreement with the float64 host restatement mpcgpu_amd/iiwa.py: ~1e-7 after
+ * rounding to float), not GRiD's analytic recursion.  num_joints = 7 is the compiled specialisation. */
+typedef struct mpcg_plant mpcg_plant;
+int mpcg_plant_create(mpcg_plant **out, int device, uint32_t num_joints, const double *X_const, const double *I_spatial,
+                      const double *Xhom_const, const int32_t *X_trig_idx, const double *X_trig_coef, const int32_t *X_trig_j,
+                      uint32_t n_X_trig, const int32_t *Xhom_trig_idx, const double *Xhom_trig_coef, const int32_t *Xhom_trig_j,
+                      uint32_t n_Xhom_trig);
+int mpcg_plant_destroy(mpcg_plant *p);
+int mpcg_generate_kkt(mpcg_handle *h, const mpcg_plant *plant, uint32_t control_size, float timestep, const float *d_eePos_traj,
+                      const float *d_xs, const float *d_xu, float qd_cost, float r_cost, float *d_G_dense, float *d_C_dense,
+                      float *d_g, float *d_c, uint32_t batch, void *stream);
+
 /* ---- LINSYS_SOLVE == 0 as a selectable solver: the reference's CPU LDL^T path ----
  * The reference's second linear-system path factors the (negated) Schur matrix on the HOST with QDLDL
  * (include/qdldl/sqp.cuh: pattern prep_csr :164 + QDLDL_etree :193 once per SQP call; per SQP iteration D2H(values,

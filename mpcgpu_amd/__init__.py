@@ -3,6 +3,6 @@
 Product = libmpcg_hip.so (C ABI in include/mpcg.h, kernels in mpcgpu_amd/csrc/).
 This package is the thin host-side mirror of the reference's interface for that path.
 """
-from .solver import PcgSolver, QdldlSolver, pcg_config, pcgSharedMemSize  # noqa: F401
+from .solver import PcgSolver, Plant, QdldlSolver, pcg_config, pcgSharedMemSize  # noqa: F401
 
-__all__ = ["PcgSolver", "QdldlSolver", "pcg_config", "pcgSharedMemSize"]
+__all__ = ["PcgSolver", "Plant", "QdldlSolver", "pcg_config", "pcgSharedMemSize"]

@@ -48,6 +48,11 @@ SYMBOLS = {
                                      C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mpcg_pcg_solve_ref_f64": (C.c_int, [C.c_void_p] * 11 + [C.c_uint32, C.c_double, C.c_void_p]),
     "mpcg_block_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "mpcg_plant_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "mpcg_plant_destroy": (C.c_int, [C.c_void_p]),
+    "mpcg_generate_kkt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "mpcg_ldl_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32]),
     "mpcg_ldl_destroy": (C.c_int, [C.c_void_p]),
     "mpcg_ldl_pattern": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32)),

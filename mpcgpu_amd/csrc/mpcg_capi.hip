@@ -15,6 +15,7 @@
 #include "block_solve.hip.h"
 #include "pcg_f64.hip.h"
 #include "ldl_host.hpp"
+#include "kkt_plant.hip.h"
 
 using namespace mpcg;
 
@@ -853,6 +854,97 @@ int mpcg_bd_to_csr_lowertri(mpcg_handle* h, const float* d_S, float* d_val, floa
     const long cap = (long)h->num_cus * 64;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(bd_to_csr_kernel, dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
+
+// ---- the producer of the path's inputs: KKT block assembly with the robot as data (kkt_plant.hip.h) ----
+struct mpcg_plant { int device = 0; PlantDev* d = nullptr; };
+
+int mpcg_plant_create(mpcg_plant** out, int device, uint32_t num_joints, const double* X_const, const double* I_spatial, const double* Xhom_const,
+                      const int32_t* X_trig_idx, const double* X_trig_coef, const int32_t* X_trig_j, uint32_t n_X_trig,
+                      const int32_t* Xhom_trig_idx, const double* Xhom_trig_coef, const int32_t* Xhom_trig_j, uint32_t n_Xhom_trig) {
+    if (!out) return MPCG_ERR_INVALID;
+    *out = nullptr;
+    if (num_joints != (uint32_t)PJ) return fail(nullptr, MPCG_ERR_UNSUPPORTED, "mpcg_plant_create: the compiled specialisation has 7 joints (IIWA-14)");
+    if (!X_const || !I_spatial || !Xhom_const || (n_X_trig && (!X_trig_idx || !X_trig_coef || !X_trig_j)) ||
+        (n_Xhom_trig && (!Xhom_trig_idx || !Xhom_trig_coef || !Xhom_trig_j)))
+        return fail(nullptr, MPCG_ERR_INVALID, "mpcg_plant_create: null table");
+    PlantDev* hp = new (std::nothrow) PlantDev();
+    if (!hp) return MPCG_ERR_NOMEM;
+    memset(hp, 0, sizeof(PlantDev));
+    // tables are column-major (6x6 / 4x4), PlantDev is row-major 3x3 blocks
+    auto place = [&](int k, int r, int c, double v, int which /*0 const, 1 sin, 2 cos*/) -> bool {
+        double(*E)[9] = which == 0 ? hp->E0 : (which == 1 ? hp->Es : hp->Ec);
+        double(*B)[9] = which == 0 ? hp->B0 : (which == 1 ? hp->Bs : hp->Bc);
+        if (r < 3 && c < 3) { E[k][3 * r + c] = v; return true; }
+        if (r >= 3 && c < 3) { B[k][3 * (r - 3) + c] = v; return true; }
+        return v == 0.0 || (r >= 3 && c >= 3);             // upper-right block must be zero; lower-right repeats E
+    };
+    bool ok = true;
+    for (int k = 0; k < PJ; ++k) {
+        for (int c = 0; c < 6; ++c)
+            for (int r = 0; r < 6; ++r) {
+                ok = ok && place(k, r, c, X_const[k * 36 + c * 6 + r], 0);
+                hp->I[k][6 * r + c] = I_spatial[k * 36 + c * 6 + r];
+            }
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r) hp->R0[k][3 * r + c] = Xhom_const[k * 16 + c * 4 + r];
+        for (int r = 0; r < 3; ++r) hp->p[k][r] = Xhom_const[k * 16 + 12 + r];
+    }
+    for (uint32_t t = 0; t < n_X_trig && ok; ++t) {
+        const int idx = X_trig_idx[t], k = idx / 36, c = (idx % 36) / 6, r = idx % 6, j = X_trig_j[t];
+        if (idx < 0 || k >= PJ || j < 0 || j >= 2 * PJ || j % PJ != k) { ok = false; break; }     // joint k's transform depends on q_k only
+        // a trig entry REPLACES the constant at that position (load_update_XImats_helpers overwrites it)
+        place(k, r, c, 0.0, 0);
+        ok = place(k, r, c, X_trig_coef[t], j < PJ ? 1 : 2);
+    }
+    for (uint32_t t = 0; t < n_Xhom_trig && ok; ++t) {
+        const int idx = Xhom_trig_idx[t], k = idx / 16, c = (idx % 16) / 4, r = idx % 4, j = Xhom_trig_j[t];
+        if (idx < 0 || k >= PJ || j < 0 || j >= 2 * PJ || j % PJ != k || r >= 3 || c >= 3) { ok = false; break; }
+        hp->R0[k][3 * r + c] = 0.0;
+        (j < PJ ? hp->Rs : hp->Rc)[k][3 * r + c] = Xhom_trig_coef[t];
+    }
+    if (!ok) { delete hp; return fail(nullptr, MPCG_ERR_INVALID, "mpcg_plant_create: tables do not describe a serial chain of revolute joints (X = [[E, 0], [B, E]], joint k depends on q_k)"); }
+    mpcg_plant* pl = new (std::nothrow) mpcg_plant();
+    if (!pl) { delete hp; return MPCG_ERR_NOMEM; }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) { delete hp; delete pl; return fail(nullptr, MPCG_ERR_HIP, "mpcg_plant_create: no HIP device"); }
+    pl->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&pl->d), sizeof(PlantDev)) != hipSuccess ||
+        hipMemcpy(pl->d, hp, sizeof(PlantDev), hipMemcpyHostToDevice) != hipSuccess) {
+        delete hp; delete pl;
+        return fail(nullptr, MPCG_ERR_HIP, "mpcg_plant_create: cannot place the model on the device");
+    }
+    delete hp;
+    *out = pl;
+    return MPCG_OK;
+}
+
+int mpcg_plant_destroy(mpcg_plant* p) {
+    if (p && p->d) { (void)hipSetDevice(p->device); (void)hipFree(p->d); }
+    delete p;
+    return MPCG_OK;
+}
+
+int mpcg_generate_kkt(mpcg_handle* h, const mpcg_plant* plant, uint32_t control_size, float timestep, const float* d_eePos_traj,
+                      const float* d_xs, const float* d_xu, float qd_cost, float r_cost, float* d_G_dense, float* d_C_dense,
+                      float* d_g, float* d_c, uint32_t batch, void* stream) {
+    if (!h || !plant) return MPCG_ERR_INVALID;
+    if (!d_eePos_traj || !d_xs || !d_xu || !d_G_dense || !d_C_dense || !d_g || !d_c)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_generate_kkt: null device pointer");
+    if (control_size != (uint32_t)PJ || h->n != 2u * PJ) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_generate_kkt: state_size 14 / control_size 7 (IIWA-14) only");
+    if (plant->device != h->device) return fail(h, MPCG_ERR_INVALID, "mpcg_generate_kkt: plant and handle live on different devices");
+    if (batch == 0) return MPCG_OK;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_generate_kkt: batch exceeds max_batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    KktArgs a;
+    a.plant = plant->d; a.eePos_traj = d_eePos_traj; a.xs = d_xs; a.xu = d_xu;
+    a.G = d_G_dense; a.C = d_C_dense; a.g = d_g; a.c = d_c;
+    a.N = (int)h->N; a.batch = (int)batch; a.dt = timestep; a.qd_cost = qd_cost; a.r_cost = r_cost;
+    long blocks = (long)batch * (h->N - 1);
+    const long cap = (long)h->num_cus * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(generate_kkt_kernel, dim3((unsigned)blocks), dim3(KKT_THREADS), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRY(h, hipGetLastError());
     return MPCG_OK;
 }

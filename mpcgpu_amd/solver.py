@@ -40,6 +40,36 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class Plant:
+    """Device-side robot model for mpcg_generate_kkt: the reference's d_dynMem_const (GRiD robotModel,
+    gato_plant::initializeDynamicsConstMem, include/dynamics/iiwa/iiwa_eepos_plant.cuh:63-66) as data."""
+
+    def __init__(self, model=None, device: int | None = None):
+        import numpy as np
+        from . import iiwa
+        self.lib = _lib.load()
+        self.model = model or iiwa.Model()
+        m = self.model
+        dev = torch.cuda.current_device() if device is None else int(device)
+        xi = np.array([t[0] for t in m.X_trig], np.int32); xc = np.array([t[1] for t in m.X_trig], np.float64); xj = np.array([t[2] for t in m.X_trig], np.int32)
+        hi = np.array([t[0] for t in m.Xhom_trig], np.int32); hc = np.array([t[1] for t in m.Xhom_trig], np.float64); hj = np.array([t[2] for t in m.Xhom_trig], np.int32)
+        Icol = np.ascontiguousarray(m.I.transpose(0, 2, 1).reshape(-1))          # back to the column-major table
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        Xc, Hc = np.ascontiguousarray(m.X_const), np.ascontiguousarray(m.Xhom_const)
+        h = C.c_void_p()
+        rc = self.lib.mpcg_plant_create(C.byref(h), dev, iiwa.NJ, p(Xc), p(Icol), p(Hc), p(xi), p(xc), p(xj), len(xi), p(hi), p(hc), p(hj), len(hi))
+        if rc != _lib.MPCG_OK:
+            raise _lib.MpcgError(rc, self.lib.mpcg_last_error(None).decode())
+        self._p = h
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.lib.mpcg_plant_destroy(self._p)
+            self._p = None
+
+    __del__ = close
+
+
 class QdldlSolver:
     """The reference's LINSYS_SOLVE == 0 path (include/qdldl/sqp.cuh) as a selectable solver: CSR lower-triangle pattern
     (include/utils/csr.cuh:40-73) + elimination tree once, then numeric LDL^T factor + solve per call on the HOST
@@ -245,6 +275,24 @@ class PcgSolver:
         self._check(self.lib.mpcg_form_schur(self._h, m, _ptr(G_dense), _ptr(C_dense), _ptr(g), _ptr(c), _ptr(S),
                                              _ptr(Pinv), _ptr(gamma), float(rho), B, pc, _stream()))
         return S, Pinv, gamma
+
+    def generate_kkt(self, plant: "Plant", eePos_traj, xs, xu, timestep: float, qd_cost: float, r_cost: float,
+                     control_size: int = CONTROL_SIZE):
+        """generate_kkt_submatrices (include/common/kkt.cuh:22-163), batched: eePos_traj [B, 6N], xs [B, n], xu [B, (n+m)N - m]
+        -> (G_dense, C_dense, g, c) device tensors in the layouts form_schur consumes."""
+        B = xu.shape[0] if xu.dim() > 1 else 1
+        n, m, N = self.n, control_size, self.N
+        self._chk(eePos_traj, B * 6 * N, torch.float32, "eePos_traj")
+        self._chk(xs, B * n, torch.float32, "xs")
+        self._chk(xu, B * ((n + m) * N - m), torch.float32, "xu")
+        dev = xu.device
+        G = torch.empty(B, (n * n + m * m) * N - m * m, device=dev)
+        Cd = torch.empty(B, (n * n + n * m) * (N - 1), device=dev)
+        g = torch.empty(B, (n + m) * N - m, device=dev)
+        c = torch.empty(B, n * N, device=dev)
+        self._check(self.lib.mpcg_generate_kkt(self._h, plant._p, m, float(timestep), _ptr(eePos_traj), _ptr(xs), _ptr(xu), float(qd_cost),
+                                               float(r_cost), _ptr(G), _ptr(Cd), _ptr(g), _ptr(c), B, _stream()))
+        return G, Cd, g, c
 
     def compute_dz(self, Ginv_dense, C_dense, g, lam, dz=None, control_size: int = CONTROL_SIZE):
         """compute_dz (include/common/dz.cuh:124-136), batched."""

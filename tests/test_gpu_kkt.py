@@ -1,0 +1,129 @@
+"""GPU: mpcg_generate_kkt (mpcgpu_amd/csrc/kkt_plant.hip.h) — the HIP twin of generate_kkt_submatrices
+(include/common/kkt.cuh:22-163) with the IIWA-14 plant as data — against the float64 host restatement mpcgpu_amd/iiwa.py
+(itself pinned on the reference's eepos fixture, tests/test_iiwa_plant.py) and the committed KKT fixtures, and the whole
+device-side chain of one SQP iteration on real IIWA systems (include/pcg/sqp.cuh:190-259): KKT -> Schur -> PCG -> dz."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from mpcgpu_amd import iiwa, synth
+from util import relinf
+
+pytestmark = pytest.mark.gpu
+n, m = 14, 7
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+@pytest.fixture(scope="module")
+def env():
+    from mpcgpu_amd import PcgSolver, Plant, pcg_config
+    return PcgSolver, Plant(), pcg_config, iiwa.Model()
+
+
+def windows(N, B, seed):
+    """B windows of the reference trajectory (tests/golden/iiwa_traj_0_0.npz): different offsets, goals a few steps
+    ahead, measured state and iterate perturbed — 'random-init trajectories' in the sense of BASELINE config 4."""
+    d = np.load(os.path.join(GOLDEN, "iiwa_traj_0_0.npz"))
+    traj, eep = d["xu"].astype(np.float64), d["eepos"].astype(np.float64)
+    rng = np.random.default_rng(seed)
+    xu = np.zeros((B, (n + m) * N - m))
+    goals = np.zeros((B, N, 6))
+    xs = np.zeros((B, n))
+    for b in range(B):
+        t0 = int(rng.integers(0, 200 - N - 8))
+        sh = int(rng.integers(0, 9))
+        w = traj[t0:t0 + N].reshape(-1)[:(n + m) * N - m].copy()
+        amp = 0.05 * rng.random()
+        xs[b] = w[:n] + amp * rng.standard_normal(n)
+        w += 0.3 * amp * rng.standard_normal(w.shape)
+        w[:n] = xs[b]
+        xu[b], goals[b] = w, eep[t0 + sh:t0 + sh + N]
+    return xu, goals, xs
+
+
+@pytest.mark.parametrize("N,B", [(8, 3), (32, 5)])
+def test_generate_kkt_vs_host_restatement(env, N, B):
+    PcgSolver, plant, _, M = env
+    xu, goals, xs = windows(N, B, 11 + N)
+    sol = PcgSolver(N, max_batch=B)
+    G, C, g, c = sol.generate_kkt(plant, dev(goals.reshape(B, -1)), dev(xs), dev(xu), iiwa.TIMESTEP, iiwa.QD_COST, iiwa.r_cost(N))
+    torch.cuda.synchronize()
+    G, C, g, c = (t.cpu().numpy() for t in (G, C, g, c))
+    assert all(np.isfinite(a).all() for a in (G, C, g, c))
+    for b in range(B):
+        # (the device sees the float32-rounded inputs: restate on exactly those)
+        want = iiwa.generate_kkt(M, xu[b].astype(np.float32).astype(np.float64), goals[b].astype(np.float32).astype(np.float64),
+                                 xs[b].astype(np.float32).astype(np.float64), N)
+        for got, ref, name in zip((G[b], C[b], g[b], c[b]), want, "GCgc"):
+            # float output rounding (6e-8 relative) + central-difference noise of the dynamics gradients (~1e-9 x |dID| / h)
+            assert np.abs(got - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max()), (b, name, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def test_generate_kkt_matches_committed_fixture(env):
+    PcgSolver, plant, _, _ = env
+    d = np.load(os.path.join(GOLDEN, "iiwa_kkt_N32.npz"))
+    N = 32
+    sol = PcgSolver(N, max_batch=1)
+    for s in range(3):
+        G, C, g, c = sol.generate_kkt(plant, dev(d[f"s{s}_goals"].reshape(1, -1)), dev(d[f"s{s}_xs"].reshape(1, -1)), dev(d[f"s{s}_xu"].reshape(1, -1)),
+                                      iiwa.TIMESTEP, iiwa.QD_COST, iiwa.r_cost(N))
+        torch.cuda.synchronize()
+        for got, name in ((G, "G"), (C, "C"), (g, "g"), (c, "c")):
+            ref = d[f"s{s}_{name}"]
+            assert np.abs(got.cpu().numpy()[0] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (s, name)
+
+
+def test_sqp_iteration_chain_on_real_iiwa_systems(env, orc):
+    """include/pcg/sqp.cuh:190-259 on the device for a batch of real IIWA-14 windows: generate_kkt -> form_schur -> PCG ->
+    compute_dz.  The step must satisfy the (regularised) KKT conditions assembled on the host from the host restatement
+    of the same blocks; PCG (warm-started from the direct solution of a slightly different system, as the MPC loop does)
+    exits on the tolerance."""
+    PcgSolver, plant, pcg_config, M = env
+    N, B = 32, 6
+    xu, goals, xs = windows(N, B, 5)
+    sol = PcgSolver(N, max_batch=B)
+    G, C, g, c = sol.generate_kkt(plant, dev(goals.reshape(B, -1)), dev(xs), dev(xu), iiwa.TIMESTEP, iiwa.QD_COST, iiwa.r_cost(N))
+    Gh, Ch, gh, ch = (t.cpu().numpy().astype(np.float64) for t in (G, C, g, c))
+    rho = synth.RHO_INIT
+    S, Pinv, gam = sol.form_schur(G, C, g, c, rho, "ss")                      # G <- G^-1 in place
+    lam = sol.block_solve(S, gam)                                            # warm start: the direct solution ...
+    lam = lam * (1 + 0.02 * torch.randn_like(lam))                           # ... perturbed by 2 %
+    it, ex = sol.solve(S, Pinv, gam, lam, pcg_config(pcg_exit_tol=1e-6, pcg_max_iter=5000), "ss")
+    dz = sol.compute_dz(G, C, g, lam)
+    schur_res = (sol.bt_spmv(S, lam) - gam).cpu().numpy().astype(np.float64)      # S lam - gamma (both stored negated)
+    torch.cuda.synchronize()
+    assert (ex.cpu().numpy() == 0).all() and (it.cpu().numpy() > 0).all() and sol.get_option("last_kernel_family") == 2
+    dz, lamh = dz.cpu().numpy().astype(np.float64), lam.cpu().numpy().astype(np.float64)
+    gamh = np.abs(gam.cpu().numpy()).max(axis=1)
+    nn, mm, nm = n * n, m * m, n * m
+    for b in range(B):
+        cerr = serr = ident = 0.0
+        cmax = gmax = 1e-30
+        for k in range(N):
+            x = dz[b, k * (n + m):k * (n + m) + n]
+            acc = x.copy()                                                   # constraint rows: C dz = c
+            if k > 0:
+                A = Ch[b, (k - 1) * (nn + nm):(k - 1) * (nn + nm) + nn].reshape(n, n).T
+                Bm = Ch[b, (k - 1) * (nn + nm) + nn:(k) * (nn + nm)].reshape(m, n).T
+                acc = acc + A @ dz[b, (k - 1) * (n + m):(k - 1) * (n + m) + n] + Bm @ dz[b, (k - 1) * (n + m) + n:k * (n + m)]
+            cerr = max(cerr, np.abs(acc - ch[b, k * n:(k + 1) * n]).max())
+            ident = max(ident, np.abs((acc - ch[b, k * n:(k + 1) * n]) - schur_res[b, k * n:(k + 1) * n]).max())
+            cmax = max(cmax, np.abs(ch[b, k * n:(k + 1) * n]).max())
+            Q = Gh[b, k * (nn + mm):k * (nn + mm) + nn].reshape(n, n).T       # stationarity rows of x_k
+            st = (Q + rho * np.eye(n)) @ x + lamh[b, k * n:(k + 1) * n]
+            if k < N - 1:
+                A = Ch[b, k * (nn + nm):k * (nn + nm) + nn].reshape(n, n).T
+                st = st + A.T @ lamh[b, (k + 1) * n:(k + 2) * n]
+            serr = max(serr, np.abs(st - gh[b, k * (n + m):k * (n + m) + n]).max())
+            gmax = max(gmax, np.abs(gh[b, k * (n + m):k * (n + m) + n]).max(), np.abs(lamh[b]).max())
+        # C dz - c = C G^-1 (g - C^T lam) - c = S lam - gamma (stored signs): the constraint defect of the step IS the
+        # residual of the Schur system, whatever accuracy PCG stopped at (fp32 PCG at cond ~1e6 leaves 1e-3..3e-2 of
+        # |gamma|) — the identity holds to fp32 rounding of the three kernels involved; the stationarity rows hold
+        # to rounding for any lambda
+        assert ident / gamh[b] < 1e-3 and cerr / gamh[b] < 0.1 and serr / gmax < 1e-5, (b, ident / gamh[b], cerr / gamh[b], serr / gmax)
