@@ -479,6 +479,55 @@ def main():
                                  "pcg_iterations_per_sec": float(itw.sum() / (ms_w * 1e-3)),
                                  "linsolves_per_sec": B / (ms_w * 1e-3)}
 
+    if extras and not lean and N <= 256:
+        # ---- the same path on REAL IIWA-14 systems, produced on the device like the reference's SQP iteration does
+        # (include/pcg/sqp.cuh:190-232): generate_kkt -> form_schur -> PCG, cold and warm-started the way the MPC loop
+        # warm-starts (lambda of the previous, slightly different, linear system: include/mpcsim.cuh:186,267,337) ----
+        from mpcgpu_amd import Plant, iiwa
+        plant = Plant(device=local_rank)
+        xu_h, goals_h, xs_h = iiwa.random_windows(N, B, 2024 + rank)
+        f32 = lambda a_: torch.from_numpy(np.ascontiguousarray(a_, np.float32)).to(dev)
+        d_xu, d_goal, d_xs = f32(xu_h), f32(goals_h.reshape(B, -1)), f32(xs_h)
+        rc = iiwa.r_cost(N)
+        ms_kkt = timed(lambda: sol.generate_kkt(plant, d_goal, d_xs, d_xu, iiwa.TIMESTEP, iiwa.QD_COST, rc), 3, warm=1)
+        Gk, Ck, gk, ck = sol.generate_kkt(plant, d_goal, d_xs, d_xu, iiwa.TIMESTEP, iiwa.QD_COST, rc)
+        Gk0 = Gk.clone()
+        ms_schur = timed(lambda: (Gk.copy_(Gk0), sol.form_schur(Gk, Ck, gk, ck, synth.RHO_INIT, "ss")), 3, warm=1) - timed(lambda: Gk.copy_(Gk0), 3, warm=1)
+        Gk.copy_(Gk0)
+        rS, rP, rg = sol.form_schur(Gk, Ck, gk, ck, synth.RHO_INIT, "ss")
+        # previous SQP iterate = this one plus a small change of the trajectory -> its multipliers are the warm start
+        d_xu_prev = d_xu + 2e-3 * torch.randn_like(d_xu)
+        d_xu_prev[:, :14] = d_xu[:, :14]
+        Gp, Cp, gp, cp = sol.generate_kkt(plant, d_goal, d_xs, d_xu_prev, iiwa.TIMESTEP, iiwa.QD_COST, rc)
+        pS, _, pg = sol.form_schur(Gp, Cp, gp, cp, synth.RHO_INIT, "none")
+        lam_prev = sol.block_solve(pS, pg)
+        gn = rg.double().norm(dim=1)
+        resid = lambda l_: ((rg - sol.bt_spmv(rS, l_)).double().norm(dim=1) / gn)
+        res = {}
+        for name, lam0 in (("cold", torch.zeros(B, 14 * N, device=dev)), ("warm", lam_prev)):
+            l_ = lam0.clone()
+            r0 = resid(l_)
+
+            def go():
+                l_.copy_(lam0)
+                sol.solve(rS, rP, rg, l_, cfg, "ss", iters=d_it, exits=d_ex)
+            ms_copy = timed(lambda: l_.copy_(lam0), 3, warm=1)
+            ms_ = timed(go, 3, warm=1) - ms_copy               # (l_ now holds the solution of the last run)
+            iti = d_it.cpu().numpy().astype(np.int64)
+            r1 = resid(l_)
+            res[name] = {"mean_pcg_iters": float(iti.mean()), "min_pcg_iters": int(iti.min()), "max_pcg_iters": int(iti.max()),
+                         "max_iter_exit_rate": float(d_ex.float().mean().item()), "kernel_ms": ms_,
+                         "pcg_iterations_per_sec": float(iti.sum() / (ms_ * 1e-3)), "linsolves_per_sec": B / (ms_ * 1e-3),
+                         "true_rel_residual_before_median": float(r0.median().item()), "true_rel_residual_after_median": float(r1.median().item()),
+                         "true_rel_residual_after_max": float(r1.max().item())}
+        out["iiwa_run"] = {"inputs": f"{B} windows of the reference trajectory examples/trajfiles/0_0_traj.csv (first 400 rows), random offset, goals 0..8 steps ahead, "
+                                     "state / iterate noise <= 0.05; KKT blocks by mpcg_generate_kkt (IIWA-14 dynamics on the device), Schur by mpcg_form_schur, rho = 1e-3",
+                           "pcg": {"max_iter": max_iter, "exit_tol": args.exit_tol, "precond": "ss"}, "generate_kkt_ms": ms_kkt, "form_schur_ms": ms_schur,
+                           "cold_start": res["cold"], "warm_start_from_previous_sqp_iterate": res["warm"],
+                           "note": "cond(-S) of these systems is 1e7-2e7 at N=128 (synthetic generator: ~1e5): from lambda0 = 0 most solves hit the reference's iteration "
+                                   "cap, which presupposes the MPC loop's warm starts (tests/make_iiwa_golden.py prints the study)"}
+        del Gk, Ck, Gp, Cp, rS, rP, pS
+
     if extras and rank == 0 and world == 1 and not lean:
         out["config2_latency"] = latency_config2(dev)
         # the headline horizon as ONE trajectory (the reference's own mode of use): ms per SQP-linsolve

@@ -187,3 +187,30 @@ def generate_kkt(model: Model, xu, ee_goals, xs, knot_points: int, dt: float = T
 def read_csv(path):
     """readCSVToVecVec (include/utils/experiment.cuh:145-169)."""
     return np.array([[float(v) for v in line.strip().split(",") if v != ""] for line in open(path) if line.strip()])
+
+
+TRAJ_FIXTURE = os.path.join(os.path.dirname(_HERE), "tests", "golden", "iiwa_traj_0_0.npz")
+
+
+def random_windows(knot_points: int, batch: int, seed: int, max_noise: float = 0.05):
+    """`batch` tracking problems cut from the reference's precomputed trajectory (tests/golden/iiwa_traj_0_0.npz = the
+    first 400 rows of examples/trajfiles/0_0_traj.csv and 0_0_eepos.traj): random window offset, goals 0..8 steps ahead,
+    measured state x_s and iterate perturbed by gaussian noise of random amplitude <= max_noise (rad, rad/s) — the
+    'random-init trajectories' of BASELINE config 4 on the real robot.  Returns float64 (xu [B, (n+m)N-m], goals [B, N, 6], xs [B, n])."""
+    d = np.load(TRAJ_FIXTURE)
+    traj, eep = d["xu"].astype(np.float64), d["eepos"].astype(np.float64)
+    n, m, N = 2 * NJ, NJ, knot_points
+    rng = np.random.default_rng(seed)
+    xu = np.zeros((batch, (n + m) * N - m))
+    goals = np.zeros((batch, N, 6))
+    xs = np.zeros((batch, n))
+    for b in range(batch):
+        t0 = int(rng.integers(0, traj.shape[0] - N - 8))
+        sh = int(rng.integers(0, 9))
+        w = traj[t0:t0 + N].reshape(-1)[:(n + m) * N - m].copy()
+        amp = max_noise * rng.random()
+        xs[b] = w[:n] + amp * rng.standard_normal(n)
+        w += 0.3 * amp * rng.standard_normal(w.shape)
+        w[:n] = xs[b]
+        xu[b], goals[b] = w, eep[t0 + sh:t0 + sh + N]
+    return xu, goals, xs

@@ -27,24 +27,7 @@ def env():
 
 
 def windows(N, B, seed):
-    """B windows of the reference trajectory (tests/golden/iiwa_traj_0_0.npz): different offsets, goals a few steps
-    ahead, measured state and iterate perturbed — 'random-init trajectories' in the sense of BASELINE config 4."""
-    d = np.load(os.path.join(GOLDEN, "iiwa_traj_0_0.npz"))
-    traj, eep = d["xu"].astype(np.float64), d["eepos"].astype(np.float64)
-    rng = np.random.default_rng(seed)
-    xu = np.zeros((B, (n + m) * N - m))
-    goals = np.zeros((B, N, 6))
-    xs = np.zeros((B, n))
-    for b in range(B):
-        t0 = int(rng.integers(0, 200 - N - 8))
-        sh = int(rng.integers(0, 9))
-        w = traj[t0:t0 + N].reshape(-1)[:(n + m) * N - m].copy()
-        amp = 0.05 * rng.random()
-        xs[b] = w[:n] + amp * rng.standard_normal(n)
-        w += 0.3 * amp * rng.standard_normal(w.shape)
-        w[:n] = xs[b]
-        xu[b], goals[b] = w, eep[t0 + sh:t0 + sh + N]
-    return xu, goals, xs
+    return iiwa.random_windows(N, B, seed)
 
 
 @pytest.mark.parametrize("N,B", [(8, 3), (32, 5)])

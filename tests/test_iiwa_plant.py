@@ -1,6 +1,6 @@
 """CPU: the IIWA-14 producer side (stage A) — mpcgpu_amd/iiwa.py (numpy float64 restatement of
 include/common/kkt.cuh:22-163 + the plant it calls) against the reference's own trajectory fixtures
-(tests/golden/iiwa_traj_0_0.npz = first 200 rows of examples/trajfiles/0_0_traj.csv and 0_0_eepos.traj) and the KKT / Schur
+(tests/golden/iiwa_traj_0_0.npz = first 400 rows of examples/trajfiles/0_0_traj.csv and 0_0_eepos.traj) and the KKT / Schur
 fixtures tests/make_iiwa_golden.py produced in the build container."""
 import os
 
@@ -24,9 +24,9 @@ def traj():
 
 def test_end_effector_kinematics_reproduce_the_reference_fixture(M, traj):
     """Row t of 0_0_eepos.traj is the end-effector position of row t of 0_0_traj.csv (the reference generated one from the
-    other with its GRiD kinematics): the restated forward kinematics must reproduce all 200 rows (csv precision ~1e-6)."""
+    other with its GRiD kinematics): the restated forward kinematics must reproduce all 400 rows (csv precision ~1e-6)."""
     xu, eep = traj
-    err = max(np.abs(M.ee_pos(xu[t, :7]) - eep[t, :3]).max() for t in range(200))
+    err = max(np.abs(M.ee_pos(xu[t, :7]) - eep[t, :3]).max() for t in range(400))
     assert err < 2e-5, err
     # and the Jacobian is the derivative of that map
     q = xu[17, :7]
