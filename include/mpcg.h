@@ -66,6 +66,11 @@ const char *mpcg_build_info(void);
  * (device, knot_points) and per concurrently used stream: calls on the same handle must not overlap on the host
  * side (launch knobs are chosen per call) and their device work must be ordered (one stream, or events) because
  * they share those buffers; different handles are independent. */
+/* state_size = 14 (IIWA-14) is the tuned specialisation and the only one every entry point supports.  Any other
+ * 1 <= state_size <= 64 gets a handle whose PCG entry points (mpcg_pcg_solve, mpcg_pcg_solve_ref, mpcg_pcg_solve_f64,
+ * mpcg_pcg_solve_ref_f64, mpcg_pcg_lds_bytes, mpcg_check_pcg_occupancy) run a generic, functional kernel (matrices streamed
+ * every iteration; "last_kernel_family" = 3) — same layouts with n x n blocks, same semantics; the other entry points
+ * return MPCG_ERR_UNSUPPORTED on such a handle. */
 int mpcg_create(mpcg_handle **out, int device, uint32_t state_size, uint32_t knot_points, uint32_t max_batch);
 int mpcg_destroy(mpcg_handle *h);
 const char *mpcg_last_error(const mpcg_handle *h);   /* h may be NULL: last error of mpcg_create */

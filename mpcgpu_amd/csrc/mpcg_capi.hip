@@ -52,6 +52,7 @@ struct mpcg_handle {
     int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
     unsigned long long* cluster_scratch = nullptr;
     bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any valid pcg_* set_option clears this)
+    bool generic = false;     // state_size != 14: only the PCG entry points work, through pcg_generic_kernel
     int spmv_blocks_per_cu = 4;    // (sweep at 4096 trajectories = 1.2 GB of S, a true HBM stream: profiles/r02_tune_spmv.txt)
     int spmv_mfma = 0;        // 1 = the MFMA experiment kernel for mpcg_bt_spmv
     float* block_scratch = nullptr;  // W_k, z_k of mpcg_block_solve: max_batch x N x 210 floats (first call)
@@ -73,7 +74,12 @@ static int fail(mpcg_handle* h, int code, const std::string& msg) {
             return fail((h), MPCG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// n = 14 is the tuned specialisation (every entry point); any other 1 <= n <= 64 is served by the generic PCG kernel only
+// (mpcg_pcg_solve / _ref / _f64: pcg_generic_kernel, pcg_f64.hip.h), as long as its iterate vectors fit the LDS.
 static bool shape_supported(uint32_t n, uint32_t N) { return n == (uint32_t)NS && N >= 2 && N <= 2048; }
+static bool generic_shape_supported(uint32_t n, uint32_t N) {
+    return n >= 1 && n <= 64 && n != (uint32_t)NS && N >= 2 && N <= 2048 && pcg_generic_lds_elems((int)N, (int)n) * sizeof(float) <= 160 * 1024;
+}
 
 static size_t lds_bytes_for(uint32_t N, int nw) { return pcg_lds_floats((int)N, nw) * sizeof(float); }
 static constexpr size_t kLdsMax = 160 * 1024;
@@ -92,24 +98,26 @@ const char* mpcg_build_info(void) {
 }
 
 size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
+    if (generic_shape_supported(state_size, knot_points)) return pcg_generic_lds_elems((int)knot_points, (int)state_size) * sizeof(float);
     if (!shape_supported(state_size, knot_points)) return 0;
     if (knot_points > kLpbMaxN && lds_bytes_for(knot_points, 16) > kLdsMax) return 0;
     return default_launch_lds_bytes(knot_points, 256);
 }
 
 size_t mpcg_pcg_lds_bytes_f64(uint32_t state_size, uint32_t knot_points) {
-    if (!shape_supported(state_size, knot_points)) return 0;
-    const size_t b = pcg_f64_lds_doubles((int)knot_points) * sizeof(double);
+    if (!shape_supported(state_size, knot_points) && !generic_shape_supported(state_size, knot_points)) return 0;
+    const size_t b = pcg_generic_lds_elems((int)knot_points, (int)state_size) * sizeof(double);
     return b <= kLdsMax ? b : 0;
 }
 
 int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t knot_points, uint32_t max_batch) {
     if (!out) return fail(nullptr, MPCG_ERR_INVALID, "mpcg_create: out is null");
     *out = nullptr;
-    if (!shape_supported(state_size, knot_points) || lds_bytes_for(knot_points, 16) > kLdsMax)
+    const bool generic = generic_shape_supported(state_size, knot_points);
+    if (!generic && (!shape_supported(state_size, knot_points) || lds_bytes_for(knot_points, 16) > kLdsMax))
         return fail(nullptr, MPCG_ERR_UNSUPPORTED,
-                    "mpcg_create: only state_size=14 and 2 <= knot_points with the iterate vectors fitting "
-                    "160 KiB of LDS are compiled in");
+                    "mpcg_create: state_size = 14 (tuned; every entry point) or 1..64 (generic PCG kernel only), 2 <= knot_points, "
+                    "and the iterate vectors must fit 160 KiB of LDS");
     if (max_batch == 0) return fail(nullptr, MPCG_ERR_INVALID, "mpcg_create: max_batch is 0");
     int ndev = 0;
     HIP_TRY(nullptr, hipGetDeviceCount(&ndev));
@@ -123,6 +131,7 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     mpcg_handle* h = new (std::nothrow) mpcg_handle();
     if (!h) return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: out of host memory");
     h->device = device; h->n = state_size; h->N = knot_points; h->max_batch = max_batch;
+    h->generic = generic;
     h->num_cus = prop.multiProcessorCount;
     h->nt_loads = 1;                    // SpMV kernel only: the matrix is read once — non-temporal loads, +4..9 % (profiles/r02_tune_spmv.txt)
     choose_auto(h, h->k, 1, 4);         // knobs of the single-workgroup kernels as a batch-1 call would pick them
@@ -392,9 +401,12 @@ static int launch_lpb_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStr
 static int launch_lpb(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
     return h->N <= 64 ? launch_lpb_t<1>(h, a, batch, st) : launch_lpb_t<2>(h, a, batch, st);
 }
+// Automatic use: 48 < N <= 128.  Its per-lane work does not shrink with the horizon (one block per lane whatever N), so for
+// short horizons the row-pair kernels of pcg_traj_kernel stay ahead (N=32: 289 vs 224 M it/s at batch 2048, 0.247 vs 0.340 ms
+// for one trajectory; N=64: 202 vs 132 M it/s the other way round — profiles/r02_lpb_quick.txt).
 static bool use_lpb(const mpcg_handle* h, int esz) {
     if (esz != 4 || h->N > kLpbMaxN || h->lpb == 0) return false;
-    return h->lpb == 1 || (h->auto_cfg && h->cluster <= 0);
+    return h->lpb == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 48);
 }
 
 // ---- cluster kernel: G workgroups per trajectory, everything resident, batch*G <= #CUs ----
@@ -534,8 +546,14 @@ static int launch_traj(mpcg_handle* h, const PcgKnobs& k, const PcgArgs& a, uint
 //   2. cluster kernel: forced ("cluster" = G), or automatic configuration and a horizon one CU cannot hold;
 //   3. single-workgroup kernel <waves, reg_rows, stream_bufs> — the handle's knobs, adjusted per call by the
 //      automatic policy unless the caller set any pcg_* knob.
+static int launch_generic_f32(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st);
+
 static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->generic) {
+        if (esz != 4) return fail(h, MPCG_ERR_UNSUPPORTED, "fp16 matrix storage exists for state_size = 14 only");
+        return launch_generic_f32(h, a, batch, st);
+    }
     if (use_lpb(h, esz)) return launch_lpb(h, a, batch, st);
     {
         const int rc = try_launch_cluster(h, a, batch, st, esz);
@@ -561,7 +579,13 @@ static int occupancy(mpcg_handle* h, const PcgKnobs& k, int* per_cu) {
 
 // LDS bytes of the launch a default-configured batch-1 solve makes (what pcgSharedMemSize stands for)
 static size_t default_launch_lds_bytes(uint32_t N, int num_cus) {
-    if (N <= kLpbMaxN) return pcg_lpb_lds_floats((int)N, N <= 64 ? 4 : 8) * sizeof(float);
+    if (N > 48 && N <= kLpbMaxN) return pcg_lpb_lds_floats((int)N, N <= 64 ? 4 : 8) * sizeof(float);
+    if (N <= 48) {                                       // <8,2,0>: everything in registers, vectors in LDS
+        mpcg_handle t0;
+        t0.N = N; t0.n = NS; t0.num_cus = num_cus;
+        choose_auto(&t0, t0.k, 1, 4);
+        return traj_lds(&t0, t0.k, t0.k.waves, 0, 4).bytes;
+    }
     mpcg_handle tmp;
     tmp.N = N; tmp.n = NS; tmp.num_cus = num_cus;
     const int ntr = ((int)N + 2) / 3;
@@ -578,6 +602,33 @@ static size_t default_launch_lds_bytes(uint32_t N, int num_cus) {
     return traj_lds(&tmp, tmp.k, tmp.k.waves, sb == 0 ? 0 : 1, 4).bytes;
 }
 
+template <typename T, int NFIX>
+static int launch_generic(mpcg_handle* h, PcgArgsG<T> a, uint32_t batch, void* stream) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    a.n = (int)h->n;
+    const size_t lds = pcg_generic_lds_elems((int)h->N, (int)h->n) * sizeof(T);
+    if (lds > kLdsMax) return fail(h, MPCG_ERR_UNSUPPORTED, "generic / double-precision kernel: the iterate vectors do not fit 160 KiB of LDS");
+    auto kern = pcg_generic_kernel<T, NFIX>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(batch), dim3(F64_THREADS), lds, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(h, hipGetLastError());
+    h->last = LastKernel{3, F64_THREADS / 64, 0, 0, 2, 0, (int)lds, 0};      // family 3 = generic streaming kernel
+    return MPCG_OK;
+}
+static int launch_f64(mpcg_handle* h, PcgArgs64 a, uint32_t batch, void* stream) {
+    return h->generic ? launch_generic<double, 0>(h, a, batch, stream) : launch_generic<double, 14>(h, a, batch, stream);
+}
+// state_size != 14, float: the PcgArgs of the tuned path re-packed for the generic kernel
+static int launch_generic_f32(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    PcgArgsG<float> g;
+    g.S = static_cast<const float*>(a.S); g.Pinv = static_cast<const float*>(a.Pinv); g.gamma = a.gamma; g.lambda = a.lambda;
+    g.r_out = a.r_out; g.p_out = a.p_out; g.iters = a.iters; g.max_iter_exit = a.max_iter_exit;
+    g.N = a.N; g.max_iter = a.max_iter; g.exit_tol = a.exit_tol; g.pcols = a.pcols;
+    return launch_generic<float, 0>(h, g, batch, st);
+}
+
+
 extern "C" {
 
 // Resident trajectories of the configuration a throughput-sized call (batch = max_batch) would launch.
@@ -585,7 +636,12 @@ int mpcg_check_pcg_occupancy(mpcg_handle* h, uint32_t* resident_trajectories) {
     if (!h || !resident_trajectories) return MPCG_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     int per_cu = 0;
-    if (use_lpb(h, 4)) {
+    if (h->generic) {
+        const size_t lds = pcg_generic_lds_elems((int)h->N, (int)h->n) * sizeof(float);
+        auto kern = pcg_generic_kernel<float, 0>;
+        if (lds > 48 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, F64_THREADS, lds));
+    } else if (use_lpb(h, 4)) {
         const size_t lds = pcg_lpb_lds_floats((int)h->N, h->N <= 64 ? 4 : 8) * sizeof(float);
         if (h->N <= 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpb_kernel<1>, 256, lds));
         else HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpb_kernel<2>, 512, lds));
@@ -642,6 +698,7 @@ int mpcg_pcg_solve_ref(mpcg_handle* h, float* d_S, float* d_Pinv, float* d_gamma
 
 int mpcg_bt_spmv(mpcg_handle* h, const float* d_M, const float* d_x, float* d_y, uint32_t batch, int cols, void* stream) {
     if (!h) return MPCG_ERR_INVALID;
+    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_bt_spmv: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
     if (!d_M || !d_x || !d_y) return fail(h, MPCG_ERR_INVALID, "mpcg_bt_spmv: null device pointer");
     if (cols != 1 && cols != 3) return fail(h, MPCG_ERR_INVALID, "mpcg_bt_spmv: cols must be 1 or 3");
     if (batch == 0) return MPCG_OK;
@@ -683,6 +740,7 @@ int mpcg_pcg_solve_f16(mpcg_handle* h, const uint16_t* d_S16, const uint16_t* d_
                        float* d_lambda, uint32_t batch, uint32_t max_iter, float exit_tol, mpcg_precond precond,
                        uint32_t* d_iters, uint8_t* d_max_iter_exit, void* stream) {
     if (!h) return MPCG_ERR_INVALID;
+    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_pcg_solve_f16: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
     if (!d_S16 || !d_Pinv16 || !d_gamma || !d_lambda || !d_iters || !d_max_iter_exit)
         return fail(h, MPCG_ERR_INVALID, "mpcg_pcg_solve_f16: null device pointer");
     if (batch == 0) return MPCG_OK;
@@ -698,17 +756,6 @@ int mpcg_pcg_solve_f16(mpcg_handle* h, const uint16_t* d_S16, const uint16_t* d_
     a.iters = d_iters; a.max_iter_exit = d_max_iter_exit;
     a.N = (int)h->N; a.max_iter = (int)max_iter; a.exit_tol = exit_tol; a.pcols = (int)precond; a.lds_rows = 0;
     return launch_pcg(h, a, batch, static_cast<hipStream_t>(stream), 2);
-}
-
-static int launch_f64(mpcg_handle* h, PcgArgs64 a, uint32_t batch, void* stream) {
-    HIP_TRY(h, hipSetDevice(h->device));
-    const size_t lds = pcg_f64_lds_doubles((int)h->N) * sizeof(double);
-    if (lds > kLdsMax) return fail(h, MPCG_ERR_UNSUPPORTED, "double precision: the iterate vectors do not fit 160 KiB of LDS (knot_points <= 350)");
-    if (lds > 48 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_f64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(pcg_f64_kernel, dim3(batch), dim3(F64_THREADS), lds, static_cast<hipStream_t>(stream), a);
-    HIP_TRY(h, hipGetLastError());
-    return MPCG_OK;
 }
 
 int mpcg_pcg_solve_f64(mpcg_handle* h, const double* d_S, const double* d_Pinv, const double* d_gamma, double* d_lambda,
@@ -745,6 +792,7 @@ int mpcg_pcg_solve_ref_f64(mpcg_handle* h, double* d_S, double* d_Pinv, double* 
 
 int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, float* d_lambda, uint32_t batch, void* stream) {
     if (!h) return MPCG_ERR_INVALID;
+    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_block_solve: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
     if (!d_S || !d_gamma || !d_lambda) return fail(h, MPCG_ERR_INVALID, "mpcg_block_solve: null device pointer");
     if (batch == 0) return MPCG_OK;
     if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_block_solve: batch exceeds max_batch");
@@ -768,6 +816,7 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
                     const float* d_c, float* d_S, float* d_Pinv, float* d_gamma, float rho, uint32_t batch,
                     mpcg_precond precond, void* stream) {
     if (!h) return MPCG_ERR_INVALID;
+    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
     if (!d_G_dense || !d_C_dense || !d_g || !d_c || !d_S || (!d_Pinv && precond != MPCG_PRECOND_NONE) || !d_gamma)
         return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: null device pointer");
     if (control_size != 7) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur: control_size must be 7 (IIWA-14)");
@@ -817,6 +866,7 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
 int mpcg_compute_dz(mpcg_handle* h, uint32_t control_size, const float* d_Ginv_dense, const float* d_C_dense,
                     const float* d_g, const float* d_lambda, float* d_dz, uint32_t batch, void* stream) {
     if (!h) return MPCG_ERR_INVALID;
+    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_compute_dz: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
     if (!d_Ginv_dense || !d_C_dense || !d_g || !d_lambda || !d_dz)
         return fail(h, MPCG_ERR_INVALID, "mpcg_compute_dz: null device pointer");
     if (control_size != 7) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_compute_dz: control_size must be 7 (IIWA-14)");
@@ -835,6 +885,7 @@ int mpcg_compute_dz(mpcg_handle* h, uint32_t control_size, const float* d_Ginv_d
 
 int mpcg_prep_csr(mpcg_handle* h, int32_t* d_col_ptr, int32_t* d_row_ind, void* stream) {
     if (!h) return MPCG_ERR_INVALID;
+    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_prep_csr: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
     if (!d_col_ptr || !d_row_ind) return fail(h, MPCG_ERR_INVALID, "mpcg_prep_csr: null device pointer");
     HIP_TRY(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(prep_csr_kernel, dim3(h->N), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), (int)h->n, (int)h->N,
@@ -845,6 +896,7 @@ int mpcg_prep_csr(mpcg_handle* h, int32_t* d_col_ptr, int32_t* d_row_ind, void* 
 
 int mpcg_bd_to_csr_lowertri(mpcg_handle* h, const float* d_S, float* d_val, float mult, uint32_t batch, void* stream) {
     if (!h) return MPCG_ERR_INVALID;
+    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_bd_to_csr_lowertri: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
     if (!d_S || !d_val) return fail(h, MPCG_ERR_INVALID, "mpcg_bd_to_csr_lowertri: null device pointer");
     if (batch == 0) return MPCG_OK;
     if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_bd_to_csr_lowertri: batch exceeds max_batch");

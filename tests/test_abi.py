@@ -45,14 +45,17 @@ def test_version_and_lds_size(hiplib):
     # 2 partials per wave
     r4 = lambda x: (x + 3) & ~3
     lpb = lambda nmax, nw: 4 * (3 * nmax * 14 + 3 * r4((nmax + 1) * 14) + r4(2 * nw))
-    for N in (2, 32, 64):
-        assert hiplib.mpcg_pcg_lds_bytes(14, N) == lpb(64, 4) == 21728
+    assert hiplib.mpcg_pcg_lds_bytes(14, 64) == lpb(64, 4) == 21728
+    # N <= 48: the all-register row-pair kernel <8,2,0>: xp, xr padded by a knot either side, lambda, tmp, 16 partials
+    for N in (2, 32, 48):
+        assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (2 * r4((N + 2) * 14) + 2 * r4(N * 14) + 16)
     for N in (65, 128):
         assert hiplib.mpcg_pcg_lds_bytes(14, N) == lpb(128, 8) == 43264
     # N > 128: a cluster member — its own knots (+ halo) only
     assert 0 < hiplib.mpcg_pcg_lds_bytes(14, 512) < 29024
     assert hiplib.mpcg_pcg_lds_bytes_f64(14, 32) == 8 * ((32 + 2) * 14 * 2 + 32 * 14 * 2 + 8)
-    assert hiplib.mpcg_pcg_lds_bytes(12, 128) == 0          # only n = 14 is compiled in
+    assert hiplib.mpcg_pcg_lds_bytes(12, 128) == 4 * (2 * 130 * 12 + 2 * 128 * 12 + 8)   # n != 14: the generic kernel's vectors
+    assert hiplib.mpcg_pcg_lds_bytes(65, 8) == 0            # state sizes beyond 64 are not served
     assert hiplib.mpcg_pcg_lds_bytes(14, 1024) == 0         # vectors would not fit 160 KiB LDS
 
 
@@ -60,7 +63,7 @@ def test_create_argument_errors(hiplib):
     from mpcgpu_amd import _lib
     h = C.c_void_p()
     assert hiplib.mpcg_create(None, 0, 14, 32, 1) == _lib.MPCG_ERR_INVALID
-    assert hiplib.mpcg_create(C.byref(h), 0, 12, 32, 1) == _lib.MPCG_ERR_UNSUPPORTED
+    assert hiplib.mpcg_create(C.byref(h), 0, 65, 32, 1) == _lib.MPCG_ERR_UNSUPPORTED
     assert b"state_size" in hiplib.mpcg_last_error(None)
     assert hiplib.mpcg_create(C.byref(h), 0, 14, 32, 0) == _lib.MPCG_ERR_INVALID
     assert hiplib.mpcg_destroy(None) == _lib.MPCG_OK

@@ -44,11 +44,13 @@ def lpb_solve(P, N, S, Pinv, g, lam0, max_iter, tol, pc="ss"):
     PcgSolver, pcg_config = P
     B = S.shape[0]
     sol = PcgSolver(N, max_batch=B)
+    if N <= 48:
+        sol.set_option("pcg_lpb", 1)          # (the automatic policy uses this kernel for 48 < N <= 128)
     lam = dev(np.asarray(lam0, np.float32))
     it, ex = sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=tol, pcg_max_iter=max_iter), pc)
     torch.cuda.synchronize()
     assert sol.get_option("last_kernel_family") == 2 and sol.get_option("last_kernel_waves") == (4 if N <= 64 else 8)
-    assert sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes(14, N)
+    assert N <= 48 or sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes(14, N)
     return lam.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy()
 
 
@@ -131,6 +133,7 @@ def test_lpb_flags_warm_start_and_r_p_outputs(P, orc):
     G = golden(32)
     N = 32
     sol = P[0](N)
+    sol.set_option("pcg_lpb", 1)
     d_lambda = torch.zeros(n * N, device="cuda")
     d_r = torch.full((n * N,), 7.0, device="cuda")
     d_p = torch.full((n * N,), 7.0, device="cuda")

@@ -314,7 +314,7 @@ def test_cpp_callsite_over_shim_headers():
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["pcg_exit"] == 0 and 0 < out["pcg_iters"] < 200 and out["rel_residual"] < 1e-4
-    assert out["smem"] == 21728                   # pcgSharedMemSize = the dynamic LDS of the launch a default solve makes (N <= 64: lane-per-block kernel, 4 waves)
+    assert out["smem"] == 4 * ((32 + 2) * 14 * 2 + 32 * 14 * 2 + 16)   # pcgSharedMemSize = the dynamic LDS of the launch a default solve makes (N = 32: <8,2,0>)
     # the same source with -DUSE_DOUBLES: pcg<double, n, N>, mpcgLaunchPcg<double>
     exe64 = build.EXAMPLE_BIN64 if os.path.exists(build.EXAMPLE_BIN64) else build.build_example_f64()
     r = subprocess.run([exe64], capture_output=True, text=True, timeout=120)
@@ -405,7 +405,6 @@ def test_short_horizon_batches_run_two_trajectories_per_cu(P, orc):
     dS, dP, dg = dev(S), dev(Pinv), dev(g)
     cfg = pcg_config(pcg_exit_tol=1e-5, pcg_max_iter=173)
     sol = PcgSolver(N, max_batch=B)
-    sol.set_option("pcg_lpb", 0)          # the automatic policy of the single-workgroup kernels (lane-per-block kernel off)
     lam = torch.zeros(B, n * N, device="cuda")
     it, ex = sol.solve(dS, dP, dg, lam, cfg, "ss")
     torch.cuda.synchronize()
