@@ -10,7 +10,7 @@
 //     phase 1  lanes 0..6: columns of the joint-space inertia matrix M = ID(q, 0, e_j);  lane 7: bias c = ID(q, qd, 0)
 //     phase 2  lanes 0..6: column j of Minv by a Cholesky solve (7x7, redundantly factorised per lane);  qdd = Minv (u - c)
 //     phase 3  lanes 0..27: ID(q +- h e_j, qd, qdd), ID(q, qd +- h e_j, qdd)  ->  central differences of the inverse dynamics
-//              lane 32: forward kinematics, end-effector position and geometric Jacobian z_j x (p_ee - p_j)
+//              lane 28: forward kinematics, end-effector position and geometric Jacobian z_j x (p_ee - p_j)
 //     phase 4  dqdd/d(q,qd) = -Minv dID,  A, B, integrator defect, Gauss-Newton cost blocks, written as float in the
 //              reference's dense layouts (column-major blocks, C = -A, -B).
 // Arithmetic is float64 inside (h = 1e-6 central differences are exact to ~1e-9 there; the MI355X has the fp64 rate
@@ -22,6 +22,11 @@
 namespace mpcg {
 
 constexpr int PJ = 7;                    // joints of the compiled specialisation (state 2 PJ, control PJ)
+constexpr int KKT_LANES = 64;            // one wavefront per (trajectory, knot)
+constexpr int KKT_FLANES = 29;           // lanes that own a record in LDS: the 28 finite-difference tasks + the kinematics lane
+constexpr int RN_SIN = 6 * PJ, RN_COS = RN_SIN + PJ, RN_ROWS = RN_COS + PJ + 1;   // record: link forces [PJ][6], sin, cos (+1: an odd row
+                                                                                  //  count = conflict-free 8-byte accesses at lane stride)
+__host__ __device__ constexpr int RN_TAU(int k) { return 6 * k + 2; }             // tau_k overwrites row 2 of link k's force once consumed
 
 struct PlantDev {                        // all row-major 3x3 unless noted
     double E0[PJ][9], Es[PJ][9], Ec[PJ][9];      // rotation block of X_k(q_k) = E0 + Es sin q_k + Ec cos q_k
@@ -46,17 +51,28 @@ __device__ __forceinline__ void mat3(double (&M)[9], const double* c0, const dou
     for (int e = 0; e < 9; ++e) M[e] = c0[e] + cs[e] * s + cc[e] * c;
 }
 
-// tau = ID(q, qd, qdd) without gravity (gato_plant::GRAVITY = 0, iiwa_eepos_plant.cuh:53).  Everything stays in registers.
-__device__ void rnea(const PlantDev& P, const double (&q)[PJ], const double (&qd)[PJ], const double (&qdd)[PJ], double (&tau)[PJ]) {
-    double f[PJ][6];
-    double sn[PJ], cs[PJ];
+// tau = ID(q, qd, qdd) without gravity (gato_plant::GRAVITY = 0, iiwa_eepos_plant.cuh:53).  Inputs, the link forces that wait
+// for the backward sweep, sin / cos and the result all live in this lane's column `fl` of an LDS record (rows RN_*), and both
+// sweeps are RUNTIME loops over the joints.  Measured alternatives on gfx950 (hipcc 7.2): everything in registers with unrolled
+// sweeps = 3.4 KB of scratch per lane (the 84 force registers, plus the seven E_k / B_k pairs the compiler keeps from the
+// forward sweep for the backward one instead of recomputing them: 252 doubles); plain (non-volatile) LDS accesses get
+// store-forwarded back into registers.  This form compiles one joint body and fits two waves per SIMD.
+//   q_k  = xq[k] + (k == prow ? ph : 0),  qd_k = qdscale * xq[PJ + k] + (PJ + k == prow ? ph : 0)   (xq: [q; qd], shared by the lanes)
+//   qdd_k = qdd ? qdd[k] : (k == unit ? 1 : 0)
+__device__ __forceinline__ void rnea(const PlantDev& P, volatile double* fl, const double* xq, double qdscale, int prow, double ph,
+                                     const double* qdd, int unit) {
     double vw[3] = {0, 0, 0}, vu[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, au[3] = {0, 0, 0};
-#pragma unroll
+#pragma nounroll
     for (int k = 0; k < PJ; ++k) {
-        sincos(q[k], &sn[k], &cs[k]);
+        const double qk = xq[k] + (k == prow ? ph : 0.0), qdk = qdscale * xq[PJ + k] + (PJ + k == prow ? ph : 0.0);
+        const double qddk = qdd ? qdd[k] : (k == unit ? 1.0 : 0.0);
+        double sn, cs;
+        sincos(qk, &sn, &cs);
+        fl[RN_SIN + k] = sn;
+        fl[RN_COS + k] = cs;
         double E[9], B[9];
-        mat3(E, P.E0[k], P.Es[k], P.Ec[k], sn[k], cs[k]);
-        mat3(B, P.B0[k], P.Bs[k], P.Bc[k], sn[k], cs[k]);
+        mat3(E, P.E0[k], P.Es[k], P.Ec[k], sn, cs);
+        mat3(B, P.B0[k], P.Bs[k], P.Bc[k], sn, cs);
         double w[3], u[3], bw[3], bu[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {                    // v = X v_parent, a = X a_parent
@@ -65,11 +81,11 @@ __device__ void rnea(const PlantDev& P, const double (&q)[PJ], const double (&qd
             bw[r] = E[3 * r] * aw[0] + E[3 * r + 1] * aw[1] + E[3 * r + 2] * aw[2];
             bu[r] = B[3 * r] * aw[0] + B[3 * r + 1] * aw[1] + B[3 * r + 2] * aw[2] + E[3 * r] * au[0] + E[3 * r + 1] * au[1] + E[3 * r + 2] * au[2];
         }
-        w[2] += qd[k];                                   // + S qd, S = e_z (angular)
-        bw[2] += qdd[k];
+        w[2] += qdk;                                     // + S qd, S = e_z (angular)
+        bw[2] += qddk;
         // + v x (S qd): column 2 of crm(v) times qd
-        bw[0] += w[1] * qd[k]; bw[1] -= w[0] * qd[k];
-        bu[0] += u[1] * qd[k]; bu[1] -= u[0] * qd[k];
+        bw[0] += w[1] * qdk; bw[1] -= w[0] * qdk;
+        bu[0] += u[1] * qdk; bu[1] -= u[0] * qdk;
         // f = I a + v x* (I v)
         double Ia[6], Iv[6];
         const double v6[6] = {w[0], w[1], w[2], u[0], u[1], u[2]}, a6[6] = {bw[0], bw[1], bw[2], bu[0], bu[1], bu[2]};
@@ -81,38 +97,50 @@ __device__ void rnea(const PlantDev& P, const double (&q)[PJ], const double (&qd
             Ia[r] = sa; Iv[r] = sv;
         }
         // crf(v) h = [w x n + u x l ; w x l],  h = [n; l]
-        f[k][0] = Ia[0] + (w[1] * Iv[2] - w[2] * Iv[1]) + (u[1] * Iv[5] - u[2] * Iv[4]);
-        f[k][1] = Ia[1] + (w[2] * Iv[0] - w[0] * Iv[2]) + (u[2] * Iv[3] - u[0] * Iv[5]);
-        f[k][2] = Ia[2] + (w[0] * Iv[1] - w[1] * Iv[0]) + (u[0] * Iv[4] - u[1] * Iv[3]);
-        f[k][3] = Ia[3] + (w[1] * Iv[5] - w[2] * Iv[4]);
-        f[k][4] = Ia[4] + (w[2] * Iv[3] - w[0] * Iv[5]);
-        f[k][5] = Ia[5] + (w[0] * Iv[4] - w[1] * Iv[3]);
+        volatile double* f = fl + k * 6;
+        f[0] = Ia[0] + (w[1] * Iv[2] - w[2] * Iv[1]) + (u[1] * Iv[5] - u[2] * Iv[4]);
+        f[1] = Ia[1] + (w[2] * Iv[0] - w[0] * Iv[2]) + (u[2] * Iv[3] - u[0] * Iv[5]);
+        f[2] = Ia[2] + (w[0] * Iv[1] - w[1] * Iv[0]) + (u[0] * Iv[4] - u[1] * Iv[3]);
+        f[3] = Ia[3] + (w[1] * Iv[5] - w[2] * Iv[4]);
+        f[4] = Ia[4] + (w[2] * Iv[3] - w[0] * Iv[5]);
+        f[5] = Ia[5] + (w[0] * Iv[4] - w[1] * Iv[3]);
 #pragma unroll
         for (int r = 0; r < 3; ++r) { vw[r] = w[r]; vu[r] = u[r]; aw[r] = bw[r]; au[r] = bu[r]; }
     }
+    double fc[6];                                        // force of the link being folded into its parent
 #pragma unroll
-    for (int k = PJ - 1; k >= 0; --k) {
-        tau[k] = f[k][2];
-        if (k > 0) {                                     // f_parent += X^T f = [E^T n + B^T l ; E^T l]
-            double E[9], B[9];
-            mat3(E, P.E0[k], P.Es[k], P.Ec[k], sn[k], cs[k]);
-            mat3(B, P.B0[k], P.Bs[k], P.Bc[k], sn[k], cs[k]);
+    for (int r = 0; r < 6; ++r) fc[r] = fl[(PJ - 1) * 6 + r];   // tau_6 = row 2 of the last link's force: already in place
+#pragma nounroll
+    for (int k = PJ - 1; k >= 1; --k) {                  // f_parent += X^T f = [E^T n + B^T l ; E^T l]
+        const double sk = fl[RN_SIN + k], ck = fl[RN_COS + k];
+        double E[9], B[9];
+        mat3(E, P.E0[k], P.Es[k], P.Ec[k], sk, ck);
+        mat3(B, P.B0[k], P.Bs[k], P.Bc[k], sk, ck);
+        double fp[6];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                f[k - 1][r] += E[r] * f[k][0] + E[3 + r] * f[k][1] + E[6 + r] * f[k][2] + B[r] * f[k][3] + B[3 + r] * f[k][4] + B[6 + r] * f[k][5];
-                f[k - 1][3 + r] += E[r] * f[k][3] + E[3 + r] * f[k][4] + E[6 + r] * f[k][5];
-            }
+        for (int r = 0; r < 3; ++r) {
+            fp[r] = fl[(k - 1) * 6 + r] + E[r] * fc[0] + E[3 + r] * fc[1] + E[6 + r] * fc[2] + B[r] * fc[3] + B[3 + r] * fc[4] + B[6 + r] * fc[5];
+            fp[3 + r] = fl[(k - 1) * 6 + 3 + r] + E[r] * fc[3] + E[3 + r] * fc[4] + E[6 + r] * fc[5];
         }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) fc[r] = fp[r];
+        fl[RN_TAU(k - 1)] = fc[2];                       // (link k-1's own force row 2: consumed just above)
     }
 }
 
-constexpr int KKT_THREADS = 64;
+constexpr int KKT_THREADS = KKT_LANES;
+constexpr int KKT_KIN_LANE = 4 * PJ;     // the lane after the 28 finite-difference tasks: forward kinematics + Jacobian
 constexpr double KKT_FD_H = 1e-6;
 
-__global__ __launch_bounds__(KKT_THREADS) void generate_kkt_kernel(KktArgs a) {
+__global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a) {
     constexpr int n = 2 * PJ, m = PJ, nn = n * n, mm = m * m, nm = n * m;
     __shared__ double sM[PJ][PJ], sMinv[PJ][PJ], sBias[PJ], sQdd[PJ], sId[4 * PJ][PJ], sDq[PJ][PJ], sDqd[PJ][PJ];
     __shared__ double sJ[3][PJ], sEe[3], sGq[PJ], sGq1[PJ];
+    __shared__ double sF[KKT_FLANES][RN_ROWS];              // per-task-lane record of the recursion (rows RN_*), 13 KB
+    __shared__ double sXq[2 * PJ];                          // [q; qd] of this knot
+    // The model tables are read through the kernel argument with RUNTIME joint indices: uniform addresses = scalar loads
+    // (s_load, scalar cache).  With compile-time indices (unrolled sweeps) all 840 doubles are loop-invariant loads that
+    // the compiler hoists into registers: 512 VGPR + AGPR and scratch.
     const int lane = threadIdx.x;
     const PlantDev& P = *a.plant;
     const int N = a.N;
@@ -123,106 +151,100 @@ __global__ __launch_bounds__(KKT_THREADS) void generate_kkt_kernel(KktArgs a) {
         double q[PJ], qd[PJ], u[PJ];
 #pragma unroll
         for (int i = 0; i < PJ; ++i) { q[i] = xu[i]; qd[i] = xu[PJ + i]; u[i] = xu[n + i]; }
-        // ---- phase 1: inertia matrix columns and bias ----
-        if (lane < 8) {
-            double z[PJ], e[PJ], t[PJ];
-#pragma unroll
-            for (int i = 0; i < PJ; ++i) { z[i] = 0.0; e[i] = (i == lane) ? 1.0 : 0.0; }
-            if (lane < PJ) {
-                rnea(P, q, z, e, t);
-#pragma unroll
-                for (int i = 0; i < PJ; ++i) sM[i][lane] = t[i];
-            } else {
-                rnea(P, q, qd, z, t);
-#pragma unroll
-                for (int i = 0; i < PJ; ++i) sBias[i] = t[i];
-            }
-        }
+        if (lane < n) sXq[lane] = (double)xu[lane];
         __syncthreads();
-        // ---- phase 2: Minv (column `lane` through a Cholesky solve of the symmetrised M), qdd ----
-        if (lane < PJ) {
-            double Lm[PJ][PJ];
+        // ---- two rounds through ONE instance of the recursion (not unrolled: a second inlined copy doubles the register
+        //      pressure).  Round 0: lanes 0..6 inertia-matrix columns ID(q, 0, e_j), lane 7 bias ID(q, qd, 0), then Minv and qdd.
+        //      Round 1: lanes 0..27 ID(q +- h e_j, qd, qdd), ID(q, qd +- h e_j, qdd); lane 28: kinematics. ----
+#pragma nounroll
+        for (int round = 0; round < 2; ++round) {
+            const int ntask = round == 0 ? PJ + 1 : 4 * PJ;
+            volatile double* fl = &sF[lane < KKT_FLANES ? lane : 0][0];
+            if (lane < ntask) {
+                // round 0: lanes 0..6 ID(q, 0, e_lane), lane 7 ID(q, qd, 0);  round 1: lane = 7 kind + j, kind 0: q_j + h, 1: q_j - h,
+                // 2: qd_j + h, 3: qd_j - h, all at qdd
+                const double ph = round == 0 ? 0.0 : (((lane / PJ) & 1) ? -KKT_FD_H : KKT_FD_H);
+                rnea(P, fl, sXq, (round == 1 || lane == PJ) ? 1.0 : 0.0, round == 0 ? -1 : (lane % PJ) + (lane / PJ >= 2 ? PJ : 0), ph, round == 0 ? nullptr : sQdd, lane);
 #pragma unroll
-            for (int i = 0; i < PJ; ++i)
-#pragma unroll
-                for (int j = 0; j <= i; ++j) {
-                    double s = 0.5 * (sM[i][j] + sM[j][i]);
-#pragma unroll
-                    for (int t = 0; t < j; ++t) s -= Lm[i][t] * Lm[j][t];
-                    Lm[i][j] = (i == j) ? sqrt(s) : s / Lm[j][j];
+                for (int i = 0; i < PJ; ++i) {
+                    const double t = fl[RN_TAU(i)];
+                    if (round == 1) sId[lane][i] = t;
+                    else if (lane < PJ) sM[i][lane] = t;
+                    else sBias[i] = t;
                 }
-            double y[PJ];
+            } else if (round == 1 && lane == KKT_KIN_LANE) {
+                // forward kinematics; joint origins and axes wait in this lane's (otherwise unused) record column
+                double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pos[3] = {0, 0, 0};
+#pragma nounroll
+                for (int jn = 0; jn < PJ; ++jn) {
+                    double s_, c_, H[9];
+                    sincos(sXq[jn], &s_, &c_);
+                    mat3(H, P.R0[jn], P.Rs[jn], P.Rc[jn], s_, c_);
+                    double Rn[9];
 #pragma unroll
-            for (int i = 0; i < PJ; ++i) {
-                double s = (i == lane) ? 1.0 : 0.0;
+                    for (int r = 0; r < 3; ++r) {
+                        pos[r] += R[3 * r] * P.p[jn][0] + R[3 * r + 1] * P.p[jn][1] + R[3 * r + 2] * P.p[jn][2];
 #pragma unroll
-                for (int t = 0; t < i; ++t) s -= Lm[i][t] * y[t];
-                y[i] = s / Lm[i][i];
-            }
+                        for (int cc_ = 0; cc_ < 3; ++cc_) Rn[3 * r + cc_] = R[3 * r] * H[cc_] + R[3 * r + 1] * H[3 + cc_] + R[3 * r + 2] * H[6 + cc_];
+                    }
 #pragma unroll
-            for (int i = PJ - 1; i >= 0; --i) {
-                double s = y[i];
+                    for (int e = 0; e < 9; ++e) R[e] = Rn[e];
 #pragma unroll
-                for (int t = i + 1; t < PJ; ++t) s -= Lm[t][i] * y[t];
-                y[i] = s / Lm[i][i];
-            }
-#pragma unroll
-            for (int i = 0; i < PJ; ++i) sMinv[i][lane] = y[i];
-        }
-        __syncthreads();
-        if (lane < PJ) {
-            double s = 0;
-#pragma unroll
-            for (int j = 0; j < PJ; ++j) s += sMinv[lane][j] * (u[j] - sBias[j]);
-            sQdd[lane] = s;
-        }
-        __syncthreads();
-        // ---- phase 3: central differences of ID at (q, qd, qdd); kinematics on a lane of its own ----
-        if (lane < 4 * PJ) {
-            double qdd[PJ], qq[PJ], qqd[PJ], t[PJ];
-#pragma unroll
-            for (int i = 0; i < PJ; ++i) { qdd[i] = sQdd[i]; qq[i] = q[i]; qqd[i] = qd[i]; }
-            const int j = lane % PJ, kind = lane / PJ;                  // 0: q + h, 1: q - h, 2: qd + h, 3: qd - h
-            const double hh = (kind & 1) ? -KKT_FD_H : KKT_FD_H;
-#pragma unroll
-            for (int i = 0; i < PJ; ++i) {
-                if (i == j && kind < 2) qq[i] += hh;
-                if (i == j && kind >= 2) qqd[i] += hh;
-            }
-            rnea(P, qq, qqd, qdd, t);
-#pragma unroll
-            for (int i = 0; i < PJ; ++i) sId[lane][i] = t[i];
-        } else if (lane == 32) {
-            double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pos[3] = {0, 0, 0};
-            double pj[PJ][3], zj[PJ][3];
-#pragma unroll
-            for (int jn = 0; jn < PJ; ++jn) {
-                double s, c, H[9];
-                sincos(q[jn], &s, &c);
-                mat3(H, P.R0[jn], P.Rs[jn], P.Rc[jn], s, c);
-                double Rn[9];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    pos[r] += R[3 * r] * P.p[jn][0] + R[3 * r + 1] * P.p[jn][1] + R[3 * r + 2] * P.p[jn][2];
-#pragma unroll
-                    for (int cc_ = 0; cc_ < 3; ++cc_) Rn[3 * r + cc_] = R[3 * r] * H[cc_] + R[3 * r + 1] * H[3 + cc_] + R[3 * r + 2] * H[6 + cc_];
+                    for (int r = 0; r < 3; ++r) { fl[jn * 6 + r] = pos[r]; fl[jn * 6 + 3 + r] = R[3 * r + 2]; }
                 }
 #pragma unroll
-                for (int e = 0; e < 9; ++e) R[e] = Rn[e];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) { pj[jn][r] = pos[r]; zj[jn][r] = R[3 * r + 2]; }
+                for (int r = 0; r < 3; ++r) sEe[r] = pos[r];
+#pragma nounroll
+                for (int jn = 0; jn < PJ; ++jn) {
+                    const double d0 = pos[0] - fl[jn * 6 + 0], d1 = pos[1] - fl[jn * 6 + 1], d2 = pos[2] - fl[jn * 6 + 2];
+                    const double z0 = fl[jn * 6 + 3], z1 = fl[jn * 6 + 4], z2 = fl[jn * 6 + 5];
+                    sJ[0][jn] = z1 * d2 - z2 * d1;
+                    sJ[1][jn] = z2 * d0 - z0 * d2;
+                    sJ[2][jn] = z0 * d1 - z1 * d0;
+                }
             }
+            __syncthreads();
+            if (round == 0) {
+                // Minv (column `lane` through a Cholesky solve of the symmetrised M), qdd = Minv (u - bias)
+                if (lane < PJ) {
+                    double Lm[PJ][PJ];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) sEe[r] = pos[r];
+                    for (int i = 0; i < PJ; ++i)
 #pragma unroll
-            for (int jn = 0; jn < PJ; ++jn) {
-                const double d0 = pos[0] - pj[jn][0], d1 = pos[1] - pj[jn][1], d2 = pos[2] - pj[jn][2];
-                sJ[0][jn] = zj[jn][1] * d2 - zj[jn][2] * d1;
-                sJ[1][jn] = zj[jn][2] * d0 - zj[jn][0] * d2;
-                sJ[2][jn] = zj[jn][0] * d1 - zj[jn][1] * d0;
+                        for (int jj = 0; jj <= i; ++jj) {
+                            double sv = 0.5 * (sM[i][jj] + sM[jj][i]);
+#pragma unroll
+                            for (int t = 0; t < jj; ++t) sv -= Lm[i][t] * Lm[jj][t];
+                            Lm[i][jj] = (i == jj) ? sqrt(sv) : sv / Lm[jj][jj];
+                        }
+                    double y[PJ];
+#pragma unroll
+                    for (int i = 0; i < PJ; ++i) {
+                        double sv = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+                        for (int t = 0; t < i; ++t) sv -= Lm[i][t] * y[t];
+                        y[i] = sv / Lm[i][i];
+                    }
+#pragma unroll
+                    for (int i = PJ - 1; i >= 0; --i) {
+                        double sv = y[i];
+#pragma unroll
+                        for (int t = i + 1; t < PJ; ++t) sv -= Lm[t][i] * y[t];
+                        y[i] = sv / Lm[i][i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < PJ; ++i) sMinv[i][lane] = y[i];
+                }
+                __syncthreads();
+                if (lane < PJ) {
+                    double sv = 0;
+#pragma unroll
+                    for (int jj = 0; jj < PJ; ++jj) sv += sMinv[lane][jj] * (u[jj] - sBias[jj]);
+                    sQdd[lane] = sv;
+                }
+                __syncthreads();
             }
         }
-        __syncthreads();
         // ---- phase 4a: dqdd = -Minv dID ; cost gradient pieces ----
         if (lane < PJ * PJ) {
             const int i = lane / PJ, j = lane % PJ;
