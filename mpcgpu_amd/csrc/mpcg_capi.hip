@@ -10,6 +10,7 @@
 #include "../../include/mpcg.h"
 #include "pcg_kernels.hip.h"
 #include "pcg_lpb.hip.h"
+#include "pcg_lpb_cluster.hip.h"
 #include "schur_kernels.hip.h"
 #include "schur_dpp.hip.h"
 #include "block_solve.hip.h"
@@ -33,7 +34,7 @@ struct PcgKnobs {
 };
 
 // What the last solve on this handle actually launched (read-only "last_kernel_*" options; tests assert on it).
-enum { FAM_NONE = -1, FAM_TRAJ = 0, FAM_CLUSTER = 1, FAM_LPB = 2 };
+enum { FAM_NONE = -1, FAM_TRAJ = 0, FAM_CLUSTER = 1, FAM_LPB = 2, FAM_GENERIC = 3, FAM_LPBC = 4 };
 struct LastKernel { int family = FAM_NONE, waves = 0, reg_rows = 0, lds_rows = 0, stream_bufs = 0, cluster = 0, lds_bytes = 0, lds_extra = 0; };
 
 struct mpcg_handle {
@@ -49,6 +50,7 @@ struct mpcg_handle {
     int cluster_waves = -1;   // waves per cluster member: 8 (one member per CU), 4 (two per CU), -1 by batch size
     int cluster_adj = 1;      // lane order of the cluster kernel (1: blocks of a row in adjacent lanes)
     int cluster = -1;         // workgroups per trajectory for the cluster kernel: 0 off, -1 auto, G > 0 forced
+    int cluster_lpb = -1;     // clustered lane-per-block kernel (pcg_lpb_cluster.hip.h) instead of the row-triple cluster kernel: -1 auto (on), 0 off, 1 on
     int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
     unsigned long long* cluster_scratch = nullptr;
     bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any valid pcg_* set_option clears this)
@@ -196,6 +198,10 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "nt_loads")) { h->nt_loads = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_adj")) { h->cluster_adj = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_fixup")) { h->cluster_fixup = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "cluster_lpb")) {
+        if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "cluster_lpb must be -1 (auto), 0 or 1");
+        h->cluster_lpb = value; return MPCG_OK;
+    }
     if (!strcmp(key, "schur_dpp")) { h->schur_dpp = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
         if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");
@@ -220,6 +226,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "cluster")) { *value = h->cluster; return MPCG_OK; }
     if (!strcmp(key, "cluster_adj")) { *value = h->cluster_adj; return MPCG_OK; }
     if (!strcmp(key, "cluster_fixup")) { *value = h->cluster_fixup; return MPCG_OK; }
+    if (!strcmp(key, "cluster_lpb")) { *value = h->cluster_lpb; return MPCG_OK; }
     if (!strcmp(key, "schur_dpp")) { *value = h->schur_dpp; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "spmv_mfma")) { *value = h->spmv_mfma; return MPCG_OK; }
@@ -499,9 +506,78 @@ static int try_launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch
     return MPCG_OK;
 }
 
+// ---- clustered lane-per-block kernel (pcg_lpb_cluster.hip.h): G members x up to 64 NWR knots, all blocks in registers ----
+// returns 1 when it does not apply.  NWR = 2: one 8-wave member per CU; NWR = 1: 4-wave members, two per CU.
+// Every launch holds at most floor(per_cu #CUs / G) trajectories (all members of a cluster must be resident); larger batches
+// run as consecutive launches on the stream, each followed by the fix-up launch of the single-workgroup kernel.
+static int lpbc_members(const mpcg_handle* h, int nmax) {
+    const int G = h->cluster > 0 ? h->cluster : ((int)h->N + nmax - 1) / nmax;
+    if (G < 2 || G > LPBC_MAX_G || G > h->num_cus || G > (int)h->N) return 0;
+    if (((int)h->N + G - 1) / G > nmax) return 0;        // the largest member: ceil(N / G) knots
+    return G;
+}
+template <int NWR>
+static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    constexpr int per_cu = NWR == 2 ? 1 : 2;
+    const int G = lpbc_members(h, 64 * NWR);
+    if (G == 0) return 1;
+    const uint32_t chunk = (uint32_t)(per_cu * h->num_cus / G);
+    const size_t lds = pcg_lpbc_lds_floats(4 * NWR) * sizeof(float);
+    auto kern = pcg_lpbc_kernel<NWR>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PcgKnobs kf = h->k;
+    choose_auto(h, kf, 1, 4);
+    const bool fixup = h->cluster_fixup && (h->N <= kLpbMaxN || lds_bytes_for(h->N, kf.waves) <= kLdsMax);
+    const size_t mstride = (size_t)h->N * ROWF, vstride = (size_t)h->N * NS;
+    for (uint32_t lo = 0; lo < batch; lo += chunk) {
+        const uint32_t nb = batch - lo < chunk ? batch - lo : chunk;
+        ClusterArgs ca;
+        ca.kl_max = 64 * NWR;
+        ca.p = a;
+        ca.p.S = static_cast<const float*>(a.S) + lo * mstride;
+        ca.p.Pinv = static_cast<const float*>(a.Pinv) + lo * mstride;
+        ca.p.gamma = a.gamma + lo * vstride;
+        ca.p.lambda = a.lambda + lo * vstride;
+        if (a.r_out) ca.p.r_out = a.r_out + lo * vstride;
+        if (a.p_out) ca.p.p_out = a.p_out + lo * vstride;
+        ca.p.iters = a.iters + lo;
+        ca.p.max_iter_exit = a.max_iter_exit + lo;
+        ca.fail_flags = h->cluster_scratch; ca.scratch = h->cluster_scratch + cluster_flag_words(h); ca.G = G;
+        const size_t zw = cluster_flag_words(h) + (size_t)nb * G * CL_WG_WORDS;
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster_scratch, zw);
+        HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(kern, dim3(nb * (unsigned)G), dim3(NWR * 256), lds, st, ca);
+        HIP_TRY(h, hipGetLastError());
+        h->last = LastKernel{FAM_LPBC, 4 * NWR, 0, 0, 0, G, (int)lds, 0};
+        if (fixup) {
+            PcgArgs c = ca.p;
+            c.redo_flags = h->cluster_scratch;
+            c.redo_stride = CL_FLAG_STRIDE;
+            const int rc = h->N <= kLpbMaxN ? launch_lpb(h, c, nb, st) : launch_traj(h, kf, c, nb, st, 4, /*record=*/false);
+            if (rc != MPCG_OK) return rc;
+            h->last = LastKernel{FAM_LPBC, 4 * NWR, 0, 0, 0, G, (int)lds, 0};
+        }
+    }
+    return MPCG_OK;
+}
+static int try_launch_lpbc(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    if (h->cluster_lpb == 0) return 1;
+    if (h->cluster <= 0 && h->N <= kLpbMaxN) return 1;   // one CU holds it: pcg_lpb_kernel
+    if (h->cluster_waves == 4) {
+        const int rc = try_launch_lpbc_t<1>(h, a, batch, st);
+        if (rc != 1) return rc;
+    }
+    return try_launch_lpbc_t<2>(h, a, batch, st);
+}
+
 static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
     if (h->cluster == 0 || esz != 4) return 1;
     if (h->cluster < 0 && !h->auto_cfg) return 1;       // explicit pcg_* knobs: the caller asked for a single-workgroup variant
+    {
+        const int rc = try_launch_lpbc(h, a, batch, st);
+        if (rc != 1) return rc;
+    }
     // "cluster_waves": 8, 4, or -1 = 4-wave members (two per CU) when the batch needs more than one launch of 8-wave
     // members anyway, i.e. when the call is about throughput
     int waves = h->cluster_waves;
@@ -588,6 +664,7 @@ static size_t default_launch_lds_bytes(uint32_t N, int num_cus) {
     }
     mpcg_handle tmp;
     tmp.N = N; tmp.n = NS; tmp.num_cus = num_cus;
+    if (lpbc_members(&tmp, 128) > 0) return pcg_lpbc_lds_floats(8) * sizeof(float);      // clustered lane-per-block kernel
     const int ntr = ((int)N + 2) / 3;
     const int G = (ntr + 23) / 24;                       // 8-wave cluster members, 3 register triples per wave and matrix
     if (G >= 2 && G <= num_cus) {

@@ -1,0 +1,315 @@
+// pcg_lpb_cluster.hip.h — the lane-per-block PCG kernel (pcg_lpb.hip.h) for horizons one CU cannot hold: G workgroups
+// on G CUs solve ONE trajectory, each with up to 64 NWR consecutive knots of S and Pinv in its register file
+// (one 14x14 block of the block lower triangle per lane, N = 256: G = 2, N = 512: G = 4 with NWR = 2).
+//
+// Decomposition.  Member g owns knots [k0, k1), their diagonal blocks D_k and the sub-diagonal blocks
+// L_k = S[k, left], k in [k0, k1) — i.e. also the block L_k0 that couples it to its left neighbour — and keeps, besides
+// its own knots of p and r, ONE replica knot k0 - 1 of both.  With the replica it forms L_k0 x_{k0-1} (for its own y_k0),
+// the coupling term of the inner product (counted twice, as in the single-workgroup kernel) and t = L_k0^T x_k0, the part
+// of y_{k0-1} that the LEFT neighbour lacks.  What crosses a boundary per matrix pass is therefore
+//     right -> left : t = L_k0^T x_k0                         (completes the left member's last knot)
+//     left -> right : s = (D x)_{k0-1} + (L x)_{k0-1}         (lets the right member update its replica of knot k0 - 1:
+//                                                              y_{k0-1} = s + t, the same bits the owner computes)
+// and both are needed at the same point as the all-reduced inner product — after the pass, before the vector update.  So
+// ONE hand-off per pass carries everything: each member publishes {partial, s[14], t[14]} as 29 epoch-tagged 8-byte
+// granules (the R2 recipe of cdna_hip_programming.md §6 G16, as pcg_cluster_kernel) and polls the partials of all
+// members, the s of its left and the t of its right neighbour.  Two exposed hand-offs per PCG iteration; the row-triple
+// cluster kernel needs four (2 all-reduces + 2 halo fetches) and re-reads nothing either, but runs the slower
+// row-pair arithmetic.  No operand halo is ever waited for inside a pass.
+//
+// Same fail-safe as pcg_cluster_kernel: bounded spins, a member that times out flags the trajectory, the host follows
+// every launch with the single-workgroup kernel restricted to flagged trajectories.
+#pragma once
+#include "pcg_lpb.hip.h"
+
+namespace mpcg {
+
+// LDS layout: six vectors of NMAX + 2 knot slots.  Slot 0 = replica of knot k0 - 1, slots 1..KL = own knots, slot NMAX + 1 = dump
+// of idle lanes.  p | r | lambda | yD | yL | yT | 2 NW wave partials | broadcast cell.
+template <int NWR> struct LpbcLds {
+    static constexpr int NMAX = 64 * NWR, NW = 4 * NWR, SLOTS = NMAX + 2, DUMP = NMAX + 1;
+    static constexpr int VS = (int)r4((size_t)SLOTS * NS);
+    static constexpr int XP = 0, XR = VS, LAM = 2 * VS, YD = 3 * VS, YL = 4 * VS, YT = 5 * VS, RED = 6 * VS, BC = RED + (int)r4(2 * NW),
+                         TOTAL = BC + 4;
+};
+__host__ __device__ constexpr size_t pcg_lpbc_lds_floats(int NW) { return NW == 4 ? (size_t)LpbcLds<1>::TOTAL : (size_t)LpbcLds<2>::TOTAL; }
+
+constexpr int LPBC_MAX_G = 16;             // members whose partials one wave polls with lanes 0..15
+constexpr int LPBC_SLOT_V = 0, LPBC_SLOT_E = 32;     // granule words of the two alternating exchanges inside a member's CL_WG_WORDS block
+
+template <int NWR>
+__global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) {
+    typedef LpbcLds<NWR> L;
+    constexpr int NW = 4 * NWR, NTHR = NW * 64;
+    const PcgArgs& a = ca.p;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int N = a.N;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = ca.G;
+    const int b = blockIdx.x / G;                       // trajectory
+    const int g = blockIdx.x - b * G;                   // member of its cluster
+    const int k0 = (int)(((long)g * N) / G), k1 = (int)(((long)(g + 1) * N) / G);
+    const int KL = k1 - k0;                             // own knots (launcher: 1 <= KL <= NMAX)
+    float* red_v = lds + L::RED;
+    float* red_e = red_v + NW;
+    float* bc = lds + L::BC;                            // [0] cluster-wide sum, [1] sticky timeout flag
+
+    const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;
+    const float* gam = a.gamma + (size_t)b * vstride;
+    float* lam_g = a.lambda + (size_t)b * vstride;
+    gu64* my_words = (gu64*)ca.scratch + (size_t)blockIdx.x * CL_WG_WORDS;
+    gu64* cl_words = (gu64*)ca.scratch + (size_t)b * G * CL_WG_WORDS;
+
+    // ---- role of this wave, block of this lane (pcg_lpb_kernel's roles; i = index of the block inside the member) ----
+    const int role = w / NWR;
+    const bool isP = role >= 2, isL = (role & 1) == 0;
+    const int i = 64 * (w - role * NWR) + lane;         // block row k0 + i: reads slot i + 1 (and i), writes slot i + 1 (and yT of slot i)
+    const bool p3 = a.pcols == 3;
+    const bool wave_on = !(isP && isL && !p3);
+    const bool valid = wave_on && i < KL && !(isL && k0 + i == 0);
+    const int sr = (i < KL ? i : KL - 1) + 1;           // slot this lane reads as "knot k" (clamped: its block is all-zero)
+    float* const xk = lds + sr * NS;
+    float* const wk = lds + (valid ? i + 1 : L::DUMP) * NS;
+
+    f4 m4[BLK4];
+    {
+        const rsrc_t M = make_rsrc((isP ? static_cast<const float*>(a.Pinv) : static_cast<const float*>(a.S)) + (size_t)b * mstride,
+                                   (uint32_t)(mstride * sizeof(float)));
+        const uint32_t off = valid ? (uint32_t)((k0 + i) * 3 + (isL ? 0 : 1)) * (BLK4 * 16u) : OOB_OFF;
+#pragma unroll
+        for (int c = 0; c < BLK4; ++c) m4[c] = buf_load4<false>(M, off + 16u * c);
+    }
+    auto mp = [&](int u, int r) -> f2 {
+        const int e = NS * u + 2 * r;
+        const f4 v = m4[e >> 2];
+        return (e & 2) ? f2{v.z, v.w} : f2{v.x, v.y};
+    };
+
+    // ---- stage: parts <- 0 (yL of the replica slot: -0, so that (s + yL) + t keeps the bits of s), p <- lambda0, r <- gamma
+    //      for the own knots AND the replica (both complete in global memory), lambda <- lambda0 ----
+    for (int e = tid; e < 6 * L::VS; e += NTHR) lds[e] = 0.f;
+    lds_barrier();
+    if (tid < NS) lds[L::YL + tid] = -0.f;
+    for (int e = tid + (g == 0 ? NS : 0); e < (KL + 1) * NS; e += NTHR) {
+        const int ge = (k0 - 1) * NS + e;               // element of the global [N][14] vector
+        const float l0 = lam_g[ge];
+        lds[L::XP + e] = l0;
+        lds[L::LAM + e] = l0;
+        lds[L::XR + e] = gam[ge];
+    }
+    if (tid == 0) { bc[0] = 0.f; bc[1] = 0.f; }
+    lds_barrier();
+
+    auto wave_fold = [&](float part) -> float {
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_nop 1"
+            : "+v"(part));
+        const int pb = __builtin_bit_cast(int, part);
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 32));
+        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 48));
+        return ((part + r1) + r2) + r3;
+    };
+    // one pass of this wave's blocks over the vector at buffer offset X (pcg_lpb_kernel::pass with slot addressing)
+    auto pass = [&](int X, float* red) {
+        f2 xa[7], xb[7], acc[7];
+        {
+            const f2* xa2 = reinterpret_cast<const f2*>(xk + X + (isL ? -NS : 0));
+            const f2* xb2 = reinterpret_cast<const f2*>(xk + X);
+#pragma unroll
+            for (int r = 0; r < 7; ++r) { xa[r] = xa2[r]; xb[r] = xb2[r]; acc[r] = f2{0.f, 0.f}; }
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const float xs = (u & 1) ? xa[u >> 1].y : xa[u >> 1].x;
+#pragma unroll
+            for (int r = 0; r < 7; ++r) acc[r] = __builtin_elementwise_fma(mp(u, r), f2{xs, xs}, acc[r]);
+        }
+        f2 dt0 = {0.f, 0.f}, dt1 = {0.f, 0.f};
+        f2* yo2 = reinterpret_cast<f2*>(wk + (isL ? L::YL : L::YD));
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            yo2[r] = acc[r];
+            if (r & 1) dt1 = __builtin_elementwise_fma(acc[r], xb[r], dt1);
+            else dt0 = __builtin_elementwise_fma(acc[r], xb[r], dt0);
+        }
+        const f2 dt = dt0 + dt1;
+        const float part = wave_fold(isL ? 2.f * (dt.x + dt.y) : dt.x + dt.y);
+        if (lane == 0) red[w] = part;
+        if (isL) {
+            f2* yt2 = reinterpret_cast<f2*>(wk + L::YT + (valid ? -NS : 0));
+#pragma unroll
+            for (int u = 0; u < 12; u += 4) {
+                f2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f}, t2 = {0.f, 0.f}, t3 = {0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 7; ++r) {
+                    t0 = __builtin_elementwise_fma(mp(u, r), xb[r], t0);
+                    t1 = __builtin_elementwise_fma(mp(u + 1, r), xb[r], t1);
+                    t2 = __builtin_elementwise_fma(mp(u + 2, r), xb[r], t2);
+                    t3 = __builtin_elementwise_fma(mp(u + 3, r), xb[r], t3);
+                }
+                yt2[u >> 1] = f2{t0.x + t0.y, t1.x + t1.y};
+                yt2[(u >> 1) + 1] = f2{t2.x + t2.y, t3.x + t3.y};
+            }
+            {
+                f2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 7; ++r) {
+                    t0 = __builtin_elementwise_fma(mp(12, r), xb[r], t0);
+                    t1 = __builtin_elementwise_fma(mp(13, r), xb[r], t1);
+                }
+                yt2[6] = f2{t0.x + t0.y, t1.x + t1.y};
+            }
+        }
+    };
+
+    unsigned epoch = 0;
+    bool failed = false;                               // uniform across the workgroup (published through LDS)
+    // The one hand-off of a pass.  Called by all threads after the pass; returns the cluster-wide inner product.  On return
+    // yD[slot 0] holds the left neighbour's s and yT[slot KL] the right neighbour's t (where those neighbours exist).
+    // parts3: the pass wrote off-diagonal parts (false for the block-Jacobi preconditioner pass: s = yD alone).
+    auto exchange = [&](float* red, int base, bool parts3) -> float {
+        lds_barrier();                                  // parts and wave partials are in LDS
+        ++epoch;
+        if (w == 0) {
+            float val = 0.f;
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < NW; ++c) val += red[c];
+            } else if (lane <= NS) {
+                const int e = KL * NS + lane - 1;       // s: last own knot
+                val = parts3 ? lds[L::YD + e] + lds[L::YL + e] : lds[L::YD + e];
+            } else if (lane <= 2 * NS) {
+                val = lds[L::YT + lane - 1 - NS];       // t: slot 0 (zero on member 0 and for a block-Jacobi pass... never read then)
+            }
+            if (lane <= 2 * NS)
+                __hip_atomic_store(my_words + base + lane, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, val),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // lanes 0..G-1: partial of member `lane` | 16..29: s of member g-1 | 32..45: t of member g+1
+            const bool want = lane < G || (g > 0 && lane >= 16 && lane < 16 + NS) || (g < G - 1 && lane >= 32 && lane < 32 + NS);
+            const gu64* src = lane < 16 ? cl_words + (size_t)(lane < G ? lane : 0) * CL_WG_WORDS + base
+                            : lane < 32 ? cl_words + (size_t)(g > 0 ? g - 1 : 0) * CL_WG_WORDS + base + 1 + (lane < 16 + NS ? lane - 16 : 0)
+                                        : cl_words + (size_t)(g < G - 1 ? g + 1 : 0) * CL_WG_WORDS + base + 1 + NS + (lane < 32 + NS ? lane - 32 : 0);
+            unsigned long long x = 0;
+            unsigned spins = 0;
+            bool ok;
+            do {
+                ok = true;
+                if (want) {
+                    x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (unsigned)(x >> 32) == epoch;
+                }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+            } while (++spins < CL_SPIN_LIMIT);
+            const int bits = (int)(unsigned)x;
+            float tot = 0.f;
+            for (int c = 0; c < G; ++c) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, c));
+            const float rv = __builtin_bit_cast(float, bits);
+            if (want && lane >= 16 && lane < 32) lds[L::YD + lane - 16] = rv;
+            if (want && lane >= 32) lds[L::YT + KL * NS + lane - 32] = rv;
+            if (lane == 0) { bc[0] = tot; if (spins >= CL_SPIN_LIMIT) bc[1] = 1.f; }
+        }
+        lds_barrier();
+        if (bc[1] != 0.f) failed = true;
+        return bc[0];
+    };
+
+    f2* xp2 = reinterpret_cast<f2*>(lds + L::XP);
+    f2* xr2 = reinterpret_cast<f2*>(lds + L::XR);
+    f2* lam2 = reinterpret_cast<f2*>(lds + L::LAM);
+    const f2* yD2 = reinterpret_cast<const f2*>(lds + L::YD);
+    const f2* yL2 = reinterpret_cast<const f2*>(lds + L::YL);
+    const f2* yT2 = reinterpret_cast<const f2*>(lds + L::YT);
+    // element-wise phases: float2 items of slots [0 or 1, KL]; every thread owns items e0 and e0 + NTHR (7 (KL + 1) <= 2 NTHR)
+    const int e_lo = g == 0 ? NS / 2 : 0, e_hi = (NS / 2) * (KL + 1);
+    const bool ok0 = e_lo + tid < e_hi, ok1 = e_lo + tid + NTHR < e_hi;
+    const int e0 = ok0 ? e_lo + tid : e_lo, e1 = ok1 ? e_lo + tid + NTHR : e0;
+
+    // ---- setup: r = gamma - S lambda0 ; r~ = Pinv r ; p = r~ ; eta = r . r~ ----
+    if (lane == 0) { red_v[w] = 0.f; red_e[w] = 0.f; }
+    if (!isP) pass(L::XP, red_v);
+    (void)exchange(red_v, LPBC_SLOT_V, true);
+    if (ok0) xr2[e0] = xr2[e0] - ((yD2[e0] + yL2[e0]) + yT2[e0]);
+    if (ok1) xr2[e1] = xr2[e1] - ((yD2[e1] + yL2[e1]) + yT2[e1]);
+    lds_barrier();
+    if (isP && wave_on) pass(L::XR, red_e);
+    float eta = exchange(red_e, LPBC_SLOT_E, p3);
+    if (ok0) xp2[e0] = p3 ? (yD2[e0] + yL2[e0]) + yT2[e0] : yD2[e0];
+    if (ok1) xp2[e1] = p3 ? (yD2[e1] + yL2[e1]) + yT2[e1] : yD2[e1];
+    lds_barrier();
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): see pcg_lpb_kernel
+
+    uint32_t iters = 0;
+    uint32_t max_iter_exit = 1;
+    if (failed) {
+        iters = 0xFFFFFFFFu; max_iter_exit = 2;
+    } else if (fabsf(eta) < a.exit_tol) {
+        max_iter_exit = 0;
+    } else {
+        for (int it = 0; it < a.max_iter; ++it) {
+            // upsilon = S p ; v = p . upsilon
+            if (!isP) pass(L::XP, red_v);
+            const float alpha = eta / exchange(red_v, LPBC_SLOT_V, true);
+            {
+                const f2 d0 = yD2[e0], l0 = yL2[e0], t0 = yT2[e0], r0 = xr2[e0];
+                const f2 d1 = yD2[e1], l1 = yL2[e1], t1 = yT2[e1], r1 = xr2[e1];
+                if (ok0) xr2[e0] = r0 - alpha * ((d0 + l0) + t0);
+                if (ok1) xr2[e1] = r1 - alpha * ((d1 + l1) + t1);
+            }
+            lds_barrier();
+            // r~ = Pinv r ; eta' = r . r~          | S waves: lambda += alpha p (own knots)
+            if (isP) {
+                if (wave_on) pass(L::XR, red_e);
+            } else {
+                for (int e = NS / 2 + tid; e < e_hi; e += NTHR / 2) lam2[e] = lam2[e] + alpha * xp2[e];
+            }
+            const float eta_new = exchange(red_e, LPBC_SLOT_E, p3);
+            if (failed) { iters = 0xFFFFFFFFu; max_iter_exit = 2; break; }
+            iters = (uint32_t)(it + 1);
+            if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
+            {
+                f2 rt0 = yD2[e0], rt1 = yD2[e1];
+                const f2 p0 = xp2[e0], p1 = xp2[e1];
+                if (p3) {
+                    const f2 l0 = yL2[e0], t0 = yT2[e0], l1 = yL2[e1], t1 = yT2[e1];
+                    rt0 = (rt0 + l0) + t0;
+                    rt1 = (rt1 + l1) + t1;
+                }
+                const float beta = eta_new / eta;
+                if (ok0) xp2[e0] = rt0 + beta * p0;
+                if (ok1) xp2[e1] = rt1 + beta * p1;
+                eta = eta_new;
+            }
+            lds_barrier();
+        }
+    }
+
+    // ---- write back own knots (a member that gave up leaves lambda alone and flags the trajectory for the fix-up launch) ----
+    if (failed) {
+        if (tid == 0) __hip_atomic_store(ca.fail_flags + (size_t)b * CL_FLAG_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        for (int e = tid; e < KL * NS; e += NTHR) {
+            const size_t ge = (size_t)k0 * NS + e;
+            lam_g[ge] = lds[L::LAM + NS + e];
+            if (a.r_out) a.r_out[(size_t)b * vstride + ge] = lds[L::XR + NS + e];
+            if (a.p_out) a.p_out[(size_t)b * vstride + ge] = lds[L::XP + NS + e];
+        }
+    }
+    if (tid == 0 && g == 0) {
+        a.iters[b] = iters;
+        a.max_iter_exit[b] = (uint8_t)max_iter_exit;
+    }
+}
+
+}  // namespace mpcg

@@ -20,7 +20,8 @@ def dev(a):
 @pytest.mark.parametrize("N,G,B", [(128, 2, 3), (200, 3, 2), (256, 4, 2), (512, 8, 2), (512, 16, 1), (64, 2, 1),
                                    (512, -411, 40), (256, -406, 70)])      # G < 0: 4-wave members, -(400 + G), two per CU
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
-def test_cluster_matches_oracle_and_single_workgroup(orc, N, G, B, pc):
+@pytest.mark.parametrize("lpbc", [1, 0])       # 1: clustered lane-per-block kernel (family 4), 0: row-triple cluster kernel (family 1)
+def test_cluster_matches_oracle_and_single_workgroup(orc, N, G, B, pc, lpbc):
     from mpcgpu_amd import PcgSolver, pcg_config
     waves4 = G < 0
     if waves4:
@@ -34,11 +35,15 @@ def test_cluster_matches_oracle_and_single_workgroup(orc, N, G, B, pc):
         sol = PcgSolver(N, max_batch=B)
         sol.set_option("cluster", G if mode == "cluster" else 0)
         sol.set_option("cluster_waves", 4 if waves4 else 8)
+        sol.set_option("cluster_lpb", lpbc)
         for K, tol in ((3, 0.0), (30, 0.0), (400, 1e-3)):
             lam = dev(lam0)
             it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=tol, pcg_max_iter=K), pc)
             torch.cuda.synchronize()
             out[(mode, K)] = (lam.cpu().numpy(), it.cpu().numpy().astype(np.int64), ex.cpu().numpy())
+            if mode == "cluster":                      # the kernel under test really ran
+                assert sol.get_option("last_kernel_family") == (4 if lpbc else 1) and sol.get_option("last_kernel_cluster") == G
+                assert sol.get_option("last_kernel_waves") == (4 if waves4 else 8)
         if mode == "cluster":      # deterministic: bitwise identical on a second run
             lam = dev(lam0)
             sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=1e-3, pcg_max_iter=400), pc)
