@@ -46,7 +46,28 @@ struct KktArgs {
     double dt, qd_cost, r_cost;
 };
 
-__device__ __forceinline__ void mat3(double (&M)[9], const double* c0, const double* cs, const double* cc, double s, double c) {
+// The model tables are read through the CONSTANT address space (same 64-bit address as the global pointer): loads from it are
+// invariant by definition, so a uniform address makes them scalar loads (s_load, scalar cache).  Through the plain global
+// pointer the compiler must assume the kernel's own stores may clobber the table and emits ~1,300 vector loads per knot
+// (rocprofv3: SQ_INSTS_VMEM_RD; waves waited on memory half of their cycles).
+typedef const __attribute__((address_space(4))) double cdouble;
+struct PlantC {
+    cdouble* base;
+    __device__ __forceinline__ cdouble* at(size_t byte_off, int k, int per) const { return base + byte_off / sizeof(double) + (size_t)k * per; }
+    __device__ __forceinline__ cdouble* E0(int k) const { return at(offsetof(PlantDev, E0), k, 9); }
+    __device__ __forceinline__ cdouble* Es(int k) const { return at(offsetof(PlantDev, Es), k, 9); }
+    __device__ __forceinline__ cdouble* Ec(int k) const { return at(offsetof(PlantDev, Ec), k, 9); }
+    __device__ __forceinline__ cdouble* B0(int k) const { return at(offsetof(PlantDev, B0), k, 9); }
+    __device__ __forceinline__ cdouble* Bs(int k) const { return at(offsetof(PlantDev, Bs), k, 9); }
+    __device__ __forceinline__ cdouble* Bc(int k) const { return at(offsetof(PlantDev, Bc), k, 9); }
+    __device__ __forceinline__ cdouble* I(int k) const { return at(offsetof(PlantDev, I), k, 36); }
+    __device__ __forceinline__ cdouble* R0(int k) const { return at(offsetof(PlantDev, R0), k, 9); }
+    __device__ __forceinline__ cdouble* Rs(int k) const { return at(offsetof(PlantDev, Rs), k, 9); }
+    __device__ __forceinline__ cdouble* Rc(int k) const { return at(offsetof(PlantDev, Rc), k, 9); }
+    __device__ __forceinline__ cdouble* p(int k) const { return at(offsetof(PlantDev, p), k, 3); }
+};
+
+__device__ __forceinline__ void mat3(double (&M)[9], cdouble* c0, cdouble* cs, cdouble* cc, double s, double c) {
 #pragma unroll
     for (int e = 0; e < 9; ++e) M[e] = c0[e] + cs[e] * s + cc[e] * c;
 }
@@ -59,11 +80,12 @@ __device__ __forceinline__ void mat3(double (&M)[9], const double* c0, const dou
 // store-forwarded back into registers.  This form compiles one joint body and fits two waves per SIMD.
 //   q_k  = xq[k] + (k == prow ? ph : 0),  qd_k = qdscale * xq[PJ + k] + (PJ + k == prow ? ph : 0)   (xq: [q; qd], shared by the lanes)
 //   qdd_k = qdd ? qdd[k] : (k == unit ? 1 : 0)
-__device__ __forceinline__ void rnea(const PlantDev& P, volatile double* fl, const double* xq, double qdscale, int prow, double ph,
+__device__ __forceinline__ void rnea(const PlantC& P, volatile double* fl, const double* xq, double qdscale, int prow, double ph,
                                      const double* qdd, int unit) {
     double vw[3] = {0, 0, 0}, vu[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, au[3] = {0, 0, 0};
 #pragma nounroll
-    for (int k = 0; k < PJ; ++k) {
+    for (int kv = 0; kv < PJ; ++kv) {
+        const int k = __builtin_amdgcn_readfirstlane(kv);    // uniform by construction; said so, the model tables come through s_load
         const double qk = xq[k] + (k == prow ? ph : 0.0), qdk = qdscale * xq[PJ + k] + (PJ + k == prow ? ph : 0.0);
         const double qddk = qdd ? qdd[k] : (k == unit ? 1.0 : 0.0);
         double sn, cs;
@@ -71,8 +93,8 @@ __device__ __forceinline__ void rnea(const PlantDev& P, volatile double* fl, con
         fl[RN_SIN + k] = sn;
         fl[RN_COS + k] = cs;
         double E[9], B[9];
-        mat3(E, P.E0[k], P.Es[k], P.Ec[k], sn, cs);
-        mat3(B, P.B0[k], P.Bs[k], P.Bc[k], sn, cs);
+        mat3(E, P.E0(k), P.Es(k), P.Ec(k), sn, cs);
+        mat3(B, P.B0(k), P.Bs(k), P.Bc(k), sn, cs);
         double w[3], u[3], bw[3], bu[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {                    // v = X v_parent, a = X a_parent
@@ -88,12 +110,13 @@ __device__ __forceinline__ void rnea(const PlantDev& P, volatile double* fl, con
         bu[0] += u[1] * qdk; bu[1] -= u[0] * qdk;
         // f = I a + v x* (I v)
         double Ia[6], Iv[6];
+        cdouble* Ik = P.I(k);
         const double v6[6] = {w[0], w[1], w[2], u[0], u[1], u[2]}, a6[6] = {bw[0], bw[1], bw[2], bu[0], bu[1], bu[2]};
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             double sa = 0, sv = 0;
 #pragma unroll
-            for (int cc_ = 0; cc_ < 6; ++cc_) { sa += P.I[k][6 * r + cc_] * a6[cc_]; sv += P.I[k][6 * r + cc_] * v6[cc_]; }
+            for (int cc_ = 0; cc_ < 6; ++cc_) { sa += Ik[6 * r + cc_] * a6[cc_]; sv += Ik[6 * r + cc_] * v6[cc_]; }
             Ia[r] = sa; Iv[r] = sv;
         }
         // crf(v) h = [w x n + u x l ; w x l],  h = [n; l]
@@ -111,11 +134,12 @@ __device__ __forceinline__ void rnea(const PlantDev& P, volatile double* fl, con
 #pragma unroll
     for (int r = 0; r < 6; ++r) fc[r] = fl[(PJ - 1) * 6 + r];   // tau_6 = row 2 of the last link's force: already in place
 #pragma nounroll
-    for (int k = PJ - 1; k >= 1; --k) {                  // f_parent += X^T f = [E^T n + B^T l ; E^T l]
+    for (int kv = PJ - 1; kv >= 1; --kv) {               // f_parent += X^T f = [E^T n + B^T l ; E^T l]
+        const int k = __builtin_amdgcn_readfirstlane(kv);
         const double sk = fl[RN_SIN + k], ck = fl[RN_COS + k];
         double E[9], B[9];
-        mat3(E, P.E0[k], P.Es[k], P.Ec[k], sk, ck);
-        mat3(B, P.B0[k], P.Bs[k], P.Bc[k], sk, ck);
+        mat3(E, P.E0(k), P.Es(k), P.Ec(k), sk, ck);
+        mat3(B, P.B0(k), P.Bs(k), P.Bc(k), sk, ck);
         double fp[6];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -138,11 +162,10 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
     __shared__ double sJ[3][PJ], sEe[3], sGq[PJ], sGq1[PJ];
     __shared__ double sF[KKT_FLANES][RN_ROWS];              // per-task-lane record of the recursion (rows RN_*), 13 KB
     __shared__ double sXq[2 * PJ];                          // [q; qd] of this knot
-    // The model tables are read through the kernel argument with RUNTIME joint indices: uniform addresses = scalar loads
-    // (s_load, scalar cache).  With compile-time indices (unrolled sweeps) all 840 doubles are loop-invariant loads that
-    // the compiler hoists into registers: 512 VGPR + AGPR and scratch.
+    // The model tables are read with RUNTIME joint indices.  With compile-time indices (unrolled sweeps) all 840 doubles are
+    // loop-invariant loads that the compiler hoists into registers: 512 VGPR + AGPR and scratch.
     const int lane = threadIdx.x;
-    const PlantDev& P = *a.plant;
+    const PlantC P{reinterpret_cast<cdouble*>(reinterpret_cast<unsigned long long>(a.plant))};
     const int N = a.N;
     const long total = (long)a.batch * (N - 1);
     for (long item = blockIdx.x; item < total; item += gridDim.x) {
@@ -176,14 +199,16 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
                 // forward kinematics; joint origins and axes wait in this lane's (otherwise unused) record column
                 double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pos[3] = {0, 0, 0};
 #pragma nounroll
-                for (int jn = 0; jn < PJ; ++jn) {
+                for (int jv = 0; jv < PJ; ++jv) {
+                    const int jn = __builtin_amdgcn_readfirstlane(jv);
                     double s_, c_, H[9];
                     sincos(sXq[jn], &s_, &c_);
-                    mat3(H, P.R0[jn], P.Rs[jn], P.Rc[jn], s_, c_);
+                    mat3(H, P.R0(jn), P.Rs(jn), P.Rc(jn), s_, c_);
                     double Rn[9];
+                    cdouble* pj = P.p(jn);
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
-                        pos[r] += R[3 * r] * P.p[jn][0] + R[3 * r + 1] * P.p[jn][1] + R[3 * r + 2] * P.p[jn][2];
+                        pos[r] += R[3 * r] * pj[0] + R[3 * r + 1] * pj[1] + R[3 * r + 2] * pj[2];
 #pragma unroll
                         for (int cc_ = 0; cc_ < 3; ++cc_) Rn[3 * r + cc_] = R[3 * r] * H[cc_] + R[3 * r + 1] * H[3 + cc_] + R[3 * r + 2] * H[6 + cc_];
                     }
