@@ -24,8 +24,7 @@ namespace mpcg {
 constexpr int PJ = 7;                    // joints of the compiled specialisation (state 2 PJ, control PJ)
 constexpr int KKT_LANES = 64;            // one wavefront per (trajectory, knot)
 constexpr int KKT_FLANES = 29;           // lanes that own a record in LDS: the 28 finite-difference tasks + the kinematics lane
-constexpr int RN_SIN = 6 * PJ, RN_COS = RN_SIN + PJ, RN_ROWS = RN_COS + PJ + 1;   // record: link forces [PJ][6], sin, cos (+1: an odd row
-                                                                                  //  count = conflict-free 8-byte accesses at lane stride)
+constexpr int RN_ROWS = 6 * PJ + 1;        // record: link forces [PJ][6] (+1: an odd row count = conflict-free 8-byte accesses at lane stride)
 __host__ __device__ constexpr int RN_TAU(int k) { return 6 * k + 2; }             // tau_k overwrites row 2 of link k's force once consumed
 
 struct PlantDev {                        // all row-major 3x3 unless noted
@@ -78,20 +77,20 @@ __device__ __forceinline__ void mat3(double (&M)[9], cdouble* c0, cdouble* cs, c
 // sweeps = 3.4 KB of scratch per lane (the 84 force registers, plus the seven E_k / B_k pairs the compiler keeps from the
 // forward sweep for the backward one instead of recomputing them: 252 doubles); plain (non-volatile) LDS accesses get
 // store-forwarded back into registers.  This form compiles one joint body and fits two waves per SIMD.
-//   q_k  = xq[k] + (k == prow ? ph : 0),  qd_k = qdscale * xq[PJ + k] + (PJ + k == prow ? ph : 0)   (xq: [q; qd], shared by the lanes)
-//   qdd_k = qdd ? qdd[k] : (k == unit ? 1 : 0)
-__device__ __forceinline__ void rnea(const PlantC& P, volatile double* fl, const double* xq, double qdscale, int prow, double ph,
-                                     const double* qdd, int unit) {
+//   sin / cos of the joint angles come from a table sc[variant][2][PJ] shared by the lanes (variant 0: q, 1: q + h e_j, 2: q - h e_j;
+//   ONE sincos call per knot fills it — every recursion used to recompute all seven, 29 % of the kernel's VALU instructions):
+//   joint k uses variant (k == sj ? sv : 0).
+//   qd_k = qdscale * xqd[k] + (k == prow ? ph : 0)   (xqd shared by the lanes),   qdd_k = qdd ? qdd[k] : (k == unit ? 1 : 0)
+__device__ __forceinline__ void rnea(const PlantC& P, volatile double* fl, const double* sc, int sj, int sv, const double* xqd, double qdscale,
+                                     int prow, double ph, const double* qdd, int unit) {
     double vw[3] = {0, 0, 0}, vu[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, au[3] = {0, 0, 0};
 #pragma nounroll
     for (int kv = 0; kv < PJ; ++kv) {
         const int k = __builtin_amdgcn_readfirstlane(kv);    // uniform by construction; said so, the model tables come through s_load
-        const double qk = xq[k] + (k == prow ? ph : 0.0), qdk = qdscale * xq[PJ + k] + (PJ + k == prow ? ph : 0.0);
+        const double qdk = qdscale * xqd[k] + (k == prow ? ph : 0.0);
         const double qddk = qdd ? qdd[k] : (k == unit ? 1.0 : 0.0);
-        double sn, cs;
-        sincos(qk, &sn, &cs);
-        fl[RN_SIN + k] = sn;
-        fl[RN_COS + k] = cs;
+        const double* sck = sc + (k == sj ? sv : 0) * (2 * PJ) + k;
+        const double sn = sck[0], cs = sck[PJ];
         double E[9], B[9];
         mat3(E, P.E0(k), P.Es(k), P.Ec(k), sn, cs);
         mat3(B, P.B0(k), P.Bs(k), P.Bc(k), sn, cs);
@@ -136,7 +135,8 @@ __device__ __forceinline__ void rnea(const PlantC& P, volatile double* fl, const
 #pragma nounroll
     for (int kv = PJ - 1; kv >= 1; --kv) {               // f_parent += X^T f = [E^T n + B^T l ; E^T l]
         const int k = __builtin_amdgcn_readfirstlane(kv);
-        const double sk = fl[RN_SIN + k], ck = fl[RN_COS + k];
+        const double* sck = sc + (k == sj ? sv : 0) * (2 * PJ) + k;
+        const double sk = sck[0], ck = sck[PJ];
         double E[9], B[9];
         mat3(E, P.E0(k), P.Es(k), P.Ec(k), sk, ck);
         mat3(B, P.B0(k), P.Bs(k), P.Bc(k), sk, ck);
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
     __shared__ double sJ[3][PJ], sEe[3], sGq[PJ], sGq1[PJ];
     __shared__ double sF[KKT_FLANES][RN_ROWS];              // per-task-lane record of the recursion (rows RN_*), 13 KB
     __shared__ double sXq[2 * PJ];                          // [q; qd] of this knot
+    __shared__ double sSc[3][2][PJ];                        // sin / cos of q, q + h e_j, q - h e_j
     // The model tables are read with RUNTIME joint indices.  With compile-time indices (unrolled sweeps) all 840 doubles are
     // loop-invariant loads that the compiler hoists into registers: 512 VGPR + AGPR and scratch.
     const int lane = threadIdx.x;
@@ -175,6 +176,13 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
 #pragma unroll
         for (int i = 0; i < PJ; ++i) { q[i] = xu[i]; qd[i] = xu[PJ + i]; u[i] = xu[n + i]; }
         if (lane < n) sXq[lane] = (double)xu[lane];
+        if (lane < 3 * PJ) {                                // sin / cos table: q_j, q_j + h, q_j - h
+            const int v = lane / PJ, j = lane - v * PJ;
+            double sn_, cs_;
+            sincos((double)xu[j] + (v == 0 ? 0.0 : v == 1 ? KKT_FD_H : -KKT_FD_H), &sn_, &cs_);
+            sSc[v][0][j] = sn_;
+            sSc[v][1][j] = cs_;
+        }
         __syncthreads();
         // ---- two rounds through ONE instance of the recursion (not unrolled: a second inlined copy doubles the register
         //      pressure).  Round 0: lanes 0..6 inertia-matrix columns ID(q, 0, e_j), lane 7 bias ID(q, qd, 0), then Minv and qdd.
@@ -187,7 +195,9 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
                 // round 0: lanes 0..6 ID(q, 0, e_lane), lane 7 ID(q, qd, 0);  round 1: lane = 7 kind + j, kind 0: q_j + h, 1: q_j - h,
                 // 2: qd_j + h, 3: qd_j - h, all at qdd
                 const double ph = round == 0 ? 0.0 : (((lane / PJ) & 1) ? -KKT_FD_H : KKT_FD_H);
-                rnea(P, fl, sXq, (round == 1 || lane == PJ) ? 1.0 : 0.0, round == 0 ? -1 : (lane % PJ) + (lane / PJ >= 2 ? PJ : 0), ph, round == 0 ? nullptr : sQdd, lane);
+                const int kind = lane / PJ, jj = lane - kind * PJ;
+                rnea(P, fl, &sSc[0][0][0], (round == 1 && kind < 2) ? jj : -1, 1 + kind, sXq + PJ, (round == 1 || lane == PJ) ? 1.0 : 0.0,
+                     (round == 1 && kind >= 2) ? jj : -1, ph, round == 0 ? nullptr : sQdd, lane);
 #pragma unroll
                 for (int i = 0; i < PJ; ++i) {
                     const double t = fl[RN_TAU(i)];
@@ -201,8 +211,8 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
 #pragma nounroll
                 for (int jv = 0; jv < PJ; ++jv) {
                     const int jn = __builtin_amdgcn_readfirstlane(jv);
-                    double s_, c_, H[9];
-                    sincos(sXq[jn], &s_, &c_);
+                    double H[9];
+                    const double s_ = sSc[0][0][jn], c_ = sSc[0][1][jn];
                     mat3(H, P.R0(jn), P.Rs(jn), P.Rc(jn), s_, c_);
                     double Rn[9];
                     cdouble* pj = P.p(jn);

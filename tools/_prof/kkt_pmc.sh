@@ -11,4 +11,4 @@ d=json.load(open('gpurun_out/kk_pmc.json'))
 for k,v in d.items():
     if 'kkt' in k: print(k, json.dumps(v, indent=0)[:1500])
 PY
-tail -2 gpurun_out/kk1.err gpurun_out/kk2.err
+
