@@ -255,9 +255,14 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * bounded spin: d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for that trajectory.
  * "lds_extra" (single-triple LDS slots beyond the uniform cache of the <.,.,1> kernels: -1 what fits, 0 none),
  * "cluster_waves" (waves per cluster member: 8 = one member per CU, 4 = two per CU, -1 by horizon and batch),
- * "cluster_adj" (lane order of the cluster kernel), "schur_dpp" (1: register/DPP Schur kernels, 0: the LDS versions),
+ * "cluster_lpb" (-1 auto / 0 / 1: the clustered lane-per-block kernel — members of up to 128 knots, everything in registers, one
+ * hand-off per matrix pass — instead of the row-triple cluster kernel; default on), "cluster_fixup" (1: trajectories whose cluster
+ * gave up are re-solved by the single-workgroup kernel in a follow-up launch; default on),
+ * "cluster_adj" (lane order of the row-triple cluster kernel), "schur_dpp" (1: register/DPP Schur kernels, 0: the LDS versions),
  * "block_solve_wide" (mpcg_block_solve: 1 one trajectory per wavefront, 0 four, -1 by batch size; same bits);
- * read-only: "num_cus", "pcg_resident" (1 if the current configuration streams nothing inside the PCG loop).
+ * read-only: "num_cus", "pcg_resident" (1 if the current configuration streams nothing inside the PCG loop),
+ * "last_kernel_family" (kernel of the last solve: 0 single-workgroup row-pair, 1 row-triple cluster, 2 lane-per-block, 3 generic,
+ * 4 clustered lane-per-block), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
  * None of the residency knobs changes results within a lane-order family (bitwise identical, tested); kernels that
  * keep everything resident use the adjacent-lane order and agree with the streaming ones to fp32 round-off of the
  * inner products, as does the cluster kernel, which sums the inner products per workgroup first. */

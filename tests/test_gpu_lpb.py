@@ -248,7 +248,7 @@ def test_batch_composition_independence(P):
 
 def test_cluster_falls_back_when_peers_are_not_resident(P, orc):
     """The cluster kernel (N > 128) needs all members of a trajectory resident.  Keep 255 of the 256 CUs busy with a
-    long solve on another stream, then run a batch-1 N=256 solve (4 members): the members that do get a CU give up
+    long solve on another stream, then run a batch-1 N=256 solve (2 members of the clustered lane-per-block kernel): the members that do get a CU give up
     after the bounded spin, and the fix-up launch re-solves the trajectory with the single-workgroup kernel —
     the caller gets a normal result (no flag 2, no 0xFFFFFFFF)."""
     PcgSolver, pcg_config = P
