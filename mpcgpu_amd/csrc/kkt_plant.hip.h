@@ -6,11 +6,12 @@
 // The reference runs GRiD-generated, robot-specific code (10 k lines of unrolled recursions) with one thread block per
 // knot.  Here the robot is DATA (struct PlantDev: spatial transforms as constant + sin + cos parts, spatial inertias,
 // homogeneous transforms) and the algorithms are the generic ones, mapped for a 64-wide wavefront:
-//   one wavefront per (trajectory, knot); every lane runs a whole recursive Newton-Euler pass in registers:
-//     phase 1  lanes 0..6: columns of the joint-space inertia matrix M = ID(q, 0, e_j);  lane 7: bias c = ID(q, qd, 0)
-//     phase 2  lanes 0..6: column j of Minv by a Cholesky solve (7x7, redundantly factorised per lane);  qdd = Minv (u - c)
-//     phase 3  lanes 0..27: ID(q +- h e_j, qd, qdd), ID(q, qd +- h e_j, qdd)  ->  central differences of the inverse dynamics
-//              lane 28: forward kinematics, end-effector position and geometric Jacobian z_j x (p_ee - p_j)
+//   one wavefront per FOUR (trajectory, knot) pairs, 16 lanes each; a lane runs a whole recursive Newton-Euler pass:
+//     round 0  lanes 0..6: columns of the joint-space inertia matrix M = ID(q, 0, e_j);  lane 7: bias c = ID(q, qd, 0)
+//              then lanes 0..6: column j of Minv by a Cholesky solve (7x7, redundantly factorised per lane);  qdd = Minv (u - c)
+//     round 1  lanes 0..6: ID(q + h e_j, qd, qdd), lanes 7..13: ID(q, qd + h e_j, qdd);  lane 14: forward kinematics, end-effector
+//              position and geometric Jacobian z_j x (p_ee - p_j)
+//     round 2  the same at - h; every lane stores tau(+h) - tau(-h): central differences of the inverse dynamics
 //     phase 4  dqdd/d(q,qd) = -Minv dID,  A, B, integrator defect, Gauss-Newton cost blocks, written as float in the
 //              reference's dense layouts (column-major blocks, C = -A, -B).
 // Arithmetic is float64 inside (h = 1e-6 central differences are exact to ~1e-9 there; the MI355X has the fp64 rate
@@ -23,7 +24,6 @@ namespace mpcg {
 
 constexpr int PJ = 7;                    // joints of the compiled specialisation (state 2 PJ, control PJ)
 constexpr int KKT_LANES = 64;            // one wavefront per (trajectory, knot)
-constexpr int KKT_FLANES = 29;           // lanes that own a record in LDS: the 28 finite-difference tasks + the kinematics lane
 constexpr int RN_ROWS = 6 * PJ + 1;        // record: link forces [PJ][6] (+1: an odd row count = conflict-free 8-byte accesses at lane stride)
 __host__ __device__ constexpr int RN_TAU(int k) { return 6 * k + 2; }             // tau_k overwrites row 2 of link k's force once consumed
 
@@ -153,66 +153,80 @@ __device__ __forceinline__ void rnea(const PlantC& P, volatile double* fl, const
 }
 
 constexpr int KKT_THREADS = KKT_LANES;
-constexpr int KKT_KIN_LANE = 4 * PJ;     // the lane after the 28 finite-difference tasks: forward kinematics + Jacobian
+constexpr int KKT_ITEMS = 4;             // (trajectory, knot) pairs per wavefront: 16 lanes each
+constexpr int KKT_GL = KKT_LANES / KKT_ITEMS;
+constexpr int KKT_KIN_LANE = 2 * PJ;     // lane of a group after the 14 finite-difference tasks: forward kinematics + Jacobian
 constexpr double KKT_FD_H = 1e-6;
+
+struct KktItemLds {                      // per-knot scratch in LDS (3.3 KB)
+    double M[PJ][PJ], Minv[PJ][PJ], Bias[PJ], Qdd[PJ];
+    double Id[2 * PJ][PJ];               // central differences ID(. + h e_j) - ID(. - h e_j): rows 0..6 w.r.t. q_j, 7..13 w.r.t. qd_j
+    double Dq[PJ][PJ], Dqd[PJ][PJ];
+    double J[3][PJ], Ee[3], Gq[PJ], Gq1[PJ];
+    double Xq[2 * PJ], U[PJ];            // [q; qd], u of this knot
+    double Sc[3][2][PJ];                 // sin / cos of q, q + h e_j, q - h e_j
+};
 
 __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a) {
     constexpr int n = 2 * PJ, m = PJ, nn = n * n, mm = m * m, nm = n * m;
-    __shared__ double sM[PJ][PJ], sMinv[PJ][PJ], sBias[PJ], sQdd[PJ], sId[4 * PJ][PJ], sDq[PJ][PJ], sDqd[PJ][PJ];
-    __shared__ double sJ[3][PJ], sEe[3], sGq[PJ], sGq1[PJ];
-    __shared__ double sF[KKT_FLANES][RN_ROWS];              // per-task-lane record of the recursion (rows RN_*), 13 KB
-    __shared__ double sXq[2 * PJ];                          // [q; qd] of this knot
-    __shared__ double sSc[3][2][PJ];                        // sin / cos of q, q + h e_j, q - h e_j
+    __shared__ KktItemLds sI[KKT_ITEMS];
+    __shared__ double sF[KKT_LANES][RN_ROWS];               // per-lane record of the recursion: link forces (22 KB)
     // The model tables are read with RUNTIME joint indices.  With compile-time indices (unrolled sweeps) all 840 doubles are
     // loop-invariant loads that the compiler hoists into registers: 512 VGPR + AGPR and scratch.
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, gi = lane / KKT_GL, l = lane - gi * KKT_GL;
+    KktItemLds& I = sI[gi];
+    volatile double* fl = &sF[lane][0];
     const PlantC P{reinterpret_cast<cdouble*>(reinterpret_cast<unsigned long long>(a.plant))};
     const int N = a.N;
     const long total = (long)a.batch * (N - 1);
-    for (long item = blockIdx.x; item < total; item += gridDim.x) {
+    for (long base = (long)blockIdx.x * KKT_ITEMS; base < total; base += (long)gridDim.x * KKT_ITEMS) {
+        const bool live = base + gi < total;                // (a group without a knot recomputes the last one and writes nothing)
+        const long item = live ? base + gi : total - 1;
         const int b = (int)(item / (N - 1)), k = (int)(item - (long)b * (N - 1));
         const float* xu = a.xu + (size_t)b * ((size_t)(n + m) * N - m) + (size_t)k * (n + m);      // x_k, u_k, x_{k+1}
-        double q[PJ], qd[PJ], u[PJ];
-#pragma unroll
-        for (int i = 0; i < PJ; ++i) { q[i] = xu[i]; qd[i] = xu[PJ + i]; u[i] = xu[n + i]; }
-        if (lane < n) sXq[lane] = (double)xu[lane];
-        if (lane < 3 * PJ) {                                // sin / cos table: q_j, q_j + h, q_j - h
-            const int v = lane / PJ, j = lane - v * PJ;
-            double sn_, cs_;
-            sincos((double)xu[j] + (v == 0 ? 0.0 : v == 1 ? KKT_FD_H : -KKT_FD_H), &sn_, &cs_);
-            sSc[v][0][j] = sn_;
-            sSc[v][1][j] = cs_;
+        if (l < n) I.Xq[l] = (double)xu[l];
+        if (l < m) I.U[l] = (double)xu[n + l];
+        // sin / cos table, two sweeps through one sincos: lanes 0..13 -> q_j and q_j + h, then lanes 0..6 -> q_j - h
+#pragma nounroll
+        for (int c = 0; c < 2; ++c) {
+            const int v = c == 0 ? l / PJ : 2, j = l % PJ;
+            if (l < (c == 0 ? 2 * PJ : PJ)) {
+                double sn_, cs_;
+                sincos((double)xu[j] + (v == 0 ? 0.0 : v == 1 ? KKT_FD_H : -KKT_FD_H), &sn_, &cs_);
+                I.Sc[v][0][j] = sn_;
+                I.Sc[v][1][j] = cs_;
+            }
         }
         __syncthreads();
-        // ---- two rounds through ONE instance of the recursion (not unrolled: a second inlined copy doubles the register
-        //      pressure).  Round 0: lanes 0..6 inertia-matrix columns ID(q, 0, e_j), lane 7 bias ID(q, qd, 0), then Minv and qdd.
-        //      Round 1: lanes 0..27 ID(q +- h e_j, qd, qdd), ID(q, qd +- h e_j, qdd); lane 28: kinematics. ----
+        // ---- three rounds through ONE instance of the recursion (a runtime loop: a second inlined copy doubles the register
+        //      pressure).  Round 0: lanes 0..6 inertia-matrix columns ID(q, 0, e_l), lane 7 bias ID(q, qd, 0), then Minv and qdd.
+        //      Round 1: lanes 0..6 ID(q + h e_j, qd, qdd), 7..13 ID(q, qd + h e_j, qdd); lane 14: kinematics.  Round 2: the same at - h;
+        //      the lane keeps tau(+h) in registers and stores the difference. ----
+        double tp[PJ];
+#pragma unroll
+        for (int i = 0; i < PJ; ++i) tp[i] = 0.0;
 #pragma nounroll
-        for (int round = 0; round < 2; ++round) {
-            const int ntask = round == 0 ? PJ + 1 : 4 * PJ;
-            volatile double* fl = &sF[lane < KKT_FLANES ? lane : 0][0];
-            if (lane < ntask) {
-                // round 0: lanes 0..6 ID(q, 0, e_lane), lane 7 ID(q, qd, 0);  round 1: lane = 7 kind + j, kind 0: q_j + h, 1: q_j - h,
-                // 2: qd_j + h, 3: qd_j - h, all at qdd
-                const double ph = round == 0 ? 0.0 : (((lane / PJ) & 1) ? -KKT_FD_H : KKT_FD_H);
-                const int kind = lane / PJ, jj = lane - kind * PJ;
-                rnea(P, fl, &sSc[0][0][0], (round == 1 && kind < 2) ? jj : -1, 1 + kind, sXq + PJ, (round == 1 || lane == PJ) ? 1.0 : 0.0,
-                     (round == 1 && kind >= 2) ? jj : -1, ph, round == 0 ? nullptr : sQdd, lane);
+        for (int round = 0; round < 3; ++round) {
+            const bool fd = round > 0;
+            if (l < (fd ? 2 * PJ : PJ + 1)) {
+                const int kind = l / PJ, jj = l - kind * PJ;            // fd: kind 0 perturbs q_jj, kind 1 qd_jj
+                rnea(P, fl, &I.Sc[0][0][0], (fd && kind == 0) ? jj : -1, round, I.Xq + PJ, (fd || l == PJ) ? 1.0 : 0.0,
+                     (fd && kind == 1) ? jj : -1, round == 1 ? KKT_FD_H : -KKT_FD_H, fd ? I.Qdd : nullptr, l);
 #pragma unroll
                 for (int i = 0; i < PJ; ++i) {
                     const double t = fl[RN_TAU(i)];
-                    if (round == 1) sId[lane][i] = t;
-                    else if (lane < PJ) sM[i][lane] = t;
-                    else sBias[i] = t;
+                    if (round == 0) { if (l < PJ) I.M[i][l] = t; else I.Bias[i] = t; }
+                    else if (round == 1) tp[i] = t;
+                    else I.Id[l][i] = tp[i] - t;
                 }
-            } else if (round == 1 && lane == KKT_KIN_LANE) {
-                // forward kinematics; joint origins and axes wait in this lane's (otherwise unused) record column
+            } else if (round == 1 && l == KKT_KIN_LANE) {
+                // forward kinematics; joint origins and axes wait in this lane's (otherwise unused) record
                 double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pos[3] = {0, 0, 0};
 #pragma nounroll
                 for (int jv = 0; jv < PJ; ++jv) {
                     const int jn = __builtin_amdgcn_readfirstlane(jv);
                     double H[9];
-                    const double s_ = sSc[0][0][jn], c_ = sSc[0][1][jn];
+                    const double s_ = I.Sc[0][0][jn], c_ = I.Sc[0][1][jn];
                     mat3(H, P.R0(jn), P.Rs(jn), P.Rc(jn), s_, c_);
                     double Rn[9];
                     cdouble* pj = P.p(jn);
@@ -228,26 +242,26 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
                     for (int r = 0; r < 3; ++r) { fl[jn * 6 + r] = pos[r]; fl[jn * 6 + 3 + r] = R[3 * r + 2]; }
                 }
 #pragma unroll
-                for (int r = 0; r < 3; ++r) sEe[r] = pos[r];
+                for (int r = 0; r < 3; ++r) I.Ee[r] = pos[r];
 #pragma nounroll
                 for (int jn = 0; jn < PJ; ++jn) {
                     const double d0 = pos[0] - fl[jn * 6 + 0], d1 = pos[1] - fl[jn * 6 + 1], d2 = pos[2] - fl[jn * 6 + 2];
                     const double z0 = fl[jn * 6 + 3], z1 = fl[jn * 6 + 4], z2 = fl[jn * 6 + 5];
-                    sJ[0][jn] = z1 * d2 - z2 * d1;
-                    sJ[1][jn] = z2 * d0 - z0 * d2;
-                    sJ[2][jn] = z0 * d1 - z1 * d0;
+                    I.J[0][jn] = z1 * d2 - z2 * d1;
+                    I.J[1][jn] = z2 * d0 - z0 * d2;
+                    I.J[2][jn] = z0 * d1 - z1 * d0;
                 }
             }
             __syncthreads();
             if (round == 0) {
-                // Minv (column `lane` through a Cholesky solve of the symmetrised M), qdd = Minv (u - bias)
-                if (lane < PJ) {
+                // Minv (column l through a Cholesky solve of the symmetrised M), qdd = Minv (u - bias)
+                if (l < PJ) {
                     double Lm[PJ][PJ];
 #pragma unroll
                     for (int i = 0; i < PJ; ++i)
 #pragma unroll
                         for (int jj = 0; jj <= i; ++jj) {
-                            double sv = 0.5 * (sM[i][jj] + sM[jj][i]);
+                            double sv = 0.5 * (I.M[i][jj] + I.M[jj][i]);
 #pragma unroll
                             for (int t = 0; t < jj; ++t) sv -= Lm[i][t] * Lm[jj][t];
                             Lm[i][jj] = (i == jj) ? sqrt(sv) : sv / Lm[jj][jj];
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
                     double y[PJ];
 #pragma unroll
                     for (int i = 0; i < PJ; ++i) {
-                        double sv = (i == lane) ? 1.0 : 0.0;
+                        double sv = (i == l) ? 1.0 : 0.0;
 #pragma unroll
                         for (int t = 0; t < i; ++t) sv -= Lm[i][t] * y[t];
                         y[i] = sv / Lm[i][i];
@@ -268,81 +282,83 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
                         y[i] = sv / Lm[i][i];
                     }
 #pragma unroll
-                    for (int i = 0; i < PJ; ++i) sMinv[i][lane] = y[i];
+                    for (int i = 0; i < PJ; ++i) I.Minv[i][l] = y[i];
                 }
                 __syncthreads();
-                if (lane < PJ) {
+                if (l < PJ) {
                     double sv = 0;
 #pragma unroll
-                    for (int jj = 0; jj < PJ; ++jj) sv += sMinv[lane][jj] * (u[jj] - sBias[jj]);
-                    sQdd[lane] = sv;
+                    for (int jj = 0; jj < PJ; ++jj) sv += I.Minv[l][jj] * (I.U[jj] - I.Bias[jj]);
+                    I.Qdd[l] = sv;
                 }
                 __syncthreads();
             }
         }
         // ---- phase 4a: dqdd = -Minv dID ; cost gradient pieces ----
-        if (lane < PJ * PJ) {
-            const int i = lane / PJ, j = lane % PJ;
+        for (int pi = l; pi < PJ * PJ; pi += KKT_GL) {
+            const int i = pi / PJ, j = pi - i * PJ;
             double sq = 0, sd = 0;
 #pragma unroll
             for (int t = 0; t < PJ; ++t) {
-                sq += sMinv[i][t] * (sId[j][t] - sId[PJ + j][t]);
-                sd += sMinv[i][t] * (sId[2 * PJ + j][t] - sId[3 * PJ + j][t]);
+                sq += I.Minv[i][t] * I.Id[j][t];
+                sd += I.Minv[i][t] * I.Id[PJ + j][t];
             }
-            sDq[i][j] = -sq / (2 * KKT_FD_H);
-            sDqd[i][j] = -sd / (2 * KKT_FD_H);
-        } else if (lane >= 56 && lane < 56 + PJ) {
-            const int j = lane - 56;
+            I.Dq[i][j] = -sq / (2 * KKT_FD_H);
+            I.Dqd[i][j] = -sd / (2 * KKT_FD_H);
+        }
+        if (l < PJ) {
             const float* goal = a.eePos_traj + ((size_t)b * N + k) * 6;
             double s0 = 0, s1 = 0;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                s0 += sJ[r][j] * (sEe[r] - (double)goal[r]);
-                s1 += sJ[r][j] * (sEe[r] - (double)goal[6 + r]);       // goal of knot k+1: used by the last block only
+                s0 += I.J[r][l] * (I.Ee[r] - (double)goal[r]);
+                s1 += I.J[r][l] * (I.Ee[r] - (double)goal[6 + r]);       // goal of knot k+1: used by the last block only
             }
-            sGq[j] = s0;
-            sGq1[j] = s1;
+            I.Gq[l] = s0;
+            I.Gq1[l] = s1;
         }
         __syncthreads();
         // ---- phase 4b: outputs, float, the reference's dense layouts ----
-        float* G = a.G + (size_t)b * ((size_t)(nn + mm) * N - mm) + (size_t)(nn + mm) * k;
-        float* Cm = a.C + (size_t)b * (size_t)(nn + nm) * (N - 1) + (size_t)(nn + nm) * k;
-        float* g = a.g + (size_t)b * ((size_t)(n + m) * N - m) + (size_t)(n + m) * k;
-        float* c = a.c + (size_t)b * (size_t)n * N;
-        const double dt = a.dt;
-        for (int e = lane; e < nn; e += KKT_THREADS) {
-            const int r = e % n, col = e / n;                          // column-major
-            // A = I + dt [[0, I], [dqdd/dq, dqdd/dqd]]
-            double av = (r == col) ? 1.0 : 0.0;
-            if (r < PJ) av += (col == r + PJ) ? dt : 0.0;
-            else av += dt * (col < PJ ? sDq[r - PJ][col] : sDqd[r - PJ][col - PJ]);
-            Cm[e] = (float)(-av);
-            // Q = blkdiag(g g^T, QD I)
-            double qv = 0.0;
-            if (r < PJ && col < PJ) qv = sGq[r] * sGq[col];
-            else if (r == col) qv = a.qd_cost;
-            G[e] = (float)qv;
-            if (k == N - 2) {
-                double q1 = 0.0;
-                if (r < PJ && col < PJ) q1 = sGq1[r] * sGq1[col];
-                else if (r == col) q1 = a.qd_cost;
-                G[(nn + mm) + e] = (float)q1;
+        if (live) {
+            float* G = a.G + (size_t)b * ((size_t)(nn + mm) * N - mm) + (size_t)(nn + mm) * k;
+            float* Cm = a.C + (size_t)b * (size_t)(nn + nm) * (N - 1) + (size_t)(nn + nm) * k;
+            float* g = a.g + (size_t)b * ((size_t)(n + m) * N - m) + (size_t)(n + m) * k;
+            float* c = a.c + (size_t)b * (size_t)n * N;
+            const double dt = a.dt;
+            for (int e = l; e < nn; e += KKT_GL) {
+                const int col = e / n, r = e - col * n;                    // column-major
+                // A = I + dt [[0, I], [dqdd/dq, dqdd/dqd]]
+                double av = (r == col) ? 1.0 : 0.0;
+                if (r < PJ) av += (col == r + PJ) ? dt : 0.0;
+                else av += dt * (col < PJ ? I.Dq[r - PJ][col] : I.Dqd[r - PJ][col - PJ]);
+                Cm[e] = (float)(-av);
+                // Q = blkdiag(g g^T, QD I)
+                double qv = 0.0;
+                if (r < PJ && col < PJ) qv = I.Gq[r] * I.Gq[col];
+                else if (r == col) qv = a.qd_cost;
+                G[e] = (float)qv;
+                if (k == N - 2) {
+                    double q1 = 0.0;
+                    if (r < PJ && col < PJ) q1 = I.Gq1[r] * I.Gq1[col];
+                    else if (r == col) q1 = a.qd_cost;
+                    G[(nn + mm) + e] = (float)q1;
+                }
             }
-        }
-        for (int e = lane; e < nm; e += KKT_THREADS) {
-            const int r = e % n, col = e / n;                          // B = dt [0; Minv]
-            Cm[nn + e] = (float)(-(r < PJ ? 0.0 : dt * sMinv[r - PJ][col]));
-        }
-        for (int e = lane; e < mm; e += KKT_THREADS) G[nn + e] = (float)((e % m == e / m) ? a.r_cost : 0.0);
-        if (lane < n) {
-            g[lane] = (float)(lane < PJ ? sGq[lane] : a.qd_cost * qd[lane - PJ]);
-            if (k == N - 2) g[(n + m) + lane] = (float)(lane < PJ ? sGq1[lane] : a.qd_cost * qd[lane - PJ]);     // (evaluated at x_{N-2}: iiwa_eepos_plant.cuh:407)
-            // integrator defect c_{k+1} = x_{k+1} - (x_k + dt [qd; qdd])
-            const double pred = lane < PJ ? q[lane] + dt * qd[lane] : qd[lane - PJ] + dt * sQdd[lane - PJ];
-            c[(size_t)n * (k + 1) + lane] = (float)((double)xu[(n + m) + lane] - pred);
-            if (k == 0) c[lane] = (float)((double)xu[lane] - (double)a.xs[(size_t)b * n + lane]);
-        } else if (lane < n + m) {
-            g[lane] = (float)(a.r_cost * u[lane - n]);
+            for (int e = l; e < nm; e += KKT_GL) {
+                const int col = e / n, r = e - col * n;                    // B = dt [0; Minv]
+                Cm[nn + e] = (float)(-(r < PJ ? 0.0 : dt * I.Minv[r - PJ][col]));
+            }
+            for (int e = l; e < mm; e += KKT_GL) G[nn + e] = (float)((e % m == e / m) ? a.r_cost : 0.0);
+            if (l < n) {
+                const double qdl = I.Xq[l < PJ ? l + PJ : l];              // qd_{l mod 7}
+                g[l] = (float)(l < PJ ? I.Gq[l] : a.qd_cost * qdl);
+                if (k == N - 2) g[(n + m) + l] = (float)(l < PJ ? I.Gq1[l] : a.qd_cost * qdl);     // (evaluated at x_{N-2}: iiwa_eepos_plant.cuh:407)
+                // integrator defect c_{k+1} = x_{k+1} - (x_k + dt [qd; qdd])
+                const double pred = l < PJ ? I.Xq[l] + dt * qdl : qdl + dt * I.Qdd[l - PJ];
+                c[(size_t)n * (k + 1) + l] = (float)((double)xu[(n + m) + l] - pred);
+                if (k == 0) c[l] = (float)((double)xu[l] - (double)a.xs[(size_t)b * n + l]);
+            }
+            if (l < m) g[n + l] = (float)(a.r_cost * I.U[l]);
         }
         __syncthreads();
     }

@@ -1070,7 +1070,7 @@ int mpcg_generate_kkt(mpcg_handle* h, const mpcg_plant* plant, uint32_t control_
     a.plant = plant->d; a.eePos_traj = d_eePos_traj; a.xs = d_xs; a.xu = d_xu;
     a.G = d_G_dense; a.C = d_C_dense; a.g = d_g; a.c = d_c;
     a.N = (int)h->N; a.batch = (int)batch; a.dt = timestep; a.qd_cost = qd_cost; a.r_cost = r_cost;
-    long blocks = (long)batch * (h->N - 1);
+    long blocks = ((long)batch * (h->N - 1) + KKT_ITEMS - 1) / KKT_ITEMS;      // one wavefront per KKT_ITEMS (trajectory, knot) pairs
     const long cap = (long)h->num_cus * 32;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(generate_kkt_kernel, dim3((unsigned)blocks), dim3(KKT_THREADS), 0, static_cast<hipStream_t>(stream), a);
