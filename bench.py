@@ -545,6 +545,34 @@ def main():
                                             "us_per_pcg_iter": ms1 * 1e3 / max(int(i1.item()), 1),
                                             "kernel_family": sol1.get_option("last_kernel_family"), "kernel_waves": sol1.get_option("last_kernel_waves")}
 
+    if extras and rank == 0 and world == 1 and not lean:
+        # horizons one CU cannot hold (BASELINE config 5's N = 512, and N = 256): the clustered lane-per-block kernel, fixed
+        # iteration counts = the reference's caps (settings.cuh:123-139); 256 resident systems tiled to the batch
+        lh = {}
+        for Nl in (256, 512):
+            sl = PcgSolver(Nl, max_batch=B, device=local_rank)
+            S0, P0, g0 = build_inputs(sl, Nl, 32, seed0, "ss", dev, chunk=32)
+            rep = (B + 31) // 32
+            Sl, Pl, gl = (t.repeat(rep, 1)[:B].contiguous() for t in (S0, P0, g0))
+            del S0, P0
+            cl = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=synth.pcg_max_iter(Nl))
+            ll = torch.zeros(B, 14 * Nl, device=dev)
+            il = torch.zeros(B, dtype=torch.int32, device=dev)
+            xl = torch.zeros(B, dtype=torch.uint8, device=dev)
+
+            def run_b(nb):
+                ll[:nb].zero_()
+                sl.solve(Sl[:nb], Pl[:nb], gl[:nb], ll[:nb], cl, "ss", iters=il[:nb], exits=xl[:nb])
+            ms_b = timed(lambda: run_b(B), 5, warm=1)
+            its = int(il.sum().item())
+            ms_1 = timed(lambda: run_b(1), 15, warm=3)
+            assert int(xl.max().item()) <= 1, "a cluster gave up"
+            lh[f"N{Nl}"] = {"pcg_iters_per_solve": synth.pcg_max_iter(Nl), "batch": B, "kernel_ms": ms_b, "pcg_iterations_per_sec": its / (ms_b * 1e-3),
+                            "ms_one_trajectory": ms_1, "us_per_pcg_iter_one_trajectory": ms_1 * 1e3 / synth.pcg_max_iter(Nl),
+                            "kernel_family": sl.get_option("last_kernel_family"), "members_per_trajectory": sl.get_option("last_kernel_cluster")}
+            del Sl, Pl, gl, ll, sl
+        out["long_horizon"] = lh
+
     if extras and rank == 0 and not lean:
         # the other selectable solver on the same resident systems: batched block-tridiagonal direct solve
         # (GPU counterpart of the reference's QDLDL path, i.e. of what cpu_baseline times on the host)
