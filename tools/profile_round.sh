@@ -18,4 +18,4 @@ cd $R
 python tools/rocprof_summary.py stats $(find gpurun_out/${TAG}_prof -name "*.db" | head -1) > gpurun_out/${TAG}_kernel_stats.txt
 python tools/rocprof_summary.py pmc $(find gpurun_out/${TAG}_pmc_f gpurun_out/${TAG}_pmc_w gpurun_out/${TAG}_pmc_s1 gpurun_out/${TAG}_pmc_s2 -name "*.db") > gpurun_out/${TAG}_pmc.json
 for d in prof pmc_f pmc_w pmc_s1 pmc_s2; do rm -rf gpurun_out/${TAG}_$d; done
-cat gpurun_out/${TAG}_pytest_gpu.log; head -14 gpurun_out/${TAG}_kernel_stats.txt; tail -c 300 gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/rocprof*.err
+cat gpurun_out/${TAG}_pytest_gpu.log; head -14 gpurun_out/${TAG}_kernel_stats.txt; tail -c 300 gpurun_out/${TAG}_bench.json; for f in gpurun_out/rocprof*.err; do tail -n 3 $f; done

@@ -26,6 +26,19 @@ def stats(db):
     tot = sum(r[2] for r in rows)
     for nm, n, t, a, mn, mx in rows:
         print(f"{short(nm):90s} {n:6d} {t:12.2f} {a:12.2f} {mn:12.2f} {mx:12.2f} {100 * t / tot:6.2f}")
+    # the same kernels by launch shape (grid size): a bench run launches one kernel on several batch sizes, and bench.py's
+    # roofline objects each describe ONE of them; median = robust against the few small side launches of persistent-grid kernels
+    print("# by launch shape: kernel | grid_x | calls | avg_us | median_us")
+    try:
+        shapes = {}
+        for nm, grid, dur in c.execute("select k.name, d.grid_size_x, (k.end - k.start) / 1e3 from kernels k join rocpd_kernel_dispatch d "
+                                       "on d.dispatch_id = k.dispatch_id where k.name like '%mpcg%'"):
+            shapes.setdefault((nm, grid), []).append(dur)
+        for (nm, grid), ds in sorted(shapes.items(), key=lambda kv: -sum(kv[1])):
+            ds.sort()
+            print(f"#   {short(nm):80s} {grid:9d} {len(ds):6d} {sum(ds) / len(ds):12.2f} {ds[len(ds) // 2]:12.2f}")
+    except sqlite3.Error as e:
+        print("#   (shape join failed:", e, ")")
     print("# per-dispatch resources")
     try:
         for r in c.execute("select distinct k.name, s.arch_vgpr_count, s.accum_vgpr_count, s.sgpr_count, d.group_segment_size, "
