@@ -99,6 +99,16 @@ const char* mpcg_build_info(void) {
     return "libmpcg_hip gfx950 fp32 n=14 (lane-per-block register-resident PCG, clustered PCG for long horizons, wave64 row-triple streaming PCG)";
 }
 
+// device scratch of the cluster kernels, shared by both (they never run concurrently on one handle):
+//   row-triple cluster kernel   [flags: one 128-byte line per trajectory of a launch, at most one per CU][cells: 512 B per member]
+//   clustered lane-per-block    [cells][queue line][flags: one line per trajectory of the CALL, up to max_batch]
+static size_t cluster_alloc_words(const mpcg_handle* h) {
+    const size_t cells = (size_t)2 * h->num_cus * CL_WG_WORDS;
+    const size_t a = (size_t)h->num_cus * CL_FLAG_STRIDE + cells;
+    const size_t b = cells + CL_FLAG_STRIDE + (size_t)h->max_batch * CL_FLAG_STRIDE;
+    return a > b ? a : b;
+}
+
 size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
     if (generic_shape_supported(state_size, knot_points)) return pcg_generic_lds_elems((int)knot_points, (int)state_size) * sizeof(float);
     if (!shape_supported(state_size, knot_points)) return 0;
@@ -141,11 +151,11 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     // hand-off cells of the cluster kernel (512 B per member, up to two members per CU), allocated here so that every solve is pure stream work
     // and can be captured into a hipGraph
     if (hipSetDevice(device) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&h->cluster_scratch), ((size_t)h->num_cus * CL_FLAG_STRIDE + (size_t)2 * h->num_cus * CL_WG_WORDS) * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void**>(&h->cluster_scratch), cluster_alloc_words(h) * sizeof(unsigned long long)) != hipSuccess) {
         delete h;
         return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the cluster scratch");
     }
-    (void)hipMemset(h->cluster_scratch, 0, ((size_t)h->num_cus * CL_FLAG_STRIDE + (size_t)2 * h->num_cus * CL_WG_WORDS) * sizeof(unsigned long long));
+    (void)hipMemset(h->cluster_scratch, 0, cluster_alloc_words(h) * sizeof(unsigned long long));
     *out = h;
     return MPCG_OK;
 }
@@ -516,12 +526,16 @@ static int lpbc_members(const mpcg_handle* h, int nmax) {
     if (((int)h->N + G - 1) / G > nmax) return 0;        // the largest member: ceil(N / G) knots
     return G;
 }
+// scratch of the clustered lane-per-block kernel: [queue: one 128-byte line][flags: one line per trajectory of the call = members that
+// finished it][cells: 512 B per member of the launch] — what a call uses is contiguous, so one small fill precedes every launch
 template <int NWR>
 static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
     constexpr int per_cu = NWR == 2 ? 1 : 2;
     const int G = lpbc_members(h, 64 * NWR);
     if (G == 0) return 1;
-    const uint32_t chunk = (uint32_t)(per_cu * h->num_cus / G);
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "batch exceeds max_batch");
+    const uint32_t resident = (uint32_t)(per_cu * h->num_cus / G);       // clusters the chip holds
+    const uint32_t clusters = batch < resident ? batch : resident;
     const size_t lds = pcg_lpbc_lds_floats(4 * NWR) * sizeof(float);
     auto kern = pcg_lpbc_kernel<NWR>;
     if (lds > 48 * 1024)
@@ -529,36 +543,29 @@ static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, h
     PcgKnobs kf = h->k;
     choose_auto(h, kf, 1, 4);
     const bool fixup = h->cluster_fixup && (h->N <= kLpbMaxN || lds_bytes_for(h->N, kf.waves) <= kLdsMax);
-    const size_t mstride = (size_t)h->N * ROWF, vstride = (size_t)h->N * NS;
-    for (uint32_t lo = 0; lo < batch; lo += chunk) {
-        const uint32_t nb = batch - lo < chunk ? batch - lo : chunk;
-        ClusterArgs ca;
-        ca.kl_max = 64 * NWR;
-        ca.p = a;
-        ca.p.S = static_cast<const float*>(a.S) + lo * mstride;
-        ca.p.Pinv = static_cast<const float*>(a.Pinv) + lo * mstride;
-        ca.p.gamma = a.gamma + lo * vstride;
-        ca.p.lambda = a.lambda + lo * vstride;
-        if (a.r_out) ca.p.r_out = a.r_out + lo * vstride;
-        if (a.p_out) ca.p.p_out = a.p_out + lo * vstride;
-        ca.p.iters = a.iters + lo;
-        ca.p.max_iter_exit = a.max_iter_exit + lo;
-        ca.fail_flags = h->cluster_scratch; ca.scratch = h->cluster_scratch + cluster_flag_words(h); ca.G = G;
-        const size_t zw = cluster_flag_words(h) + (size_t)nb * G * CL_WG_WORDS;
-        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster_scratch, zw);
-        HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL(kern, dim3(nb * (unsigned)G), dim3(NWR * 256), lds, st, ca);
-        HIP_TRY(h, hipGetLastError());
-        h->last = LastKernel{FAM_LPBC, 4 * NWR, 0, 0, 0, G, (int)lds, 0};
-        if (fixup) {
-            PcgArgs c = ca.p;
-            c.redo_flags = h->cluster_scratch;
-            c.redo_stride = CL_FLAG_STRIDE;
-            const int rc = h->N <= kLpbMaxN ? launch_lpb(h, c, nb, st) : launch_traj(h, kf, c, nb, st, 4, /*record=*/false);
-            if (rc != MPCG_OK) return rc;
-            h->last = LastKernel{FAM_LPBC, 4 * NWR, 0, 0, 0, G, (int)lds, 0};
-        }
+    ClusterArgs ca;
+    ca.kl_max = 64 * NWR;
+    ca.p = a;
+    ca.queue = h->cluster_scratch;
+    ca.fail_flags = ca.queue + CL_FLAG_STRIDE;
+    ca.scratch = ca.fail_flags + (size_t)batch * CL_FLAG_STRIDE;
+    ca.G = G;
+    ca.batch = (int)batch;
+    // one fill: the queue counter, this call's flags and the cells of this launch (their tags restart at 1 every launch)
+    const size_t zw = CL_FLAG_STRIDE + (size_t)batch * CL_FLAG_STRIDE + (size_t)clusters * G * CL_WG_WORDS;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster_scratch, zw);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(kern, dim3(clusters * (unsigned)G), dim3(NWR * 256), lds, st, ca);
+    HIP_TRY(h, hipGetLastError());
+    if (fixup) {
+        PcgArgs c = a;
+        c.redo_flags = ca.fail_flags;
+        c.redo_stride = CL_FLAG_STRIDE;
+        c.redo_skip = (unsigned)G;
+        const int rc = h->N <= kLpbMaxN ? launch_lpb(h, c, batch, st) : launch_traj(h, kf, c, batch, st, 4, /*record=*/false);
+        if (rc != MPCG_OK) return rc;
     }
+    h->last = LastKernel{FAM_LPBC, 4 * NWR, 0, 0, 0, G, (int)lds, 0};
     return MPCG_OK;
 }
 static int try_launch_lpbc(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {

@@ -184,9 +184,11 @@ struct PcgArgs {
     int N; int max_iter; float exit_tol; int pcols;   // pcols: 3 = SS, 1 = block-Jacobi
     int lds_rows;                          // LT: triples per matrix per wave cached in LDS
     int lds_extra_s, lds_extra_p;          // <.,.,1> kernels: waves 0..x-1 cache one more triple of S / of Pinv in LDS
-    // fix-up launches behind the cluster kernel: trajectory b runs only if redo_flags[b * redo_stride] != 0
+    // fix-up launches behind a cluster kernel: trajectory b runs only if redo_flags[b * redo_stride] != redo_skip
+    // (row-triple cluster kernel: flag = "a member gave up", skip 0;  clustered lane-per-block kernel: flag = members that finished, skip G)
     const unsigned long long* redo_flags = nullptr;
     int redo_stride = 0;
+    unsigned redo_skip = 0;
 };
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : N
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     constexpr int NTHR = NW * 64;
-    if (a.redo_flags && __hip_atomic_load(a.redo_flags + (size_t)b * a.redo_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+    if (a.redo_flags && __hip_atomic_load(a.redo_flags + (size_t)b * a.redo_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.redo_skip)
         return;                                        // (uniform) nothing to redo for this trajectory
 
     float* xp = lds;                                   // knot j at xp + (j+1)*NS
@@ -709,8 +711,10 @@ struct ClusterArgs {
     int kl_max;                              // knots of the largest member: 3 * ceil(#triples / G)
     PcgArgs p;
     unsigned long long* scratch;         // [batch*G][CL_WG_WORDS], zeroed before the launch
-    unsigned long long* fail_flags;      // [batch][CL_FLAG_STRIDE], zeroed before the launch
+    unsigned long long* fail_flags;      // [batch][CL_FLAG_STRIDE], zeroed before the launch (lane-per-block clusters: count of members that finished)
     int G;
+    unsigned long long* queue = nullptr; // lane-per-block clusters: next trajectory to hand out (zeroed before the launch)
+    int batch = 0;                       //   "  : trajectories of the call
 };
 
 template <int NW, int RT, bool ADJ>

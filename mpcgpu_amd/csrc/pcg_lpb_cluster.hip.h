@@ -17,50 +17,78 @@
 // cluster kernel needs four (2 all-reduces + 2 halo fetches) and re-reads nothing either, but runs the slower
 // row-pair arithmetic.  No operand halo is ever waited for inside a pass.
 //
-// Same fail-safe as pcg_cluster_kernel: bounded spins, a member that times out flags the trajectory, the host follows
-// every launch with the single-workgroup kernel restricted to flagged trajectories.
+// Clusters are PERSISTENT: the launch holds as many clusters as fit the chip (every member resident) and each cluster draws
+// trajectories from a queue (one atomic counter; the leader publishes the index to its peers as one more tagged granule)
+// until the batch is done.  A call of any batch size is ONE launch, and solves that exit early on the tolerance — the MPC
+// loop's warm-started solves: 25 iterations on average, a few at the cap — do not hold a whole wave of clusters back.
+//
+// Same fail-safe as pcg_cluster_kernel: bounded spins; every member that FINISHES a trajectory counts itself in that
+// trajectory's flag word, a member that times out stops (and so, one bounded spin later, do its peers); the host follows the
+// launch with the single-workgroup kernel restricted to the trajectories whose count is not G — abandoned or never drawn.
 #pragma once
 #include "pcg_lpb.hip.h"
 
 namespace mpcg {
 
 // LDS layout: six vectors of NMAX + 2 knot slots.  Slot 0 = replica of knot k0 - 1, slots 1..KL = own knots, slot NMAX + 1 = dump
-// of idle lanes.  p | r | lambda | yD | yL | yT | 2 NW wave partials | broadcast cell.
+// of idle lanes.  p | r | lambda | yD | yL | yT | 2 NW wave partials | broadcast cell | hand-off tables.
 template <int NWR> struct LpbcLds {
     static constexpr int NMAX = 64 * NWR, NW = 4 * NWR, SLOTS = NMAX + 2, DUMP = NMAX + 1;
     static constexpr int VS = (int)r4((size_t)SLOTS * NS);
     static constexpr int XP = 0, XR = VS, LAM = 2 * VS, YD = 3 * VS, YL = 4 * VS, YT = 5 * VS, RED = 6 * VS, BC = RED + (int)r4(2 * NW),
-                         TOTAL = BC + 4;
+                         TAB = BC + 4,          // 3 x 64 ints: what lane l of the publishing wave polls / publishes (filled once per launch)
+                         TOTAL = TAB + 3 * 64;
 };
 __host__ __device__ constexpr size_t pcg_lpbc_lds_floats(int NW) { return NW == 4 ? (size_t)LpbcLds<1>::TOTAL : (size_t)LpbcLds<2>::TOTAL; }
 
 constexpr int LPBC_MAX_G = 16;             // members whose partials one wave polls with lanes 0..15
 constexpr int LPBC_SLOT_V = 0, LPBC_SLOT_E = 32;     // granule words of the two alternating exchanges inside a member's CL_WG_WORDS block
+constexpr int LPBC_SLOT_T = 62;                      // leader only: {sequence number, trajectory index} of the cluster's current trajectory
+
+// Granule accesses in the "uniform 64-bit base (SGPR pair) + 32-bit lane byte offset" addressing form, spelled out: left to
+// the compiler, the per-lane addresses of the two exchange slots become 64-bit VGPR pointers that are hoisted out of the PCG
+// loop — four registers this kernel does not have; they spill, and the publishing wave reloads its store address from scratch
+// right in front of every hand-off.  (s_nop 4: the base may just have been written by a v_readlane — an SGPR spill reload — and a
+// VMEM instruction reading a VALU-written SGPR needs 5 wait states; the compiler's hazard recogniser does not look into asm.)
+// sc1 = agent scope (write-through store / L2-coherent load), as __hip_atomic_*(relaxed, agent).
+// WORD = compile-time word index inside the member's block of cells: the instruction's immediate offset, so that the two exchange
+// slots and the hand-out word share ONE base register pair.
+template <int WORD>
+__device__ __forceinline__ void granule_store(gu64* sbase, unsigned byte_off, unsigned long long v) {
+    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 offset:%3 sc1" : : "v"(byte_off), "v"(v), "s"(sbase), "n"(8 * WORD) : "memory");
+}
+template <int WORD>
+__device__ __forceinline__ unsigned long long granule_load(const gu64* sbase, unsigned byte_off) {
+    unsigned long long x;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:%3 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(byte_off), "s"(sbase), "n"(8 * WORD) : "memory");
+    return x;
+}
 
 template <int NWR>
 __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) {
     typedef LpbcLds<NWR> L;
     constexpr int NW = 4 * NWR, NTHR = NW * 64;
     const PcgArgs& a = ca.p;
+    typedef const __attribute__((address_space(4))) ClusterArgs* kargp_t;
+    const kargp_t kp = (kargp_t)__builtin_amdgcn_kernarg_segment_ptr();     // `ca` itself, in the constant address space
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int N = a.N;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = ca.G;
-    const int b = blockIdx.x / G;                       // trajectory
-    const int g = blockIdx.x - b * G;                   // member of its cluster
+    const int cl = blockIdx.x / G;                      // cluster of this launch
+    const unsigned nclusters = gridDim.x / (unsigned)G;
+    const int g = blockIdx.x - cl * G;                  // member of its cluster
     const int k0 = (int)(((long)g * N) / G), k1 = (int)(((long)(g + 1) * N) / G);
     const int KL = k1 - k0;                             // own knots (launcher: 1 <= KL <= NMAX)
     float* red_v = lds + L::RED;
     float* red_e = red_v + NW;
-    float* bc = lds + L::BC;                            // [0] cluster-wide sum, [1] sticky timeout flag
+    float* bc = lds + L::BC;                            // [0] cluster-wide sum, [1] sticky timeout flag, [2] trajectory index (int)
 
     const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;
-    const float* gam = a.gamma + (size_t)b * vstride;
-    float* lam_g = a.lambda + (size_t)b * vstride;
     gu64* my_words = (gu64*)ca.scratch + (size_t)blockIdx.x * CL_WG_WORDS;
-    gu64* cl_words = (gu64*)ca.scratch + (size_t)b * G * CL_WG_WORDS;
+    gu64* cl_words = (gu64*)ca.scratch + (size_t)cl * G * CL_WG_WORDS;
 
     // ---- role of this wave, block of this lane (pcg_lpb_kernel's roles; i = index of the block inside the member) ----
     const int role = w / NWR;
@@ -74,33 +102,11 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
     float* const wk = lds + (valid ? i + 1 : L::DUMP) * NS;
 
     f4 m4[BLK4];
-    {
-        const rsrc_t M = make_rsrc((isP ? static_cast<const float*>(a.Pinv) : static_cast<const float*>(a.S)) + (size_t)b * mstride,
-                                   (uint32_t)(mstride * sizeof(float)));
-        const uint32_t off = valid ? (uint32_t)((k0 + i) * 3 + (isL ? 0 : 1)) * (BLK4 * 16u) : OOB_OFF;
-#pragma unroll
-        for (int c = 0; c < BLK4; ++c) m4[c] = buf_load4<false>(M, off + 16u * c);
-    }
     auto mp = [&](int u, int r) -> f2 {
         const int e = NS * u + 2 * r;
         const f4 v = m4[e >> 2];
         return (e & 2) ? f2{v.z, v.w} : f2{v.x, v.y};
     };
-
-    // ---- stage: parts <- 0 (yL of the replica slot: -0, so that (s + yL) + t keeps the bits of s), p <- lambda0, r <- gamma
-    //      for the own knots AND the replica (both complete in global memory), lambda <- lambda0 ----
-    for (int e = tid; e < 6 * L::VS; e += NTHR) lds[e] = 0.f;
-    lds_barrier();
-    if (tid < NS) lds[L::YL + tid] = -0.f;
-    for (int e = tid + (g == 0 ? NS : 0); e < (KL + 1) * NS; e += NTHR) {
-        const int ge = (k0 - 1) * NS + e;               // element of the global [N][14] vector
-        const float l0 = lam_g[ge];
-        lds[L::XP + e] = l0;
-        lds[L::LAM + e] = l0;
-        lds[L::XR + e] = gam[ge];
-    }
-    if (tid == 0) { bc[0] = 0.f; bc[1] = 0.f; }
-    lds_barrier();
 
     auto wave_fold = [&](float part) -> float {
         asm volatile(
@@ -173,40 +179,42 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
         }
     };
 
-    unsigned epoch = 0;
+    unsigned epoch = 0, seq = 0;                       // hand-offs / trajectories of this cluster so far: tags never repeat inside a launch
     bool failed = false;                               // uniform across the workgroup (published through LDS)
     // The one hand-off of a pass.  Called by all threads after the pass; returns the cluster-wide inner product.  On return
     // yD[slot 0] holds the left neighbour's s and yT[slot KL] the right neighbour's t (where those neighbours exist).
     // parts3: the pass wrote off-diagonal parts (false for the block-Jacobi preconditioner pass: s = yD alone).
-    auto exchange = [&](float* red, int base, bool parts3) -> float {
+    using SlotV = std::integral_constant<int, LPBC_SLOT_V>;
+    using SlotE = std::integral_constant<int, LPBC_SLOT_E>;
+    auto exchange = [&](float* red, auto slot, bool parts3) -> float {
+        constexpr int base = decltype(slot)::value;
         lds_barrier();                                  // parts and wave partials are in LDS
         ++epoch;
         if (w == 0) {
-            float val = 0.f;
+            // What this lane publishes and polls comes from three small LDS tables (filled once per launch): as registers they would be
+            // live across the PCG loop, which has none to spare; recomputed here they were 80 instructions on the serial path of every hand-off.
+            int lane;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+            const int* tab = reinterpret_cast<const int*>(lds + L::TAB) + lane;
+            const unsigned poll_byte = (unsigned)tab[0];           // 0xFFFFFFFF: nothing to poll
+            const int ia = tab[64], ib = parts3 ? tab[128] : L::BC + 3;   // s = yD + yL (block-Jacobi pass: yD + 0), t = yT + 0
+            const bool want = poll_byte != 0xFFFFFFFFu;
+            float val;
             if (lane == 0) {
+                val = 0.f;
 #pragma unroll
                 for (int c = 0; c < NW; ++c) val += red[c];
-            } else if (lane <= NS) {
-                const int e = KL * NS + lane - 1;       // s: last own knot
-                val = parts3 ? lds[L::YD + e] + lds[L::YL + e] : lds[L::YD + e];
-            } else if (lane <= 2 * NS) {
-                val = lds[L::YT + lane - 1 - NS];       // t: slot 0 (zero on member 0 and for a block-Jacobi pass... never read then)
+            } else {
+                val = lds[ia] + lds[ib];
             }
-            if (lane <= 2 * NS)
-                __hip_atomic_store(my_words + base + lane, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, val),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // lanes 0..G-1: partial of member `lane` | 16..29: s of member g-1 | 32..45: t of member g+1
-            const bool want = lane < G || (g > 0 && lane >= 16 && lane < 16 + NS) || (g < G - 1 && lane >= 32 && lane < 32 + NS);
-            const gu64* src = lane < 16 ? cl_words + (size_t)(lane < G ? lane : 0) * CL_WG_WORDS + base
-                            : lane < 32 ? cl_words + (size_t)(g > 0 ? g - 1 : 0) * CL_WG_WORDS + base + 1 + (lane < 16 + NS ? lane - 16 : 0)
-                                        : cl_words + (size_t)(g < G - 1 ? g + 1 : 0) * CL_WG_WORDS + base + 1 + NS + (lane < 32 + NS ? lane - 32 : 0);
+            if (lane <= 2 * NS) granule_store<base>(my_words, 8u * (unsigned)lane, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, val));
             unsigned long long x = 0;
             unsigned spins = 0;
             bool ok;
             do {
                 ok = true;
                 if (want) {
-                    x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x = granule_load<base>(cl_words, poll_byte);
                     ok = (unsigned)(x >> 32) == epoch;
                 }
                 if (__all(ok)) break;
@@ -236,79 +244,170 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
     const bool ok0 = e_lo + tid < e_hi, ok1 = e_lo + tid + NTHR < e_hi;
     const int e0 = ok0 ? e_lo + tid : e_lo, e1 = ok1 ? e_lo + tid + NTHR : e0;
 
-    // ---- setup: r = gamma - S lambda0 ; r~ = Pinv r ; p = r~ ; eta = r . r~ ----
-    if (lane == 0) { red_v[w] = 0.f; red_e[w] = 0.f; }
-    if (!isP) pass(L::XP, red_v);
-    (void)exchange(red_v, LPBC_SLOT_V, true);
-    if (ok0) xr2[e0] = xr2[e0] - ((yD2[e0] + yL2[e0]) + yT2[e0]);
-    if (ok1) xr2[e1] = xr2[e1] - ((yD2[e1] + yL2[e1]) + yT2[e1]);
-    lds_barrier();
-    if (isP && wave_on) pass(L::XR, red_e);
-    float eta = exchange(red_e, LPBC_SLOT_E, p3);
-    if (ok0) xp2[e0] = p3 ? (yD2[e0] + yL2[e0]) + yT2[e0] : yD2[e0];
-    if (ok1) xp2[e1] = p3 ? (yD2[e1] + yL2[e1]) + yT2[e1] : yD2[e1];
-    lds_barrier();
-    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): see pcg_lpb_kernel
-
-    uint32_t iters = 0;
-    uint32_t max_iter_exit = 1;
-    if (failed) {
-        iters = 0xFFFFFFFFu; max_iter_exit = 2;
-    } else if (fabsf(eta) < a.exit_tol) {
-        max_iter_exit = 0;
-    } else {
-        for (int it = 0; it < a.max_iter; ++it) {
-            // upsilon = S p ; v = p . upsilon
-            if (!isP) pass(L::XP, red_v);
-            const float alpha = eta / exchange(red_v, LPBC_SLOT_V, true);
-            {
-                const f2 d0 = yD2[e0], l0 = yL2[e0], t0 = yT2[e0], r0 = xr2[e0];
-                const f2 d1 = yD2[e1], l1 = yL2[e1], t1 = yT2[e1], r1 = xr2[e1];
-                if (ok0) xr2[e0] = r0 - alpha * ((d0 + l0) + t0);
-                if (ok1) xr2[e1] = r1 - alpha * ((d1 + l1) + t1);
-            }
-            lds_barrier();
-            // r~ = Pinv r ; eta' = r . r~          | S waves: lambda += alpha p (own knots)
-            if (isP) {
-                if (wave_on) pass(L::XR, red_e);
-            } else {
-                for (int e = NS / 2 + tid; e < e_hi; e += NTHR / 2) lam2[e] = lam2[e] + alpha * xp2[e];
-            }
-            const float eta_new = exchange(red_e, LPBC_SLOT_E, p3);
-            if (failed) { iters = 0xFFFFFFFFu; max_iter_exit = 2; break; }
-            iters = (uint32_t)(it + 1);
-            if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
-            {
-                f2 rt0 = yD2[e0], rt1 = yD2[e1];
-                const f2 p0 = xp2[e0], p1 = xp2[e1];
-                if (p3) {
-                    const f2 l0 = yL2[e0], t0 = yT2[e0], l1 = yL2[e1], t1 = yT2[e1];
-                    rt0 = (rt0 + l0) + t0;
-                    rt1 = (rt1 + l1) + t1;
+    if (tid == 0) { bc[0] = 0.f; bc[1] = 0.f; bc[3] = 0.f; }     // bc[3]: the zero a one-part message adds
+    if (tid < 64) {
+        // lanes 0..G-1 poll the partial of member `lane` | 16..29: s of member g-1 | 32..45: t of member g+1 (byte offset into the cluster's cells)
+        const int l = tid;
+        const bool want = l < G || (g > 0 && l >= 16 && l < 16 + NS) || (g < G - 1 && l >= 32 && l < 32 + NS);
+        const int word = l < 16 ? l * CL_WG_WORDS : l < 32 ? (g - 1) * CL_WG_WORDS + 1 + (l - 16) : (g + 1) * CL_WG_WORDS + 1 + NS + (l - 32);
+        int* tab = reinterpret_cast<int*>(lds + L::TAB) + l;
+        tab[0] = want ? 8 * word : -1;
+        // lanes 1..14 publish s = (yD + yL) of the last own knot, lanes 15..28 t = yT of slot 0
+        tab[64] = l >= 1 && l <= NS ? L::YD + KL * NS + l - 1 : l > NS && l <= 2 * NS ? L::YT + l - 1 - NS : L::BC + 3;
+        tab[128] = l >= 1 && l <= NS ? L::YL + KL * NS + l - 1 : L::BC + 3;
+    }
+    for (;;) {
+        // ---- next trajectory of this cluster.  The first one is its own index; further ones the leader draws from the queue
+        //      (which therefore starts at the number of clusters) and hands to its peers.  A call that fits the chip in one go
+        //      — the single-trajectory MPC case — never touches the queue. ----
+        ++seq;
+        if (seq > 1) {
+            if ((unsigned)ca.batch <= nclusters) break;
+            if (w == 0) {
+                int bn = 0;
+                if (g == 0) {
+                    if (lane == 0) {
+                        kargp_t k_q = kp;
+                        asm volatile("" : "+s"(k_q));
+                        bn = (int)nclusters + (int)__hip_atomic_fetch_add(k_q->queue, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        granule_store<LPBC_SLOT_T>(my_words, 0u, ((unsigned long long)seq << 32) | (unsigned)bn);
+                    }
+                } else {
+                    unsigned long long x = 0;
+                    unsigned spins = 0;
+                    do {
+                        x = granule_load<LPBC_SLOT_T>(cl_words, 0u);
+                        if ((unsigned)(x >> 32) == seq) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    } while (++spins < CL_SPIN_LIMIT);
+                    bn = (int)(unsigned)x;
+                    if (spins >= CL_SPIN_LIMIT && lane == 0) bc[1] = 1.f;
                 }
-                const float beta = eta_new / eta;
-                if (ok0) xp2[e0] = rt0 + beta * p0;
-                if (ok1) xp2[e1] = rt1 + beta * p1;
-                eta = eta_new;
+                if (lane == 0) reinterpret_cast<int*>(bc)[2] = bn;
             }
-            lds_barrier();
+        } else if (tid == 0) {
+            reinterpret_cast<int*>(bc)[2] = cl;
         }
-    }
+        lds_barrier();
+        const int b = reinterpret_cast<const int*>(bc)[2];
+        if (bc[1] != 0.f || b >= ca.batch) break;
+        // Per-trajectory pointers are read from the kernel-argument segment where they are used (opaque copy of its address per
+        // use site): kept in SGPRs for the whole kernel they push the scalar register file over its 102 — the compiler then
+        // parks SGPRs in VGPR lanes (two fewer VGPRs for the matrix, v_readlane traffic inside the PCG loop).
+        kargp_t k_in = kp;
+        asm volatile("" : "+s"(k_in));
+        const float* gam = k_in->p.gamma + (size_t)b * vstride;
+        const float* lam_in = k_in->p.lambda + (size_t)b * vstride;
+        // Per-lane addresses of the staging and write-back code are invariant across trajectories; hoisted out of this loop they
+        // are live across the whole PCG loop, where there is not one free register (22 dwords spilled, reloads inside the PCG
+        // loop: -6 %).  An opaque copy of the thread index per trajectory keeps them where they are used.
+        int t_st = tid, i_st = i;
+        asm volatile("" : "+v"(t_st), "+v"(i_st));
+        {
+            const rsrc_t M = make_rsrc((isP ? static_cast<const float*>(k_in->p.Pinv) : static_cast<const float*>(k_in->p.S)) + (size_t)b * mstride,
+                                       (uint32_t)(mstride * sizeof(float)));
+            const uint32_t off = valid ? (uint32_t)((k0 + i_st) * 3 + (isL ? 0 : 1)) * (BLK4 * 16u) : OOB_OFF;
+#pragma unroll
+            for (int c = 0; c < BLK4; ++c) m4[c] = buf_load4<false>(M, off + 16u * c);
+        }
+        // ---- stage: parts <- 0 (yL of the replica slot: -0, so that (s + yL) + t keeps the bits of s), p <- lambda0, r <- gamma
+        //      for the own knots AND the replica (both complete in global memory), lambda <- lambda0 ----
+        for (int e = t_st; e < 6 * L::VS; e += NTHR) lds[e] = 0.f;
+        lds_barrier();
+        if (t_st < NS) lds[L::YL + t_st] = -0.f;
+        for (int e = t_st + (g == 0 ? NS : 0); e < (KL + 1) * NS; e += NTHR) {
+            const int ge = (k0 - 1) * NS + e;               // element of the global [N][14] vector
+            const float l0 = lam_in[ge];
+            lds[L::XP + e] = l0;
+            lds[L::LAM + e] = l0;
+            lds[L::XR + e] = gam[ge];
+        }
+        lds_barrier();
 
-    // ---- write back own knots (a member that gave up leaves lambda alone and flags the trajectory for the fix-up launch) ----
-    if (failed) {
-        if (tid == 0) __hip_atomic_store(ca.fail_flags + (size_t)b * CL_FLAG_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        for (int e = tid; e < KL * NS; e += NTHR) {
-            const size_t ge = (size_t)k0 * NS + e;
-            lam_g[ge] = lds[L::LAM + NS + e];
-            if (a.r_out) a.r_out[(size_t)b * vstride + ge] = lds[L::XR + NS + e];
-            if (a.p_out) a.p_out[(size_t)b * vstride + ge] = lds[L::XP + NS + e];
+        // ---- setup: r = gamma - S lambda0 ; r~ = Pinv r ; p = r~ ; eta = r . r~ ----
+        if (lane == 0) { red_v[w] = 0.f; red_e[w] = 0.f; }
+        if (!isP) pass(L::XP, red_v);
+        (void)exchange(red_v, SlotV{}, true);
+        if (ok0) xr2[e0] = xr2[e0] - ((yD2[e0] + yL2[e0]) + yT2[e0]);
+        if (ok1) xr2[e1] = xr2[e1] - ((yD2[e1] + yL2[e1]) + yT2[e1]);
+        lds_barrier();
+        if (isP && wave_on) pass(L::XR, red_e);
+        float eta = exchange(red_e, SlotE{}, p3);
+        if (ok0) xp2[e0] = p3 ? (yD2[e0] + yL2[e0]) + yT2[e0] : yD2[e0];
+        if (ok1) xp2[e1] = p3 ? (yD2[e1] + yL2[e1]) + yT2[e1] : yD2[e1];
+        lds_barrier();
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): see pcg_lpb_kernel
+
+        uint32_t iters = 0;
+        uint32_t max_iter_exit = 1;
+        if (failed) {
+            iters = 0xFFFFFFFFu; max_iter_exit = 2;
+        } else if (fabsf(eta) < a.exit_tol) {
+            max_iter_exit = 0;
+        } else {
+            for (int it = 0; it < a.max_iter; ++it) {
+                // upsilon = S p ; v = p . upsilon
+                if (!isP) pass(L::XP, red_v);
+                const float alpha = eta / exchange(red_v, SlotV{}, true);
+                {
+                    const f2 d0 = yD2[e0], l0 = yL2[e0], t0 = yT2[e0], r0 = xr2[e0];
+                    const f2 d1 = yD2[e1], l1 = yL2[e1], t1 = yT2[e1], r1 = xr2[e1];
+                    if (ok0) xr2[e0] = r0 - alpha * ((d0 + l0) + t0);
+                    if (ok1) xr2[e1] = r1 - alpha * ((d1 + l1) + t1);
+                }
+                lds_barrier();
+                // r~ = Pinv r ; eta' = r . r~          | S waves: lambda += alpha p (own knots)
+                if (isP) {
+                    if (wave_on) pass(L::XR, red_e);
+                } else {
+                    for (int e = NS / 2 + tid; e < e_hi; e += NTHR / 2) lam2[e] = lam2[e] + alpha * xp2[e];
+                }
+                const float eta_new = exchange(red_e, SlotE{}, p3);
+                if (failed) { iters = 0xFFFFFFFFu; max_iter_exit = 2; break; }
+                iters = (uint32_t)(it + 1);
+                if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
+                {
+                    f2 rt0 = yD2[e0], rt1 = yD2[e1];
+                    const f2 p0 = xp2[e0], p1 = xp2[e1];
+                    if (p3) {
+                        const f2 l0 = yL2[e0], t0 = yT2[e0], l1 = yL2[e1], t1 = yT2[e1];
+                        rt0 = (rt0 + l0) + t0;
+                        rt1 = (rt1 + l1) + t1;
+                    }
+                    const float beta = eta_new / eta;
+                    if (ok0) xp2[e0] = rt0 + beta * p0;
+                    if (ok1) xp2[e1] = rt1 + beta * p1;
+                    eta = eta_new;
+                }
+                lds_barrier();
+            }
         }
-    }
-    if (tid == 0 && g == 0) {
-        a.iters[b] = iters;
-        a.max_iter_exit[b] = (uint8_t)max_iter_exit;
+
+        // ---- write back own knots (a member that gave up leaves lambda alone and flags the trajectory for the fix-up launch) ----
+        kargp_t k_out = kp;
+        asm volatile("" : "+s"(k_out));
+        if (failed) {                                      // this trajectory's count stays short of G: the fix-up launch re-solves it
+            if (tid == 0) { k_out->p.iters[b] = 0xFFFFFFFFu; k_out->p.max_iter_exit[b] = 2; }      // (what the caller sees with "cluster_fixup" = 0)
+            break;
+        }
+        {
+            int t_wb = tid;
+            asm volatile("" : "+v"(t_wb));
+            for (int e = t_wb; e < KL * NS; e += NTHR) {
+                const size_t ge = (size_t)b * vstride + (size_t)k0 * NS + e;
+                k_out->p.lambda[ge] = lds[L::LAM + NS + e];
+                if (k_out->p.r_out) k_out->p.r_out[ge] = lds[L::XR + NS + e];
+                if (k_out->p.p_out) k_out->p.p_out[ge] = lds[L::XP + NS + e];
+            }
+        }
+        if (tid == 0) {
+            if (g == 0) {
+                k_out->p.iters[b] = iters;
+                k_out->p.max_iter_exit[b] = (uint8_t)max_iter_exit;
+            }
+            __hip_atomic_fetch_add(k_out->fail_flags + (size_t)b * CL_FLAG_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lds_barrier();                                      // LDS is restaged for the next trajectory
     }
 }
 
