@@ -137,12 +137,14 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpb_kernel(PcgArgs a) {
 #pragma unroll
             for (int i = 0; i < 7; ++i) { xa[i] = xa2[i]; xb[i] = xb2[i]; acc[i] = f2{0.f, 0.f}; }
         }
+#if !(defined(MPCG_ABLATE) && (MPCG_ABLATE & 1))     // (timing experiments only: tools/lpb_ablate.sh)
 #pragma unroll
         for (int u = 0; u < NS; ++u) {                   // direct: M xa
             const float xs = (u & 1) ? xa[u >> 1].y : xa[u >> 1].x;
 #pragma unroll
             for (int i = 0; i < 7; ++i) acc[i] = __builtin_elementwise_fma(mp(u, i), f2{xs, xs}, acc[i]);
         }
+#endif
         // x_k . (M xa) in two chains; an off-diagonal lane counts it twice: x_{k-1} . (L_k^T x_k) is the same number
         f2 dt0 = {0.f, 0.f}, dt1 = {0.f, 0.f};
         f2* yo2 = reinterpret_cast<f2*>(wk + (isL ? L::YL : L::YD));
@@ -156,10 +158,18 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpb_kernel(PcgArgs a) {
         MPCG_STAMP(prof_base + 1);
         // the wave partial is published BEFORE the transposed product: the fold's readlanes and the LDS write's
         // latency hide behind 98 more FMAs instead of sitting in front of the barrier
+#if defined(MPCG_ABLATE) && (MPCG_ABLATE & 8)
+        const float part = dt.x + dt.y;
+#else
         const float part = wave_fold(isL ? 2.f * (dt.x + dt.y) : dt.x + dt.y);
+#endif
         if (lane == 0) red[w] = part;
         MPCG_STAMP(prof_base + 2);
+#if defined(MPCG_ABLATE) && (MPCG_ABLATE & 2)
+        if (false) {
+#else
         if (isL) {
+#endif
             // transposed: yT[k-1] = L_k^T x_k
             // (four independent chains: a wave issues a v_pk_fma_f32 every ~5 cycles, its result is ready after ~2 issues)
             f2* yt2 = reinterpret_cast<f2*>(wk + L::YT + (valid ? -NS : 0));
@@ -254,8 +264,10 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpb_kernel(PcgArgs a) {
                 const f2 d0 = yD2[e0], l0 = yL2[e0], t0 = yT2[e0], r0 = xr2[e0];
                 const f2 d1 = yD2[e1], l1 = yL2[e1], t1 = yT2[e1], r1 = xr2[e1];
                 alpha = eta / sum_red(rv);
+#if !(defined(MPCG_ABLATE) && (MPCG_ABLATE & 4))
                 if (ok0) xr2[e0] = r0 - alpha * ((d0 + l0) + t0);
                 if (ok1) xr2[e1] = r1 - alpha * ((d1 + l1) + t1);
+#endif
             }
             MPCG_STAMP(6);
             lds_barrier();
@@ -288,8 +300,10 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpb_kernel(PcgArgs a) {
                 iters = (uint32_t)(it + 1);
                 if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
                 const float beta = eta_new / eta;
+#if !(defined(MPCG_ABLATE) && (MPCG_ABLATE & 4))
                 if (ok0) xp2[e0] = rt0 + beta * p0;
                 if (ok1) xp2[e1] = rt1 + beta * p1;
+#endif
                 eta = eta_new;
             }
             MPCG_STAMP(14);

@@ -4,6 +4,9 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as orc
+import mpcgpu_amd._lib as _L
+if os.environ.get("AB_LIB"):                      # A/B against another build of the library (tools/_prof/ab/)
+    _L.LIB_PATH = os.environ["AB_LIB"]
 from mpcgpu_amd import PcgSolver, pcg_config, synth
 from util import fp32_band, relinf
 
