@@ -249,10 +249,14 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * are accepted at launch), "pcg_lds_rows" (rows per matrix per wave cached in LDS, -1 = what fits),
  * "pcg_stream_bufs", "nt_loads" (SpMV kernel), "pcg_max_wg_per_cu", "spmv_blocks_per_cu"; "pcg16_*" = the
  * same for fp16 storage.  reg/lds rows count TRIPLES of block rows per matrix per wave.  "cluster": workgroups
- * (= CUs) per trajectory for the cluster kernel that long horizons use (-1 auto, 0 off, G forced); it exchanges
- * halo knots and inner-product partials between workgroups through global memory and therefore needs
- * batch * G <= #CUs per launch (larger batches are chunked).  A cluster that cannot make progress gives up after a
- * bounded spin: d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for that trajectory.
+ * (= CUs) per trajectory for the cluster kernels that long horizons use (-1 auto, 0 off, G forced).  Members exchange
+ * inner-product partials and boundary knots through global memory, so all members of a cluster must be resident:
+ * the clustered lane-per-block kernel (default) launches as many clusters as fit the chip and lets each draw trajectories
+ * from a queue (any batch = one launch); the row-triple cluster kernel ("cluster_lpb" = 0) runs floor(#CUs / G)
+ * trajectories per launch, larger batches in consecutive launches (automatic mode, N >= 256) or on the single-workgroup
+ * kernel (forced G).  A cluster that cannot make progress (a peer not resident: another stream holds its CU) gives up after
+ * a bounded spin and the follow-up launch of the single-workgroup kernel re-solves its trajectory ("cluster_fixup" = 0:
+ * no follow-up launch, d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for such a trajectory).
  * "lds_extra" (single-triple LDS slots beyond the uniform cache of the <.,.,1> kernels: -1 what fits, 0 none),
  * "cluster_waves" (waves per cluster member: 8 = one member per CU, 4 = two per CU, -1 by horizon and batch),
  * "cluster_lpb" (-1 auto / 0 / 1: the clustered lane-per-block kernel — members of up to 128 knots, everything in registers, one
