@@ -92,3 +92,27 @@ def test_warm_start_and_zero_iterations():
     torch.cuda.synchronize()
     assert (it2.cpu().numpy() == 0).all() and (ex2.cpu().numpy() == 0).all()
     assert torch.equal(lam, before)
+
+
+def test_options_round_trip_and_selection():
+    """cluster_lpb: -1 auto (on) / 0 (row-triple cluster kernel) / 1; invalid values are refused and leave the handle usable."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    from mpcgpu_amd._lib import MpcgError
+    N = 256
+    k = synth.make_kkt(N, 1, 2)
+    S, Pinv, g = synth.form_schur(k)
+    sol = PcgSolver(N, max_batch=1)
+    assert sol.get_option("cluster_lpb") == -1 and sol.get_option("cluster_fixup") == 1
+    with pytest.raises(MpcgError):
+        sol.set_option("cluster_lpb", 2)
+    fam = {}
+    for v in (-1, 0, 1):
+        sol.set_option("cluster_lpb", v)
+        assert sol.get_option("cluster_lpb") == v
+        lam = torch.zeros(1, n * N, device="cuda")
+        it, ex = sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=7), "ss")
+        torch.cuda.synchronize()
+        fam[v] = (sol.get_option("last_kernel_family"), int(it.item()), lam.cpu().numpy())
+    assert fam[-1][0] == 4 and fam[1][0] == 4 and fam[0][0] == 1 and all(f[1] == 7 for f in fam.values())
+    np.testing.assert_array_equal(fam[-1][2], fam[1][2])
+    assert relinf(fam[0][2][0], fam[1][2][0]) <= 2e-3          # two kernels, same PCG, 7 iterations: fp32 round-off of the products and inner products
