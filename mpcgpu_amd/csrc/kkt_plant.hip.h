@@ -158,10 +158,11 @@ constexpr int KKT_GL = KKT_LANES / KKT_ITEMS;
 constexpr int KKT_KIN_LANE = 2 * PJ;     // lane of a group after the 14 finite-difference tasks: forward kinematics + Jacobian
 constexpr double KKT_FD_H = 1e-6;
 
-struct KktItemLds {                      // per-knot scratch in LDS (3.3 KB)
+struct KktItemLds {                      // per-knot scratch in LDS (2.1 KB; LDS capacity is what bounds the resident wavefronts per CU)
     double M[PJ][PJ], Minv[PJ][PJ], Bias[PJ], Qdd[PJ];
-    double Id[2 * PJ][PJ];               // central differences ID(. + h e_j) - ID(. - h e_j): rows 0..6 w.r.t. q_j, 7..13 w.r.t. qd_j
-    double Dq[PJ][PJ], Dqd[PJ][PJ];
+    // (the central differences ID(. + h e_j) - ID(. - h e_j) wait in rows 0..6 of the finished recursion's record of lane j / 7 + j;
+    //  dqdd/dq overwrites M, which is dead after the Cholesky factorisation)
+    double Dqd[PJ][PJ];
     double J[3][PJ], Ee[3], Gq[PJ], Gq1[PJ];
     double Xq[2 * PJ], U[PJ];            // [q; qd], u of this knot
     double Sc[3][2][PJ];                 // sin / cos of q, q + h e_j, q - h e_j
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
                     const double t = fl[RN_TAU(i)];
                     if (round == 0) { if (l < PJ) I.M[i][l] = t; else I.Bias[i] = t; }
                     else if (round == 1) tp[i] = t;
-                    else I.Id[l][i] = tp[i] - t;
+                    else fl[i] = tp[i] - t;                          // (the sweep is over: the record is free)
                 }
             } else if (round == 1 && l == KKT_KIN_LANE) {
                 // forward kinematics; joint origins and axes wait in this lane's (otherwise unused) record
@@ -300,10 +301,10 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
             double sq = 0, sd = 0;
 #pragma unroll
             for (int t = 0; t < PJ; ++t) {
-                sq += I.Minv[i][t] * I.Id[j][t];
-                sd += I.Minv[i][t] * I.Id[PJ + j][t];
+                sq += I.Minv[i][t] * sF[gi * KKT_GL + j][t];
+                sd += I.Minv[i][t] * sF[gi * KKT_GL + PJ + j][t];
             }
-            I.Dq[i][j] = -sq / (2 * KKT_FD_H);
+            I.M[i][j] = -sq / (2 * KKT_FD_H);                 // dqdd/dq
             I.Dqd[i][j] = -sd / (2 * KKT_FD_H);
         }
         if (l < PJ) {
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
                 // A = I + dt [[0, I], [dqdd/dq, dqdd/dqd]]
                 double av = (r == col) ? 1.0 : 0.0;
                 if (r < PJ) av += (col == r + PJ) ? dt : 0.0;
-                else av += dt * (col < PJ ? I.Dq[r - PJ][col] : I.Dqd[r - PJ][col - PJ]);
+                else av += dt * (col < PJ ? I.M[r - PJ][col] : I.Dqd[r - PJ][col - PJ]);
                 Cm[e] = (float)(-av);
                 // Q = blkdiag(g g^T, QD I)
                 double qv = 0.0;
