@@ -551,11 +551,12 @@ static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, h
     ca.scratch = ca.fail_flags + (size_t)batch * CL_FLAG_STRIDE;
     ca.G = G;
     ca.batch = (int)batch;
+    ca.clusters = (int)clusters;
     // one fill: the queue counter, this call's flags and the cells of this launch (their tags restart at 1 every launch)
     const size_t zw = CL_FLAG_STRIDE + (size_t)batch * CL_FLAG_STRIDE + (size_t)clusters * G * CL_WG_WORDS;
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster_scratch, zw);
     HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL(kern, dim3(clusters * (unsigned)G), dim3(NWR * 256), lds, st, ca);
+    hipLaunchKernelGGL(kern, dim3(((clusters + 7) / 8) * 8 * (unsigned)G), dim3(NWR * 256), lds, st, ca);
     HIP_TRY(h, hipGetLastError());
     if (fixup) {
         PcgArgs c = a;

@@ -715,6 +715,7 @@ struct ClusterArgs {
     int G;
     unsigned long long* queue = nullptr; // lane-per-block clusters: next trajectory to hand out (zeroed before the launch)
     int batch = 0;                       //   "  : trajectories of the call
+    int clusters = 0;                    //   "  : clusters of the launch (the grid holds 8 ceil(clusters / 8) of them)
 };
 
 template <int NW, int RT, bool ADJ>

@@ -77,9 +77,14 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = ca.G;
-    const int cl = blockIdx.x / G;                      // cluster of this launch
-    const unsigned nclusters = gridDim.x / (unsigned)G;
-    const int g = blockIdx.x - cl * G;                  // member of its cluster
+    // Members of a cluster share an XCD: workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md "Contract"; a
+    // hand-off inside an XCD is 0.1-0.3 us cheaper than across), so the launch is 8 lanes of workgroups b = 8 j + x, and lane x
+    // holds the members j % G of clusters 8 (j / G) + x.  The grid is rounded up to whole groups of 8 clusters; the surplus ones leave.
+    const unsigned nclusters = (unsigned)ca.clusters;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int g = jx % G;                               // member of its cluster
+    const int cl = (jx / G) * 8 + xcd;                  // cluster of this launch
+    if ((unsigned)cl >= nclusters) return;
     const int k0 = (int)(((long)g * N) / G), k1 = (int)(((long)(g + 1) * N) / G);
     const int KL = k1 - k0;                             // own knots (launcher: 1 <= KL <= NMAX)
     float* red_v = lds + L::RED;
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
     float* bc = lds + L::BC;                            // [0] cluster-wide sum, [1] sticky timeout flag, [2] trajectory index (int)
 
     const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;
-    gu64* my_words = (gu64*)ca.scratch + (size_t)blockIdx.x * CL_WG_WORDS;
+    gu64* my_words = (gu64*)ca.scratch + ((size_t)cl * G + g) * CL_WG_WORDS;
     gu64* cl_words = (gu64*)ca.scratch + (size_t)cl * G * CL_WG_WORDS;
 
     // ---- role of this wave, block of this lane (pcg_lpb_kernel's roles; i = index of the block inside the member) ----
