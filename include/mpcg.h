@@ -260,7 +260,8 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * "lds_extra" (single-triple LDS slots beyond the uniform cache of the <.,.,1> kernels: -1 what fits, 0 none),
  * "cluster_waves" (waves per cluster member: 8 = one member per CU, 4 = two per CU, -1 by horizon and batch),
  * "cluster_lpb" (-1 auto / 0 / 1: the clustered lane-per-block kernel — members of up to 128 knots, everything in registers, one
- * hand-off per matrix pass — instead of the row-triple cluster kernel; default on), "cluster_fixup" (1: trajectories whose cluster
+ * hand-off per matrix pass — instead of the row-triple cluster kernel; default on), "cluster_l2" (1, default: its hand-offs stay in
+ * the XCD's L2 when all members of a cluster run on one XCD, which the kernel verifies; 0: always write-through), "cluster_fixup" (1: trajectories whose cluster
  * gave up are re-solved by the single-workgroup kernel in a follow-up launch; default on),
  * "cluster_adj" (lane order of the row-triple cluster kernel), "schur_dpp" (1: register/DPP Schur kernels, 0: the LDS versions),
  * "block_solve_wide" (mpcg_block_solve: 1 one trajectory per wavefront, 0 four, -1 by batch size; same bits);

@@ -51,6 +51,7 @@ struct mpcg_handle {
     int cluster_adj = 1;      // lane order of the cluster kernel (1: blocks of a row in adjacent lanes)
     int cluster = -1;         // workgroups per trajectory for the cluster kernel: 0 off, -1 auto, G > 0 forced
     int cluster_lpb = -1;     // clustered lane-per-block kernel (pcg_lpb_cluster.hip.h) instead of the row-triple cluster kernel: -1 auto (on), 0 off, 1 on
+    int cluster_l2 = 1;       // clustered lane-per-block kernel: 1 = L2-resident hand-offs when a cluster's members share an XCD, 0 = always write-through
     int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
     unsigned long long* cluster_scratch = nullptr;
     bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any valid pcg_* set_option clears this)
@@ -208,6 +209,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "nt_loads")) { h->nt_loads = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_adj")) { h->cluster_adj = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_fixup")) { h->cluster_fixup = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "cluster_l2")) { h->cluster_l2 = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_lpb")) {
         if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "cluster_lpb must be -1 (auto), 0 or 1");
         h->cluster_lpb = value; return MPCG_OK;
@@ -237,6 +239,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "cluster_adj")) { *value = h->cluster_adj; return MPCG_OK; }
     if (!strcmp(key, "cluster_fixup")) { *value = h->cluster_fixup; return MPCG_OK; }
     if (!strcmp(key, "cluster_lpb")) { *value = h->cluster_lpb; return MPCG_OK; }
+    if (!strcmp(key, "cluster_l2")) { *value = h->cluster_l2; return MPCG_OK; }
     if (!strcmp(key, "schur_dpp")) { *value = h->schur_dpp; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "spmv_mfma")) { *value = h->spmv_mfma; return MPCG_OK; }
@@ -552,6 +555,7 @@ static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, h
     ca.G = G;
     ca.batch = (int)batch;
     ca.clusters = (int)clusters;
+    ca.l2_handoff = h->cluster_l2;
     // one fill: the queue counter, this call's flags and the cells of this launch (their tags restart at 1 every launch)
     const size_t zw = CL_FLAG_STRIDE + (size_t)batch * CL_FLAG_STRIDE + (size_t)clusters * G * CL_WG_WORDS;
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster_scratch, zw);

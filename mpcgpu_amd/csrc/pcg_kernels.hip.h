@@ -716,6 +716,7 @@ struct ClusterArgs {
     unsigned long long* queue = nullptr; // lane-per-block clusters: next trajectory to hand out (zeroed before the launch)
     int batch = 0;                       //   "  : trajectories of the call
     int clusters = 0;                    //   "  : clusters of the launch (the grid holds 8 ceil(clusters / 8) of them)
+    int l2_handoff = 1;                  //   "  : 1 = hand-offs through the XCD's L2 when all members of a cluster share an XCD (verified in the kernel)
 };
 
 template <int NW, int RT, bool ADJ>

@@ -43,6 +43,7 @@ __host__ __device__ constexpr size_t pcg_lpbc_lds_floats(int NW) { return NW == 
 
 constexpr int LPBC_MAX_G = 16;             // members whose partials one wave polls with lanes 0..15
 constexpr int LPBC_SLOT_V = 0, LPBC_SLOT_E = 32;     // granule words of the two alternating exchanges inside a member's CL_WG_WORDS block
+constexpr int LPBC_SLOT_X = 61;                      // every member, once per launch: {1, XCC id} (the same-XCD check)
 constexpr int LPBC_SLOT_T = 62;                      // leader only: {sequence number, trajectory index} of the cluster's current trajectory
 
 // Granule accesses in the "uniform 64-bit base (SGPR pair) + 32-bit lane byte offset" addressing form, spelled out: left to
@@ -56,6 +57,13 @@ constexpr int LPBC_SLOT_T = 62;                      // leader only: {sequence n
 template <int WORD>
 __device__ __forceinline__ void granule_store(gu64* sbase, unsigned byte_off, unsigned long long v) {
     asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 offset:%3 sc1" : : "v"(byte_off), "v"(v), "s"(sbase), "n"(8 * WORD) : "memory");
+}
+// The same store WITHOUT sc1: the granule stays in this XCD's L2, where a poller on the same XCD finds it (its sc1 load bypasses
+// only L1) without the round trip to the memory side that a write-through store forces on both.  Only valid when the whole
+// cluster sits on one XCD, which the members verify at start-up (pcg_lpbc_kernel: `same_xcd`).
+template <int WORD>
+__device__ __forceinline__ void granule_store_l2(gu64* sbase, unsigned byte_off, unsigned long long v) {
+    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 offset:%3" : : "v"(byte_off), "v"(v), "s"(sbase), "n"(8 * WORD) : "memory");
 }
 template <int WORD>
 __device__ __forceinline__ unsigned long long granule_load(const gu64* sbase, unsigned byte_off) {
@@ -184,6 +192,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
         }
     };
 
+    bool same_xcd = false;                             // uniform: all members of this cluster run on one XCD (set below)
     unsigned epoch = 0, seq = 0;                       // hand-offs / trajectories of this cluster so far: tags never repeat inside a launch
     bool failed = false;                               // uniform across the workgroup (published through LDS)
     // The one hand-off of a pass.  Called by all threads after the pass; returns the cluster-wide inner product.  On return
@@ -212,7 +221,11 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
             } else {
                 val = lds[ia] + lds[ib];
             }
-            if (lane <= 2 * NS) granule_store<base>(my_words, 8u * (unsigned)lane, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, val));
+            if (lane <= 2 * NS) {
+                const unsigned long long gran = ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, val);
+                if (same_xcd) granule_store_l2<base>(my_words, 8u * (unsigned)lane, gran);
+                else granule_store<base>(my_words, 8u * (unsigned)lane, gran);
+            }
             unsigned long long x = 0;
             unsigned spins = 0;
             bool ok;
@@ -261,6 +274,33 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
         tab[64] = l >= 1 && l <= NS ? L::YD + KL * NS + l - 1 : l > NS && l <= 2 * NS ? L::YT + l - 1 - NS : L::BC + 3;
         tab[128] = l >= 1 && l <= NS ? L::YL + KL * NS + l - 1 : L::BC + 3;
     }
+    // ---- are all members of this cluster on one XCD?  (They are meant to be, see above, but workgroup -> XCD placement is not a
+    //      contract.)  Every member publishes its XCC id write-through; everybody compares.  If so, the hand-offs of this launch
+    //      use L2-resident stores; if not — or if a peer does not answer — write-through ones (and a dead peer shows up as a
+    //      timeout of the first real hand-off). ----
+    if (w == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xf;
+        if (lane == 0) granule_store<LPBC_SLOT_X>(my_words, 0u, (1ull << 32) | xcc);
+        unsigned long long x = 0;
+        unsigned spins = 0;
+        bool ok;
+        do {
+            ok = true;
+            if (lane < G) {
+                x = granule_load<LPBC_SLOT_X>(cl_words, 8u * (unsigned)(lane * CL_WG_WORDS));
+                ok = (unsigned)(x >> 32) == 1u;
+            }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+        } while (++spins < (CL_SPIN_LIMIT >> 4));
+        const bool all_same = __all(lane >= G || ((unsigned)(x >> 32) == 1u && (unsigned)x == xcc));
+        if (lane == 0) reinterpret_cast<int*>(bc)[2] = all_same ? 1 : 0;
+    }
+    lds_barrier();
+    same_xcd = reinterpret_cast<const int*>(bc)[2] != 0 && ca.l2_handoff != 0;
+    lds_barrier();
     for (;;) {
         // ---- next trajectory of this cluster.  The first one is its own index; further ones the leader draws from the queue
         //      (which therefore starts at the number of clusters) and hands to its peers.  A call that fits the chip in one go
@@ -275,7 +315,8 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
                         kargp_t k_q = kp;
                         asm volatile("" : "+s"(k_q));
                         bn = (int)nclusters + (int)__hip_atomic_fetch_add(k_q->queue, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        granule_store<LPBC_SLOT_T>(my_words, 0u, ((unsigned long long)seq << 32) | (unsigned)bn);
+                        if (same_xcd) granule_store_l2<LPBC_SLOT_T>(my_words, 0u, ((unsigned long long)seq << 32) | (unsigned)bn);
+                        else granule_store<LPBC_SLOT_T>(my_words, 0u, ((unsigned long long)seq << 32) | (unsigned)bn);
                     }
                 } else {
                     unsigned long long x = 0;

@@ -19,7 +19,8 @@ def dev(a):
 
 @pytest.mark.parametrize("N", [129, 131, 255, 257, 300, 512, 640])
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
-def test_auto_policy_ragged_horizons_vs_oracle(orc, N, pc):
+@pytest.mark.parametrize("l2", [1, 0])
+def test_auto_policy_ragged_horizons_vs_oracle(orc, N, pc, l2):
     """Default handle, no knobs: N > 128 runs family 4 with G = ceil(N / 128) members of floor/ceil(N / G) knots."""
     from mpcgpu_amd import PcgSolver, pcg_config
     B = 2
@@ -27,6 +28,7 @@ def test_auto_policy_ragged_horizons_vs_oracle(orc, N, pc):
     S, Pinv, g = synth.form_schur(k, poison_unused=True)
     lam0 = np.random.default_rng(N).normal(0, 0.2, (B, n * N)).astype(np.float32)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("cluster_l2", l2)               # 1 (default): L2-resident hand-offs inside an XCD; 0: write-through hand-offs
     dS, dP, dg = dev(S), dev(Pinv), dev(g)
     for K in (2, 25):
         lam = dev(lam0)
@@ -115,4 +117,12 @@ def test_options_round_trip_and_selection():
         fam[v] = (sol.get_option("last_kernel_family"), int(it.item()), lam.cpu().numpy())
     assert fam[-1][0] == 4 and fam[1][0] == 4 and fam[0][0] == 1 and all(f[1] == 7 for f in fam.values())
     np.testing.assert_array_equal(fam[-1][2], fam[1][2])
+    # hand-offs through the XCD's L2 (default, when the members of a cluster share an XCD) or write-through: same arithmetic, same bits
+    assert sol.get_option("cluster_l2") == 1
+    sol.set_option("cluster_l2", 0)
+    lam = torch.zeros(1, n * N, device="cuda")
+    sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=7), "ss")
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 4
+    np.testing.assert_array_equal(lam.cpu().numpy(), fam[1][2])
     assert relinf(fam[0][2][0], fam[1][2][0]) <= 2e-3          # two kernels, same PCG, 7 iterations: fp32 round-off of the products and inner products

@@ -33,7 +33,7 @@ for N, B in cases:
     g = torch.from_numpy(np.tile(g0, (rep, 1))[:B]).to(dev)
     cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=synth.pcg_max_iter(N))
     res = {}
-    for name, opts in (("lpbc8", {"cluster_lpb": 1, "cluster_waves": 8}), ("lpbc4", {"cluster_lpb": 1, "cluster_waves": 4}),
+    for name, opts in (("lpbc8", {"cluster_lpb": 1, "cluster_waves": 8}), ("lpbc8_wt", {"cluster_lpb": 1, "cluster_waves": 8, "cluster_l2": 0}), ("lpbc4", {"cluster_lpb": 1, "cluster_waves": 4}),
                        ("triple", {"cluster_lpb": 0}), ("single", {"cluster": 0})):
         sol = PcgSolver(N, max_batch=B)
         for kk, v in opts.items(): sol.set_option(kk, v)
