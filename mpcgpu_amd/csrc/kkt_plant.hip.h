@@ -23,7 +23,7 @@
 namespace mpcg {
 
 constexpr int PJ = 7;                    // joints of the compiled specialisation (state 2 PJ, control PJ)
-constexpr int KKT_LANES = 64;            // one wavefront per (trajectory, knot)
+constexpr int KKT_LANES = 64;            // one wavefront per KKT_ITEMS (trajectory, knot) pairs
 constexpr int RN_ROWS = 6 * PJ + 1;        // record: link forces [PJ][6] (+1: an odd row count = conflict-free 8-byte accesses at lane stride)
 __host__ __device__ constexpr int RN_TAU(int k) { return 6 * k + 2; }             // tau_k overwrites row 2 of link k's force once consumed
 
@@ -76,7 +76,8 @@ __device__ __forceinline__ void mat3(double (&M)[9], cdouble* c0, cdouble* cs, c
 // sweeps are RUNTIME loops over the joints.  Measured alternatives on gfx950 (hipcc 7.2): everything in registers with unrolled
 // sweeps = 3.4 KB of scratch per lane (the 84 force registers, plus the seven E_k / B_k pairs the compiler keeps from the
 // forward sweep for the backward one instead of recomputing them: 252 doubles); plain (non-volatile) LDS accesses get
-// store-forwarded back into registers.  This form compiles one joint body and fits two waves per SIMD.
+// store-forwarded back into registers.  This form compiles one joint body in ~225 registers without scratch; the record (LDS capacity)
+// is then what bounds the resident wavefronts per CU.
 //   sin / cos of the joint angles come from a table sc[variant][2][PJ] shared by the lanes (variant 0: q, 1: q + h e_j, 2: q - h e_j;
 //   ONE sincos call per knot fills it — every recursion used to recompute all seven, 29 % of the kernel's VALU instructions):
 //   joint k uses variant (k == sj ? sv : 0).
