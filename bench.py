@@ -310,7 +310,7 @@ def main():
     t_local = time.perf_counter() - t0
     t_all = D.max_over_ranks(t_local, dev)
 
-    fam = {0: "pcg_traj_kernel", 1: "pcg_cluster_kernel", 2: "pcg_lpb_kernel", 3: "pcg_generic_kernel", 4: "pcg_lpbc_kernel"}[sol.get_option("last_kernel_family")]
+    fam = {0: "pcg_traj_kernel", 1: "pcg_cluster_kernel", 2: "pcg_lpb_kernel", 3: "pcg_generic_kernel", 4: "pcg_lpbc_kernel", 5: "pcg_rpl_kernel"}[sol.get_option("last_kernel_family")]
     kdesc = {"family": fam, **{k: sol.get_option("last_kernel_" + k) for k in ("waves", "reg_rows", "lds_rows", "stream_bufs", "cluster", "lds_bytes")}}
     it_host = d_it.cpu().numpy().astype(np.int64)
     ex_host = d_ex.cpu().numpy()

@@ -11,6 +11,7 @@
 #include "pcg_kernels.hip.h"
 #include "pcg_lpb.hip.h"
 #include "pcg_lpb_cluster.hip.h"
+#include "pcg_rpl.hip.h"
 #include "schur_kernels.hip.h"
 #include "schur_dpp.hip.h"
 #include "block_solve.hip.h"
@@ -34,7 +35,7 @@ struct PcgKnobs {
 };
 
 // What the last solve on this handle actually launched (read-only "last_kernel_*" options; tests assert on it).
-enum { FAM_NONE = -1, FAM_TRAJ = 0, FAM_CLUSTER = 1, FAM_LPB = 2, FAM_GENERIC = 3, FAM_LPBC = 4 };
+enum { FAM_NONE = -1, FAM_TRAJ = 0, FAM_CLUSTER = 1, FAM_LPB = 2, FAM_GENERIC = 3, FAM_LPBC = 4, FAM_RPL = 5 };
 struct LastKernel { int family = FAM_NONE, waves = 0, reg_rows = 0, lds_rows = 0, stream_bufs = 0, cluster = 0, lds_bytes = 0, lds_extra = 0; };
 
 struct mpcg_handle {
@@ -44,6 +45,8 @@ struct mpcg_handle {
     PcgKnobs k;
     LastKernel last;
     int nt_loads = 1;         // non-temporal hint on the matrix stream
+    int rpl = -1;             // row-per-lane kernel (pcg_rpl.hip.h, N <= 64): -1 auto, 0 off, 1 forced
+    int rpl_waves = 0;        //   its wavefronts per trajectory: 0 auto, 4 / 8 / 16
     int lpb = -1;             // lane-per-block kernel (pcg_lpb.hip.h): -1 auto (N <= 128, fp32, automatic configuration), 0 off, 1 forced
     int block_solve_wide = -1; // mpcg_block_solve: one trajectory per wavefront (1), four (0), by batch size (-1)
     int schur_dpp = 1;        // 1: register-resident Schur formation kernels (schur_dpp.hip.h), 0: the LDS versions
@@ -86,6 +89,7 @@ static bool generic_shape_supported(uint32_t n, uint32_t N) {
 
 static size_t lds_bytes_for(uint32_t N, int nw) { return pcg_lds_floats((int)N, nw) * sizeof(float); }
 static constexpr size_t kLdsMax = 160 * 1024;
+static constexpr uint32_t kRplMaxN = 64;          // row-per-lane kernel: full block rows of S and Pinv in registers
 static constexpr uint32_t kLpbMaxN = 128;         // one block per lane: 8 waves x 64 lanes hold 2 (2N - 1) blocks
 
 static int stream_bufs_for(const mpcg_handle* h, const PcgKnobs& k, int nw, int esz);
@@ -97,12 +101,12 @@ extern "C" {
 int mpcg_abi_version(void) { return MPCG_ABI_VERSION; }
 
 const char* mpcg_build_info(void) {
-    return "libmpcg_hip gfx950 fp32 n=14 (lane-per-block register-resident PCG, clustered PCG for long horizons, wave64 row-triple streaming PCG)";
+    return "libmpcg_hip gfx950 fp32 n=14 (row-per-lane DPP PCG for short horizons, lane-per-block register-resident PCG, clustered PCG for long horizons, wave64 row-triple streaming PCG)";
 }
 
 // device scratch of the cluster kernels, shared by both (they never run concurrently on one handle):
 //   row-triple cluster kernel   [flags: one 128-byte line per trajectory of a launch, at most one per CU][cells: 512 B per member]
-//   clustered lane-per-block    [cells][queue line][flags: one line per trajectory of the CALL, up to max_batch]
+//   clustered lane-per-block    [queue line][flags: one line per trajectory of the CALL, up to max_batch][cells]
 static size_t cluster_alloc_words(const mpcg_handle* h) {
     const size_t cells = (size_t)2 * h->num_cus * CL_WG_WORDS;
     const size_t a = (size_t)h->num_cus * CL_FLAG_STRIDE + cells;
@@ -200,6 +204,15 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
         if (value < 0 || value > 8) return fail(h, MPCG_ERR_INVALID, "pcg_max_wg_per_cu out of range");
         h->k.max_wg_per_cu = value; h->auto_cfg = false; return MPCG_OK;
     }
+    if (!strcmp(key, "pcg_rpl")) {
+        if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "pcg_rpl must be -1 (auto), 0 or 1");
+        if (value == 1 && h->N > kRplMaxN) return fail(h, MPCG_ERR_UNSUPPORTED, "pcg_rpl: the row-per-lane kernel holds knot_points <= 64");
+        h->rpl = value; return MPCG_OK;
+    }
+    if (!strcmp(key, "rpl_waves")) {
+        if (value != 0 && value != 4 && value != 8 && value != 16) return fail(h, MPCG_ERR_INVALID, "rpl_waves must be 0 (auto), 4, 8 or 16");
+        h->rpl_waves = value; return MPCG_OK;
+    }
     if (!strcmp(key, "pcg_lpb")) {
         if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "pcg_lpb must be -1 (auto), 0 (off) or 1 (forced)");
         if (value == 1 && h->N > kLpbMaxN) return fail(h, MPCG_ERR_UNSUPPORTED, "pcg_lpb: the lane-per-block kernel holds knot_points <= 128");
@@ -232,6 +245,8 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "pcg_waves")) { *value = h->k.waves; return MPCG_OK; }
     if (!strcmp(key, "pcg_max_wg_per_cu")) { *value = h->k.max_wg_per_cu; return MPCG_OK; }
     if (!strcmp(key, "pcg_lpb")) { *value = h->lpb; return MPCG_OK; }
+    if (!strcmp(key, "pcg_rpl")) { *value = h->rpl; return MPCG_OK; }
+    if (!strcmp(key, "rpl_waves")) { *value = h->rpl_waves; return MPCG_OK; }
     if (const int* p = knob_ptr(const_cast<mpcg_handle*>(h), key)) { *value = *p; return MPCG_OK; }
     if (!strcmp(key, "nt_loads")) { *value = h->nt_loads; return MPCG_OK; }
     if (!strcmp(key, "pcg_resident")) { *value = stream_bufs_for(h, h->k, h->k.waves, 4) == 0; return MPCG_OK; }   // 1: the single-workgroup configuration streams nothing
@@ -427,6 +442,46 @@ static int launch_lpb(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
 static bool use_lpb(const mpcg_handle* h, int esz) {
     if (esz != 4 || h->N > kLpbMaxN || h->lpb == 0) return false;
     return h->lpb == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 48);
+}
+
+// ---- row-per-lane kernel (pcg_rpl.hip.h): short horizons, NW wavefronts x RHO slots of four knots ----
+#define MPCG_RPL_VARIANTS(X) X(4, 1) X(4, 2) X(8, 1) X(8, 2) X(16, 1)
+template <int NW, int RHO, bool PC3>
+static int launch_rpl_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    const size_t lds = pcg_rpl_lds_floats((int)h->N, NW) * sizeof(float);
+    hipLaunchKernelGGL((pcg_rpl_kernel<NW, RHO, PC3>), dim3(batch), dim3(NW * 64), lds, st, a);
+    HIP_TRY(h, hipGetLastError());
+    h->last = LastKernel{FAM_RPL, NW, RHO, 0, 0, 0, (int)lds, 0};
+    return MPCG_OK;
+}
+// (NW, RHO) of a call: NW RHO slots of four knots must cover the horizon.  Automatic (profiles/r02_rpl_quick.txt): N <= 16 four
+// wavefronts; N <= 32 eight wavefronts x one slot for a latency-sized call (at most one trajectory per CU), four x two slots for
+// throughput (N=32 SS 395 vs 376 M it/s, block-Jacobi 623 vs 484 M); N <= 64 eight x two.
+static void rpl_shape(const mpcg_handle* h, uint32_t batch, int* nw, int* rho) {
+    const int slots = ((int)h->N + 3) / 4;
+    int w = h->rpl_waves;
+    if (w == 0) w = slots <= 4 ? 4 : slots <= 8 ? (batch > (uint32_t)h->num_cus ? 4 : 8) : 8;
+    *nw = w;
+    *rho = (slots + w - 1) / w;
+}
+static int launch_rpl(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    int nw, rho;
+    rpl_shape(h, batch, &nw, &rho);
+#define X(NW_, RHO_)                                                                                   \
+    if (nw == NW_ && rho == RHO_)                                                                      \
+        return a.pcols == 3 ? launch_rpl_t<NW_, RHO_, true>(h, a, batch, st) : launch_rpl_t<NW_, RHO_, false>(h, a, batch, st);
+    MPCG_RPL_VARIANTS(X)
+#undef X
+    return fail(h, MPCG_ERR_UNSUPPORTED, "row-per-lane kernel: no compiled (waves, slots) variant covers this horizon with rpl_waves");
+}
+// Automatic use (no explicit pcg_* knob): N <= 32 always (N=32: 0.150 vs 0.247 ms for one trajectory, 395 vs 277 M it/s at batch 2048;
+// N=16: 875 vs 317 M); 32 < N <= 64 for latency-sized calls only (N=64 one trajectory 0.248 vs 0.341 ms, but 170 vs 211 M it/s at
+// batch 2048, where the lane-per-block / row-pair kernels stay ahead).
+static bool use_rpl(const mpcg_handle* h, int esz, uint32_t batch) {
+    if (esz != 4 || h->N > kRplMaxN || h->rpl == 0) return false;
+    if (h->rpl == 1) return true;
+    if (h->lpb == 1) return false;
+    return h->auto_cfg && h->cluster <= 0 && (h->N <= 32 || batch <= (uint32_t)h->num_cus);
 }
 
 // ---- cluster kernel: G workgroups per trajectory, everything resident, batch*G <= #CUs ----
@@ -642,6 +697,7 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
         if (esz != 4) return fail(h, MPCG_ERR_UNSUPPORTED, "fp16 matrix storage exists for state_size = 14 only");
         return launch_generic_f32(h, a, batch, st);
     }
+    if (use_rpl(h, esz, batch)) return launch_rpl(h, a, batch, st);      // (an explicit "pcg_lpb" = 1 wins over the automatic choice of this one)
     if (use_lpb(h, esz)) return launch_lpb(h, a, batch, st);
     {
         const int rc = try_launch_cluster(h, a, batch, st, esz);
@@ -667,6 +723,7 @@ static int occupancy(mpcg_handle* h, const PcgKnobs& k, int* per_cu) {
 
 // LDS bytes of the launch a default-configured batch-1 solve makes (what pcgSharedMemSize stands for)
 static size_t default_launch_lds_bytes(uint32_t N, int num_cus) {
+    if (N <= kRplMaxN) return pcg_rpl_lds_floats((int)N, N <= 16 ? 4 : 8) * sizeof(float);      // row-per-lane kernel (a batch-1 call)
     if (N > 48 && N <= kLpbMaxN) return pcg_lpb_lds_floats((int)N, N <= 64 ? 4 : 8) * sizeof(float);
     if (N <= 48) {                                       // <8,2,0>: everything in registers, vectors in LDS
         mpcg_handle t0;

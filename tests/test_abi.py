@@ -45,10 +45,11 @@ def test_version_and_lds_size(hiplib):
     # 2 partials per wave
     r4 = lambda x: (x + 3) & ~3
     lpb = lambda nmax, nw: 4 * (3 * nmax * 14 + 3 * r4((nmax + 1) * 14) + r4(2 * nw))
-    assert hiplib.mpcg_pcg_lds_bytes(14, 64) == lpb(64, 4) == 21728
-    # N <= 48: the all-register row-pair kernel <8,2,0>: xp, xr padded by a knot either side, lambda, tmp, 16 partials
-    for N in (2, 32, 48):
-        assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (2 * r4((N + 2) * 14) + 2 * r4(N * 14) + 16)
+    # N <= 64: the row-per-lane kernel of a batch-1 call — six vectors padded by a knot either side + 2 partials per wave (4 waves
+    # for N <= 16, else 8), DESIGN.md §3.1e
+    for N in (2, 16, 32, 48, 64):
+        assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (6 * r4((N + 2) * 14) + r4(2 * (4 if N <= 16 else 8)))
+    assert lpb(64, 4) == 21728
     for N in (65, 128):
         assert hiplib.mpcg_pcg_lds_bytes(14, N) == lpb(128, 8) == 43264
     # N > 128: a member of the clustered lane-per-block kernel — six vectors of 128 + 2 knot slots, partials, broadcast cell, hand-off tables (§3.1d)

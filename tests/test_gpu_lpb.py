@@ -44,13 +44,13 @@ def lpb_solve(P, N, S, Pinv, g, lam0, max_iter, tol, pc="ss"):
     PcgSolver, pcg_config = P
     B = S.shape[0]
     sol = PcgSolver(N, max_batch=B)
-    if N <= 48:
-        sol.set_option("pcg_lpb", 1)          # (the automatic policy uses this kernel for 48 < N <= 128)
+    if N <= 64:
+        sol.set_option("pcg_lpb", 1)          # (the automatic policy uses this kernel for 64 < N <= 128, and for 48 < N <= 64 beyond one trajectory per CU)
     lam = dev(np.asarray(lam0, np.float32))
     it, ex = sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=tol, pcg_max_iter=max_iter), pc)
     torch.cuda.synchronize()
     assert sol.get_option("last_kernel_family") == 2 and sol.get_option("last_kernel_waves") == (4 if N <= 64 else 8)
-    assert N <= 48 or sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes(14, N)
+    assert N <= 64 or sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes(14, N)
     return lam.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy()
 
 

@@ -314,7 +314,7 @@ def test_cpp_callsite_over_shim_headers():
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["pcg_exit"] == 0 and 0 < out["pcg_iters"] < 200 and out["rel_residual"] < 1e-4
-    assert out["smem"] == 4 * ((32 + 2) * 14 * 2 + 32 * 14 * 2 + 16)   # pcgSharedMemSize = the dynamic LDS of the launch a default solve makes (N = 32: <8,2,0>)
+    assert out["smem"] == 4 * (6 * (32 + 2) * 14 + 16)   # pcgSharedMemSize = the dynamic LDS of the launch a default solve makes (N = 32: the row-per-lane kernel, 8 waves)
     # the same source with -DUSE_DOUBLES: pcg<double, n, N>, mpcgLaunchPcg<double>
     exe64 = build.EXAMPLE_BIN64 if os.path.exists(build.EXAMPLE_BIN64) else build.build_example_f64()
     r = subprocess.run([exe64], capture_output=True, text=True, timeout=120)
@@ -396,8 +396,8 @@ def test_spmv_mfma_experiment_matches_valu_kernel(P, orc, cols):
 
 
 def test_short_horizon_batches_run_two_trajectories_per_cu(P, orc):
-    """N <= 36 with more trajectories than CUs: the library switches to <4,3,0> (two workgroups per CU).  Same
-    solve as the 8-wave kernel up to the summation order of the inner products, and inside the oracle's fp32 band."""
+    """The row-pair kernels' policy for N <= 36 (what runs with "pcg_rpl" = 0) with more trajectories than CUs: <4,3,0>, two
+    workgroups per CU.  Same solve as the 8-wave kernel up to the summation order of the inner products, and inside the oracle's fp32 band."""
     PcgSolver, pcg_config = P
     N, B = 32, 300
     k = synth.make_kkt(N, B, 1234)
@@ -405,6 +405,7 @@ def test_short_horizon_batches_run_two_trajectories_per_cu(P, orc):
     dS, dP, dg = dev(S), dev(Pinv), dev(g)
     cfg = pcg_config(pcg_exit_tol=1e-5, pcg_max_iter=173)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("pcg_rpl", 0)
     lam = torch.zeros(B, n * N, device="cuda")
     it, ex = sol.solve(dS, dP, dg, lam, cfg, "ss")
     torch.cuda.synchronize()
