@@ -259,6 +259,9 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * no follow-up launch, d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for such a trajectory).
  * "lds_extra" (single-triple LDS slots beyond the uniform cache of the <.,.,1> kernels: -1 what fits, 0 none),
  * "cluster_waves" (waves per cluster member: 8 = one member per CU, 4 = two per CU, -1 by horizon and batch),
+ * "pcg_rpl" (-1 auto / 0 / 1: the row-per-lane kernel for knot_points <= 64 — a DPP row per knot, vectors in registers; automatic for
+ * knot_points <= 32 and for calls of at most one trajectory per CU up to 64), "rpl_waves" (its wavefronts per trajectory: 0 auto, 4, 8, 16),
+ * "pcg_lpb" (-1 auto / 0 / 1: the lane-per-block kernel, knot_points <= 128),
  * "cluster_lpb" (-1 auto / 0 / 1: the clustered lane-per-block kernel — members of up to 128 knots, everything in registers, one
  * hand-off per matrix pass — instead of the row-triple cluster kernel; default on), "cluster_l2" (1, default: its hand-offs stay in
  * the XCD's L2 when all members of a cluster run on one XCD, which the kernel verifies; 0: always write-through), "cluster_fixup" (1: trajectories whose cluster
@@ -267,7 +270,7 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * "block_solve_wide" (mpcg_block_solve: 1 one trajectory per wavefront, 0 four, -1 by batch size; same bits);
  * read-only: "num_cus", "pcg_resident" (1 if the current configuration streams nothing inside the PCG loop),
  * "last_kernel_family" (kernel of the last solve: 0 single-workgroup row-pair, 1 row-triple cluster, 2 lane-per-block, 3 generic,
- * 4 clustered lane-per-block), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
+ * 4 clustered lane-per-block, 5 row-per-lane), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
  * None of the residency knobs changes results within a lane-order family (bitwise identical, tested); kernels that
  * keep everything resident use the adjacent-lane order and agree with the streaming ones to fp32 round-off of the
  * inner products, as does the cluster kernel, which sums the inner products per workgroup first. */
