@@ -123,6 +123,7 @@ size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
 
 size_t mpcg_pcg_lds_bytes_f64(uint32_t state_size, uint32_t knot_points) {
     if (!shape_supported(state_size, knot_points) && !generic_shape_supported(state_size, knot_points)) return 0;
+    if (state_size == NS && knot_points <= 32) return pcg_rpl_lds_floats((int)knot_points, knot_points <= 16 ? 4 : 8) * sizeof(double);   // row-per-lane kernel
     const size_t b = pcg_generic_lds_elems((int)knot_points, (int)state_size) * sizeof(double);
     return b <= kLdsMax ? b : 0;
 }
@@ -762,7 +763,23 @@ static int launch_generic(mpcg_handle* h, PcgArgsG<T> a, uint32_t batch, void* s
     h->last = LastKernel{3, F64_THREADS / 64, 0, 0, 2, 0, (int)lds, 0};      // family 3 = generic streaming kernel
     return MPCG_OK;
 }
+// double precision, N <= 32 (the real-time horizon): the row-per-lane kernel in double, one slot per wavefront
+static constexpr uint32_t kRplMaxN64 = 32;
+template <int NW, bool PC3>
+static int launch_rpl_f64_t(mpcg_handle* h, const PcgArgs64& a, uint32_t batch, hipStream_t st) {
+    const size_t lds = pcg_rpl_lds_floats((int)h->N, NW) * sizeof(double);
+    hipLaunchKernelGGL((pcg_rpl_kernel_f64<NW, 1, PC3>), dim3(batch), dim3(NW * 64), lds, st, a);
+    HIP_TRY(h, hipGetLastError());
+    h->last = LastKernel{FAM_RPL, NW, 1, 0, 0, 0, (int)lds, 0};
+    return MPCG_OK;
+}
 static int launch_f64(mpcg_handle* h, PcgArgs64 a, uint32_t batch, void* stream) {
+    if (!h->generic && h->N <= kRplMaxN64 && h->rpl != 0 && (h->rpl == 1 || h->auto_cfg)) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (h->N <= 16) return a.pcols == 3 ? launch_rpl_f64_t<4, true>(h, a, batch, st) : launch_rpl_f64_t<4, false>(h, a, batch, st);
+        return a.pcols == 3 ? launch_rpl_f64_t<8, true>(h, a, batch, st) : launch_rpl_f64_t<8, false>(h, a, batch, st);
+    }
     return h->generic ? launch_generic<double, 0>(h, a, batch, stream) : launch_generic<double, 14>(h, a, batch, stream);
 }
 // state_size != 14, float: the PcgArgs of the tuned path re-packed for the generic kernel

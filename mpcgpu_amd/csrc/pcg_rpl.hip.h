@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "pcg_kernels.hip.h"
+#include "pcg_f64.hip.h"
 
 namespace mpcg {
 
@@ -30,9 +31,38 @@ template <int C>
 __device__ __forceinline__ void fmac_bc(float& acc, float x, float m) {
     asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(C));
 }
-// column c of all three blocks of a row: three independent chains, interleaved (a v_fmac's result is ready after ~2 issue slots)
+// double precision (linsys_t = double): row_newbcast is the one DPP control gfx90a+ has for 64-bit operands — exactly the one needed
 template <int C>
-__device__ __forceinline__ void col3_bc(float& aL, float& aD, float& aR, float xm, float x, float xq, const float* m) {
+__device__ __forceinline__ void fmac_bc(double& acc, double x, double m) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(C));
+}
+// sum over the 64 lanes, fixed order, result in every lane's return value of lane 0's wave-uniform use
+__device__ __forceinline__ float rpl_wave_fold(float part) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1"
+        : "+v"(part));
+    const int pb = __builtin_bit_cast(int, part);
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 48));
+    return ((part + r1) + r2) + r3;
+}
+__device__ __forceinline__ double rpl_wave_fold(double part) {      // (no 64-bit row shifts in DPP: the LDS crossbar)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
+    return part;
+}
+// column c of all three blocks of a row: three independent chains, interleaved (a v_fmac's result is ready after ~2 issue slots)
+template <int C, typename T>
+__device__ __forceinline__ void col3_bc_t(T& aL, T& aD, T& aR, T xm, T x, T xq, const T* m) {
     fmac_bc<C>(aD, x, m[14 + C]);
     fmac_bc<C>(aL, xm, m[C]);
     fmac_bc<C>(aR, xq, m[28 + C]);
@@ -51,69 +81,76 @@ struct SFor14<14> {
     static __device__ __forceinline__ void run(F&&) {}
 };
 
-// LDS: six vectors [N + 2][14] (a zero knot either side): p and r double-buffered, r~ and upsilon | 2 NW wave partials
+// LDS: six vectors [N + 2][14] (a zero knot either side): p and r double-buffered, r~ and upsilon | 2 NW wave partials   (elements)
 __host__ __device__ constexpr size_t pcg_rpl_lds_floats(int N, int NW) { return 6 * r4((size_t)(N + 2) * NS) + r4(2 * (size_t)NW); }
 
-template <int NW, int RHO, bool PC3>
-__global__ __launch_bounds__(NW * 64, (RHO * (PC3 ? 84 : 56) + 40 <= 128 ? 4 : 2)) void pcg_rpl_kernel(PcgArgs a) {
+// the arguments of one trajectory, in the kernel's element type
+template <typename T>
+struct RplTraj {
+    const T* S; const T* Pinv; const T* gamma; T* lambda; T* r_out; T* p_out;     // r_out / p_out may be null
+    uint32_t* iters; uint8_t* max_iter_exit;
+    int N; int max_iter; T exit_tol;
+};
+
+template <typename T, int NW, int RHO, bool PC3>
+__device__ __forceinline__ void pcg_rpl_body(const RplTraj<T>& a) {
+    typedef T real;
     constexpr int NTHR = NW * 64, PW = PC3 ? 42 : 14;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    real* lds = reinterpret_cast<real*>(lds_raw);
     const int N = a.N;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
-    if (a.redo_flags && __hip_atomic_load(a.redo_flags + (size_t)b * a.redo_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.redo_skip) return;
     const int VS = (int)r4((size_t)(N + 2) * NS);
-    float* xp0 = lds;                                  // knot k at (k + 1) * NS.  p of even / odd iterations
-    float* xp1 = lds + VS;
-    float* xr0 = lds + 2 * VS;                         // r likewise
-    float* xr1 = lds + 3 * VS;
-    float* xt = lds + 4 * VS;                          // r~ of the last preconditioner pass
-    float* xu = lds + 5 * VS;                          // upsilon of the last S pass
-    float* red_v = lds + 6 * VS;
-    float* red_e = red_v + NW;
-    const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;
-    const float* Sg = static_cast<const float*>(a.S) + (size_t)b * mstride;
-    const float* Pg = static_cast<const float*>(a.Pinv) + (size_t)b * mstride;
-    const float* gam = a.gamma + (size_t)b * vstride;
-    float* lam_g = a.lambda + (size_t)b * vstride;
+    real* xp0 = lds;                                   // knot k at (k + 1) * NS.  p of even / odd iterations
+    real* xp1 = lds + VS;
+    real* xr0 = lds + 2 * VS;                          // r likewise
+    real* xr1 = lds + 3 * VS;
+    real* xt = lds + 4 * VS;                           // r~ of the last preconditioner pass
+    real* xu = lds + 5 * VS;                           // upsilon of the last S pass
+    real* red_v = lds + 6 * VS;
+    real* red_e = red_v + NW;
+    const real* Sg = a.S;
+    const real* Pg = a.Pinv;
+    const real* gam = a.gamma;
+    real* lam_g = a.lambda;
 
     const int q = lane >> 4, i = lane & 15;
     const int ii = i < NS ? i : NS - 1;                // (lanes 14, 15 of a row shadow row 13 with zero matrices)
     int kk[RHO];                                       // knot of slot j (clamped), LDS offset of its own entry
     bool act[RHO];
-    float Sm[RHO][42], Pm[RHO][PW], r[RHO], p[RHO], lam[RHO];
+    real Sm[RHO][42], Pm[RHO][PW], r[RHO], p[RHO], lam[RHO];
 #pragma unroll
     for (int j = 0; j < RHO; ++j) {
         const int k = (j * NW + w) * 4 + q;
         act[j] = k < N && i < NS;
         kk[j] = k < N ? k : N - 1;
-        const float* sb = Sg + (size_t)kk[j] * ROWF + ii;
-        const float* pb = Pg + (size_t)kk[j] * ROWF + ii;
+        const real* sb = Sg + (size_t)kk[j] * ROWF + ii;
+        const real* pb = Pg + (size_t)kk[j] * ROWF + ii;
 #pragma unroll
         for (int c = 0; c < NS; ++c) {                 // element (i, c) of block s: s * 196 + 14 c + i; blocks (0, left), (N-1, right) are never read
-            Sm[j][c] = act[j] && k > 0 ? sb[NS * c] : 0.f;
-            Sm[j][14 + c] = act[j] ? sb[196 + NS * c] : 0.f;
-            Sm[j][28 + c] = act[j] && k < N - 1 ? sb[392 + NS * c] : 0.f;
+            Sm[j][c] = act[j] && k > 0 ? sb[NS * c] : real(0);
+            Sm[j][14 + c] = act[j] ? sb[196 + NS * c] : real(0);
+            Sm[j][28 + c] = act[j] && k < N - 1 ? sb[392 + NS * c] : real(0);
             if constexpr (PC3) {
-                Pm[j][c] = act[j] && k > 0 ? pb[NS * c] : 0.f;
-                Pm[j][14 + c] = act[j] ? pb[196 + NS * c] : 0.f;
-                Pm[j][28 + c] = act[j] && k < N - 1 ? pb[392 + NS * c] : 0.f;
+                Pm[j][c] = act[j] && k > 0 ? pb[NS * c] : real(0);
+                Pm[j][14 + c] = act[j] ? pb[196 + NS * c] : real(0);
+                Pm[j][28 + c] = act[j] && k < N - 1 ? pb[392 + NS * c] : real(0);
             } else {
-                Pm[j][c] = act[j] ? pb[196 + NS * c] : 0.f;
+                Pm[j][c] = act[j] ? pb[196 + NS * c] : real(0);
             }
         }
-        const float l0 = act[j] ? lam_g[kk[j] * NS + ii] : 0.f;
+        const real l0 = act[j] ? lam_g[kk[j] * NS + ii] : real(0);
         lam[j] = l0;
         p[j] = l0;                                     // operand of the set-up product
-        r[j] = act[j] ? gam[kk[j] * NS + ii] : 0.f;
+        r[j] = act[j] ? gam[kk[j] * NS + ii] : real(0);
     }
-    for (int e = tid; e < 6 * VS; e += NTHR) lds[e] = 0.f;
+    for (int e = tid; e < 6 * VS; e += NTHR) lds[e] = real(0);
     lds_barrier();
 
     // every lane publishes its own entry of x
-    auto publish = [&](float* buf, const float (&x)[RHO]) {
+    auto publish = [&](real* buf, const real (&x)[RHO]) {
 #pragma unroll
         for (int j = 0; j < RHO; ++j)
             if (act[j]) buf[(kk[j] + 1) * NS + ii] = x[j];
@@ -122,35 +159,35 @@ __global__ __launch_bounds__(NW * 64, (RHO * (PC3 ? 84 : 56) + 40 <= 128 ? 4 : 2
     // The neighbouring knots' entries of the operand are REBUILT by the reader from what their owners published before the last
     // barrier: x_nb = fma(cb, B[nb], A[nb]) — the very operation (and bits) with which the owner updated its register copy.
     // That is what lets an iteration get by with two barriers (one per inner product) instead of four.
-    auto pass3 = [&](const float (&M)[RHO][42], const float* A, const float* B, float cb, const float (&x)[RHO], float (&y)[RHO]) -> float {
-        float xm[RHO], xq[RHO];
+    auto pass3 = [&](const real (&M)[RHO][42], const real* A, const real* B, real cb, const real (&x)[RHO], real (&y)[RHO]) -> real {
+        real xm[RHO], xq[RHO];
 #pragma unroll
         for (int j = 0; j < RHO; ++j) {                // entry i of the neighbouring knots (zero padding outside the horizon)
             const int lo = kk[j] * NS + ii, hi = (kk[j] + 2) * NS + ii;
-            xm[j] = fmaf(cb, B[lo], A[lo]);
-            xq[j] = fmaf(cb, B[hi], A[hi]);
+            xm[j] = fma_t(cb, B[lo], A[lo]);
+            xq[j] = fma_t(cb, B[hi], A[hi]);
         }
-        float aL[RHO], aD[RHO], aR[RHO];
+        real aL[RHO], aD[RHO], aR[RHO];
 #pragma unroll
-        for (int j = 0; j < RHO; ++j) { aL[j] = 0.f; aD[j] = 0.f; aR[j] = 0.f; }
-        float xo[RHO];
+        for (int j = 0; j < RHO; ++j) { aL[j] = real(0); aD[j] = real(0); aR[j] = real(0); }
+        real xo[RHO];
 #pragma unroll
         for (int j = 0; j < RHO; ++j) { xo[j] = x[j]; asm volatile("s_nop 1" : "+v"(xo[j]), "+v"(xm[j]), "+v"(xq[j])); }
         SFor14<0>::run([&](auto cc) {                  // 3 RHO independent chains, column by column
             constexpr int C = decltype(cc)::value;
 #pragma unroll
-            for (int j = 0; j < RHO; ++j) col3_bc<C>(aL[j], aD[j], aR[j], xm[j], xo[j], xq[j], M[j]);
+            for (int j = 0; j < RHO; ++j) col3_bc_t<C>(aL[j], aD[j], aR[j], xm[j], xo[j], xq[j], M[j]);
         });
-        float part = 0.f;
+        real part = real(0);
 #pragma unroll
-        for (int j = 0; j < RHO; ++j) { y[j] = (aD[j] + aL[j]) + aR[j]; part = fmaf(y[j], x[j], part); }
+        for (int j = 0; j < RHO; ++j) { y[j] = (aD[j] + aL[j]) + aR[j]; part = fma_t(y[j], x[j], part); }
         return part;
     };
     // block-Jacobi Pinv: the diagonal block only
-    auto pass1 = [&](const float (&M)[RHO][14], const float (&x)[RHO], float (&y)[RHO]) -> float {
-        float xo[RHO], a0[RHO], a1[RHO];
+    auto pass1 = [&](const real (&M)[RHO][14], const real (&x)[RHO], real (&y)[RHO]) -> real {
+        real xo[RHO], a0[RHO], a1[RHO];
 #pragma unroll
-        for (int j = 0; j < RHO; ++j) { xo[j] = x[j]; a0[j] = 0.f; a1[j] = 0.f; asm volatile("s_nop 1" : "+v"(xo[j])); }
+        for (int j = 0; j < RHO; ++j) { xo[j] = x[j]; a0[j] = real(0); a1[j] = real(0); asm volatile("s_nop 1" : "+v"(xo[j])); }
         SFor14<0>::run([&](auto cc) {                  // two chains per row (even / odd columns): a lone chain of 14 waits on itself
             constexpr int C = decltype(cc)::value;
 #pragma unroll
@@ -158,35 +195,17 @@ __global__ __launch_bounds__(NW * 64, (RHO * (PC3 ? 84 : 56) + 40 <= 128 ? 4 : 2
         });
 #pragma unroll
         for (int j = 0; j < RHO; ++j) y[j] = a0[j] + a1[j];
-        float part = 0.f;
+        real part = real(0);
 #pragma unroll
-        for (int j = 0; j < RHO; ++j) part = fmaf(y[j], x[j], part);
+        for (int j = 0; j < RHO; ++j) part = fma_t(y[j], x[j], part);
         return part;
     };
-    auto passP = [&](const float* A, const float* B, float cb, const float (&x)[RHO], float (&y)[RHO]) -> float {
+    auto passP = [&](const real* A, const real* B, real cb, const real (&x)[RHO], real (&y)[RHO]) -> real {
         if constexpr (PC3) return pass3(Pm, A, B, cb, x, y);
         else return pass1(Pm, x, y);
     };
-    auto wave_fold = [&](float part) -> float {
-        asm volatile(
-            "s_nop 1\n\t"
-            "v_add_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "s_nop 1\n\t"
-            "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "s_nop 1\n\t"
-            "v_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "s_nop 1\n\t"
-            "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "s_nop 1"
-            : "+v"(part));
-        const int pb = __builtin_bit_cast(int, part);
-        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 16));
-        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 32));
-        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 48));
-        return ((part + r1) + r2) + r3;
-    };
-    auto all_sum = [&](const float* red) -> float {   // the NW wave partials, the same fixed (pairwise) order in every thread
-        float t[NW];
+    auto all_sum = [&](const real* red) -> real {   // the NW wave partials, the same fixed (pairwise) order in every thread
+        real t[NW];
 #pragma unroll
         for (int c = 0; c < NW; ++c) t[c] = red[c];
 #pragma unroll
@@ -196,64 +215,64 @@ __global__ __launch_bounds__(NW * 64, (RHO * (PC3 ? 84 : 56) + 40 <= 128 ? 4 : 2
         return t[0];
     };
     // ---- setup: r = gamma - S lambda0 ; r~ = Pinv r ; p = r~ ; eta = r . r~ ----
-    float y[RHO];
+    real y[RHO];
     publish(xt, p);                                    // (lambda0 as the operand of the set-up product)
     lds_barrier();
-    (void)pass3(Sm, xt, xp0, 0.f, p, y);
+    (void)pass3(Sm, xt, xp0, real(0), p, y);
 #pragma unroll
     for (int j = 0; j < RHO; ++j) r[j] -= y[j];
     publish(xr0, r);                                   // r_0: "r before the update" of iteration 0
     lds_barrier();                                     // (also: every read of lambda0 in xt is done)
     {
-        const float part = wave_fold(passP(xr0, xu, 0.f, r, y));      // xu is still all zero: neighbours' r_0 = xr0 + 0 * 0
+        const real part = rpl_wave_fold(passP(xr0, xu, real(0), r, y));      // xu is still all zero: neighbours' r_0 = xr0 + 0 * 0
         if (lane == 0) red_e[w] = part;
     }
 #pragma unroll
     for (int j = 0; j < RHO; ++j) p[j] = y[j];
     publish(xt, y);                                    // r~_0; p_0 = r~_0 + 0 * p_(-1), p_(-1) = the zeros of xp0
     lds_barrier();
-    float eta = all_sum(red_e);
+    real eta = all_sum(red_e);
 
     // Iteration it: S pass on p_it, whose neighbour entries are xt + beta * xp[it & 1] (r~ and the previous p as published);
     // preconditioner pass on r_(it+1), neighbour entries xr[it & 1] - alpha * xu.  Every lane publishes its own upsilon / r~ entry
     // with the wave partial before the one barrier of the pass, and its updated r / p entry into the other buffer of the pair.
     uint32_t iters = 0;
     uint32_t max_iter_exit = 1;
-    float beta = 0.f;
-    if (fabsf(eta) < a.exit_tol) {
+    real beta = real(0);
+    if (fabs_t(eta) < a.exit_tol) {
         max_iter_exit = 0;
     } else {
         for (int it = 0; it < a.max_iter; ++it) {
-            float* xp_old = (it & 1) ? xp1 : xp0;
-            float* xp_new = (it & 1) ? xp0 : xp1;
-            float* xr_old = (it & 1) ? xr1 : xr0;
-            float* xr_new = (it & 1) ? xr0 : xr1;
+            real* xp_old = (it & 1) ? xp1 : xp0;
+            real* xp_new = (it & 1) ? xp0 : xp1;
+            real* xr_old = (it & 1) ? xr1 : xr0;
+            real* xr_new = (it & 1) ? xr0 : xr1;
             {   // upsilon = S p ; v = p . upsilon
-                const float part = wave_fold(pass3(Sm, xt, xp_old, beta, p, y));
+                const real part = rpl_wave_fold(pass3(Sm, xt, xp_old, beta, p, y));
                 if (lane == 0) red_v[w] = part;
             }
             if constexpr (PC3) publish(xu, y);
             publish(xp_new, p);                        // p_it, for the neighbours' rebuild in iteration it + 1
             lds_barrier();
-            const float alpha = eta / all_sum(red_v);
+            const real alpha = eta / all_sum(red_v);
 #pragma unroll
             for (int j = 0; j < RHO; ++j) {
-                lam[j] = fmaf(alpha, p[j], lam[j]);
-                r[j] = fmaf(-alpha, y[j], r[j]);
+                lam[j] = fma_t(alpha, p[j], lam[j]);
+                r[j] = fma_t(-alpha, y[j], r[j]);
             }
             if constexpr (PC3) publish(xr_new, r);     // r_(it+1), "r before the update" of the next iteration
             {   // r~ = Pinv r ; eta' = r . r~
-                const float part = wave_fold(passP(xr_old, xu, -alpha, r, y));
+                const real part = rpl_wave_fold(passP(xr_old, xu, -alpha, r, y));
                 if (lane == 0) red_e[w] = part;
             }
             publish(xt, y);
             lds_barrier();
-            const float eta_new = all_sum(red_e);
+            const real eta_new = all_sum(red_e);
             iters = (uint32_t)(it + 1);
-            if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
+            if (fabs_t(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
             beta = eta_new / eta;
 #pragma unroll
-            for (int j = 0; j < RHO; ++j) p[j] = fmaf(beta, p[j], y[j]);
+            for (int j = 0; j < RHO; ++j) p[j] = fma_t(beta, p[j], y[j]);
             eta = eta_new;
         }
     }
@@ -263,14 +282,54 @@ __global__ __launch_bounds__(NW * 64, (RHO * (PC3 ? 84 : 56) + 40 <= 128 ? 4 : 2
         if (act[j]) {
             const size_t e = (size_t)kk[j] * NS + ii;
             lam_g[e] = lam[j];
-            if (a.r_out) a.r_out[(size_t)b * vstride + e] = r[j];
-            if (a.p_out) a.p_out[(size_t)b * vstride + e] = p[j];
+            if (a.r_out) a.r_out[e] = r[j];
+            if (a.p_out) a.p_out[e] = p[j];
         }
     }
     if (tid == 0) {
-        a.iters[b] = iters;
-        a.max_iter_exit[b] = (uint8_t)max_iter_exit;
+        *a.iters = iters;
+        *a.max_iter_exit = (uint8_t)max_iter_exit;
     }
 }
+
+// register estimate -> minimum waves per SIMD the kernel is compiled for (4 when a wave needs <= 128 registers, else 2)
+template <typename T, int RHO, bool PC3>
+constexpr int rpl_min_waves() { return (int)(sizeof(T) / 4) * RHO * (PC3 ? 84 : 56) + 40 <= 128 ? 4 : 2; }
+
+template <int NW, int RHO, bool PC3>
+__global__ __launch_bounds__(NW * 64, (rpl_min_waves<float, RHO, PC3>())) void pcg_rpl_kernel(PcgArgs a) {
+    const int b = blockIdx.x;
+    if (a.redo_flags && __hip_atomic_load(a.redo_flags + (size_t)b * a.redo_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.redo_skip) return;
+    const size_t mstride = (size_t)a.N * ROWF, vstride = (size_t)a.N * NS;
+    RplTraj<float> t;
+    t.S = static_cast<const float*>(a.S) + (size_t)b * mstride;
+    t.Pinv = static_cast<const float*>(a.Pinv) + (size_t)b * mstride;
+    t.gamma = a.gamma + (size_t)b * vstride;
+    t.lambda = a.lambda + (size_t)b * vstride;
+    t.r_out = a.r_out ? a.r_out + (size_t)b * vstride : nullptr;
+    t.p_out = a.p_out ? a.p_out + (size_t)b * vstride : nullptr;
+    t.iters = a.iters + b; t.max_iter_exit = a.max_iter_exit + b;
+    t.N = a.N; t.max_iter = a.max_iter; t.exit_tol = a.exit_tol;
+    pcg_rpl_body<float, NW, RHO, PC3>(t);
+}
+
+// linsys_t = double (USE_DOUBLES of the reference): the same kernel in double precision; one slot per wavefront, N <= 32
+template <int NW, int RHO, bool PC3>
+__global__ __launch_bounds__(NW * 64, (rpl_min_waves<double, RHO, PC3>())) void pcg_rpl_kernel_f64(PcgArgs64 a) {
+    const int b = blockIdx.x;
+    const size_t mstride = (size_t)a.N * ROWF, vstride = (size_t)a.N * NS;
+    RplTraj<double> t;
+    t.S = a.S + (size_t)b * mstride;
+    t.Pinv = a.Pinv + (size_t)b * mstride;
+    t.gamma = a.gamma + (size_t)b * vstride;
+    t.lambda = a.lambda + (size_t)b * vstride;
+    t.r_out = a.r_out ? a.r_out + (size_t)b * vstride : nullptr;
+    t.p_out = a.p_out ? a.p_out + (size_t)b * vstride : nullptr;
+    t.iters = a.iters + b; t.max_iter_exit = a.max_iter_exit + b;
+    t.N = a.N; t.max_iter = a.max_iter; t.exit_tol = a.exit_tol;
+    pcg_rpl_body<double, NW, RHO, PC3>(t);
+}
+
+
 
 }  // namespace mpcg

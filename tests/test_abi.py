@@ -55,7 +55,8 @@ def test_version_and_lds_size(hiplib):
     # N > 128: a member of the clustered lane-per-block kernel — six vectors of 128 + 2 knot slots, partials, broadcast cell, hand-off tables (§3.1d)
     for N in (129, 256, 512):
         assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (6 * r4(130 * 14) + r4(16) + 4 + 3 * 64) == 44528
-    assert hiplib.mpcg_pcg_lds_bytes_f64(14, 32) == 8 * ((32 + 2) * 14 * 2 + 32 * 14 * 2 + 8)
+    assert hiplib.mpcg_pcg_lds_bytes_f64(14, 32) == 8 * (6 * r4((32 + 2) * 14) + 16)          # N <= 32: the row-per-lane kernel in double
+    assert hiplib.mpcg_pcg_lds_bytes_f64(14, 64) == 8 * ((64 + 2) * 14 * 2 + 64 * 14 * 2 + 8)   # beyond: the generic streaming kernel
     assert hiplib.mpcg_pcg_lds_bytes(12, 128) == 4 * (2 * 130 * 12 + 2 * 128 * 12 + 8)   # n != 14: the generic kernel's vectors
     assert hiplib.mpcg_pcg_lds_bytes(65, 8) == 0            # state sizes beyond 64 are not served
     assert hiplib.mpcg_pcg_lds_bytes(14, 1024) == 0         # vectors would not fit 160 KiB LDS

@@ -133,3 +133,26 @@ def test_rpl_default_policy_and_batch_composition():
         lam = lam.cpu().numpy()
         for b in range(8, B, 97):          # tiled inputs: trajectory b must equal trajectory b mod 8, bit for bit
             np.testing.assert_array_equal(lam[b], lam[b % 8])
+
+
+@pytest.mark.parametrize("N,waves", [(5, 4), (16, 4), (17, 8), (32, 8)])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+def test_rpl_double_precision(orc, N, waves, pc):
+    """linsys_t = double (USE_DOUBLES of the reference) at N <= 32 runs the same kernel in double (v_fmac_f64_dpp): against the float64
+    oracle the iterate differs by summation order only."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    B, K = 2, 25
+    k = synth.make_kkt(N, B, 4100 + N)
+    S, Pinv, g = synth.form_schur(k, poison_unused=True)
+    sol = PcgSolver(N, max_batch=B)
+    lam = torch.zeros(B, n * N, device="cuda", dtype=torch.float64)
+    it, ex = sol.solve_f64(dev(S.astype(np.float64)), dev(Pinv.astype(np.float64)), dev(g.astype(np.float64)), lam,
+                           pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), pc)
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 5 and sol.get_option("last_kernel_waves") == waves
+    assert sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes_f64(14, N)
+    assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all()
+    for b in range(B):
+        Sz, Pz = np.nan_to_num(S[b]).astype(np.float64), np.nan_to_num(Pinv[b]).astype(np.float64)
+        r64 = orc.pcg(Sz, Pz, g[b].astype(np.float64), np.zeros(n * N), N, K, 0.0, pc)
+        assert relinf(lam.cpu().numpy()[b], r64["lam"]) <= 1e-8, (N, pc, b, relinf(lam.cpu().numpy()[b], r64["lam"]))
