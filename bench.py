@@ -529,6 +529,27 @@ def main():
         del Gk, Ck, Gp, Cp, rS, rP, pS
 
     if extras and rank == 0 and world == 1 and not lean:
+        # the short-horizon regime in throughput mode (N = 32, the reference's real-time horizon; row-per-lane kernel)
+        sh = {}
+        for pc_ in ("ss", "jacobi"):
+            Ns, Bs = 32, 2048
+            ss_ = PcgSolver(Ns, max_batch=Bs, device=local_rank)
+            S0, P0, g0 = build_inputs(ss_, Ns, 64, seed0, pc_, dev, chunk=64)
+            Sl, Pl, gl = (t.repeat(Bs // 64, 1).contiguous() for t in (S0, P0, g0))
+            cs = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=synth.pcg_max_iter(Ns))
+            ls = torch.zeros(Bs, 14 * Ns, device=dev)
+            is_ = torch.zeros(Bs, dtype=torch.int32, device=dev)
+            xs_ = torch.zeros(Bs, dtype=torch.uint8, device=dev)
+
+            def run_s():
+                ls.zero_()
+                ss_.solve(Sl, Pl, gl, ls, cs, pc_, iters=is_, exits=xs_)
+            ms_s = timed(run_s, 5, warm=1)
+            sh[pc_] = {"knots": Ns, "batch": Bs, "pcg_iters_per_solve": synth.pcg_max_iter(Ns), "kernel_ms": ms_s,
+                       "pcg_iterations_per_sec": int(is_.sum().item()) / (ms_s * 1e-3), "kernel_family": ss_.get_option("last_kernel_family"),
+                       "kernel_waves": ss_.get_option("last_kernel_waves")}
+            del Sl, Pl, gl, ls, ss_
+        out["short_horizon"] = sh
         out["config2_latency"] = latency_config2(dev)
         # the headline horizon as ONE trajectory (the reference's own mode of use): ms per SQP-linsolve
         sol1 = PcgSolver(N, max_batch=1, device=local_rank)
