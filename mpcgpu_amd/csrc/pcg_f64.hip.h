@@ -13,6 +13,11 @@
 
 namespace mpcg {
 
+// Contraction is OFF in this header (as in the Schur headers): the vector updates are a rounded multiply followed by a rounded add,
+// like the C oracle's; only the products spelled fma_t are fused.  (Until round 2 this was an accident of the include order — the
+// pragma of schur_dpp.hip.h reached this file; the double-precision iteration counts the tests pin depend on it.)
+#pragma clang fp contract(off)
+
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double fabs_t(double a) { return fabs(a); }
@@ -128,5 +133,7 @@ if constexpr (NFIX > 0) {
     }
     if (tid == 0) { a.iters[b] = iters; a.max_iter_exit[b] = (uint8_t)flag; }
 }
+
+#pragma clang fp contract(fast)     // (hipcc's default for device code: what the headers included after this one are written for)
 
 }  // namespace mpcg
