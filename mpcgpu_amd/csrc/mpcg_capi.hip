@@ -437,12 +437,13 @@ static int launch_lpb_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStr
 static int launch_lpb(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
     return h->N <= 64 ? launch_lpb_t<1>(h, a, batch, st) : launch_lpb_t<2>(h, a, batch, st);
 }
-// Automatic use: 48 < N <= 128.  Its per-lane work does not shrink with the horizon (one block per lane whatever N), so for
-// short horizons the row-pair kernels of pcg_traj_kernel stay ahead (N=32: 289 vs 224 M it/s at batch 2048, 0.247 vs 0.340 ms
-// for one trajectory; N=64: 202 vs 132 M it/s the other way round — profiles/r02_lpb_quick.txt).
+// Automatic use: 36 < N <= 128 (where the row-per-lane kernel has not taken the call).  Its per-lane work does not shrink with the horizon
+// (one block per lane whatever N), so up to N = 36 — where the row-pair kernel <4,3,0> fits two trajectories per CU — that one stays
+// ahead in throughput (N=36: 292 vs 222 M it/s at batch 2048); beyond it the order flips (N=40: 240 vs 209 M, N=48: 229 vs 205 M,
+// N=64: 220 vs 139 M — tools/_prof/n48.py).
 static bool use_lpb(const mpcg_handle* h, int esz) {
     if (esz != 4 || h->N > kLpbMaxN || h->lpb == 0) return false;
-    return h->lpb == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 48);
+    return h->lpb == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 36);
 }
 
 // ---- row-per-lane kernel (pcg_rpl.hip.h): short horizons, NW wavefronts x RHO slots of four knots ----
