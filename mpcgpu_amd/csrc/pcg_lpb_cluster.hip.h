@@ -192,6 +192,10 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
         }
     };
 
+#ifdef MPCG_PROF
+    bool prof_on = false;
+    int prof_base = 0;
+#endif
     bool same_xcd = false;                             // uniform: all members of this cluster run on one XCD (set below)
     unsigned epoch = 0, seq = 0;                       // hand-offs / trajectories of this cluster so far: tags never repeat inside a launch
     bool failed = false;                               // uniform across the workgroup (published through LDS)
@@ -202,7 +206,9 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
     using SlotE = std::integral_constant<int, LPBC_SLOT_E>;
     auto exchange = [&](float* red, auto slot, bool parts3) -> float {
         constexpr int base = decltype(slot)::value;
+        MPCG_STAMP(prof_base + 0);
         lds_barrier();                                  // parts and wave partials are in LDS
+        MPCG_STAMP(prof_base + 1);
         ++epoch;
         if (w == 0) {
             // What this lane publishes and polls comes from three small LDS tables (filled once per launch): as registers they would be
@@ -211,21 +217,32 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
             const int* tab = reinterpret_cast<const int*>(lds + L::TAB) + lane;
             const unsigned poll_byte = (unsigned)tab[0];           // 0xFFFFFFFF: nothing to poll
-            const int ia = tab[64], ib = parts3 ? tab[128] : L::BC + 3;   // s = yD + yL (block-Jacobi pass: yD + 0), t = yT + 0
             const bool want = poll_byte != 0xFFFFFFFFu;
-            float val;
-            if (lane == 0) {
-                val = 0.f;
-#pragma unroll
-                for (int c = 0; c < NW; ++c) val += red[c];
-            } else {
-                val = lds[ia] + lds[ib];
+            // one straight-line read for every lane: lanes 1..28 their message value (s = yD + yL, block-Jacobi pass: yD + 0; t = yT + 0),
+            // lanes 32..32+NW-1 one wave partial each (+ 0), which a three-step DPP tree then folds into lane 32 — a lane-0 branch with a serial
+            // sum of the partials in front of the other lanes' reads made this 600 cycles on the critical path of every hand-off
+            const int ia = tab[64] + (lane >= 32 && lane < 32 + NW ? (int)(red - (lds + L::RED)) : 0), ib = parts3 ? tab[128] : L::BC + 3;
+            float val = lds[ia] + lds[ib];
+            {
+                float ps = val;
+                asm volatile(
+                    "s_nop 1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "s_nop 1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "s_nop 1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "s_nop 1"
+                    : "+v"(ps));
+                const float tot_w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ps), 32));
+                val = lane == 0 ? tot_w : val;
             }
             if (lane <= 2 * NS) {
                 const unsigned long long gran = ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, val);
                 if (same_xcd) granule_store_l2<base>(my_words, 8u * (unsigned)lane, gran);
                 else granule_store<base>(my_words, 8u * (unsigned)lane, gran);
             }
+            MPCG_STAMP(prof_base + 2);
             unsigned long long x = 0;
             unsigned spins = 0;
             bool ok;
@@ -238,6 +255,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
             } while (++spins < CL_SPIN_LIMIT);
+            MPCG_STAMP(prof_base + 3);
             const int bits = (int)(unsigned)x;
             float tot = 0.f;
             for (int c = 0; c < G; ++c) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, c));
@@ -247,6 +265,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
             if (lane == 0) { bc[0] = tot; if (spins >= CL_SPIN_LIMIT) bc[1] = 1.f; }
         }
         lds_barrier();
+        MPCG_STAMP(prof_base + 4);
         if (bc[1] != 0.f) failed = true;
         return bc[0];
     };
@@ -271,7 +290,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
         int* tab = reinterpret_cast<int*>(lds + L::TAB) + l;
         tab[0] = want ? 8 * word : -1;
         // lanes 1..14 publish s = (yD + yL) of the last own knot, lanes 15..28 t = yT of slot 0
-        tab[64] = l >= 1 && l <= NS ? L::YD + KL * NS + l - 1 : l > NS && l <= 2 * NS ? L::YT + l - 1 - NS : L::BC + 3;
+        tab[64] = l >= 1 && l <= NS ? L::YD + KL * NS + l - 1 : l > NS && l <= 2 * NS ? L::YT + l - 1 - NS : l >= 32 && l < 32 + NW ? L::RED + l - 32 : L::BC + 3;
         tab[128] = l >= 1 && l <= NS ? L::YL + KL * NS + l - 1 : L::BC + 3;
     }
     // ---- are all members of this cluster on one XCD?  (They are meant to be, see above, but workgroup -> XCD placement is not a
@@ -392,6 +411,11 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
             max_iter_exit = 0;
         } else {
             for (int it = 0; it < a.max_iter; ++it) {
+#ifdef MPCG_PROF
+                prof_on = cl == 0 && g == 0 && it == 20;
+                prof_base = 1;
+#endif
+                MPCG_STAMP(0);
                 // upsilon = S p ; v = p . upsilon
                 if (!isP) pass(L::XP, red_v);
                 const float alpha = eta / exchange(red_v, SlotV{}, true);
@@ -402,6 +426,10 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
                     if (ok1) xr2[e1] = r1 - alpha * ((d1 + l1) + t1);
                 }
                 lds_barrier();
+                MPCG_STAMP(6);
+#ifdef MPCG_PROF
+                prof_base = 7;
+#endif
                 // r~ = Pinv r ; eta' = r . r~          | S waves: lambda += alpha p (own knots)
                 if (isP) {
                     if (wave_on) pass(L::XR, red_e);
@@ -426,6 +454,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
                     eta = eta_new;
                 }
                 lds_barrier();
+                MPCG_STAMP(12);
             }
         }
 
