@@ -110,7 +110,7 @@ const char* mpcg_build_info(void) {
 static size_t cluster_alloc_words(const mpcg_handle* h) {
     const size_t cells = (size_t)2 * h->num_cus * CL_WG_WORDS;
     const size_t a = (size_t)h->num_cus * CL_FLAG_STRIDE + cells;
-    const size_t b = cells + CL_FLAG_STRIDE + (size_t)h->max_batch * CL_FLAG_STRIDE;
+    const size_t b = (size_t)2 * h->num_cus * LPBC_WG_WORDS + CL_FLAG_STRIDE + (size_t)h->max_batch * CL_FLAG_STRIDE;
     return a > b ? a : b;
 }
 
@@ -587,7 +587,7 @@ static int lpbc_members(const mpcg_handle* h, int nmax) {
     return G;
 }
 // scratch of the clustered lane-per-block kernel: [queue: one 128-byte line][flags: one line per trajectory of the call = members that
-// finished it][cells: 512 B per member of the launch] — what a call uses is contiguous, so one small fill precedes every launch
+// finished it][cells: 1 KB per member of the launch] — what a call uses is contiguous, so one small fill precedes every launch
 template <int NWR>
 static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
     constexpr int per_cu = NWR == 2 ? 1 : 2;
@@ -614,7 +614,7 @@ static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, h
     ca.clusters = (int)clusters;
     ca.l2_handoff = h->cluster_l2;
     // one fill: the queue counter, this call's flags and the cells of this launch (their tags restart at 1 every launch)
-    const size_t zw = CL_FLAG_STRIDE + (size_t)batch * CL_FLAG_STRIDE + (size_t)clusters * G * CL_WG_WORDS;
+    const size_t zw = CL_FLAG_STRIDE + (size_t)batch * CL_FLAG_STRIDE + (size_t)clusters * G * LPBC_WG_WORDS;
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster_scratch, zw);
     HIP_TRY(h, hipGetLastError());
     hipLaunchKernelGGL(kern, dim3(((clusters + 7) / 8) * 8 * (unsigned)G), dim3(NWR * 256), lds, st, ca);

@@ -11,11 +11,12 @@
 //     left -> right : s = (D x)_{k0-1} + (L x)_{k0-1}         (lets the right member update its replica of knot k0 - 1:
 //                                                              y_{k0-1} = s + t, the same bits the owner computes)
 // and both are needed at the same point as the all-reduced inner product — after the pass, before the vector update.  So
-// ONE hand-off per pass carries everything: each member publishes {partial, s[14], t[14]} as 29 epoch-tagged 8-byte
-// granules (the R2 recipe of cdna_hip_programming.md §6 G16, as pcg_cluster_kernel) and polls the partials of all
-// members, the s of its left and the t of its right neighbour.  Two exposed hand-offs per PCG iteration; the row-triple
-// cluster kernel needs four (2 all-reduces + 2 halo fetches) and re-reads nothing either, but runs the slower
-// row-pair arithmetic.  No operand halo is ever waited for inside a pass.
+// ONE hand-off per pass carries everything, and it is published straight from the registers that hold it, the moment it exists: every
+// wave its partial of the inner product (an 8-byte {tag, value} granule), the lanes of block row k1 - 1 the diagonal and the
+// sub-diagonal part of s, lane 0 of the first off-diagonal wave t (five 16-byte {tag, v0, v1, v2} granules each) — the R2 recipe of
+// cdna_hip_programming.md §6 G16.  One wave polls all of them, drops the neighbours' parts into LDS and folds the partials; one
+// barrier ends the exchange.  Two exposed hand-offs per PCG iteration; the row-triple cluster kernel needs four (2 all-reduces + 2
+// halo fetches) and re-reads nothing either, but runs the slower row-pair arithmetic.  No operand halo is ever waited for inside a pass.
 //
 // Clusters are PERSISTENT: the launch holds as many clusters as fit the chip (every member resident) and each cluster draws
 // trajectories from a queue (one atomic counter; the leader publishes the index to its peers as one more tagged granule)
@@ -41,10 +42,14 @@ template <int NWR> struct LpbcLds {
 };
 __host__ __device__ constexpr size_t pcg_lpbc_lds_floats(int NW) { return NW == 4 ? (size_t)LpbcLds<1>::TOTAL : (size_t)LpbcLds<2>::TOTAL; }
 
-constexpr int LPBC_MAX_G = 16;             // members whose partials one wave polls with lanes 0..15
-constexpr int LPBC_SLOT_V = 0, LPBC_SLOT_E = 32;     // granule words of the two alternating exchanges inside a member's CL_WG_WORDS block
-constexpr int LPBC_SLOT_X = 61;                      // every member, once per launch: {1, XCC id} (the same-XCD check)
-constexpr int LPBC_SLOT_T = 62;                      // leader only: {sequence number, trajectory index} of the cluster's current trajectory
+constexpr int LPBC_MAX_G = 8;              // members: G x NW wave partials are polled by the 64 lanes of one wave
+constexpr int LPBC_WG_WORDS = 128;         // u64 words of hand-off cells per member (1 KB)
+// Cells of one member: two alternating exchange slots, each = NW 8-byte granules {tag, wave partial} (words 0..7) and three groups of
+// five 16-byte granules {tag, v0, v1, v2} — 14 values each: yD and yL of the last own knot (for the right neighbour), t (for the left one).
+constexpr int LPBC_SLOT_V = 0, LPBC_SLOT_E = 40;
+constexpr int LPBC_W_YD = 8, LPBC_W_YL = 18, LPBC_W_T = 28;
+constexpr int LPBC_SLOT_T = 120;                     // leader only: {sequence number, trajectory index} of the cluster's current trajectory
+constexpr int LPBC_SLOT_X = 121;                     // every member, once per launch: {1, XCC id} (the same-XCD check)
 
 // Granule accesses in the "uniform 64-bit base (SGPR pair) + 32-bit lane byte offset" addressing form, spelled out: left to
 // the compiler, the per-lane addresses of the two exchange slots become 64-bit VGPR pointers that are hoisted out of the PCG
@@ -70,6 +75,46 @@ __device__ __forceinline__ unsigned long long granule_load(const gu64* sbase, un
     unsigned long long x;
     asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:%3 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(byte_off), "s"(sbase), "n"(8 * WORD) : "memory");
     return x;
+}
+
+// 16-byte granules {tag, v0, v1, v2}: one dwordx4 store / load (observed untorn on gfx950, MI355X_MICROARCH.md "R2's granule"), three
+// values per fabric / L2 transaction instead of one.  L2 = without sc1 (see granule_store_l2).
+template <int WORD, bool L2>
+__device__ __forceinline__ void granule_store16(gu64* sbase, unsigned byte_off, f4 v) {
+    if constexpr (L2) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(byte_off), "v"(v), "s"(sbase), "n"(8 * WORD) : "memory");
+    else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3 sc1\n\ts_nop 1" : : "v"(byte_off), "v"(v), "s"(sbase), "n"(8 * WORD) : "memory");
+}
+__device__ __forceinline__ f4 granule_load16(const gu64* sbase, unsigned byte_off) {
+    f4 x;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(byte_off), "s"(sbase) : "memory");
+    return x;
+}
+// 14 values as five 16-byte granules at word WORD of the member's cells (executed by the one lane that holds them): one asm block —
+// one hazard pad for the base, five stores back to back
+template <int WORD, bool L2>
+__device__ __forceinline__ void publish14(gu64* sbase, unsigned ep, const f2 (&v)[7]) {
+    const float tg = __builtin_bit_cast(float, ep);
+    const f4 g0 = {tg, v[0].x, v[0].y, v[1].x}, g1 = {tg, v[1].y, v[2].x, v[2].y}, g2 = {tg, v[3].x, v[3].y, v[4].x},
+             g3 = {tg, v[4].y, v[5].x, v[5].y}, g4 = {tg, v[6].x, v[6].y, 0.f};
+    const unsigned z = 0u;
+    if constexpr (L2)
+        asm volatile("s_nop 4\n\t"
+                     "global_store_dwordx4 %0, %1, %6 offset:%7\n\t"
+                     "global_store_dwordx4 %0, %2, %6 offset:%7+16\n\t"
+                     "global_store_dwordx4 %0, %3, %6 offset:%7+32\n\t"
+                     "global_store_dwordx4 %0, %4, %6 offset:%7+48\n\t"
+                     "global_store_dwordx4 %0, %5, %6 offset:%7+64\n\t"
+                     "s_nop 1"
+                     : : "v"(z), "v"(g0), "v"(g1), "v"(g2), "v"(g3), "v"(g4), "s"(sbase), "n"(8 * WORD) : "memory");
+    else
+        asm volatile("s_nop 4\n\t"
+                     "global_store_dwordx4 %0, %1, %6 offset:%7 sc1\n\t"
+                     "global_store_dwordx4 %0, %2, %6 offset:%7+16 sc1\n\t"
+                     "global_store_dwordx4 %0, %3, %6 offset:%7+32 sc1\n\t"
+                     "global_store_dwordx4 %0, %4, %6 offset:%7+48 sc1\n\t"
+                     "global_store_dwordx4 %0, %5, %6 offset:%7+64 sc1\n\t"
+                     "s_nop 1"
+                     : : "v"(z), "v"(g0), "v"(g1), "v"(g2), "v"(g3), "v"(g4), "s"(sbase), "n"(8 * WORD) : "memory");
 }
 
 template <int NWR>
@@ -100,8 +145,8 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
     float* bc = lds + L::BC;                            // [0] cluster-wide sum, [1] sticky timeout flag, [2] trajectory index (int)
 
     const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;
-    gu64* my_words = (gu64*)ca.scratch + ((size_t)cl * G + g) * CL_WG_WORDS;
-    gu64* cl_words = (gu64*)ca.scratch + (size_t)cl * G * CL_WG_WORDS;
+    gu64* my_words = (gu64*)ca.scratch + ((size_t)cl * G + g) * LPBC_WG_WORDS;
+    gu64* cl_words = (gu64*)ca.scratch + (size_t)cl * G * LPBC_WG_WORDS;
 
     // ---- role of this wave, block of this lane (pcg_lpb_kernel's roles; i = index of the block inside the member) ----
     const int role = w / NWR;
@@ -139,8 +184,20 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
         const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 48));
         return ((part + r1) + r2) + r3;
     };
+#ifdef MPCG_PROF
+    bool prof_on = false;
+    int prof_base = 0;
+#endif
+    bool same_xcd = false;                             // uniform: all members of this cluster run on one XCD (set below)
+    unsigned epoch = 0, seq = 0;                       // hand-offs / trajectories of this cluster so far: tags never repeat inside a launch
+    bool failed = false;                               // uniform across the workgroup (published through LDS)
+    // The one hand-off of a pass.  Called by all threads after the pass; returns the cluster-wide inner product.  On return
+    // yD[slot 0] holds the left neighbour's s and yT[slot KL] the right neighbour's t (where those neighbours exist).
+    // parts3: the pass wrote off-diagonal parts (false for the block-Jacobi preconditioner pass: s = yD alone).
     // one pass of this wave's blocks over the vector at buffer offset X (pcg_lpb_kernel::pass with slot addressing)
-    auto pass = [&](int X, float* red) {
+    auto pass = [&](int X, auto slot) {
+        constexpr int base = decltype(slot)::value;
+        const unsigned ep = epoch + 1;                  // tag of the hand-off that follows this pass
         f2 xa[7], xb[7], acc[7];
         {
             const f2* xa2 = reinterpret_cast<const f2*>(xk + X + (isL ? -NS : 0));
@@ -164,8 +221,19 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
         }
         const f2 dt = dt0 + dt1;
         const float part = wave_fold(isL ? 2.f * (dt.x + dt.y) : dt.x + dt.y);
-        if (lane == 0) red[w] = part;
+        // published straight from the registers that hold them, the moment they exist: the wave partial by lane 0, the last own
+        // knot's yD / yL (the right neighbour's s) by the lane of block row KL - 1
+        if (lane == 0) {
+            const unsigned long long gran = ((unsigned long long)ep << 32) | __builtin_bit_cast(unsigned, part);
+            if (same_xcd) granule_store_l2<base>(my_words, 8u * (unsigned)w, gran);
+            else granule_store<base>(my_words, 8u * (unsigned)w, gran);
+        }
+        if (valid && i == KL - 1 && g < G - 1) {
+            if (isL) { if (same_xcd) publish14<base + LPBC_W_YL, true>(my_words, ep, acc); else publish14<base + LPBC_W_YL, false>(my_words, ep, acc); }
+            else { if (same_xcd) publish14<base + LPBC_W_YD, true>(my_words, ep, acc); else publish14<base + LPBC_W_YD, false>(my_words, ep, acc); }
+        }
         if (isL) {
+            f2 tq[7];
             f2* yt2 = reinterpret_cast<f2*>(wk + L::YT + (valid ? -NS : 0));
 #pragma unroll
             for (int u = 0; u < 12; u += 4) {
@@ -177,8 +245,10 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
                     t2 = __builtin_elementwise_fma(mp(u + 2, r), xb[r], t2);
                     t3 = __builtin_elementwise_fma(mp(u + 3, r), xb[r], t3);
                 }
-                yt2[u >> 1] = f2{t0.x + t0.y, t1.x + t1.y};
-                yt2[(u >> 1) + 1] = f2{t2.x + t2.y, t3.x + t3.y};
+                tq[u >> 1] = f2{t0.x + t0.y, t1.x + t1.y};
+                tq[(u >> 1) + 1] = f2{t2.x + t2.y, t3.x + t3.y};
+                yt2[u >> 1] = tq[u >> 1];
+                yt2[(u >> 1) + 1] = tq[(u >> 1) + 1];
             }
             {
                 f2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f};
@@ -187,85 +257,72 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
                     t0 = __builtin_elementwise_fma(mp(12, r), xb[r], t0);
                     t1 = __builtin_elementwise_fma(mp(13, r), xb[r], t1);
                 }
-                yt2[6] = f2{t0.x + t0.y, t1.x + t1.y};
+                tq[6] = f2{t0.x + t0.y, t1.x + t1.y};
+                yt2[6] = tq[6];
+            }
+            if (valid && i == 0 && g > 0) {             // t = L_k0^T x_k0: the left neighbour's missing part
+                if (same_xcd) publish14<base + LPBC_W_T, true>(my_words, ep, tq); else publish14<base + LPBC_W_T, false>(my_words, ep, tq);
             }
         }
     };
+    // a wave that sits a pass out still owes its (zero) partial to the hand-off
+    auto idle_partial = [&](auto slot) {
+        constexpr int base = decltype(slot)::value;
+        if (lane == 0) {
+            const unsigned long long gran = (unsigned long long)(epoch + 1) << 32;
+            if (same_xcd) granule_store_l2<base>(my_words, 8u * (unsigned)w, gran);
+            else granule_store<base>(my_words, 8u * (unsigned)w, gran);
+        }
+    };
 
-#ifdef MPCG_PROF
-    bool prof_on = false;
-    int prof_base = 0;
-#endif
-    bool same_xcd = false;                             // uniform: all members of this cluster run on one XCD (set below)
-    unsigned epoch = 0, seq = 0;                       // hand-offs / trajectories of this cluster so far: tags never repeat inside a launch
-    bool failed = false;                               // uniform across the workgroup (published through LDS)
-    // The one hand-off of a pass.  Called by all threads after the pass; returns the cluster-wide inner product.  On return
-    // yD[slot 0] holds the left neighbour's s and yT[slot KL] the right neighbour's t (where those neighbours exist).
-    // parts3: the pass wrote off-diagonal parts (false for the block-Jacobi preconditioner pass: s = yD alone).
     using SlotV = std::integral_constant<int, LPBC_SLOT_V>;
     using SlotE = std::integral_constant<int, LPBC_SLOT_E>;
-    auto exchange = [&](float* red, auto slot, bool parts3) -> float {
+    auto exchange = [&](auto slot, bool parts3) -> float {
         constexpr int base = decltype(slot)::value;
         MPCG_STAMP(prof_base + 0);
-        lds_barrier();                                  // parts and wave partials are in LDS
-        MPCG_STAMP(prof_base + 1);
         ++epoch;
         if (w == 0) {
-            // What this lane publishes and polls comes from three small LDS tables (filled once per launch): as registers they would be
-            // live across the PCG loop, which has none to spare; recomputed here they were 80 instructions on the serial path of every hand-off.
+            // Lane l < G NW polls wave partial l (member l / NW, wave l % NW) — 8-byte granules; lanes 0..14 also poll one 16-byte
+            // granule each: 0..4 the left neighbour's yD, 5..9 its yL, 10..14 the right neighbour's t.  Byte offsets into the cluster's
+            // cells and the LDS destinations come from two 64-entry tables filled once per launch.
             int lane;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
             const int* tab = reinterpret_cast<const int*>(lds + L::TAB) + lane;
-            const unsigned poll_byte = (unsigned)tab[0];           // 0xFFFFFFFF: nothing to poll
-            const bool want = poll_byte != 0xFFFFFFFFu;
-            // one straight-line read for every lane: lanes 1..28 their message value (s = yD + yL, block-Jacobi pass: yD + 0; t = yT + 0),
-            // lanes 32..32+NW-1 one wave partial each (+ 0), which a three-step DPP tree then folds into lane 32 — a lane-0 branch with a serial
-            // sum of the partials in front of the other lanes' reads made this 600 cycles on the critical path of every hand-off
-            const int ia = tab[64] + (lane >= 32 && lane < 32 + NW ? (int)(red - (lds + L::RED)) : 0), ib = parts3 ? tab[128] : L::BC + 3;
-            float val = lds[ia] + lds[ib];
-            {
-                float ps = val;
-                asm volatile(
-                    "s_nop 1\n\t"
-                    "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                    "s_nop 1\n\t"
-                    "v_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                    "s_nop 1\n\t"
-                    "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                    "s_nop 1"
-                    : "+v"(ps));
-                const float tot_w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ps), 32));
-                val = lane == 0 ? tot_w : val;
-            }
-            if (lane <= 2 * NS) {
-                const unsigned long long gran = ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, val);
-                if (same_xcd) granule_store_l2<base>(my_words, 8u * (unsigned)lane, gran);
-                else granule_store<base>(my_words, 8u * (unsigned)lane, gran);
-            }
-            MPCG_STAMP(prof_base + 2);
+            const unsigned pbyte = (unsigned)tab[0];               // this lane's partial granule, 0xFFFFFFFF: none
+            const unsigned vbyte = (unsigned)tab[64];              // this lane's 16-byte granule (without the slot base), 0xFFFFFFFF: none
+            const int vdst = tab[128];                             // where its three values go in LDS
+            const bool wantp = pbyte != 0xFFFFFFFFu;
+            const bool wantv = vbyte != 0xFFFFFFFFu && (parts3 || lane < 5);      // block-Jacobi pass: only yD crosses
+            MPCG_STAMP(prof_base + 1);
             unsigned long long x = 0;
+            f4 xv = {0.f, 0.f, 0.f, 0.f};
             unsigned spins = 0;
             bool ok;
             do {
                 ok = true;
-                if (want) {
-                    x = granule_load<base>(cl_words, poll_byte);
+                if (wantp) {
+                    x = granule_load<base>(cl_words, pbyte);
                     ok = (unsigned)(x >> 32) == epoch;
+                }
+                if (wantv) {
+                    xv = granule_load16(cl_words + base, vbyte);
+                    ok = ok && __builtin_bit_cast(unsigned, xv.x) == epoch;
                 }
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
             } while (++spins < CL_SPIN_LIMIT);
-            MPCG_STAMP(prof_base + 3);
-            const int bits = (int)(unsigned)x;
-            float tot = 0.f;
-            for (int c = 0; c < G; ++c) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, c));
-            const float rv = __builtin_bit_cast(float, bits);
-            if (want && lane >= 16 && lane < 32) lds[L::YD + lane - 16] = rv;
-            if (want && lane >= 32) lds[L::YT + KL * NS + lane - 32] = rv;
+            MPCG_STAMP(prof_base + 2);
+            if (wantv) {                                           // yD / yL of slot 0, yT of slot KL: three values per lane (the fifth granule: two)
+                lds[vdst] = xv.y;
+                lds[vdst + 1] = xv.z;
+                if (lane % 5 != 4) lds[vdst + 2] = xv.w;
+            }
+            // sum of all wave partials, fixed order: the 16-lane rows by DPP, the four rows in sequence (members x waves in lane order)
+            const float tot = wave_fold(wantp ? __builtin_bit_cast(float, (unsigned)x) : 0.f);
             if (lane == 0) { bc[0] = tot; if (spins >= CL_SPIN_LIMIT) bc[1] = 1.f; }
         }
-        lds_barrier();
-        MPCG_STAMP(prof_base + 4);
+        lds_barrier();                                  // parts of every wave, the neighbours' parts and the sum are in LDS
+        MPCG_STAMP(prof_base + 3);
         if (bc[1] != 0.f) failed = true;
         return bc[0];
     };
@@ -283,15 +340,17 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
 
     if (tid == 0) { bc[0] = 0.f; bc[1] = 0.f; bc[3] = 0.f; }     // bc[3]: the zero a one-part message adds
     if (tid < 64) {
-        // lanes 0..G-1 poll the partial of member `lane` | 16..29: s of member g-1 | 32..45: t of member g+1 (byte offset into the cluster's cells)
         const int l = tid;
-        const bool want = l < G || (g > 0 && l >= 16 && l < 16 + NS) || (g < G - 1 && l >= 32 && l < 32 + NS);
-        const int word = l < 16 ? l * CL_WG_WORDS : l < 32 ? (g - 1) * CL_WG_WORDS + 1 + (l - 16) : (g + 1) * CL_WG_WORDS + 1 + NS + (l - 32);
         int* tab = reinterpret_cast<int*>(lds + L::TAB) + l;
-        tab[0] = want ? 8 * word : -1;
-        // lanes 1..14 publish s = (yD + yL) of the last own knot, lanes 15..28 t = yT of slot 0
-        tab[64] = l >= 1 && l <= NS ? L::YD + KL * NS + l - 1 : l > NS && l <= 2 * NS ? L::YT + l - 1 - NS : l >= 32 && l < 32 + NW ? L::RED + l - 32 : L::BC + 3;
-        tab[128] = l >= 1 && l <= NS ? L::YL + KL * NS + l - 1 : L::BC + 3;
+        // wave partial l: member l / NW, word l % NW of its slot
+        tab[0] = l < G * NW ? 8 * ((l / NW) * LPBC_WG_WORDS + l % NW) : -1;
+        // 16-byte granule j = l % 5 of: 0..4 yD of member g-1, 5..9 yL of member g-1, 10..14 t of member g+1
+        const int grp = l / 5, j = l - 5 * grp;
+        const bool have = grp == 2 ? g < G - 1 : (grp < 2 && g > 0);
+        const int src_m = grp == 2 ? g + 1 : g - 1;
+        const int src_w = grp == 0 ? LPBC_W_YD : grp == 1 ? LPBC_W_YL : LPBC_W_T;
+        tab[64] = l < 15 && have ? 8 * (src_m * LPBC_WG_WORDS + src_w + 2 * j) : -1;
+        tab[128] = (grp == 0 ? L::YD : grp == 1 ? L::YL : L::YT + KL * NS) + 3 * j;
     }
     // ---- are all members of this cluster on one XCD?  (They are meant to be, see above, but workgroup -> XCD placement is not a
     //      contract.)  Every member publishes its XCC id write-through; everybody compares.  If so, the hand-offs of this launch
@@ -308,7 +367,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
         do {
             ok = true;
             if (lane < G) {
-                x = granule_load<LPBC_SLOT_X>(cl_words, 8u * (unsigned)(lane * CL_WG_WORDS));
+                x = granule_load<LPBC_SLOT_X>(cl_words, 8u * (unsigned)(lane * LPBC_WG_WORDS));
                 ok = (unsigned)(x >> 32) == 1u;
             }
             if (__all(ok)) break;
@@ -379,7 +438,6 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
         //      for the own knots AND the replica (both complete in global memory), lambda <- lambda0 ----
         for (int e = t_st; e < 6 * L::VS; e += NTHR) lds[e] = 0.f;
         lds_barrier();
-        if (t_st < NS) lds[L::YL + t_st] = -0.f;
         for (int e = t_st + (g == 0 ? NS : 0); e < (KL + 1) * NS; e += NTHR) {
             const int ge = (k0 - 1) * NS + e;               // element of the global [N][14] vector
             const float l0 = lam_in[ge];
@@ -390,14 +448,13 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
         lds_barrier();
 
         // ---- setup: r = gamma - S lambda0 ; r~ = Pinv r ; p = r~ ; eta = r . r~ ----
-        if (lane == 0) { red_v[w] = 0.f; red_e[w] = 0.f; }
-        if (!isP) pass(L::XP, red_v);
-        (void)exchange(red_v, SlotV{}, true);
+        if (!isP) pass(L::XP, SlotV{}); else idle_partial(SlotV{});
+        (void)exchange(SlotV{}, true);
         if (ok0) xr2[e0] = xr2[e0] - ((yD2[e0] + yL2[e0]) + yT2[e0]);
         if (ok1) xr2[e1] = xr2[e1] - ((yD2[e1] + yL2[e1]) + yT2[e1]);
         lds_barrier();
-        if (isP && wave_on) pass(L::XR, red_e);
-        float eta = exchange(red_e, SlotE{}, p3);
+        if (isP && wave_on) pass(L::XR, SlotE{}); else idle_partial(SlotE{});
+        float eta = exchange(SlotE{}, p3);
         if (ok0) xp2[e0] = p3 ? (yD2[e0] + yL2[e0]) + yT2[e0] : yD2[e0];
         if (ok1) xp2[e1] = p3 ? (yD2[e1] + yL2[e1]) + yT2[e1] : yD2[e1];
         lds_barrier();
@@ -417,8 +474,8 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
 #endif
                 MPCG_STAMP(0);
                 // upsilon = S p ; v = p . upsilon
-                if (!isP) pass(L::XP, red_v);
-                const float alpha = eta / exchange(red_v, SlotV{}, true);
+                if (!isP) pass(L::XP, SlotV{}); else idle_partial(SlotV{});
+                const float alpha = eta / exchange(SlotV{}, true);
                 {
                     const f2 d0 = yD2[e0], l0 = yL2[e0], t0 = yT2[e0], r0 = xr2[e0];
                     const f2 d1 = yD2[e1], l1 = yL2[e1], t1 = yT2[e1], r1 = xr2[e1];
@@ -432,11 +489,12 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
 #endif
                 // r~ = Pinv r ; eta' = r . r~          | S waves: lambda += alpha p (own knots)
                 if (isP) {
-                    if (wave_on) pass(L::XR, red_e);
+                    if (wave_on) pass(L::XR, SlotE{}); else idle_partial(SlotE{});
                 } else {
+                    idle_partial(SlotE{});
                     for (int e = NS / 2 + tid; e < e_hi; e += NTHR / 2) lam2[e] = lam2[e] + alpha * xp2[e];
                 }
-                const float eta_new = exchange(red_e, SlotE{}, p3);
+                const float eta_new = exchange(SlotE{}, p3);
                 if (failed) { iters = 0xFFFFFFFFu; max_iter_exit = 2; break; }
                 iters = (uint32_t)(it + 1);
                 if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }

@@ -42,7 +42,8 @@ def test_cluster_matches_oracle_and_single_workgroup(orc, N, G, B, pc, lpbc):
             torch.cuda.synchronize()
             out[(mode, K)] = (lam.cpu().numpy(), it.cpu().numpy().astype(np.int64), ex.cpu().numpy())
             if mode == "cluster":                      # the kernel under test really ran
-                assert sol.get_option("last_kernel_family") == (4 if lpbc else 1) and sol.get_option("last_kernel_cluster") == G
+                # (the clustered lane-per-block kernel takes up to 8 members; beyond, the row-triple cluster kernel runs)
+                assert sol.get_option("last_kernel_family") == (4 if lpbc and G <= 8 else 1) and sol.get_option("last_kernel_cluster") == G
                 assert sol.get_option("last_kernel_waves") == (4 if waves4 else 8)
         if mode == "cluster":      # deterministic: bitwise identical on a second run
             lam = dev(lam0)

@@ -22,13 +22,11 @@ rd = _lib.load().mpcg_debug_read_prof
 buf = (C.c_longlong * (16 * 32))()
 assert rd(buf, 16 * 32) == 0
 t = np.array(buf[:], dtype=np.int64).reshape(16, 32)[:8, :13]
-names = ["S pass", "->barrier1", "msg build", "hand-off", "->barrier2", "r update+barrier", "P pass / lam", "->barrier1", "msg build", "hand-off", "->barrier2", "p update+barrier"]
+names = ["S pass+publish", "tables", "poll", "sum+barrier", "r update+barrier", "P pass / lam", "tables", "poll", "sum+barrier", "p update+barrier"]
+pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 6), (6, 7), (7, 8), (8, 9), (9, 10), (10, 12)]
 print(f"N={N} batch={B} family {sol.get_option('last_kernel_family')} G={sol.get_option('last_kernel_cluster')}  {e0.elapsed_time(e1):.3f} ms (instrumented); ticks of iteration 20, member 0")
 print("wave " + " ".join(f"{n:>16s}" for n in names) + "   total")
 for w in range(8):
     row = t[w]
-    d = []
-    for i in range(12):
-        a, b = row[i], row[i + 1]
-        d.append(int(b - a) if a and b else 0)
+    d = [int(row[b] - row[a]) if row[a] and row[b] else 0 for a, b in pairs]
     print(f"{w:4d} " + " ".join(f"{x:16d}" for x in d) + f"   {int(row[12] - row[0]):6d}")
