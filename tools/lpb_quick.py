@@ -1,37 +1,16 @@
-"""Quick check + timing of the lane-per-block kernel against the single-workgroup kernels (GPU)."""
+"""Timing of the lane-per-block kernel against the single-workgroup kernels (GPU).  (Correctness: tests/test_gpu_lpb.py.)"""
 import os, sys, json, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import oracle as orc
+sys.path.insert(0, ROOT)
 import mpcgpu_amd._lib as _L
 if os.environ.get("AB_LIB"):                      # A/B against another build of the library (tools/_prof/ab/)
     _L.LIB_PATH = os.environ["AB_LIB"]
 from mpcgpu_amd import PcgSolver, pcg_config, synth
-from util import fp32_band, relinf
 
 dev = torch.device("cuda")
 out = {}
 # correctness
-for N in (5, 32, 64, 65, 128):
-    B, K = 3, 30
-    k = synth.make_kkt(N, B, 7000 + N)
-    S, P, g = synth.form_schur(k, poison_unused=True)
-    for pc in ("ss", "jacobi"):
-        sol = PcgSolver(N, max_batch=B)
-        lam = torch.zeros(B, 14 * N, device=dev)
-        it, ex = sol.solve(torch.from_numpy(S).to(dev), torch.from_numpy(P).to(dev), torch.from_numpy(g).to(dev), lam,
-                           pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), pc)
-        torch.cuda.synchronize()
-        fam = sol.get_option("last_kernel_family")
-        errs = []
-        for b in range(B):
-            Sz, Pz = np.nan_to_num(S[b]), np.nan_to_num(P[b])
-            r64 = orc.pcg(Sz.astype(np.float64), Pz.astype(np.float64), g[b].astype(np.float64), np.zeros(14 * N), N, K, 0.0, pc)
-            band = fp32_band(orc, Sz, Pz, g[b], np.zeros(14 * N), N, K, pc, r64["lam"])
-            errs.append((relinf(lam[b].cpu().numpy(), r64["lam"]), band))
-        print("check", N, pc, "family", fam, "iters", it.cpu().tolist(), "err/band", [(f"{e:.2e}", f"{bd:.2e}") for e, bd in errs], flush=True)
-
 def timeit(sol, S, P, g, B, N, cfg, reps=5):
     lam = torch.zeros(B, 14 * N, device=dev)
     ts = []
