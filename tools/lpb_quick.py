@@ -33,6 +33,7 @@ for N, B in ((128, 1024), (128, 256), (128, 1), (96, 1024), (64, 1024), (64, 204
     for name, lpb in (("lpb", -1), ("traj", 0)):
         sol = PcgSolver(N, max_batch=B)
         sol.set_option("pcg_lpb", lpb)
+        sol.set_option("pcg_rpl", 0)               # (this tool compares the lane-per-block and row-pair kernels; tools/rpl_quick.py the row-per-lane one)
         ms, its = timeit(sol, S, P, g, B, N, cfg)
         res[name] = {"ms": ms, "Mit_s": its / ms / 1e3, "family": sol.get_option("last_kernel_family"), "waves": sol.get_option("last_kernel_waves")}
     print("time", N, B, json.dumps(res), flush=True)
