@@ -140,8 +140,6 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpbc_kernel(ClusterArgs ca) 
     if ((unsigned)cl >= nclusters) return;
     const int k0 = (int)(((long)g * N) / G), k1 = (int)(((long)(g + 1) * N) / G);
     const int KL = k1 - k0;                             // own knots (launcher: 1 <= KL <= NMAX)
-    float* red_v = lds + L::RED;
-    float* red_e = red_v + NW;
     float* bc = lds + L::BC;                            // [0] cluster-wide sum, [1] sticky timeout flag, [2] trajectory index (int)
 
     const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;

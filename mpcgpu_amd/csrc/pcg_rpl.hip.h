@@ -243,17 +243,25 @@ __device__ __forceinline__ void pcg_rpl_body(const RplTraj<T>& a) {
         max_iter_exit = 0;
     } else {
         for (int it = 0; it < a.max_iter; ++it) {
+#ifdef MPCG_PROF
+            const bool prof_on = blockIdx.x == 0 && it == 20;      // (tools/_prof/rpl_phases.py)
+#endif
+            MPCG_STAMP(0);
             real* xp_old = (it & 1) ? xp1 : xp0;
             real* xp_new = (it & 1) ? xp0 : xp1;
             real* xr_old = (it & 1) ? xr1 : xr0;
             real* xr_new = (it & 1) ? xr0 : xr1;
             {   // upsilon = S p ; v = p . upsilon
-                const real part = rpl_wave_fold(pass3(Sm, xt, xp_old, beta, p, y));
+                const real pp = pass3(Sm, xt, xp_old, beta, p, y);
+                MPCG_STAMP(1);
+                const real part = rpl_wave_fold(pp);
                 if (lane == 0) red_v[w] = part;
             }
+            MPCG_STAMP(2);
             if constexpr (PC3) publish(xu, y);
             publish(xp_new, p);                        // p_it, for the neighbours' rebuild in iteration it + 1
             lds_barrier();
+            MPCG_STAMP(3);
             const real alpha = eta / all_sum(red_v);
 #pragma unroll
             for (int j = 0; j < RHO; ++j) {
@@ -261,12 +269,17 @@ __device__ __forceinline__ void pcg_rpl_body(const RplTraj<T>& a) {
                 r[j] = fma_t(-alpha, y[j], r[j]);
             }
             if constexpr (PC3) publish(xr_new, r);     // r_(it+1), "r before the update" of the next iteration
+            MPCG_STAMP(4);
             {   // r~ = Pinv r ; eta' = r . r~
-                const real part = rpl_wave_fold(passP(xr_old, xu, -alpha, r, y));
+                const real pp = passP(xr_old, xu, -alpha, r, y);
+                MPCG_STAMP(5);
+                const real part = rpl_wave_fold(pp);
                 if (lane == 0) red_e[w] = part;
             }
             publish(xt, y);
+            MPCG_STAMP(6);
             lds_barrier();
+            MPCG_STAMP(7);
             const real eta_new = all_sum(red_e);
             iters = (uint32_t)(it + 1);
             if (fabs_t(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
@@ -274,6 +287,7 @@ __device__ __forceinline__ void pcg_rpl_body(const RplTraj<T>& a) {
 #pragma unroll
             for (int j = 0; j < RHO; ++j) p[j] = fma_t(beta, p[j], y[j]);
             eta = eta_new;
+            MPCG_STAMP(8);
         }
     }
 
