@@ -214,6 +214,59 @@ def load_traffic(kernel_key):
         return None, None
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: re-run this very command line as N ranks under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1, a free port), stream their output through and
+    return their exit status.  Fails loudly when the node has fewer than N devices — it never degrades to fewer ranks."""
+    import subprocess
+    n = args.gpus
+    if not args.plumbing_only and not os.environ.get("MPCG_FORCE_DEVICE"):
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(f"bench.py: --gpus {n} requested but {have} HIP device(s) visible on this node; refusing to run fewer ranks", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env["MPCG_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing_only(args, rank, world):
+    """--plumbing-only: the distributed flow of main() with made-up per-trajectory results and no solve (CPU, gloo)."""
+    B_global = args.batch if args.scaling == "strong" else args.batch * world
+    lo, hi = D.shard_range(args.batch, rank, world) if args.scaling == "strong" else (rank * args.batch, (rank + 1) * args.batch)
+    it = torch.arange(lo, hi, dtype=torch.int32) % 97 + 1          # "iterations" of trajectory b: b % 97 + 1
+    ex = (torch.arange(lo, hi) % 5 == 0).to(torch.uint8)
+    D.barrier()
+    t_all = D.max_over_ranks(1.0 + rank)
+    its_all = D.sum_over_ranks(float(it.sum()))
+    per_rank = D.all_gather_floats(float(rank) + 0.5)
+    g_it, g_ex = D.gather_results(it, ex, B_global if args.scaling == "strong" else None)
+    want = torch.arange(B_global, dtype=torch.int32) % 97 + 1
+    ok = bool(torch.equal(g_it.cpu(), want) and int(g_it.sum()) == int(its_all) and t_all == float(world))
+    out = {"metric": "pcg_iterations_per_sec", "value": None, "unit": "iter/s", "n_gpus": world, "plumbing_only": True, "scaling": args.scaling,
+           "self_launched": os.environ.get("MPCG_BENCH_SELF_LAUNCHED") == "1",
+           "results_gather": {"backend": D.backend_name(), "trajectories": int(g_it.numel()), "consistent_with_allreduce_sum": ok},
+           "per_rank": per_rank, "shard": [lo, hi]}
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,13 +294,25 @@ def main():
     ap.add_argument("--spmv-batch", type=int, default=4096, help="trajectories streamed by the SpMV roofline run (S = batch x 301 KB)")
     ap.add_argument("--storage", default="f32", choices=["f32", "f16"],
                     help="matrix storage of S/Pinv; f16 = BASELINE config 5's reduced-precision experiment (arithmetic stays fp32)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="launcher / collective dry run (CPU test of the N > 1 flow, tests/test_bench_launcher.py): every rank runs the whole "
+                         "distributed flow of this file — rendezvous, barrier, shard ranges, all-reduces, all-gather of per-trajectory results — "
+                         "with made-up iteration counts and NO solve; prints value = null")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU, RCCL), it does not
+        # degrade to one rank
+        sys.exit(self_launch(args))
     rank, local_rank, world = D.init()
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} — launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it starts its own ranks)")
+    if args.plumbing_only:
+        return plumbing_only(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (the product has no CPU path)"
+    if torch.cuda.device_count() < (1 if os.environ.get("MPCG_FORCE_DEVICE") else world):
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s) visible")
     if os.environ.get("MPCG_FORCE_DEVICE"):          # dry-run of the N>1 flow on a 1-GPU box (with MPCG_DIST_BACKEND=gloo)
         local_rank = int(os.environ["MPCG_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
@@ -297,6 +362,10 @@ def main():
 
     # --- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks ---
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # the reference's linsolve ends with the D2H copies of (pcg_iters, pcg_exit) (include/pcg/sqp.cuh:231-232): SURVEY §8d puts them
+    # INSIDE the timed region — here batch x 5 bytes per step into pinned host memory, on the solve's stream
+    h_it = torch.empty(B, dtype=torch.int32).pin_memory()
+    h_ex = torch.empty(B, dtype=torch.uint8).pin_memory()
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -305,6 +374,8 @@ def main():
         ev[i][0].record()                   # HIP events on the stream the kernel is launched on
         run_solve()
         ev[i][1].record()
+        h_it.copy_(d_it, non_blocking=True)
+        h_ex.copy_(d_ex, non_blocking=True)
     torch.cuda.synchronize()
     D.barrier()
     t_local = time.perf_counter() - t0
@@ -312,12 +383,13 @@ def main():
 
     fam = {0: "pcg_traj_kernel", 1: "pcg_cluster_kernel", 2: "pcg_lpb_kernel", 3: "pcg_generic_kernel", 4: "pcg_lpbc_kernel", 5: "pcg_rpl_kernel"}[sol.get_option("last_kernel_family")]
     kdesc = {"family": fam, **{k: sol.get_option("last_kernel_" + k) for k in ("waves", "reg_rows", "lds_rows", "stream_bufs", "cluster", "lds_bytes")}}
-    it_host = d_it.cpu().numpy().astype(np.int64)
-    ex_host = d_ex.cpu().numpy()
+    it_host = h_it.numpy().astype(np.int64)          # what the timed region's last step copied back
+    ex_host = h_ex.numpy().copy()
     iters_step_local = int(it_host.sum())
     iters_step_all = D.sum_over_ranks(iters_step_local, dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     kern_ms_all = D.max_over_ranks(kern_ms, dev)
+    kern_ms_ranks = D.all_gather_floats(kern_ms, dev)
     # the only collective of the path: per-trajectory (iters, exit flag) of every shard to every rank (RCCL all-gather)
     g_it, g_ex = D.gather_results(d_it, d_ex, B_global if args.scaling == "strong" else None)
     gathered_ok = bool(int(g_it.to(torch.int64).sum().item()) == int(iters_step_all) and g_it.numel() == B_global)
@@ -346,6 +418,9 @@ def main():
         "resident_trajectories_per_gpu": sol.checkPcgOccupancy(),
         "results_gather": {"collective": "all_gather of (iters, exit) per trajectory", "backend": D.backend_name(),
                            "trajectories": int(g_it.numel()), "consistent_with_allreduce_sum": gathered_ok},
+        "per_rank_kernel_ms": kern_ms_ranks,
+        "timed_region": "K x [lambda <- 0; mpcg_pcg_solve; D2H of (iters u32, exit u8) per trajectory], barrier + synchronize on both sides, max over ranks",
+        "self_launched": os.environ.get("MPCG_BENCH_SELF_LAUNCHED") == "1",
     }
 
     # ---- the kernel `value` is measured on ----
@@ -372,6 +447,9 @@ def main():
             rr["traffic_source"] = src
             rr["traffic_gbs"] = tr["hbm_traffic_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9
             rr["traffic_frac_of_hbm_peak"] = rr["traffic_gbs"] / HBM_PEAK_GBS
+            rr["traffic_is"] = "bytes per launch from the builder's rocprofv3 --pmc passes of this command (not measured in this run); the rate uses this run's kernel time"
+            if "valu_active_frac" in tr:
+                rr["valu_active_frac"] = tr["valu_active_frac"]      # SQ_ACTIVE_INST_VALU / (4 SIMDs x SQ_BUSY_CYCLES), same passes
         out["roofline_resident"] = rr
 
     extras = not args.no_extras and args.storage == "f32"
@@ -397,8 +475,19 @@ def main():
         if tr:
             sp["traffic"] = tr["hbm_traffic_bytes_per_launch"]
             sp["traffic_source"] = src
+            sp["traffic_is"] = "bytes per launch from the builder's rocprofv3 --pmc passes of this command (not measured in this run)"
         if "roofline" not in out:
             out["roofline"] = sp
+            # the kernel `value` is measured on, inside the object the driver keeps: nested AND as flat scalars
+            rr = out.get("roofline_resident")
+            if rr:
+                sp["headline_kernel_roof"] = {k_: rr[k_] for k_ in ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "flops_per_unit",
+                                                                      "units_per_launch", "traffic", "traffic_frac_of_hbm_peak", "valu_active_frac") if k_ in rr}
+                for k_, v_ in sp["headline_kernel_roof"].items():
+                    sp["headline_" + k_] = v_
+                sp["note"] = ("top level = the HBM-bound kernel of the path (stand-alone block-tridiagonal SpMV, north_star's >= 60 % target), NOT in the timed "
+                              "region; headline_* = the register-resident PCG kernel `value` is measured on: bound by fp32 VALU issue, its HBM traffic is one read "
+                              "of the lower block triangle per solve")
         else:
             out["roofline_spmv"] = sp
         if args.spmv_mfma:
@@ -410,36 +499,6 @@ def main():
                                            "mfma_flops_issued_per_launch": 2 * 16 * 16 * 4 * 12 * Bs * N,
                                            "useful_flops_per_launch": 2 * (3 * N - 2) * 196 * Bs}
         del S_big, x, y
-
-        # ---- HBM roofline 2: the PCG solve with nothing resident (every block re-read every iteration) ----
-        if "roofline_resident" in out:
-            Bz = max(B, 4096)                    # S + Pinv = 2.5 GB >> 256 MiB Infinity Cache: re-read from HBM every iteration
-            rz = (Bz + B - 1) // B
-            zS, zP, zg = (t.repeat(rz, 1)[:Bz].contiguous() if rz > 1 else t for t in (d_S, d_P, d_g))
-            ss = PcgSolver(N, max_batch=Bz, device=local_rank)
-            ss.set_option("pcg_waves", 16); ss.set_option("pcg_reg_rows", 0); ss.set_option("pcg_lds_rows", 0)
-            l2 = torch.zeros(Bz, 14 * N, device=dev)
-            i2 = torch.zeros(Bz, dtype=torch.int32, device=dev)
-            x2 = torch.zeros(Bz, dtype=torch.uint8, device=dev)
-
-            def stream_solve():
-                l2.zero_()
-                ss.solve(zS, zP, zg, l2, cfg, args.precond, iters=i2, exits=x2)
-            ms_s = timed(stream_solve, 3, warm=1)
-            ms_z = timed(lambda: l2.zero_(), 3, warm=1)
-            its_s = int(i2.sum().item())
-            ach = its_s * bytes_iter / ((ms_s - ms_z) * 1e-3) / 1e9
-            out["roofline_pcg_streaming"] = {
-                "bound": "hbm", "kernel": "pcg_traj_kernel<16,0,2> (no resident rows)", "kernel_ms": ms_s - ms_z, "achieved": ach,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "bytes_per_unit": bytes_iter, "units_per_launch": its_s,
-                "working_set_mb": 2 * Bz * 3 * 196 * N * 4 / 1e6, "pcg_iterations_per_sec": its_s / ((ms_s - ms_z) * 1e-3),
-                "batch": Bz}
-            tr, src = load_traffic(f"pcg_traj_kernel<16,0,2>|N{N}_B{Bz}_{args.precond}_it{max_iter}_tol{args.exit_tol:g}")
-            if tr:
-                out["roofline_pcg_streaming"]["traffic"] = tr["hbm_traffic_bytes_per_launch"]
-                out["roofline_pcg_streaming"]["traffic_source"] = src
-            assert ss.get_option("last_kernel_family") == 0 and ss.get_option("last_kernel_reg_rows") == 0
-            del ss, l2, zS, zP, zg
 
     lean = args.profile_lean
     if extras and rank == 0 and not lean:
@@ -519,13 +578,24 @@ def main():
                          "max_iter_exit_rate": float(d_ex.float().mean().item()), "kernel_ms": ms_,
                          "pcg_iterations_per_sec": float(iti.sum() / (ms_ * 1e-3)), "linsolves_per_sec": B / (ms_ * 1e-3),
                          "true_rel_residual_before_median": float(r0.median().item()), "true_rel_residual_after_median": float(r1.median().item()),
-                         "true_rel_residual_after_max": float(r1.max().item())}
+                         "true_rel_residual_after_p90": float(torch.quantile(r1, 0.9).item()),
+                         "true_rel_residual_after_max": float(r1.max().item()),
+                         "trajectories_whose_true_residual_grew": int((r1 > r0 * (1 + 1e-6)).sum().item())}
         out["iiwa_run"] = {"inputs": f"{B} windows of the reference trajectory examples/trajfiles/0_0_traj.csv (first 400 rows), random offset, goals 0..8 steps ahead, "
                                      "state / iterate noise <= 0.05; KKT blocks by mpcg_generate_kkt (IIWA-14 dynamics on the device), Schur by mpcg_form_schur, rho = 1e-3",
                            "pcg": {"max_iter": max_iter, "exit_tol": args.exit_tol, "precond": "ss"}, "generate_kkt_ms": ms_kkt, "form_schur_ms": ms_schur,
                            "cold_start": res["cold"], "warm_start_from_previous_sqp_iterate": res["warm"],
                            "note": "cond(-S) of these systems is 1e7-2e7 at N=128 (synthetic generator: ~1e5): from lambda0 = 0 most solves hit the reference's iteration "
                                    "cap, which presupposes the MPC loop's warm starts (tests/make_iiwa_golden.py prints the study)"}
+        w_ = res["warm"]
+        out["config"].update({"iiwa_warm_mean_pcg_iters": w_["mean_pcg_iters"], "iiwa_warm_max_iter_exit_rate": w_["max_iter_exit_rate"],
+                              "iiwa_warm_linsolves_per_sec": w_["linsolves_per_sec"], "iiwa_warm_pcg_iterations_per_sec": w_["pcg_iterations_per_sec"],
+                              "iiwa_warm_true_residual_median": w_["true_rel_residual_after_median"], "iiwa_warm_true_residual_p90": w_["true_rel_residual_after_p90"],
+                              "iiwa_warm_true_residual_max": w_["true_rel_residual_after_max"],
+                              "iiwa_warm_trajectories_whose_residual_grew": w_["trajectories_whose_true_residual_grew"],
+                              "iiwa_generate_kkt_ms": ms_kkt, "iiwa_form_schur_ms": ms_schur, "iiwa_warm_pcg_ms": w_["kernel_ms"],
+                              "iiwa_regime": "real IIWA-14 systems made on the device (mpcg_generate_kkt -> mpcg_form_schur), lambda warm-started from the previous SQP iterate: "
+                                             "the regime the reference's iteration caps presuppose; the headline `value` is the cold-start synthetic batch"})
         del Gk, Ck, Gp, Cp, rS, rP, pS
 
     if extras and rank == 0 and world == 1 and not lean:
@@ -591,8 +661,52 @@ def main():
             lh[f"N{Nl}"] = {"pcg_iters_per_solve": synth.pcg_max_iter(Nl), "batch": B, "kernel_ms": ms_b, "pcg_iterations_per_sec": its / (ms_b * 1e-3),
                             "ms_one_trajectory": ms_1, "us_per_pcg_iter_one_trajectory": ms_1 * 1e3 / synth.pcg_max_iter(Nl),
                             "kernel_family": sl.get_option("last_kernel_family"), "members_per_trajectory": sl.get_option("last_kernel_cluster")}
+            if Nl == 512:
+                # ---- the PCG solve as an HBM stream: nothing resident (pcg_traj_kernel<16,0,2>), every block re-read every iteration.
+                # One workgroup per CU (115 KB of LDS at N=512), so the LIVE matrices are 256 x 2.41 MB = 616 MB >> the 256 MiB Infinity Cache
+                # whatever the batch: the HBM model of SURVEY §8d (2,577,344 B per trajectory-iteration) applies as written.  (Round 2 ran
+                # this leg at N=128, where the live set of 154-308 MB sat in the Infinity Cache: frac 1.06, not an HBM measurement.)
+                ss = PcgSolver(Nl, max_batch=B, device=local_rank)
+                ss.set_option("pcg_waves", 16); ss.set_option("pcg_reg_rows", 0); ss.set_option("pcg_lds_rows", 0)
+
+                def stream_solve():
+                    ll.zero_()
+                    ss.solve(Sl, Pl, gl, ll, cl, "ss", iters=il, exits=xl)
+                ms_s = timed(stream_solve, 3, warm=1) - timed(lambda: ll.zero_(), 3, warm=1)
+                its_s = int(il.sum().item())
+                b_it = synth.algorithmic_bytes(Nl, precond="ss")["pcg_iter"]
+                ach = its_s * b_it / (ms_s * 1e-3) / 1e9
+                assert ss.get_option("last_kernel_family") == 0 and ss.get_option("last_kernel_reg_rows") == 0
+                occ = ss.checkPcgOccupancy()
+                out["roofline_pcg_streaming"] = {
+                    "bound": "hbm" if ach <= HBM_PEAK_GBS else "infinity cache + hbm (frac > 1: NOT an HBM roofline fraction)",
+                    "kernel": "pcg_traj_kernel<16,0,2> (no resident rows)", "knot_points": Nl, "batch": B, "kernel_ms": ms_s, "achieved": ach,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "bytes_per_unit": b_it, "units_per_launch": its_s,
+                    "resident_trajectories": occ, "live_matrix_set_mb": occ * 2 * 3 * 196 * Nl * 4 / 1e6, "infinity_cache_mb": 268.4,
+                    "frac_of_measured_copy_ceiling_6.29TBs": ach / 6290.0, "pcg_iterations_per_sec": its_s / (ms_s * 1e-3), "traffic": None}
+                tr, src = load_traffic(f"pcg_traj_kernel<16,0,2>|N{Nl}_B{B}_ss_it{synth.pcg_max_iter(Nl)}_tol0")
+                if tr:
+                    out["roofline_pcg_streaming"]["traffic"] = tr["hbm_traffic_bytes_per_launch"]
+                    out["roofline_pcg_streaming"]["traffic_source"] = src
+                del ss
             del Sl, Pl, gl, ll, sl
         out["long_horizon"] = lh
+
+    if extras and rank == 0 and world == 1 and not lean and args.scaling == "weak":
+        # ---- what scaling to expect (measured here on one GPU, the multi-GPU curve itself is the driver's to measure) ----
+        # weak (default): every rank runs this very workload, no data-path collective: N x value(1) minus launch jitter.
+        # strong (BASELINE config 4 as written: 1024 trajectories over 8 GPUs = 128 each): a GPU holds one workgroup per trajectory, so 128
+        # trajectories occupy 128 of 256 CUs ONCE — the step takes the batch-128 time below, not 1/8 of the batch-1024 time.
+        Bq = max(1, B // 8)
+        ms_q = timed(lambda: (d_lam[:Bq].zero_(), sol.solve(d_S[:Bq], d_P[:Bq], d_g[:Bq], d_lam[:Bq], cfg, args.precond, iters=d_it[:Bq], exits=d_ex[:Bq])), 7, warm=2)
+        ms_f = timed(lambda: (d_lam.zero_(), run_solve()), 5, warm=1)
+        out["scaling_expectation"] = {
+            "weak": {"ceiling": "N x value(N=1): ranks are independent (one all-gather of 5 B per trajectory after the timed step)", "efficiency_expected": 1.0},
+            "strong": {"global_batch": B, "batch_per_gpu_at_8": Bq, "ms_step_full_batch_1gpu": ms_f, "ms_step_at_batch_per_gpu_at_8": ms_q,
+                       "speedup_ceiling_at_8_gpus": ms_f / ms_q, "efficiency_ceiling_at_8_gpus": ms_f / ms_q / 8.0,
+                       "why": f"{Bq} trajectories = {Bq} workgroups on {sol.get_option('num_cus')} CUs: the step costs one trajectory's latency however few CUs are busy; "
+                              "the chip is filled only from one trajectory per CU upwards"}}
+        out["config"]["strong_scaling_speedup_ceiling_at_8_gpus"] = ms_f / ms_q
 
     if extras and rank == 0 and not lean:
         # the other selectable solver on the same resident systems: batched block-tridiagonal direct solve

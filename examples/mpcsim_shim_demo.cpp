@@ -41,6 +41,7 @@ int main() {
     const size_t Gsz = (size_t)(nn + mm) * N - mm, Csz = (size_t)(nn + nm) * (N - 1), gsz = (size_t)(n + m) * N - m;
     auto& st = mpcgpu_compat::stages<T>();
     st.sqp_max_iter = 1;
+    st.const_update_freq = false;     // CONST_UPDATE_FREQ = 0 for the LQ run (host-assembled KKT blocks: a control step takes far longer than SQP_MAX_TIME_US)
     // generate_kkt_submatrices stand-in (host-assembled, H2D): G = [Q,R,...,Q], C = [-A,-B,...], g = cost gradient, c = constraint residual
     st.generate_kkt = [&](uint32_t, uint32_t, uint32_t, T* d_G, T* d_C, T* d_g, T* d_c, void*, float, T*, T* d_xs, T* d_xu) {
         std::vector<T> xu(gsz), xs(n), G(Gsz), C(Csz), g(gsz), c((size_t)n * N);
@@ -142,9 +143,38 @@ int main() {
                                                     0, 0, 0, (T)1e-10, std::string("demo"));
     const std::vector<toplevel_return_type>& linsys_times = std::get<0>(res);
     const std::vector<linsys_t>& tracking = std::get<1>(res);
+    // ---- the SQP time box (reference include/pcg/sqp.cuh:161-169, CONST_UPDATE_FREQ = 1): the same problem through the solver plugin
+    // directly, the step stage asking for more iterations every time.  (a) box off: all sqp_max_iter iterations run; (b) a box
+    // already used up when the first stage returns: the loop is left at its first check, no linear system is solved, and
+    // sqp_time_exit keeps its recording value 1 (:28 — only the rho > rho_max exit reports 0); (c) a generous box: as (a).
+    st.globalize_and_step = [&](uint32_t, uint32_t, uint32_t, T*, T*, T&, T, uint32_t) { return true; };
+    T* d_lambda2;
+    gpuErrchk(hipMalloc(&d_lambda2, (size_t)n * N * sizeof(T)));
+    gpuErrchk(hipMemset(d_lambda2, 0, (size_t)n * N * sizeof(T)));
+    T rho = 1e-3f;
+    unsigned box_iters[3];
+    bool box_flag[3];
+    size_t box_solves[3];
+    const double boxes[3] = {0.0, 1.0, 60e6};
+    for (int c = 0; c < 3; ++c) {
+        st.sqp_max_iter = 5;
+        st.const_update_freq = c != 0;
+        st.sqp_max_time_us = boxes[c];
+#if LINSYS_SOLVE == 1
+        pcg_config<T> cfg;
+        cfg.pcg_exit_tol = (T)1e-10; cfg.pcg_max_iter = PCG_MAX_ITER;
+        auto s2 = sqpSolvePcg<T>(state_size, control_size, knot_points, 1.0f / 64, d_eePos_traj, d_lambda2, d_xu_traj, nullptr, cfg, rho, (T)1e-3);
+#else
+        auto s2 = sqpSolveQdldl<T>(state_size, control_size, knot_points, 1.0f / 64, d_eePos_traj, d_lambda2, d_xu_traj, nullptr, rho, (T)1e-3);
+#endif
+        box_iters[c] = std::get<3>(s2); box_flag[c] = std::get<4>(s2); box_solves[c] = std::get<1>(s2).size();
+    }
+    const bool box_ok = box_iters[0] == 5 && box_solves[0] == 5 && box_flag[0] && box_iters[1] == 0 && box_solves[1] == 0 && box_flag[1] &&
+                        box_iters[2] == 5 && box_solves[2] == 5;
     printf("{\"linsys_solve\": %d, \"control_steps\": %d, \"linsolves\": %zu, \"mean_linsys_us\": %.1f, \"dynamics_defect\": %.3e, "
-           "\"stationarity_rel\": %.3e, \"tracking_first\": %.4f, \"tracking_last\": %.4f}\n",
+           "\"stationarity_rel\": %.3e, \"tracking_first\": %.4f, \"tracking_last\": %.4f, \"time_box\": {\"off_iters\": %u, \"expired_iters\": %u, "
+           "\"expired_linsolves\": %zu, \"expired_sqp_time_exit\": %d, \"generous_iters\": %u, \"ok\": %s}}\n",
            LINSYS_SOLVE, g_steps, linsys_times.size(), linsys_times.empty() ? 0.0 : (double)linsys_times.back(), g_worst_defect, g_worst_station,
-           (double)tracking.front(), (double)tracking.back());
-    return (g_steps == 4 && g_worst_defect < 1e-3 && g_worst_station < 2e-2) ? 0 : 1;
+           (double)tracking.front(), (double)tracking.back(), box_iters[0], box_iters[1], box_solves[1], (int)box_flag[1], box_iters[2], box_ok ? "true" : "false");
+    return (g_steps == 4 && g_worst_defect < 1e-3 && g_worst_station < 2e-2 && box_ok) ? 0 : 1;
 }

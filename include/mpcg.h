@@ -12,6 +12,19 @@
  *     k*3n^2 + col*n^2; col 0/1/2 = left / diagonal / right block of block row k
  *     (include/pcg/linsys_setup.cuh:36-57, 490-507).  Stored NEGATED (:15-19).  Blocks (0,col 0) and
  *     (N-1,col 2) are never written by the reference (:97,118) and are never read here.
+ *   - BLOCK SYMMETRY (precondition of the PCG entry points).  PCG needs symmetric S and Pinv, and the reference's are: it writes
+ *     S[k,right] as the transposed copy of S[k+1,left] (include/pcg/linsys_setup.cuh:536-557, bit for bit) and forms the symmetric-stair
+ *     Pinv[k,right] / Pinv[k+1,left] as the same product twice (:97-136, equal to ~1e-7 relative).  The register-resident kernels that
+ *     serve fp32 horizons above 32 knots by default ("last_kernel_family" 2, 4 and 6) READ ONLY THE LEFT AND DIAGONAL block columns and
+ *     apply L_{k+1}^T where the reference's kernel reads block (k,right); the right blocks of d_S / d_Pinv may hold anything (tests
+ *     poison them with NaN).  On the reference's matrices the results agree to fp32 round-off of the products (~1e-7 of |Pinv| per
+ *     apply; bit-identical for S).  A caller whose Pinv is NOT block-symmetric gets the solve of its symmetrised lower triangle from
+ *     these kernels, and of the full three columns from the others (families 0, 1, 3, 5 read all three) — which one depends on
+ *     knot_points and batch through kernel selection.  To detect that situation: option "check_symmetry" = 1 (debug, off by default)
+ *     makes every solve that would run a lower-triangle kernel first verify
+ *         max | M[k,right] - M[k+1,left]^T |  <=  1e-5 max | M[k,right], M[k+1,left] |     for M = S and (SS) Pinv, every k,
+ *     (one extra kernel + a blocking 8-byte D2H copy per solve) and run a three-column kernel instead when it fails;
+ *     "last_symmetry_violations" reports the number of offending block pairs of the last solve.
  *   - gamma, lambda: [N][n] floats per trajectory; lambda is in/out (warm start,
  *     include/mpcsim.cuh:186,267,337).
  *   - every pointer named d_* is a DEVICE pointer on the handle's device; `stream` is a hipStream_t
@@ -268,9 +281,16 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * gave up are re-solved by the single-workgroup kernel in a follow-up launch; default on),
  * "cluster_adj" (lane order of the row-triple cluster kernel), "schur_dpp" (1: register/DPP Schur kernels, 0: the LDS versions),
  * "block_solve_wide" (mpcg_block_solve: 1 one trajectory per wavefront, 0 four, -1 by batch size; same bits);
- * read-only: "num_cus", "pcg_resident" (1 if the current configuration streams nothing inside the PCG loop),
+ * "check_symmetry" (debug, 0/1: see BLOCK SYMMETRY above),
+ * read-only: "cluster_fixups" (trajectories re-solved by fix-up launches since mpcg_create because their cluster gave up after the bounded
+ * spin — each costs 1.5-4.5 ms of spinning; blocking 8-byte D2H read), "last_symmetry_violations", "num_cus", "pcg_resident" (1 if the current configuration streams nothing inside the PCG loop),
  * "last_kernel_family" (kernel of the last solve: 0 single-workgroup row-pair, 1 row-triple cluster, 2 lane-per-block, 3 generic,
  * 4 clustered lane-per-block, 5 row-per-lane), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
+ * WHICH kernel family serves a call depends on knot_points AND on the call's batch (e.g. 32 < N <= 64: row-per-lane kernel up to one
+ * trajectory per CU, lane-pair / lane-per-block kernel beyond; N <= 32: 8 waves x 1 slot or 4 x 2 by batch).  Families sum the inner
+ * products in different orders, so the SAME trajectory solved alone and inside a large batch may differ in the last fp32 bits (and, near
+ * the tolerance, by an iteration); within one family results are bitwise reproducible run to run and independent of batch composition.
+ * Pin a family with "pcg_rpl" / "pcg_lpb" / "pcg_lpk" / "rpl_waves" when bit-stability across batch sizes matters.
  * None of the residency knobs changes results within a lane-order family (bitwise identical, tested); kernels that
  * keep everything resident use the adjacent-lane order and agree with the streaming ones to fp32 round-off of the
  * inner products, as does the cluster kernel, which sums the inner products per workgroup first. */

@@ -12,6 +12,13 @@
 #include <cstdlib>
 #include <functional>
 
+#ifndef CONST_UPDATE_FREQ
+#define CONST_UPDATE_FREQ 1      // include/common/settings.cuh:56-58
+#endif
+#ifndef SQP_MAX_TIME_US
+#define SQP_MAX_TIME_US 2000     // include/common/settings.cuh:161-163
+#endif
+
 namespace mpcgpu_compat {
 
 template <typename T>
@@ -29,6 +36,11 @@ struct sqp_stages {
     std::function<T(uint32_t state_size, uint32_t control_size, uint32_t knot_points, T* d_xs, T* d_xu, T* d_lambda,
                     T* d_eePos_goal, double sqp_solve_time_us, bool& done)> simulate_and_shift;
     uint32_t sqp_max_iter = 20;          // SQP_MAX_ITER with TIME_LINSYS (include/common/settings.cuh:152-158)
+    // The SQP time box (include/common/settings.cuh:56-58 CONST_UPDATE_FREQ = 1, :161-163 SQP_MAX_TIME_US = 2000): with
+    // const_update_freq the loop is left as soon as sqpTimecheck() — wall time since the start of the call, allocation included,
+    // as the reference measures it (include/pcg/sqp.cuh:35, :161-169) — exceeds sqp_max_time_us; checked after every stage.
+    bool const_update_freq = CONST_UPDATE_FREQ != 0;
+    double sqp_max_time_us = SQP_MAX_TIME_US;
 };
 
 template <typename T>

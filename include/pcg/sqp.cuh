@@ -78,13 +78,26 @@ auto sqpSolvePcg(const uint32_t state_size, const uint32_t control_size, const u
                              (void*)&max_iter, (void*)&exit_tol};
     size_t ppcg_kernel_smem_size = pcgSharedMemSize<T>(state_size, knot_points);
 
+    // the SQP time box (:161-169): true once the call has used more than SQP_MAX_TIME_US of wall time; the loop is left after
+    // whichever stage crosses it (:205, :221, :226, :247, :261, :345) and sqp_time_exit keeps its recording value 1 (:28) —
+    // only the stage's own "give up" (rho beyond rho_max, :308-313) reports 0
+    timespec sqp_cur;
+    auto sqpTimecheck = [&]() {
+        if (!st.const_update_freq) return false;
+        clock_gettime(CLOCK_MONOTONIC, &sqp_cur);
+        return mpcgpu_compat::time_delta_us(sqp_solve_start, sqp_cur) > st.sqp_max_time_us;
+    };
+
     uint32_t sqp_iter = 0;
     for (uint32_t sqpiter = 0; sqpiter < st.sqp_max_iter; ++sqpiter) {
         st.generate_kkt(state_size, control_size, knot_points, b.d_G_dense, b.d_C_dense, b.d_g, b.d_c, d_dynMem_const, timestep,
                         d_eePos_traj, b.d_xs, d_xu);                                                         // (:190-204)
+        if (sqpTimecheck()) break;                                                                           // (:205)
         form_schur_system<T>(state_size, control_size, knot_points, b.d_G_dense, b.d_C_dense, b.d_g, b.d_c, b.d_S, b.d_Pinv,
                              b.d_gamma, rho);                                                                // (:207-219)
+        if (sqpTimecheck()) break;                                                                           // (:221)
         gpuErrchk(hipDeviceSynchronize());
+        if (sqpTimecheck()) break;                                                                           // (:226)
         clock_gettime(CLOCK_MONOTONIC, &linsys_start);                                                       // (:224-228)
         gpuErrchk(mpcgLaunchPcg<T>(pcg_kernel, knot_points, PCG_NUM_THREADS, pcgKernelArgs, ppcg_kernel_smem_size));   // (:230)
         gpuErrchk(hipMemcpy(&pcg_iters, b.d_pcg_iters, sizeof(uint32_t), hipMemcpyDeviceToHost));            // (:231)
@@ -94,9 +107,13 @@ auto sqpSolvePcg(const uint32_t state_size, const uint32_t control_size, const u
         linsys_time_vec.push_back(mpcgpu_compat::time_delta_us(linsys_start, linsys_end));                   // (:236-241)
         pcg_iter_vec.push_back((int)pcg_iters);
         pcg_exit_vec.push_back(pcg_exit);                                                                    // (:243-244)
+        if (sqpTimecheck()) break;                                                                           // (:247)
         compute_dz<T>(state_size, control_size, knot_points, d_Ginv_dense, b.d_C_dense, b.d_g, d_lambda, b.d_dz);   // (:250-259)
-        ++sqp_iter;
-        if (!st.globalize_and_step(state_size, control_size, knot_points, d_xu, b.d_dz, rho, rho_reset, sqpiter)) { sqp_time_exit = 0; break; }
+        if (sqpTimecheck()) break;                                                                           // (:261)
+        const bool go_on = st.globalize_and_step(state_size, control_size, knot_points, d_xu, b.d_dz, rho, rho_reset, sqpiter);
+        ++sqp_iter;                                                                                          // (:306, :341: counted once the step is decided)
+        if (!go_on) { sqp_time_exit = 0; break; }                                                            // (:308-313)
+        if (sqpTimecheck()) break;                                                                           // (:345)
     }
     gpuErrchk(hipDeviceSynchronize());
     clock_gettime(CLOCK_MONOTONIC, &sqp_solve_end);

@@ -38,23 +38,38 @@ auto sqpSolveQdldl(uint32_t state_size, uint32_t control_size, uint32_t knot_poi
     T* d_val;
     gpuErrchk(hipMalloc(&d_val, nnz * sizeof(T)));
 
+    // the SQP time box (reference include/qdldl/sqp.cuh:206-214; checks at :254, :259, :263, :284, :298, :382)
+    timespec sqp_cur;
+    auto sqpTimecheck = [&]() {
+        if (!st.const_update_freq) return false;
+        clock_gettime(CLOCK_MONOTONIC, &sqp_cur);
+        return mpcgpu_compat::time_delta_us(sqp_solve_start, sqp_cur) > st.sqp_max_time_us;
+    };
+
     uint32_t sqp_iter = 0;
     for (uint32_t sqpiter = 0; sqpiter < st.sqp_max_iter; ++sqpiter) {
         st.generate_kkt(state_size, control_size, knot_points, b.d_G_dense, b.d_C_dense, b.d_g, b.d_c, d_dynMem_const, timestep,
                         d_eePos_traj, b.d_xs, d_xu);
+        if (sqpTimecheck()) break;                                                                            // (:254)
         // form_schur_system_qdldl (:257): S in the bd layout, then its lower triangle in CSR order
         if (mpcg_form_schur(h, control_size, b.d_G_dense, b.d_C_dense, b.d_g, b.d_c, b.d_S, nullptr, b.d_gamma, rho, 1, MPCG_PRECOND_NONE, nullptr) != MPCG_OK ||
             mpcg_bd_to_csr_lowertri(h, b.d_S, d_val, 1.0f, 1, nullptr) != MPCG_OK)
             mpcg_compat::die("form_schur_system_qdldl", h);
+        if (sqpTimecheck()) break;                                                                            // (:259)
         gpuErrchk(hipDeviceSynchronize());
+        if (sqpTimecheck()) break;                                                                            // (:263)
         clock_gettime(CLOCK_MONOTONIC, &linsys_start);                                                        // (:261-265)
         if (mpcg_qdldl_solve_schur(h, ldl, d_val, b.d_gamma, d_lambda, nullptr) != MPCG_OK) mpcg_compat::die("qdldl_solve_schur", h);   // (:268-273)
         gpuErrchk(hipDeviceSynchronize());
         clock_gettime(CLOCK_MONOTONIC, &linsys_end);
         linsys_time_vec.push_back(mpcgpu_compat::time_delta_us(linsys_start, linsys_end));                    // (:276-281)
+        if (sqpTimecheck()) break;                                                                            // (:284)
         compute_dz<T>(state_size, control_size, knot_points, b.d_G_dense, b.d_C_dense, b.d_g, d_lambda, b.d_dz);
+        if (sqpTimecheck()) break;                                                                            // (:298)
+        const bool go_on = st.globalize_and_step(state_size, control_size, knot_points, d_xu, b.d_dz, rho, rho_reset, sqpiter);
         ++sqp_iter;
-        if (!st.globalize_and_step(state_size, control_size, knot_points, d_xu, b.d_dz, rho, rho_reset, sqpiter)) { sqp_time_exit = 0; break; }
+        if (!go_on) { sqp_time_exit = 0; break; }                                                             // (:345-350)
+        if (sqpTimecheck()) break;                                                                            // (:382)
     }
     gpuErrchk(hipFree(d_val));
     mpcg_ldl_destroy(ldl);

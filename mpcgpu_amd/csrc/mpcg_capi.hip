@@ -56,6 +56,8 @@ struct mpcg_handle {
     int cluster_lpb = -1;     // clustered lane-per-block kernel (pcg_lpb_cluster.hip.h) instead of the row-triple cluster kernel: -1 auto (on), 0 off, 1 on
     int cluster_l2 = 1;       // clustered lane-per-block kernel: 1 = L2-resident hand-offs when a cluster's members share an XCD, 0 = always write-through
     int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
+    int check_symmetry = 0;   // debug: 1 = every solve that would run a lower-triangle kernel first verifies block symmetry of S and Pinv (synchronises)
+    int last_sym_violations = 0;   //   block pairs that failed the check in the last solve (then solved by a three-column kernel)
     unsigned long long* cluster_scratch = nullptr;
     bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any valid pcg_* set_option clears this)
     bool generic = false;     // state_size != 14: only the PCG entry points work, through pcg_generic_kernel
@@ -111,8 +113,9 @@ static size_t cluster_alloc_words(const mpcg_handle* h) {
     const size_t cells = (size_t)2 * h->num_cus * CL_WG_WORDS;
     const size_t a = (size_t)h->num_cus * CL_FLAG_STRIDE + cells;
     const size_t b = (size_t)2 * h->num_cus * LPBC_WG_WORDS + CL_FLAG_STRIDE + (size_t)h->max_batch * CL_FLAG_STRIDE;
-    return a > b ? a : b;
+    return (a > b ? a : b) + 16;         // + one line for the "cluster_fixups" counter (never re-zeroed by a launch)
 }
+static unsigned long long* fixup_counter(const mpcg_handle* h) { return h->cluster_scratch + cluster_alloc_words(h) - 16; }
 
 size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
     if (generic_shape_supported(state_size, knot_points)) return pcg_generic_lds_elems((int)knot_points, (int)state_size) * sizeof(float);
@@ -224,6 +227,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "cluster_adj")) { h->cluster_adj = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_fixup")) { h->cluster_fixup = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_l2")) { h->cluster_l2 = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "check_symmetry")) { h->check_symmetry = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_lpb")) {
         if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "cluster_lpb must be -1 (auto), 0 or 1");
         h->cluster_lpb = value; return MPCG_OK;
@@ -256,11 +260,21 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "cluster_fixup")) { *value = h->cluster_fixup; return MPCG_OK; }
     if (!strcmp(key, "cluster_lpb")) { *value = h->cluster_lpb; return MPCG_OK; }
     if (!strcmp(key, "cluster_l2")) { *value = h->cluster_l2; return MPCG_OK; }
+    if (!strcmp(key, "check_symmetry")) { *value = h->check_symmetry; return MPCG_OK; }
+    if (!strcmp(key, "last_symmetry_violations")) { *value = h->last_sym_violations; return MPCG_OK; }
     if (!strcmp(key, "schur_dpp")) { *value = h->schur_dpp; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "spmv_mfma")) { *value = h->spmv_mfma; return MPCG_OK; }
     if (!strcmp(key, "num_cus")) { *value = h->num_cus; return MPCG_OK; }
     if (!strcmp(key, "auto_cfg")) { *value = h->auto_cfg ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "cluster_fixups")) {
+        // trajectories re-solved by fix-up launches since mpcg_create (their cluster gave up after the bounded spin): a blocking
+        // 8-byte D2H copy — it waits for the device work queued before it
+        unsigned long long v = 0;
+        if (hipSetDevice(h->device) != hipSuccess || hipMemcpy(&v, fixup_counter(h), sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return MPCG_ERR_HIP;
+        *value = v > 0x7fffffffull ? 0x7fffffff : (int)v;
+        return MPCG_OK;
+    }
     // what the last solve on this handle launched
     if (!strcmp(key, "last_kernel_family")) { *value = h->last.family; return MPCG_OK; }      // 0 single-workgroup, 1 cluster, 2 lane-per-block
     if (!strcmp(key, "last_kernel_waves")) { *value = h->last.waves; return MPCG_OK; }
@@ -569,6 +583,7 @@ static int try_launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch
         if (fixup) {
             c.redo_flags = h->cluster_scratch;                     // flag of trajectory b of this chunk
             c.redo_stride = CL_FLAG_STRIDE;
+            c.redo_count = fixup_counter(h);
             rc = launch_traj(h, kf, c, nb, st, 4, /*record=*/false);
             if (rc != MPCG_OK) return rc;
         }
@@ -594,7 +609,11 @@ static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, h
     const int G = lpbc_members(h, 64 * NWR);
     if (G == 0) return 1;
     if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "batch exceeds max_batch");
-    const uint32_t resident = (uint32_t)(per_cu * h->num_cus / G);       // clusters the chip holds
+    // clusters the chip holds: the kernel pins cluster cl to XCD cl % 8 (all its members on one XCD, 32 CUs each), so residency is a
+    // per-XCD count — 8 x floor(slots of one XCD / G).  (Sized chip-wide, G = 3, 5, 6, 7 over-subscribed some XCDs by a member that could
+    // not start while the persistent clusters held the CUs: its peers spun to the limit and the trajectories fell to the fix-up launch.)
+    const int xcd_slots = per_cu * (h->num_cus / 8);
+    const uint32_t resident = h->num_cus >= 8 && xcd_slots >= G ? (uint32_t)(8 * (xcd_slots / G)) : (uint32_t)(per_cu * h->num_cus / G);
     const uint32_t clusters = batch < resident ? batch : resident;
     const size_t lds = pcg_lpbc_lds_floats(4 * NWR) * sizeof(float);
     auto kern = pcg_lpbc_kernel<NWR>;
@@ -624,6 +643,7 @@ static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, h
         c.redo_flags = ca.fail_flags;
         c.redo_stride = CL_FLAG_STRIDE;
         c.redo_skip = (unsigned)G;
+        c.redo_count = fixup_counter(h);
         const int rc = h->N <= kLpbMaxN ? launch_lpb(h, c, batch, st) : launch_traj(h, kf, c, batch, st, 4, /*record=*/false);
         if (rc != MPCG_OK) return rc;
     }
@@ -693,6 +713,24 @@ static int launch_traj(mpcg_handle* h, const PcgKnobs& k, const PcgArgs& a, uint
 //      automatic policy unless the caller set any pcg_* knob.
 static int launch_generic_f32(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st);
 
+// block pairs (k, right) / (k+1, left) of S and (SS only) Pinv that are not transposes of each other within 1e-5 of their largest entry
+// (the reference's construction gives 0 for S and ~1e-7 for the symmetric-stair Pinv).  Blocking: waits for `st`.
+static int symmetry_violations(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int* out) {
+    unsigned long long* cnt = fixup_counter(h) + 8;
+    HIP_TRY(h, hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st));
+    const long items = (long)batch * ((long)h->N - 1);
+    const unsigned blocks = (unsigned)((items + 3) / 4);
+    hipLaunchKernelGGL(bd_symmetry_check_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.S), (int)h->N, (int)batch, 1e-5f, cnt);
+    if (a.pcols == 3)
+        hipLaunchKernelGGL(bd_symmetry_check_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.Pinv), (int)h->N, (int)batch, 1e-5f, cnt);
+    HIP_TRY(h, hipGetLastError());
+    unsigned long long v = 0;
+    HIP_TRY(h, hipMemcpyAsync(&v, cnt, sizeof v, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    *out = v > 0x7fffffffull ? 0x7fffffff : (int)v;
+    return MPCG_OK;
+}
+
 static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->generic) {
@@ -700,10 +738,23 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
         return launch_generic_f32(h, a, batch, st);
     }
     if (use_rpl(h, esz, batch)) return launch_rpl(h, a, batch, st);      // (an explicit "pcg_lpb" = 1 wins over the automatic choice of this one)
-    if (use_lpb(h, esz)) return launch_lpb(h, a, batch, st);
-    {
+    // "check_symmetry" (debug, off by default): the kernels below read only the left + diagonal block columns (mpcg.h "Block symmetry").
+    // Verify the precondition on this call's matrices; a call that violates it is solved by a kernel that reads all three columns.
+    bool lower_ok = true;
+    h->last_sym_violations = 0;
+    if (h->check_symmetry && esz == 4 && (use_lpb(h, esz) || (h->cluster != 0 && h->cluster_lpb != 0 && (h->cluster > 0 || h->N > kLpbMaxN)))) {
+        int v = 0;
+        const int rc = symmetry_violations(h, a, batch, st, &v);
+        if (rc != MPCG_OK) return rc;
+        h->last_sym_violations = v;
+        lower_ok = v == 0;
+    }
+    if (lower_ok) {
+        if (use_lpb(h, esz)) return launch_lpb(h, a, batch, st);
         const int rc = try_launch_cluster(h, a, batch, st, esz);
         if (rc != 1) return rc;
+    } else if (h->N <= kRplMaxN && h->rpl != 0) {
+        return launch_rpl(h, a, batch, st);              // full block rows in registers
     }
     PcgKnobs k = h->k;
     if (h->auto_cfg) choose_auto(h, k, batch, esz);

@@ -189,6 +189,7 @@ struct PcgArgs {
     const unsigned long long* redo_flags = nullptr;
     int redo_stride = 0;
     unsigned redo_skip = 0;
+    unsigned long long* redo_count = nullptr;   // fix-up launches: += 1 per trajectory they re-solve (the handle's "cluster_fixups" counter)
 };
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : N
     constexpr int NTHR = NW * 64;
     if (a.redo_flags && __hip_atomic_load(a.redo_flags + (size_t)b * a.redo_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.redo_skip)
         return;                                        // (uniform) nothing to redo for this trajectory
+    if (a.redo_flags && a.redo_count && tid == 0) __hip_atomic_fetch_add(a.redo_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     float* xp = lds;                                   // knot j at xp + (j+1)*NS
     float* xr = xp + r4((size_t)(N + 2) * NS);
@@ -1063,6 +1065,37 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && RT <= 3 ? 2 : NW / 4)) void pc
 __global__ __launch_bounds__(256) void zero_words_kernel(unsigned long long* p, size_t count) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < count) p[i] = 0ull;
+}
+
+// Debug check behind the "check_symmetry" option: the lane-per-block / lane-pair kernels read only the left and diagonal block
+// columns of S and Pinv and use L_{k+1}^T where the reference's kernel reads block (k, right).  One wavefront per (trajectory,
+// k < N-1): counts the pairs whose blocks differ by more than rel_tol x the largest entry of the pair,
+//   max_ij | M[k, right](i, j) - M[k+1, left](j, i) |  >  rel_tol * max | M[k, right], M[k+1, left] |        (NaN counts as a violation).
+__global__ __launch_bounds__(256) void bd_symmetry_check_kernel(const float* __restrict__ M, int N, int batch, float rel_tol,
+                                                                unsigned long long* __restrict__ violations) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)batch * (N - 1)) return;
+    const long b = item / (N - 1);
+    const int k = (int)(item - b * (N - 1));
+    const float* R = M + ((size_t)b * N + k) * ROWF + 2 * NS * NS;          // block (k, right), column-major
+    const float* Lt = M + ((size_t)b * N + k + 1) * ROWF;                   // block (k+1, left)
+    float dmax = 0.f, amax = 0.f;
+    bool bad = false;
+    for (int e = lane; e < NS * NS; e += 64) {
+        const int i = e % NS, j = e / NS;
+        const float x = R[j * NS + i], y = Lt[i * NS + j];
+        const float d = fabsf(x - y);
+        bad |= !(d == d);
+        dmax = fmaxf(dmax, d);
+        amax = fmaxf(amax, fmaxf(fabsf(x), fabsf(y)));
+    }
+    for (int o = 32; o; o >>= 1) {
+        dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+        amax = fmaxf(amax, __shfl_xor(amax, o));
+        bad |= __shfl_xor((int)bad, o) != 0;
+    }
+    if (lane == 0 && (bad || dmax > rel_tol * amax)) atomicAdd(violations, 1ull);
 }
 
 // fp32 -> fp16 copy of a bd-layout matrix (round to nearest even), 8 elements per thread.

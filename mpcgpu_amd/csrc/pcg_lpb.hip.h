@@ -58,6 +58,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpb_kernel(PcgArgs a) {
     const int b = blockIdx.x;
     // fix-up launch behind a cluster kernel: only the flagged trajectories run
     if (a.redo_flags && __hip_atomic_load(a.redo_flags + (size_t)b * a.redo_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.redo_skip) return;
+    if (a.redo_flags && a.redo_count && tid == 0) __hip_atomic_fetch_add(a.redo_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float* red_v = lds + L::RED;
     float* red_e = red_v + NW;
 

@@ -70,6 +70,16 @@ def sum_over_ranks(value: float, device="cpu") -> float:
     return float(t.item())
 
 
+def all_gather_floats(value: float, device="cpu") -> list[float]:
+    """One float of every rank, in rank order (per-rank kernel times of the bench line)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def gather_results(iters: torch.Tensor, exits: torch.Tensor, total: int | None) -> tuple[torch.Tensor, torch.Tensor]:
     """All-gather the per-trajectory (iters, max_iter_exit) of every rank's shard into global
     order.  total = N: shards follow shard_range(N, rank, world) and may be ragged, so each rank pads to the

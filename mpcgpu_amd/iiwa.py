@@ -189,11 +189,11 @@ def read_csv(path):
     return np.array([[float(v) for v in line.strip().split(",") if v != ""] for line in open(path) if line.strip()])
 
 
-TRAJ_FIXTURE = os.path.join(os.path.dirname(_HERE), "tests", "golden", "iiwa_traj_0_0.npz")
+TRAJ_FIXTURE = os.path.join(_HERE, "data", "iiwa_traj_0_0.npz")
 
 
 def random_windows(knot_points: int, batch: int, seed: int, max_noise: float = 0.05):
-    """`batch` tracking problems cut from the reference's precomputed trajectory (tests/golden/iiwa_traj_0_0.npz = the
+    """`batch` tracking problems cut from the reference's precomputed trajectory (mpcgpu_amd/data/iiwa_traj_0_0.npz = the
     first 400 rows of examples/trajfiles/0_0_traj.csv and 0_0_eepos.traj): random window offset, goals 0..8 steps ahead,
     measured state x_s and iterate perturbed by gaussian noise of random amplitude <= max_noise (rad, rad/s) — the
     'random-init trajectories' of BASELINE config 4 on the real robot.  Returns float64 (xu [B, (n+m)N-m], goals [B, N, 6], xs [B, n])."""

@@ -5,7 +5,7 @@ reference's trajectory fixtures, and writes
                                       coef*sin(q_j) / coef*cos(q_j)), spatial inertias I, homogeneous transforms Xhom, as tabulated in
                                       include/dynamics/iiwa/iiwa_eepos_grid.cuh (init_XImats :909-1640, load_update_XImats_helpers
                                       :1770-1845, load_update_XmatsHom_helpers :1857-1904)
-  tests/golden/iiwa_traj_0_0.npz      first 400 rows of examples/trajfiles/0_0_traj.csv (x(14), u(7)) and 0_0_eepos.traj (6)
+  mpcgpu_amd/data/iiwa_traj_0_0.npz   first 400 rows of examples/trajfiles/0_0_traj.csv (x(14), u(7)) and 0_0_eepos.traj (6)
   tests/golden/iiwa_kkt_N32.npz       KKT blocks (G, C, g, c) of three N=32 windows produced by mpcgpu_amd.iiwa.generate_kkt
                                       (float64 restatement of include/common/kkt.cuh:22-163), the Schur systems the oracle forms
                                       from them and float64 PCG statistics
@@ -75,7 +75,7 @@ def main():
     err = max(np.abs(M.ee_pos(traj[t, :7]) - eep[t, :3]).max() for t in (0, 1, 50, 199, 400, 665))
     print("end-effector position vs 0_0_eepos.traj: max abs err", err)
     assert err < 2e-5
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "iiwa_traj_0_0.npz"), xu=traj[:400].astype(np.float32), eepos=eep[:400].astype(np.float32))
+    np.savez_compressed(os.path.join(ROOT, "mpcgpu_amd", "data", "iiwa_traj_0_0.npz"), xu=traj[:400].astype(np.float32), eepos=eep[:400].astype(np.float32))
 
     n, m = 14, 7
     rng = np.random.default_rng(7)

@@ -1,0 +1,114 @@
+"""GPU: round-3 contract items of the C ABI.
+ * "check_symmetry": the lower-triangle kernels' precondition (include/mpcg.h, BLOCK SYMMETRY) verified per call; a caller whose
+   Pinv is not block-symmetric is served by a three-column kernel and gets the three-column answer;
+ * "cluster_fixups": fix-up launches report how many trajectories they re-solved;
+ * cluster residency is sized per XCD: horizons whose member count does not divide an XCD's 32 CUs (G = 3, 5) at FULL batch need
+   no fix-up (sized chip-wide they over-subscribed some XCDs)."""
+import numpy as np
+import pytest
+import torch
+
+from mpcgpu_amd import synth
+from util import fp32_band, relinf
+
+pytestmark = pytest.mark.gpu
+n = 14
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("N", [48, 128, 256])
+def test_check_symmetry_passes_on_reference_matrices_and_catches_asymmetric_pinv(orc, N):
+    from mpcgpu_amd import PcgSolver, pcg_config
+    B, K = 2, 12
+    k = synth.make_kkt(N, B, 4400 + N)
+    S, Pinv, g = synth.form_schur(k, precond="ss")
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    sol = PcgSolver(N, max_batch=B)
+    if N <= 64:
+        sol.set_option("pcg_rpl", 0)
+    lam = torch.zeros(B, n * N, device="cuda")
+    sol.solve(dev(S), dev(Pinv), dev(g), lam, cfg, "ss")
+    fam_default = sol.get_option("last_kernel_family")
+    assert fam_default in (2, 4, 6)                       # a lower-triangle kernel serves this call
+    sol.set_option("check_symmetry", 1)
+    lam1 = torch.zeros(B, n * N, device="cuda")
+    sol.solve(dev(S), dev(Pinv), dev(g), lam1, cfg, "ss")
+    assert sol.get_option("last_symmetry_violations") == 0 and sol.get_option("last_kernel_family") == fam_default
+    assert torch.equal(lam, lam1)
+    # a caller-made, NOT block-symmetric preconditioner: right blocks scaled by 0.9 (still a valid, if worse, preconditioner
+    # for a kernel that reads all three columns as the reference's does)
+    Pa = np.array(Pinv, np.float32).reshape(B, N, 3, 196).copy()
+    Pa[:, :, 2] *= 0.9
+    Pa = Pa.reshape(B, -1)
+    lam2 = torch.zeros(B, n * N, device="cuda")
+    sol.solve(dev(S), dev(Pa), dev(g), lam2, cfg, "ss")
+    assert sol.get_option("last_symmetry_violations") == B * (N - 1)
+    assert sol.get_option("last_kernel_family") in (0, 5)          # three-column kernels
+    for b in range(B):
+        ref = orc.pcg(S[b].astype(np.float64), Pa[b].astype(np.float64), g[b].astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")["lam"]
+        band = fp32_band(orc, S[b], Pa[b], g[b], np.zeros(n * N), N, K, "ss", ref)
+        assert relinf(lam2[b].cpu().numpy(), ref) <= max(1e-3, 4 * band)
+    # with the check off the same call silently gets the lower-triangle solve: a different answer (that is the documented hazard)
+    sol.set_option("check_symmetry", 0)
+    lam3 = torch.zeros(B, n * N, device="cuda")
+    sol.solve(dev(S), dev(Pa), dev(g), lam3, cfg, "ss")
+    assert sol.get_option("last_kernel_family") == fam_default
+    assert relinf(lam3.cpu().numpy(), lam.cpu().numpy()) < 1e-6 < relinf(lam3.cpu().numpy(), lam2.cpu().numpy())
+
+
+@pytest.mark.parametrize("N,G", [(384, 3), (640, 5), (256, 2)])
+def test_full_batch_ragged_member_counts_need_no_fixup(N, G):
+    """Every cluster of a persistent launch must be resident on ITS XCD: full-chip batches at G = 3 and 5."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    B, K = 300, 6
+    k = synth.make_kkt(N, 4, 5100 + N)
+    S, Pinv, g = synth.form_schur(k, precond="ss")
+    rep = (B + 3) // 4
+    dS, dP, dg = (dev(a).repeat(rep, 1)[:B].contiguous() for a in (S, Pinv, g))
+    sol = PcgSolver(N, max_batch=B)
+    before = sol.get_option("cluster_fixups")
+    lam = torch.zeros(B, n * N, device="cuda")
+    it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), "ss")
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 4 and sol.get_option("last_kernel_cluster") == G
+    assert sol.get_option("cluster_fixups") == before, "a cluster gave up on an otherwise idle GPU"
+    assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all()
+    l = lam.cpu().numpy()
+    np.testing.assert_array_equal(l[:4], l[4:8])            # the same four systems, whichever cluster drew them
+
+
+def test_fixup_counter_counts_abandoned_trajectories():
+    """A 2-member cluster whose peers cannot start (another stream holds the CUs) gives up; the fix-up launch re-solves and counts."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, B, K = 256, 2, 8
+    k = synth.make_kkt(N, B, 777)
+    S, Pinv, g = synth.form_schur(k, precond="ss")
+    sol = PcgSolver(N, max_batch=B)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    lam_ref = torch.zeros(B, n * N, device="cuda")
+    sol.solve(dS, dP, dg, lam_ref, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), "ss")
+    torch.cuda.synchronize()
+    assert sol.get_option("cluster_fixups") == 0
+    # occupy the chip on a second stream with spinning workgroups holding most of every CU's LDS, then solve on the default stream
+    blocker = torch.cuda.Stream()
+    ncu = sol.get_option("num_cus")
+    big = PcgSolver(128, max_batch=4 * ncu)
+    kb = synth.make_kkt(128, 2, 3)
+    Sb, Pb, gb = synth.form_schur(kb, precond="ss")
+    bS, bP, bg = (dev(a).repeat(2 * ncu, 1).contiguous() for a in (Sb, Pb, gb))
+    bl = torch.zeros(4 * ncu, n * 128, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(blocker):
+        for _ in range(3):
+            big.solve(bS, bP, bg, bl, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=4000), "ss")
+    lam = torch.zeros(B, n * N, device="cuda")
+    it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), "ss")
+    torch.cuda.synchronize()
+    fixed = sol.get_option("cluster_fixups")
+    assert 0 <= fixed <= B
+    assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all() and np.isfinite(lam.cpu().numpy()).all()
+    if fixed == 0:       # the clusters found their CUs anyway: same bits as the undisturbed solve
+        assert torch.equal(lam, lam_ref)

@@ -276,6 +276,10 @@ def test_mpcsim_entry_points_with_both_linsys_solvers():
         outs[sel] = json.loads(r.stdout.strip().splitlines()[-1])
         assert outs[sel]["linsys_solve"] == sel and outs[sel]["control_steps"] == 4 and outs[sel]["linsolves"] == 4
         assert outs[sel]["dynamics_defect"] < 1e-3 and outs[sel]["stationarity_rel"] < 2e-2
+        # the SQP time box (sqpTimecheck, reference include/pcg/sqp.cuh:161-169): off / already expired / generous
+        tb = outs[sel]["time_box"]
+        assert tb["ok"] is True and tb["off_iters"] == 5 and tb["generous_iters"] == 5
+        assert tb["expired_iters"] == 0 and tb["expired_linsolves"] == 0 and tb["expired_sqp_time_exit"] == 1
     # the two solvers steer the same problem the same way
     assert abs(outs[0]["tracking_last"] - outs[1]["tracking_last"]) < 1e-2 * max(1.0, outs[1]["tracking_first"])
 

@@ -1,13 +1,13 @@
 """CPU: the IIWA-14 producer side (stage A) — mpcgpu_amd/iiwa.py (numpy float64 restatement of
 include/common/kkt.cuh:22-163 + the plant it calls) against the reference's own trajectory fixtures
-(tests/golden/iiwa_traj_0_0.npz = first 400 rows of examples/trajfiles/0_0_traj.csv and 0_0_eepos.traj) and the KKT / Schur
+(mpcgpu_amd/data/iiwa_traj_0_0.npz = first 400 rows of examples/trajfiles/0_0_traj.csv and 0_0_eepos.traj) and the KKT / Schur
 fixtures tests/make_iiwa_golden.py produced in the build container."""
 import os
 
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 from mpcgpu_amd import iiwa, synth
 
 
@@ -18,7 +18,7 @@ def M():
 
 @pytest.fixture(scope="module")
 def traj():
-    d = np.load(os.path.join(GOLDEN, "iiwa_traj_0_0.npz"))
+    d = np.load(os.path.join(ROOT, "mpcgpu_amd", "data", "iiwa_traj_0_0.npz"))
     return d["xu"].astype(np.float64), d["eepos"].astype(np.float64)
 
 
