@@ -10,6 +10,7 @@
 #include "../../include/mpcg.h"
 #include "pcg_kernels.hip.h"
 #include "pcg_lpb.hip.h"
+#include "pcg_lpk.hip.h"
 #include "pcg_lpb_cluster.hip.h"
 #include "pcg_rpl.hip.h"
 #include "schur_kernels.hip.h"
@@ -35,7 +36,7 @@ struct PcgKnobs {
 };
 
 // What the last solve on this handle actually launched (read-only "last_kernel_*" options; tests assert on it).
-enum { FAM_NONE = -1, FAM_TRAJ = 0, FAM_CLUSTER = 1, FAM_LPB = 2, FAM_GENERIC = 3, FAM_LPBC = 4, FAM_RPL = 5 };
+enum { FAM_NONE = -1, FAM_TRAJ = 0, FAM_CLUSTER = 1, FAM_LPB = 2, FAM_GENERIC = 3, FAM_LPBC = 4, FAM_RPL = 5, FAM_LPK = 6 };
 struct LastKernel { int family = FAM_NONE, waves = 0, reg_rows = 0, lds_rows = 0, stream_bufs = 0, cluster = 0, lds_bytes = 0, lds_extra = 0; };
 
 struct mpcg_handle {
@@ -47,6 +48,7 @@ struct mpcg_handle {
     int nt_loads = 1;         // non-temporal hint on the matrix stream
     int rpl = -1;             // row-per-lane kernel (pcg_rpl.hip.h, N <= 64): -1 auto, 0 off, 1 forced
     int rpl_waves = 0;        //   its wavefronts per trajectory: 0 auto, 4 / 8 / 16
+    int lpk = -1;             // lane-pair-per-knot kernel (pcg_lpk.hip.h, N <= 128): -1 auto (wherever the lane-per-block kernel would run), 0 off, 1 forced
     int lpb = -1;             // lane-per-block kernel (pcg_lpb.hip.h): -1 auto (N <= 128, fp32, automatic configuration), 0 off, 1 forced
     int block_solve_wide = -1; // mpcg_block_solve: one trajectory per wavefront (1), four (0), by batch size (-1)
     int schur_dpp = 1;        // 1: register-resident Schur formation kernels (schur_dpp.hip.h), 0: the LDS versions
@@ -217,6 +219,11 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
         if (value != 0 && value != 4 && value != 8 && value != 16) return fail(h, MPCG_ERR_INVALID, "rpl_waves must be 0 (auto), 4, 8 or 16");
         h->rpl_waves = value; return MPCG_OK;
     }
+    if (!strcmp(key, "pcg_lpk")) {
+        if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "pcg_lpk must be -1 (auto), 0 (off) or 1 (forced)");
+        if (value == 1 && h->N > kLpbMaxN) return fail(h, MPCG_ERR_UNSUPPORTED, "pcg_lpk: the lane-pair kernel holds knot_points <= 128");
+        h->lpk = value; return MPCG_OK;
+    }
     if (!strcmp(key, "pcg_lpb")) {
         if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "pcg_lpb must be -1 (auto), 0 (off) or 1 (forced)");
         if (value == 1 && h->N > kLpbMaxN) return fail(h, MPCG_ERR_UNSUPPORTED, "pcg_lpb: the lane-per-block kernel holds knot_points <= 128");
@@ -250,6 +257,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "pcg_waves")) { *value = h->k.waves; return MPCG_OK; }
     if (!strcmp(key, "pcg_max_wg_per_cu")) { *value = h->k.max_wg_per_cu; return MPCG_OK; }
     if (!strcmp(key, "pcg_lpb")) { *value = h->lpb; return MPCG_OK; }
+    if (!strcmp(key, "pcg_lpk")) { *value = h->lpk; return MPCG_OK; }
     if (!strcmp(key, "pcg_rpl")) { *value = h->rpl; return MPCG_OK; }
     if (!strcmp(key, "rpl_waves")) { *value = h->rpl_waves; return MPCG_OK; }
     if (const int* p = knob_ptr(const_cast<mpcg_handle*>(h), key)) { *value = *p; return MPCG_OK; }
@@ -448,7 +456,22 @@ static int launch_lpb_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStr
     h->last = LastKernel{FAM_LPB, 4 * NWR, 0, 0, 0, 0, (int)lds, 0};
     return MPCG_OK;
 }
+// ---- lane-pair-per-knot kernel (pcg_lpk.hip.h): the round-3 successor of the lane-per-block kernel, same residency ----
+template <int NWR>
+static int launch_lpk_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    const size_t lds = pcg_lpk_lds_floats(4 * NWR) * sizeof(float);
+    auto kern = pcg_lpk_kernel<NWR>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(batch), dim3(NWR * 256), lds, st, a);
+    HIP_TRY(h, hipGetLastError());
+    h->last = LastKernel{FAM_LPK, 4 * NWR, 0, 0, 0, 0, (int)lds, 0};
+    return MPCG_OK;
+}
+// which of the two one-CU register-resident kernels serves a call that use_lpb() accepted
+static bool prefer_lpk(const mpcg_handle* h) { return h->lpk == 1 || (h->lpk == -1 && h->lpb != 1); }
 static int launch_lpb(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    if (prefer_lpk(h)) return h->N <= 64 ? launch_lpk_t<1>(h, a, batch, st) : launch_lpk_t<2>(h, a, batch, st);
     return h->N <= 64 ? launch_lpb_t<1>(h, a, batch, st) : launch_lpb_t<2>(h, a, batch, st);
 }
 // Automatic use: 36 < N <= 128 (where the row-per-lane kernel has not taken the call).  Its per-lane work does not shrink with the horizon
@@ -456,8 +479,8 @@ static int launch_lpb(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
 // ahead in throughput (N=36: 292 vs 222 M it/s at batch 2048); beyond it the order flips (N=40: 240 vs 209 M, N=48: 229 vs 205 M,
 // N=64: 220 vs 139 M — tools/_prof/n48.py).
 static bool use_lpb(const mpcg_handle* h, int esz) {
-    if (esz != 4 || h->N > kLpbMaxN || h->lpb == 0) return false;
-    return h->lpb == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 36);
+    if (esz != 4 || h->N > kLpbMaxN || (h->lpb == 0 && h->lpk != 1)) return false;
+    return h->lpb == 1 || h->lpk == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 36);
 }
 
 // ---- row-per-lane kernel (pcg_rpl.hip.h): short horizons, NW wavefronts x RHO slots of four knots ----
@@ -496,7 +519,7 @@ static int launch_rpl(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
 static bool use_rpl(const mpcg_handle* h, int esz, uint32_t batch) {
     if (esz != 4 || h->N > kRplMaxN || h->rpl == 0) return false;
     if (h->rpl == 1) return true;
-    if (h->lpb == 1) return false;
+    if (h->lpb == 1 || h->lpk == 1) return false;
     return h->auto_cfg && h->cluster <= 0 && (h->N <= 32 || batch <= (uint32_t)h->num_cus);
 }
 
@@ -777,7 +800,7 @@ static int occupancy(mpcg_handle* h, const PcgKnobs& k, int* per_cu) {
 // LDS bytes of the launch a default-configured batch-1 solve makes (what pcgSharedMemSize stands for)
 static size_t default_launch_lds_bytes(uint32_t N, int num_cus) {
     if (N <= kRplMaxN) return pcg_rpl_lds_floats((int)N, N <= 16 ? 4 : 8) * sizeof(float);      // row-per-lane kernel (a batch-1 call)
-    if (N > 48 && N <= kLpbMaxN) return pcg_lpb_lds_floats((int)N, N <= 64 ? 4 : 8) * sizeof(float);
+    if (N > 64 && N <= kLpbMaxN) return pcg_lpk_lds_floats(8) * sizeof(float);          // lane-pair kernel (N <= 64: a batch-1 call runs the row-per-lane kernel)
     if (N <= 48) {                                       // <8,2,0>: everything in registers, vectors in LDS
         mpcg_handle t0;
         t0.N = N; t0.n = NS; t0.num_cus = num_cus;

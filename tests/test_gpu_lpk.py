@@ -1,5 +1,5 @@
-"""GPU (MI355X): the lane-per-block PCG kernel (mpcgpu_amd/csrc/pcg_lpb.hip.h) — the default for fp32,
-knot_points <= 128 — through the C ABI, against the CPU oracle, the golden vectors and the single-workgroup kernels.
+"""GPU (MI355X): the lane-pair-per-knot PCG kernel (mpcgpu_amd/csrc/pcg_lpk.hip.h) — round 3's default for fp32,
+36 < knot_points <= 128 — through the C ABI, against the CPU oracle, the golden vectors and the single-workgroup kernels.
 
 It reads only the block lower triangle (left + diagonal blocks) of S and Pinv: S[k,right] is the bitwise transpose of
 S[k+1,left] in the reference's construction (include/pcg/linsys_setup.cuh:536-557) and the symmetric-stair Pinv
@@ -40,21 +40,23 @@ def poison_right(M, N, jacobi=False):
     return M.reshape(M.shape[0], -1)
 
 
-def lpb_solve(P, N, S, Pinv, g, lam0, max_iter, tol, pc="ss"):
+def lpk_solve(P, N, S, Pinv, g, lam0, max_iter, tol, pc="ss"):
     PcgSolver, pcg_config = P
     B = S.shape[0]
     sol = PcgSolver(N, max_batch=B)
-    sol.set_option("pcg_lpb", 1)              # (round 3: the automatic policy runs the lane-pair kernel, tests/test_gpu_lpk.py, where this one used to run)
+    if N <= 64:
+        sol.set_option("pcg_lpk", 1)          # (the automatic policy uses this kernel for 64 < N <= 128, and for 36 < N <= 64 beyond one trajectory per CU)
     lam = dev(np.asarray(lam0, np.float32))
     it, ex = sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=tol, pcg_max_iter=max_iter), pc)
     torch.cuda.synchronize()
-    assert sol.get_option("last_kernel_family") == 2 and sol.get_option("last_kernel_waves") == (4 if N <= 64 else 8)
+    assert sol.get_option("last_kernel_family") == 6 and sol.get_option("last_kernel_waves") == (4 if N <= 64 else 8)
+    assert N <= 64 or sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes(14, N)
     return lam.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy()
 
 
 @pytest.mark.parametrize("N", [2, 3, 17, 32, 33, 63, 64, 65, 100, 127, 128])
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
-def test_lpb_fixed_iterations_vs_oracle(P, orc, N, pc):
+def test_lpk_fixed_iterations_vs_oracle(P, orc, N, pc):
     """Ragged / odd / maximum horizons, 3 trajectories each, 30 fixed iterations vs the float64 oracle inside the
     fp32 band; bitwise run-to-run determinism."""
     B, K = 3, 30
@@ -62,8 +64,8 @@ def test_lpb_fixed_iterations_vs_oracle(P, orc, N, pc):
     S, Pinv, g = synth.form_schur(k, precond="ss")
     Sp, Pp = poison_right(S, N), poison_right(Pinv, N, jacobi=(pc == "jacobi"))
     lam0 = np.zeros((B, n * N), np.float32)
-    lam, it, ex = lpb_solve(P, N, Sp, Pp, g, lam0, K, 0.0, pc)
-    lam2, _, _ = lpb_solve(P, N, Sp, Pp, g, lam0, K, 0.0, pc)
+    lam, it, ex = lpk_solve(P, N, Sp, Pp, g, lam0, K, 0.0, pc)
+    lam2, _, _ = lpk_solve(P, N, Sp, Pp, g, lam0, K, 0.0, pc)
     np.testing.assert_array_equal(lam, lam2)
     assert (it == K).all() and (ex == 1).all() and np.isfinite(lam).all()
     for b in range(B):
@@ -74,19 +76,19 @@ def test_lpb_fixed_iterations_vs_oracle(P, orc, N, pc):
 
 @pytest.mark.parametrize("N", [8, 32])
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
-def test_lpb_vs_golden(P, orc, N, pc):
+def test_lpk_vs_golden(P, orc, N, pc):
     G = golden(N)
     Sp = poison_right(G["S"], N)
     Pp = poison_right(G["Pinv"], N, jacobi=(pc == "jacobi"))
     for K in (5, 20, 50):
-        lam, it, ex = lpb_solve(P, N, Sp, Pp, G["gamma"].reshape(1, -1), np.zeros((1, n * N)), K, 0.0, pc)
+        lam, it, ex = lpk_solve(P, N, Sp, Pp, G["gamma"].reshape(1, -1), np.zeros((1, n * N)), K, 0.0, pc)
         want = G[f"lam_{pc}_K{K}"]
         band = fp32_band(orc, G["S"], G["Pinv"], G["gamma"], np.zeros(n * N), N, K, pc, want)
         assert it[0] == K and ex[0] == 1
         assert relinf(lam[0], want) <= max(1e-3, 4 * band), (K, relinf(lam[0], want), band)
     # tolerance exit
     want_it = int(G[f"iters_tol_{pc}"])
-    lam, it, ex = lpb_solve(P, N, Sp, Pp, G["gamma"].reshape(1, -1), np.zeros((1, n * N)), 5000, 1e-4, pc)
+    lam, it, ex = lpk_solve(P, N, Sp, Pp, G["gamma"].reshape(1, -1), np.zeros((1, n * N)), 5000, 1e-4, pc)
     assert ex[0] == 0
     lo, hi = exit_iter_bounds(orc, G["S"], G["Pinv"], G["gamma"], np.zeros(n * N), N, 5000, 1e-4, pc)
     assert lo <= int(it[0]) <= hi and lo <= want_it <= hi, (int(it[0]), lo, hi, want_it)
@@ -96,14 +98,14 @@ def test_lpb_vs_golden(P, orc, N, pc):
 
 @pytest.mark.parametrize("N", [64, 128])
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
-def test_lpb_first_iterations_tight(P, orc, N, pc):
+def test_lpk_first_iterations_tight(P, orc, N, pc):
     """K = 1, 2, 3 from a random warm start: rounding has not been amplified yet — a wrong block, transpose,
     sign or reduction would show as O(1); the bound is a few 1e-5."""
     k = synth.make_kkt(N, 2, 531 + N)
     S, Pinv, g = synth.form_schur(k)
     lam0 = np.random.default_rng(N).normal(0, 0.5, (2, n * N)).astype(np.float32)
     for K in (1, 2, 3):
-        lam, it, ex = lpb_solve(P, N, poison_right(S, N), poison_right(Pinv, N, pc == "jacobi"), g, lam0, K, 0.0, pc)
+        lam, it, ex = lpk_solve(P, N, poison_right(S, N), poison_right(Pinv, N, pc == "jacobi"), g, lam0, K, 0.0, pc)
         for b in range(2):
             r64 = orc.pcg(S[b].astype(np.float64), Pinv[b].astype(np.float64), g[b].astype(np.float64),
                           lam0[b].astype(np.float64), N, K, 0.0, pc)
@@ -112,26 +114,26 @@ def test_lpb_first_iterations_tight(P, orc, N, pc):
             assert relinf(lam[b], r64["lam"]) <= max(2e-5, 4 * band), (K, b, relinf(lam[b], r64["lam"]), band)
 
 
-def test_lpb_flags_warm_start_and_r_p_outputs(P, orc):
+def test_lpk_flags_warm_start_and_r_p_outputs(P, orc):
     G = golden(8)
     N = 8
     args = (poison_right(G["S"], N), poison_right(G["Pinv"], N), G["gamma"].reshape(1, -1))
-    lam, it, ex = lpb_solve(P, N, *args, np.zeros((1, n * N)), 7, 1e-4)
+    lam, it, ex = lpk_solve(P, N, *args, np.zeros((1, n * N)), 7, 1e-4)
     assert it[0] == 7 and ex[0] == 1
-    lam, it, ex = lpb_solve(P, N, *args, G["lam_warm"].reshape(1, -1), 20, 0.0)
+    lam, it, ex = lpk_solve(P, N, *args, G["lam_warm"].reshape(1, -1), 20, 0.0)
     band = fp32_band(orc, G["S"], G["Pinv"], G["gamma"], G["lam_warm"], N, 20, "ss", G["lam_warm_ss_K20"])
     assert relinf(lam[0], G["lam_warm_ss_K20"]) <= max(1e-3, 4 * band)
     lam0 = G["lam_direct"].astype(np.float32).reshape(1, -1)
-    lam, it, ex = lpb_solve(P, N, *args, lam0, 50, 1e-2)          # already converged: lambda untouched bit for bit
+    lam, it, ex = lpk_solve(P, N, *args, lam0, 50, 1e-2)          # already converged: lambda untouched bit for bit
     assert it[0] == 0 and ex[0] == 0
     np.testing.assert_array_equal(lam, lam0)
-    lam, it, ex = lpb_solve(P, N, *args, np.zeros((1, n * N)), 0, 1e-9)
+    lam, it, ex = lpk_solve(P, N, *args, np.zeros((1, n * N)), 0, 1e-9)
     assert it[0] == 0 and ex[0] == 1 and (lam == 0).all()
     # the reference's 12-argument entry: d_r / d_p receive the final residual and search direction
     G = golden(32)
     N = 32
     sol = P[0](N)
-    sol.set_option("pcg_lpb", 1)
+    sol.set_option("pcg_lpk", 1)
     d_lambda = torch.zeros(n * N, device="cuda")
     d_r = torch.full((n * N,), 7.0, device="cuda")
     d_p = torch.full((n * N,), 7.0, device="cuda")
@@ -140,12 +142,12 @@ def test_lpb_flags_warm_start_and_r_p_outputs(P, orc):
     sol.solve_ref(dev(poison_right(G["S"], N)[0]), dev(poison_right(G["Pinv"], N)[0]), dev(G["gamma"]), d_lambda, d_r, d_p,
                   torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), d_it, d_ex, 20, 0.0)
     torch.cuda.synchronize()
-    assert sol.get_option("last_kernel_family") == 2
+    assert sol.get_option("last_kernel_family") == 6
     r64 = orc.pcg(G["S"].astype(np.float64), G["Pinv"].astype(np.float64), G["gamma"].astype(np.float64), np.zeros(n * N), N, 20, 0.0, "ss")
     assert relinf(d_r.cpu().numpy(), r64["r"]) < 5e-2 and relinf(d_p.cpu().numpy(), r64["p"]) < 5e-2
 
 
-def test_lpb_reference_style_pinv_is_inside_the_band(P, orc):
+def test_lpk_reference_style_pinv_is_inside_the_band(P, orc):
     """Pinv formed the reference's way (oracle restatement of include/pcg/linsys_setup.cuh:97-136, bit-exact twin of
     mpcg_form_schur): its right blocks are NOT bitwise transposes of the next row's left blocks (two independent
     fp32 products), S's are.  The kernel reads the left blocks only; the result stays inside the fp32 band of the
@@ -160,13 +162,13 @@ def test_lpb_reference_style_pinv_is_inside_the_band(P, orc):
         assert all(np.array_equal(S4[j, 2], S4[j + 1, 0].T) for j in range(N - 1))          # bitwise symmetric
         asym = max(np.abs(P4[j, 2] - P4[j + 1, 0].T).max() for j in range(N - 1)) / np.abs(Pinv).max()
         assert 0 < asym < 1e-6
-        lam, it, ex = lpb_solve(P, N, poison_right(S, N), poison_right(Pinv, N), g.reshape(1, -1), np.zeros((1, n * N)), K, 0.0)
+        lam, it, ex = lpk_solve(P, N, poison_right(S, N), poison_right(Pinv, N), g.reshape(1, -1), np.zeros((1, n * N)), K, 0.0)
         r64 = orc.pcg(S.astype(np.float64), Pinv.astype(np.float64), g.astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")
         band = fp32_band(orc, S, Pinv, g, np.zeros(n * N), N, K, "ss", r64["lam"])
         assert relinf(lam[0], r64["lam"]) <= max(1e-3, 4 * band), (relinf(lam[0], r64["lam"]), band)
 
 
-def test_lpb_agrees_with_single_workgroup_kernel(P):
+def test_lpk_agrees_with_single_workgroup_kernel(P):
     """Same systems through the lane-per-block kernel and the streaming single-workgroup kernel <16,0,2>: different
     summation orders, same solve — iteration counts within 5 %, solutions within fp32 CG drift."""
     PcgSolver, pcg_config = P
@@ -178,14 +180,12 @@ def test_lpb_agrees_with_single_workgroup_kernel(P):
     res = []
     for lpb in (True, False):
         sol = PcgSolver(N, max_batch=B)
-        if lpb:
-            sol.set_option("pcg_lpb", 1)
         if not lpb:
             sol.set_option("pcg_waves", 16); sol.set_option("pcg_reg_rows", 0); sol.set_option("pcg_lds_rows", 0)
         lam = torch.zeros(B, n * N, device="cuda")
         it, ex = sol.solve(dS, dP, dg, lam, cfg, "ss")
         torch.cuda.synchronize()
-        assert sol.get_option("last_kernel_family") == (2 if lpb else 0)
+        assert sol.get_option("last_kernel_family") == (6 if lpb else 0)
         res.append((lam.cpu().numpy(), it.cpu().numpy().astype(int), ex.cpu().numpy()))
     assert np.abs(res[0][1] - res[1][1]).max() <= max(3, int(0.05 * res[1][1].max()))
     assert (res[0][2] == res[1][2]).all()
@@ -194,7 +194,7 @@ def test_lpb_agrees_with_single_workgroup_kernel(P):
     assert all(a <= 2 * c + 1e-6 for a, c in zip(r0, r1))
 
 
-def test_config4_workload_n128_batch1024(P, orc):
+def test_lpk_config4_workload_n128_batch1024(P, orc):
     """BASELINE config 4 on one GPU = the workload bench.py times: N=128, SS, batch 1024, lambda0 = 0, max_iter 167,
     exit_tol 1e-4, default configuration.  Oracle band on 8 sampled trajectories, determinism, residual decrease
     for all 1024 (size-independent property, evaluated with the library's own SpMV)."""
@@ -207,11 +207,10 @@ def test_config4_workload_n128_batch1024(P, orc):
     outs = []
     for rep in range(2):
         sol = PcgSolver(N, max_batch=B)
-        sol.set_option("pcg_lpb", 1)
         lam = torch.zeros(B, n * N, device="cuda")
         it, ex = sol.solve(dS, dP, dg, lam, cfg, "ss")
         torch.cuda.synchronize()
-        assert sol.get_option("last_kernel_family") == 2 and sol.get_option("last_kernel_waves") == 8
+        assert sol.get_option("last_kernel_family") == 6 and sol.get_option("last_kernel_waves") == 8
         outs.append((lam, it.cpu().numpy().astype(int), ex.cpu().numpy()))
     assert torch.equal(outs[0][0], outs[1][0]) and (outs[0][1] == outs[1][1]).all()
     lam, it, ex = outs[0]
@@ -240,49 +239,8 @@ def test_batch_composition_independence(P):
     k = synth.make_kkt(N, B, 31)
     S, Pinv, g = synth.form_schur(k, poison_unused=True)
     cfg = (60, 1e-5)
-    lam, it, ex = lpb_solve(P, N, S, Pinv, g, np.zeros((B, n * N)), *cfg)
+    lam, it, ex = lpk_solve(P, N, S, Pinv, g, np.zeros((B, n * N)), *cfg)
     sub = [5, 257, 299]
-    lam_s, it_s, _ = lpb_solve(P, N, S[sub], Pinv[sub], g[sub], np.zeros((3, n * N)), *cfg)
+    lam_s, it_s, _ = lpk_solve(P, N, S[sub], Pinv[sub], g[sub], np.zeros((3, n * N)), *cfg)
     np.testing.assert_array_equal(lam_s, lam[sub])
     np.testing.assert_array_equal(it_s, it[sub])
-
-
-def test_cluster_falls_back_when_peers_are_not_resident(P, orc):
-    """The cluster kernel (N > 128) needs all members of a trajectory resident.  Keep 255 of the 256 CUs busy with a
-    long solve on another stream, then run a batch-1 N=256 solve (2 members of the clustered lane-per-block kernel): the members that do get a CU give up
-    after the bounded spin, and the fix-up launch re-solves the trajectory with the single-workgroup kernel —
-    the caller gets a normal result (no flag 2, no 0xFFFFFFFF)."""
-    PcgSolver, pcg_config = P
-    # the blocker: N=128 lane-per-block, one workgroup per CU, 255 trajectories, ~20 ms
-    Nb, Bb = 128, 255
-    kb = synth.make_kkt(Nb, 8, 5)
-    Sb, Pb, gb = synth.form_schur(kb)
-    rep = (Bb + 7) // 8
-    dSb, dPb, dgb = (dev(np.tile(a, (rep, 1))[:Bb]) for a in (Sb, Pb, gb))
-    blocker = PcgSolver(Nb, max_batch=Bb)
-    lam_b = torch.zeros(Bb, n * Nb, device="cuda")
-    N, K = 256, 25
-    k = synth.make_kkt(N, 1, 6)
-    S, Pinv, g = synth.form_schur(k, poison_unused=True)
-    dS, dP, dg = dev(S), dev(Pinv), dev(g)
-    sol = PcgSolver(N, max_batch=1)
-    assert sol.get_option("num_cus") == 256
-    lam = torch.zeros(1, n * N, device="cuda")
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    torch.cuda.synchronize()
-    with torch.cuda.stream(s1):
-        blocker.solve(dSb, dPb, dgb, lam_b, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=12000))
-    with torch.cuda.stream(s2):
-        it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
-    torch.cuda.synchronize()
-    assert sol.get_option("last_kernel_family") == 4 and sol.get_option("last_kernel_cluster") == 2
-    assert int(it.item()) == K and int(ex.item()) == 1, (it, ex)
-    Sz, Pz = np.nan_to_num(S[0]), np.nan_to_num(Pinv[0])
-    r64 = orc.pcg(Sz.astype(np.float64), Pz.astype(np.float64), g[0].astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")
-    band = fp32_band(orc, Sz, Pz, g[0], np.zeros(n * N), N, K, "ss", r64["lam"])
-    assert relinf(lam.cpu().numpy()[0], r64["lam"]) <= max(1e-3, 4 * band)
-    # and undisturbed, the same call runs the cluster kernel to the same answer (fp32 round-off of the inner products)
-    lam2 = torch.zeros(1, n * N, device="cuda")
-    it2, ex2 = sol.solve(dS, dP, dg, lam2, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
-    torch.cuda.synchronize()
-    assert int(it2.item()) == K and relinf(lam2.cpu().numpy()[0], r64["lam"]) <= max(1e-3, 4 * band)

@@ -36,9 +36,14 @@ NAMES = ["S regs", "S lds", "S stream", "S fold", "S barrier", "vec update", "ba
 IDX = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]
 LPB_NAMES = ["S direct", "S transp", "S fold", "(to red)", "S barrier", "alpha+r upd", "barrier", "(P start)",
              "P direct", "P transp", "P fold", "(to red)", "P barrier", "eta+p upd", "barrier"]
+LPK_NAMES = ["S transp", "S direct", "S merge+dot", "(to barrier)", "barrier A", "alpha+r/lam", "barrier B", "(P start)",
+             "P transp", "P direct", "P merge+dot", "(to barrier)", "barrier C", "eta+p upd", "barrier D"]
 for spec in args.cfg or ["4:7:-1"]:
-    f = [int(x) for x in spec.split(":")] if spec != "lpb" else [4 if N <= 64 else 8]
-    if spec == "lpb":      # the lane-per-block kernel (default for N <= 128): waves 0-1 S off-diagonal, 2-3 S diagonal, 4-5 / 6-7 Pinv
+    f = [int(x) for x in spec.split(":")] if spec not in ("lpb", "lpk") else [4 if N <= 64 else 8]
+    if spec == "lpk":      # lane-pair-per-knot kernel (round 3 default for 36 < N <= 128): waves 0-3 S, 4-7 Pinv (stamps of the other role's pass stay 0)
+        NAMES = LPK_NAMES
+        sol.set_option("pcg_lpk", 1)
+    elif spec == "lpb":      # the lane-per-block kernel (default for N <= 128): waves 0-1 S off-diagonal, 2-3 S diagonal, 4-5 / 6-7 Pinv
         NAMES = LPB_NAMES
     else:
         sol.set_option("cluster", 0)
@@ -56,6 +61,10 @@ for spec in args.cfg or ["4:7:-1"]:
           f"[s_memtime ticks; one iteration of workgroup 0, per wave]")
     d = np.diff(t, axis=1)
     tot = t[:, 15] - t[:, 0]
+    print("raw stamps relative to the earliest stamp of the iteration (0 = not stamped by this wave):")
+    t0 = t[t > 0].min()
+    for w in range(f[0]):
+        print(f"{w:4d} " + " ".join(f"{int(x - t0) if x > 0 else 0:7d}" for x in t[w]))
     print("wave " + " ".join(f"{n:>10s}" for n in NAMES) + "      total")
     for w in range(f[0]):
         print(f"{w:4d} " + " ".join(f"{int(x):10d}" for x in d[w]) + f" {int(tot[w]):10d}")
