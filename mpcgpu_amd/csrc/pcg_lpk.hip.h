@@ -1,53 +1,60 @@
 // pcg_lpk.hip.h — "lane pair per knot" PCG kernel for gfx950 (round 3): the register-resident successor of the
-// lane-per-block kernel (pcg_lpb.hip.h) for fp32, knot_points <= 128.
+// lane-per-block kernel (pcg_lpb.hip.h) for fp32, knot_points <= 128.  TWO barriers per PCG iteration.
 //
 // What the lane-per-block kernel left on the table (profiles/r02_lpb_ablate.txt): of 5,812 cycles per
 // iteration only 46 % were FMA chains; the off-diagonal waves carried 196 packed FMAs per pass against 98 on the diagonal
 // waves (two of four SIMDs idle half of every pass); every pass wrote three PART vectors (yD, yL, yT) to LDS that an
-// element-wise phase of ALL waves read back, summed and wrote again (914 cycles), between four barriers.
+// element-wise phase of ALL waves read back, summed and wrote again — FOUR "LDS write -> barrier -> LDS read" stages per
+// iteration, ~500 cycles of pure latency each, which is what bounds a kernel with one active wavefront per SIMD.
 //
-// Mapping.  A knot k owns TWO ADJACENT LANES of one wavefront, per matrix; lane h (0/1) of the pair holds the column half
-// c = 7h .. 7h+6 of BOTH blocks of block row k that the lower triangle keeps — D_k = M[k,diag] and L_k = M[k,left] — as
-// 2 x 49 register pairs (196 VGPRs, as before: a trajectory of 128 knots fills 2 x 256 lanes = the 512 KB register file).
+// Mapping.  A knot k owns TWO ADJACENT LANES of one wavefront, per matrix; lane h (0/1) of the pair holds seven columns of BOTH
+// blocks of block row k that the lower triangle keeps — D_k = M[k,diag] and L_k = M[k,left] — as 2 x 49 register pairs (196 VGPRs,
+// as before: a trajectory of 128 knots fills 2 x 256 lanes = the 512 KB register file).  Lane 0: columns 0..6, lane 1: 8..13, 7.
 //   direct      acc[rows]  = sum_{c in half} D_k[:,c] x_k[c] + L_k[:,c] x_{k-1}[c]        98 v_pk_fma_f32, ONE accumulator set
 //   transposed  z[c]       = sum_rows L_k[row,c] x_k[row],  c in half                       49 v_pk_fma_f32 + 7 adds
-// => 147 packed FMAs in EVERY lane of EVERY wave of the pass (was 196 / 98): four S waves and four Pinv waves, one of each
-// per SIMD.  The two column-half partial sums of a knot are merged with DPP (quad_perm [1,0,3,2]: the partner lane), so a
-// lane pair ends the pass with the complete (D x_k + L x_{k-1}) of its knot IN REGISTERS, split by rows: lane 0 owns row
-// pairs P0..P3 (entries 0..7), lane 1 owns P4..P6 (entries 8..13).  Only z — the coupling L_k^T x_k that belongs to knot
-// k-1 — goes through LDS (7 floats per lane), and it is read back together with the reduction partials after the barrier
-// the inner product needs anyway.  No part vectors, no all-wave element-wise phases: after the barrier the S lanes update
-// THEIR 8 entries of r (r -= alpha (acc + z_{k+1})) and publish them, the Pinv lanes likewise p.
-// Inner product without the merged vector: x^T M x = sum_k x_k^T (D_k x_k + L_k x_{k-1}) + x_{k-1}^T (L_k^T x_k), and the
-// lane has both factors of both terms: acc . x_k (all rows, own columns) + z . x_{k-1}[own columns].
+// => 147 packed FMAs in EVERY lane of EVERY wave of the pass (was 196 / 98): four S waves and four Pinv waves, one of each per
+// SIMD.  The two column-half partial sums of a knot are merged with DPP (quad_perm [1,0,3,2]: the partner lane): a lane pair ends
+// the pass with the complete (D x_k + L x_{k-1}) of its knot IN REGISTERS, split by rows — lane 0 owns row pairs P0..P3 (entries
+// 0..7), lane 1 owns P4..P6 (entries 8..13) — and publishes just that (4 x 8 bytes) plus z, the coupling L_k^T x_k that belongs
+// to knot k-1 (7 floats).
+// Uniform instruction stream for both lanes of a pair: lane 1 keeps its row pairs in the order P4 P5 P6 P3 P0 P1 P2 (lane 0:
+// P0 .. P6), so "own pairs" are register slots 0..3 in both, the partner's copy of own slot s is its slot (4, 5, 6, 3)[s], and —
+// because the column order follows the same pattern — the lane's own COLUMNS of a vector are its own row-pair slots 0..2 plus one
+// half of slot 3: no separate per-column operand loads.  (Lane 1's slot 3 duplicates lane 0's: same bits, written to the same place.)
 //
-// Uniform instruction stream for both lanes of a pair: lane 1 keeps its row pairs in the order P4 P5 P6 P3 P0 P1 P2
-// (lane 0: P0 .. P6), so "own pairs" are register slots 0..3 in both, and the partner's copy of own slot s is its slot
-// f(s) = (4, 5, 6, 3)[s].  (Lane 1's slot 3 is a duplicate of P3: same bits as lane 0's, written to the same place.)
+// Two barriers per iteration ("the reader rebuilds").  A pass does not wait for a separate vector-update phase: the lanes of the
+// NEXT pass form their operand themselves, from what the previous pass published and the scalar that pass's inner product gives,
+//     Pinv pass:  r_new = r_old - alpha (US + ZS<<1)         S pass:  p_new = (RT + ZP<<1) + beta p_old
+// (US / RT = the merged row halves, ZS / ZP = the z vectors, <<1 = knot k+1's) — for the 14 entries of knot k and the own 8 of knot
+// k-1, 33 ds_read_b64 instead of 11 — with the very operations, hence the very bits, every other reader of that entry uses; each
+// lane publishes its own 8 entries of the new vector into the other half of a double buffer (the old one is still being read).
+// lambda += alpha p is done by the S lanes while the Pinv pass runs.  Per iteration: S half | barrier | Pinv half | barrier.
+// Inner product without the assembled vector: x^T M x = sum_k x_k^T (D_k x_k + L_k x_{k-1}) + x_{k-1}^T (L_k^T x_k); the lane has
+// both factors of both terms in registers.
 //
 // Reads only the left + diagonal block columns (include/mpcg.h, BLOCK SYMMETRY), like the lane-per-block kernel.
-// LDS: four vectors (p, r, lambda, z) of 7 row pairs x (NMAX + 4) knot slots, pair-major (see LpkLds) + wave partials: 29.6 KB at NWR = 2.
-// Per iteration: S pass | barrier | alpha, r update (S lanes), lambda update (Pinv lanes) | barrier | Pinv pass | barrier |
-// eta', exit test, p update (Pinv lanes) | barrier.
 #pragma once
 #include "pcg_kernels.hip.h"
 
 namespace mpcg {
 
-// LDS layout of one iterate vector: PAIR-MAJOR, V[q][slot] = entries (2q, 2q+1) of knot slot - 1 as one float2, q = 0..6,
+// LDS layout of one vector: PAIR-MAJOR, V[q][slot] = entries (2q, 2q+1) of knot slot - 1 as one float2, q = 0..6,
 // slot = 0..KN-1 (one zero knot in front: knot k lives in slot k + 1; zero knots behind).  Why: every access of the kernel is then
-// bank-conflict-free (MI355X_MICROARCH.md §LDS: ds_read_b64 is served in two groups of 32 lanes over 64 banks, ds_read_b32 over 32) —
+// bank-conflict-free (MI355X_MICROARCH.md §LDS: ds_read_b64 is served in two groups of 32 lanes over 64 banks) —
 //   * a lane pair reads row pairs q and q + 4 of the SAME knot (slot orders P0.. / P4..): KN = 4 (mod 8) puts them 32 banks apart;
-//   * consecutive knots of one pair are consecutive float2: 16 knots x 2 lanes of a group cover the 64 banks exactly once;
-//   * the per-column scalars x[7h + j] of the two lanes of a knot have opposite parity (7 is odd): distinct banks.
-// The first version used knot-major [knot][16 floats]: 8- to 16-way conflicts on every access, the LDS pipe was the bottleneck
-// (profiles/r03_lpk_phases.txt: 1,100-1,300 ticks for the 49-FMA transposed stage, 900 for the 8-entry vector updates).
+//   * consecutive knots of one pair are consecutive float2: 16 knots x 2 lanes of a group cover the 64 banks exactly once.
+// The first version used knot-major [knot][16 floats]: 8- to 16-way conflicts on every access made the LDS pipe the bottleneck
+// (profiles/r03_lpk_phases.txt).
 template <int NWR> struct LpkLds {
     static constexpr int NMAX = 64 * NWR, NW = 4 * NWR;
     static constexpr int KN = NMAX + 4;                        // knot slots per row pair: NMAX + 2 rounded up to 4 (mod 8)
     static_assert(KN % 8 == 4, "row pairs q and q + 4 must sit 32 banks apart");
     static constexpr int VS = 7 * KN * 2;                      // floats per vector
-    static constexpr int XP = 0, XR = VS, LAM = 2 * VS, Z = 3 * VS, RED = 4 * VS, TOTAL = RED + NW;     // RED: NW/2 wave partials per inner product
+    // p and r double-buffered (P0 P1, R0 R1) | US, ZS: what the S pass publishes | RT, ZP: the Pinv pass | lambda | wave partials
+    static constexpr int P0 = 0, R0 = 2 * VS, US = 4 * VS, ZS = 5 * VS, RT = 6 * VS, ZP = 7 * VS, LAM = 8 * VS, RED = 9 * VS, MX = RED + NW, NPARK = 3, TOTAL = MX + NPARK * 2 * NW * 64;
+    // MX: NPARK matrix register pairs per lane parked in LDS (lane-private float2 slots, [pair][thread]: conflict-free): the register file
+    // holds 196 matrix registers + the working set of a half-iteration only just; left to the compiler the overflow goes to SCRATCH, whose
+    // reloads (global-memory latency, three per pass) cost more than the whole FMA stream
     // float index of entry i of knot k inside a vector
     __host__ __device__ static constexpr int at(int k, int i) { return 2 * ((i >> 1) * KN + k + 1) + (i & 1); }
 };
@@ -60,10 +67,19 @@ __device__ __forceinline__ f2 buf_load2(rsrc_t r, uint32_t voff) {
     const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0);
     return __builtin_bit_cast(f2, v);
 }
+// Operand loads are VOLATILE float2 reads: plain ones get merged into ds_read2_b64, which is served in 16-lane groups over a 32-bank
+// modulus (MI355X_MICROARCH.md §LDS) — the layout above is conflict-free for ds_read_b64 (32-lane groups, 64 banks) and 2-way conflicted
+// for the merged form, at 8 instead of 2 LDS cycles to begin with: 16 cycles per pair of loads instead of 4, which made the operand fetch
+// of a half-iteration its longest phase (profiles/r03_lpk_phases.txt).  Volatile accesses are neither merged nor reordered.
+typedef __attribute__((address_space(3))) const volatile f2 lds_cv_f2;
+__device__ __forceinline__ f2 lds_ld64(const float* p) { return *(lds_cv_f2*)(p); }     // (explicit LDS address space: a volatile access through a generic pointer is a flat load)
 // a value every lane holds identically, moved to a scalar register
 __device__ __forceinline__ float uniform(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
+// (alpha and beta are IEEE divisions: v_rcp_f32 + multiply is ~100 cycles shorter on the critical path of a half-iteration, but v_rcp_f32
+//  has no denormal support — an over-iterated, exactly converged system (p^T S p underflowing) then turns lambda into inf/NaN where the
+//  correctly rounded quotient stays finite: tests/test_gpu_lpk.py, N = 2, 30 fixed iterations.)
 // value of `v` in the partner lane (lane ^ 1): DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ float dpp_partner(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -97,45 +113,68 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
     const bool hasL = !isP || p3;                          // wave-uniform: block-Jacobi has no off-diagonal Pinv blocks
     const bool valid = k < N;
     // float indices inside a vector (add the vector's offset; K2 = floats between consecutive row pairs):
-    //   register slots 0..2 -> pairs (h ? 4 + s : s): bA + K2 s | slot 3 -> pair 3: b0 + 3 K2 | slots 4..6 -> pairs (h ? s - 4 : s): bB + K2 (s - 4)
-    //   own column c = 7h + j:  j = 2i -> bE + K2 i,  j = 2i + 1 -> bO + K2 i       (knot k - 1: subtract 2; knot k + 1: add 2)
+    //   register slots 0..2 -> pairs 4h + s: bA + K2 s | slot 3 -> pair 3: b0 + 3 K2 | slots 4..6 -> pairs 4 (1 - h) + s - 4: bB + K2 (s - 4)
+    //   knot k - 1: subtract 2; knot k + 1: add 2
     constexpr int KN = L::KN, K2 = 2 * KN;
     const int b0 = 2 * (k + 1);
     const int bA = b0 + (h ? 4 * K2 : 0), bB = b0 + (h ? 0 : 4 * K2);
-    const int bE = b0 + (h ? 3 * K2 + 1 : 0), bO = b0 + (h ? 4 * K2 : 1);
-    const float w3 = h ? 0.f : 1.f;                        // weight of register slot 3 in sums over a knot's entries (lane 1's is lane 0's duplicate)
 
-    // ---- matrix registers: column half c = 7h + j of D_k and L_k, row pairs in this lane's slot order ----
+    // ---- matrix registers: seven columns of D_k and L_k (lane 0: columns 0..6; lane 1: 8..13, 7), row pairs in this lane's slot order ----
     f2 Md[7][7], Ml[7][7];                                 // [slot][j]
     {
         const rsrc_t M = make_rsrc((isP ? static_cast<const float*>(a.Pinv) : static_cast<const float*>(a.S)) + (size_t)b * mstride,
                                    (uint32_t)(mstride * sizeof(float)));
         const uint32_t rowb = (uint32_t)k * (ROWF * 4u);
         const bool okD = valid, okL = valid && k > 0 && hasL;
+        // Column-major issue order: the seven row pairs of one column of a block are 56 contiguous bytes, so seven consecutive loads of a lane
+        // stay inside one or two 128-byte lines (slot-major order touched 64 lines per load and came back to each 13 loads later: the 16 KB
+        // L1 had long evicted it, every line crossed L2 -> L1 seven times).
+        // slot s holds row pair P_q: lane 0: q = s; lane 1: q = (4, 5, 6, 3, 0, 1, 2)[s].  Byte of (pair q, column c) inside a block = 56 c + 8 q:
+        // one lane-variable base per slot, the column as the instruction's immediate offset (columns 8h + j for j < 6, 6 + h for j = 6)
+        uint32_t bL[7], bD[7], bL6[7], bD6[7];
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
-            // slot s holds row pair P_q: lane 0: q = s; lane 1: q = (4, 5, 6, 3, 0, 1, 2)[s].  Byte of (pair q, column 7h + j) inside a
-            // block = 56 (7h + j) + 8 q: one lane-variable base per slot, the column as the instruction's immediate offset
             const int q1 = s < 3 ? s + 4 : (s == 3 ? 3 : s - 4);
-            const uint32_t bs = rowb + (uint32_t)(NS * 4 * 7) * (uint32_t)h + 8u * (uint32_t)(h ? q1 : s);
-            const uint32_t bL = okL ? bs : OOB_OFF, bD = okD ? bs + BLK4 * 16u : OOB_OFF;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                Ml[s][j] = buf_load2(M, bL + (uint32_t)(NS * 4 * j));
-                Md[s][j] = buf_load2(M, bD + (uint32_t)(NS * 4 * j));
-            }
+            const uint32_t bs = rowb + 8u * (uint32_t)(h ? q1 : s);
+            bL[s] = okL ? bs + (uint32_t)(NS * 4 * 8) * (uint32_t)h : OOB_OFF;
+            bD[s] = okD ? bs + (uint32_t)(NS * 4 * 8) * (uint32_t)h + BLK4 * 16u : OOB_OFF;
+            bL6[s] = okL ? bs + (uint32_t)(NS * 4) * (uint32_t)(6 + h) : OOB_OFF;
+            bD6[s] = okD ? bs + (uint32_t)(NS * 4) * (uint32_t)(6 + h) + BLK4 * 16u : OOB_OFF;
         }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+#pragma unroll
+            for (int s = 0; s < 7; ++s) Ml[s][j] = buf_load2(M, bL[s] + (uint32_t)(NS * 4 * j));
+            __builtin_amdgcn_sched_barrier(0);               // (the scheduler would regroup the loads by base register = slot-major)
+        }
+#pragma unroll
+        for (int s = 0; s < 7; ++s) Ml[s][6] = buf_load2(M, bL6[s]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+#pragma unroll
+            for (int s = 0; s < 7; ++s) Md[s][j] = buf_load2(M, bD[s] + (uint32_t)(NS * 4 * j));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < 7; ++s) Md[s][6] = buf_load2(M, bD6[s]);
     }
 
-    // ---- stage vectors: p <- lambda0 (operand of the setup product), lambda <- lambda0, r <- gamma, z and all pads <- 0 ----
-    for (int e = tid; e < 4 * L::VS; e += NTHR) lds[e] = 0.f;
+    // park the pairs the pass uses last (rows 4..6 of the diagonal block's seventh column) in LDS; they are fetched back inside the pass
+    f2* const park = reinterpret_cast<f2*>(lds + L::MX) + tid;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+#pragma unroll
+    for (int i = 0; i < L::NPARK; ++i) park[i * NTHR] = Md[4 + i][6];
+
+    // ---- stage vectors: P0 <- lambda0 (operand of the setup product), lambda <- lambda0, R0 <- gamma, everything else (pads included) <- 0 ----
+    for (int e = tid; e < L::RED; e += NTHR) lds[e] = 0.f;
     lds_barrier();
     for (int e = tid; e < N * NS; e += NTHR) {
         const int kk = e / NS, i = e - kk * NS;
         const float l0 = lam_g[e];
-        lds[L::XP + L::at(kk, i)] = l0;
+        lds[L::P0 + L::at(kk, i)] = l0;
         lds[L::LAM + L::at(kk, i)] = l0;
-        lds[L::XR + L::at(kk, i)] = gam[e];
+        lds[L::R0 + L::at(kk, i)] = gam[e];
     }
     lds_barrier();
 
@@ -160,103 +199,18 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
         const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 48));
         return ((part + r1) + r2) + r3;
     };
-
-    // One pass of this wave's matrix over the vector at float offset X.  Returns the lane's OWN four row pairs of
-    // D_k x_k + L_k x_{k-1} (complete over both column halves); z = L_k^T x_k goes to Z[k]; the wave's share of x^T M x to red[w].
-    struct Own { f2 v[4]; };
-    auto pass = [&](int X, float* red, int pb) -> Own {
-        MPCG_STAMP(pb + 0);
-        const float* x = lds + X;
-        // x_k, all rows, in this lane's slot order; x_{k-1}[own columns]
-        f2 xk[7];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            xk[s] = *reinterpret_cast<const f2*>(x + bA + K2 * s);
-            xk[4 + s] = *reinterpret_cast<const f2*>(x + bB + K2 * s);
-        }
-        xk[3] = *reinterpret_cast<const f2*>(x + b0 + 3 * K2);
-        float xmc[7];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) xmc[j] = x[((j & 1) ? bO : bE) + K2 * (j >> 1) - 2];
-        f2 acc[7];
-        float cterm = 0.f;
-        if (hasL) {
-            // transposed: z[c_j] = sum over row pairs of L[pair][c_j] (.) x_k[pair]; two groups of four / three independent chains
-            // (register budget: fourteen chain registers at once spill matrix rows)
-            float z[7];
-            {
-                f2 t[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[j] = Ml[0][j] * xk[0];
-#pragma unroll
-                for (int s = 1; s < 7; ++s)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) t[j] = __builtin_elementwise_fma(Ml[s][j], xk[s], t[j]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) z[j] = t[j].x + t[j].y;
-            }
-            {
-                f2 t[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) t[j] = Ml[0][4 + j] * xk[0];
-#pragma unroll
-                for (int s = 1; s < 7; ++s)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) t[j] = __builtin_elementwise_fma(Ml[s][4 + j], xk[s], t[j]);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) z[4 + j] = t[j].x + t[j].y;
-            }
-            if (valid) {
-#pragma unroll
-                for (int j = 0; j < 7; ++j) lds[L::Z + ((j & 1) ? bO : bE) + K2 * (j >> 1)] = z[j];
-            }
-            // second copy of the coupling term of the inner product: x_{k-1}^T (L_k^T x_k), own columns
-#pragma unroll
-            for (int j = 0; j < 7; ++j) cterm = fmaf(z[j], xmc[j], cterm);
-        }
-        __builtin_amdgcn_sched_barrier(0);             // (register budget: x_k[own columns] is not requested before the transposed chains retire)
-        MPCG_STAMP(pb + 1);
-        float xkc[7];                                            // x_k[own columns]
-#pragma unroll
-        for (int j = 0; j < 7; ++j) xkc[j] = x[((j & 1) ? bO : bE) + K2 * (j >> 1)];
-        if (hasL) {
-            // direct, off-diagonal half: acc = L[:, c_j] x_{k-1}[c_j]
-#pragma unroll
-            for (int s = 0; s < 7; ++s) acc[s] = Ml[s][0] * f2{xmc[0], xmc[0]};
-#pragma unroll
-            for (int j = 1; j < 7; ++j)
-#pragma unroll
-                for (int s = 0; s < 7; ++s) acc[s] = __builtin_elementwise_fma(Ml[s][j], f2{xmc[j], xmc[j]}, acc[s]);
-#pragma unroll
-            for (int s = 0; s < 7; ++s) acc[s] = __builtin_elementwise_fma(Md[s][0], f2{xkc[0], xkc[0]}, acc[s]);
+    // sum of the NW/2 wave partials of one inner product (the waves of one matrix), same order in every thread: deterministic
+    auto sum_red = [&](const float* red) -> float {
+        if constexpr (NW == 8) {
+            const f4 v = *reinterpret_cast<const f4*>(red);
+            return ((v.x + v.y) + v.z) + v.w;
         } else {
-#pragma unroll
-            for (int s = 0; s < 7; ++s) acc[s] = Md[s][0] * f2{xkc[0], xkc[0]};
+            const f2 v = *reinterpret_cast<const f2*>(red);
+            return v.x + v.y;
         }
-        // direct, diagonal half
-#pragma unroll
-        for (int j = 1; j < 7; ++j)
-#pragma unroll
-            for (int s = 0; s < 7; ++s) acc[s] = __builtin_elementwise_fma(Md[s][j], f2{xkc[j], xkc[j]}, acc[s]);
-        MPCG_STAMP(pb + 2);
-        // merge the two column halves: own slot s + the partner's slot (4, 5, 6, 3)[s]
-        Own o;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const f2 oth = acc[s < 3 ? s + 4 : 3];
-            o.v[s] = f2{acc[s].x + dpp_partner(oth.x), acc[s].y + dpp_partner(oth.y)};
-        }
-        // inner product share: x_k . (D x_k + L x_{k-1}) over this lane's OWN rows (lane 1's slot 3 duplicates lane 0's: weight 0) + the coupling copy
-        f2 d0 = o.v[0] * xk[0], d1 = o.v[1] * xk[1];
-        d0 = __builtin_elementwise_fma(o.v[2], xk[2], d0);
-        d1 = __builtin_elementwise_fma(o.v[3], xk[3] * f2{w3, w3}, d1);
-        const f2 dd = d0 + d1;
-        const float part = wave_fold((dd.x + dd.y) + cterm);
-        if (lane == 0) red[wl] = part;
-        MPCG_STAMP(pb + 3);
-        return o;
     };
-    // own entries (slots 0..3) of knot k (+ dk) of the vector at float offset X
+    struct Own { f2 v[4]; };
+    // own entries (register slots 0..3) of knot k + dk of the vector at float offset X
     auto load_own = [&](int X, int dk) -> Own {
         const float* x = lds + X + 2 * dk;
         Own o;
@@ -273,50 +227,162 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
             *reinterpret_cast<f2*>(x + b0 + 3 * K2) = o.v[3];
         }
     };
-    // sum of the NW/2 wave partials of one inner product (the waves of one matrix), same order in every thread: deterministic
-    auto sum_red = [&](const float* red) -> float {
-        if constexpr (NW == 8) {
-            const f4 v = *reinterpret_cast<const f4*>(red);
-            return ((v.x + v.y) + v.z) + v.w;
-        } else {
-            const f2 v = *reinterpret_cast<const f2*>(red);
-            return v.x + v.y;
+
+    // One half-iteration of this wave's matrix.
+    //   MODE 0: the operand is the vector at XOLD as it stands (setup product S lambda0);
+    //   MODE 1: operand = XOLD - c (T + Z<<1)          (Pinv half: r_new, c = alpha; setup: c = 1)
+    //   MODE 2: operand = (T + Z<<1) + c XOLD          (S half: p_new, c = beta; first iteration: c = 0);  useZ = false: T alone (block-Jacobi r~)
+    // The lane forms the operand for knot k (all 14 entries, its slot order) and knot k-1 (its own 8 entries), publishes its own
+    // entries of knot k to XNEW (MODE != 0), runs the pass, publishes the merged own row pairs to TOUT and z to ZOUT, the wave's
+    // share of x^T M x to red[wl].  Returns the own entries of the operand (the S lanes' lambda update needs p).
+    auto half = [&](auto mode_tag, int XOLD, int XNEW, int T, int Z, bool useZ, float c, int TOUT, int ZOUT, float* red, int pb) -> Own {
+        constexpr int MODE = decltype(mode_tag)::value;
+        MPCG_STAMP(pb + 0);
+        // Operand: every lane forms its OWN row pairs (register slots 0..3) of knot k and of knot k-1 — 24 loads, all requested up front —
+        // and takes slots 4..6 of knot k (the partner lane's own pairs 0..2) from the partner's registers by DPP.
+        f2 xk[7];
+        Own om;                                                  // knot k-1, own entries
+        {
+            const float* xo = lds + XOLD;
+            if constexpr (MODE == 0) {
+                const Own a_ = load_own(XOLD, 0);
+                om = load_own(XOLD, -1);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) xk[s] = a_.v[s];
+            } else {
+                const float* xt = lds + T;
+                const float* xz = lds + Z + 2;
+                f2 t[4], z[4], o[4], gt[4], gz[4], go[4];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) { t[s] = lds_ld64(xt + bA + K2 * s); z[s] = lds_ld64(xz + bA + K2 * s); o[s] = lds_ld64(xo + bA + K2 * s); }
+                t[3] = lds_ld64(xt + b0 + 3 * K2); z[3] = lds_ld64(xz + b0 + 3 * K2); o[3] = lds_ld64(xo + b0 + 3 * K2);
+#pragma unroll
+                for (int s = 0; s < 3; ++s) { gt[s] = lds_ld64(xt - 2 + bA + K2 * s); gz[s] = lds_ld64(xz - 2 + bA + K2 * s); go[s] = lds_ld64(xo - 2 + bA + K2 * s); }
+                gt[3] = lds_ld64(xt - 2 + b0 + 3 * K2); gz[3] = lds_ld64(xz - 2 + b0 + 3 * K2); go[3] = lds_ld64(xo - 2 + b0 + 3 * K2);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { const f2 u = t[s] + z[s]; xk[s] = MODE == 1 ? o[s] - c * u : u + c * o[s]; }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { const f2 u = gt[s] + gz[s]; om.v[s] = MODE == 1 ? go[s] - c * u : u + c * go[s]; }
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) xk[4 + s] = f2{dpp_partner(xk[s].x), dpp_partner(xk[s].y)};
         }
+        Own me;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) me.v[s] = xk[s];
+        if constexpr (MODE != 0) store_own(XNEW, me);
+        MPCG_STAMP(pb + 1);
+        f2 acc[7];
+        float cterm = 0.f;
+        const float xk6 = h ? xk[3].y : xk[3].x;
+        if (hasL) {
+            // transposed: z[j] = sum over row pairs of L[pair][column j] (.) x_k[pair]; four + three independent chains (register budget)
+            f2 z2[3];
+            float z6;
+            {
+                f2 t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = Ml[0][j] * xk[0];
+#pragma unroll
+                for (int s = 1; s < 7; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] = __builtin_elementwise_fma(Ml[s][j], xk[s], t[j]);
+                z2[0] = f2{t[0].x + t[0].y, t[1].x + t[1].y};
+                z2[1] = f2{t[2].x + t[2].y, t[3].x + t[3].y};
+            }
+            {
+                f2 t[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) t[j] = Ml[0][4 + j] * xk[0];
+#pragma unroll
+                for (int s = 1; s < 7; ++s)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) t[j] = __builtin_elementwise_fma(Ml[s][4 + j], xk[s], t[j]);
+                z2[2] = f2{t[0].x + t[0].y, t[1].x + t[1].y};
+                z6 = t[2].x + t[2].y;
+            }
+            const float xm6 = h ? om.v[3].y : om.v[3].x;        // x_{k-1} at this lane's seventh column (entry 6 + h)
+            if (valid) {                                         // z belongs to knot k-1's vector: entries of this lane's columns
+                float* zo = lds + ZOUT;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) *reinterpret_cast<f2*>(zo + bA + K2 * s) = z2[s];
+                zo[b0 + 3 * K2 + h] = z6;
+            }
+            // second copy of the coupling term of the inner product: x_{k-1}^T (L_k^T x_k), own columns
+            f2 ct = z2[0] * om.v[0];
+            ct = __builtin_elementwise_fma(z2[1], om.v[1], ct);
+            ct = __builtin_elementwise_fma(z2[2], om.v[2], ct);
+            cterm = fmaf(z6, xm6, ct.x + ct.y);
+            MPCG_STAMP(pb + 2);
+            // direct, off-diagonal columns: acc = L[:, c_j] x_{k-1}[c_j]
+#pragma unroll
+            for (int s = 0; s < 7; ++s) acc[s] = Ml[s][0] * f2{om.v[0].x, om.v[0].x};
+#pragma unroll
+            for (int j = 1; j < 6; ++j) {
+                const float xs = (j & 1) ? om.v[j >> 1].y : om.v[j >> 1].x;
+#pragma unroll
+                for (int s = 0; s < 7; ++s) acc[s] = __builtin_elementwise_fma(Ml[s][j], f2{xs, xs}, acc[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 7; ++s) acc[s] = __builtin_elementwise_fma(Ml[s][6], f2{xm6, xm6}, acc[s]);
+#pragma unroll
+            for (int s = 0; s < 7; ++s) acc[s] = __builtin_elementwise_fma(Md[s][0], f2{xk[0].x, xk[0].x}, acc[s]);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 7; ++s) acc[s] = Md[s][0] * f2{xk[0].x, xk[0].x};
+        }
+        // (the parked pairs are requested here, volatile = in program order, and consumed by the last FMAs of the pass)
+        f2 pk_[L::NPARK];
+#pragma unroll
+        for (int i = 0; i < L::NPARK; ++i) pk_[i] = lds_ld64(reinterpret_cast<const float*>(park + i * NTHR));
+        // direct, diagonal columns
+#pragma unroll
+        for (int j = 1; j < 6; ++j) {
+            const float xs = (j & 1) ? xk[j >> 1].y : xk[j >> 1].x;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) acc[s] = __builtin_elementwise_fma(Md[s][j], f2{xs, xs}, acc[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] = __builtin_elementwise_fma(Md[s][6], f2{xk6, xk6}, acc[s]);
+#pragma unroll
+        for (int i = 0; i < L::NPARK; ++i) acc[4 + i] = __builtin_elementwise_fma(pk_[i], f2{xk6, xk6}, acc[4 + i]);
+        MPCG_STAMP(pb + 3);
+        // merge the two column halves: own slot s + the partner's slot (4, 5, 6, 3)[s]
+        Own o;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f2 oth = acc[s < 3 ? s + 4 : 3];
+            o.v[s] = f2{acc[s].x + dpp_partner(oth.x), acc[s].y + dpp_partner(oth.y)};
+        }
+        store_own(TOUT, o);
+        // inner product share: x_k . (D x_k + L x_{k-1}) over this lane's OWN rows (lane 1's slot 3 duplicates lane 0's: weight 0) + the coupling copy
+        f2 d0 = o.v[0] * me.v[0], d1 = o.v[1] * me.v[1];
+        d0 = __builtin_elementwise_fma(o.v[2], me.v[2], d0);
+        const f2 d3 = o.v[3] * me.v[3];
+        const f2 dd = d0 + d1;
+        const float part = wave_fold(((dd.x + dd.y) + (h ? 0.f : d3.x + d3.y)) + cterm);
+        if (lane == 0) red[wl] = part;
+        MPCG_STAMP(pb + 4);
+        return me;
     };
 
-    // The S waves and the Pinv waves run the same barrier sequence through two SEPARATE code paths (the role is wave-uniform): written as
-    // one path with `if (isP)` around each piece, the pass result `own` is a loop-carried value of the "other" role in the compiler's
-    // eyes — eight registers live through both passes, which spill matrix rows.
+    // The S waves and the Pinv waves run the same barrier sequence through two SEPARATE code paths (the role is wave-uniform).
     uint32_t iters = 0;
     uint32_t max_iter_exit = 1;
+    int cp = 0, cr = 0;                                        // halves of the double buffers that hold the current p / r
+    float beta = 0.f;                                          // scalar of the NEXT p update (the S half applies it)
+    bool p_pending = true;                                     // that update has not been applied to the buffer (write-back of d_p does it)
+    auto PB = [&](int c_) { return L::P0 + c_ * L::VS; };
+    auto RB = [&](int c_) { return L::R0 + c_ * L::VS; };
     auto run_role = [&](auto role_tag) {
         constexpr bool P = decltype(role_tag)::value;
-        // ---- setup: r = gamma - S lambda0 ; r~ = Pinv r ; p = r~ ; eta = r . r~ ----
-        if constexpr (!P) {
-            const Own own = pass(L::XP, red_v, 0);
-            lds_barrier();
-            const Own zin = load_own(L::Z, 1), r0 = load_own(L::XR, 0);
-            Own r1;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) r1.v[s] = r0.v[s] - (own.v[s] + zin.v[s]);
-            store_own(L::XR, r1);
-            lds_barrier();
-            lds_barrier();
-        } else {
-            lds_barrier();
-            lds_barrier();
-            const Own own = pass(L::XR, red_e, 8);
-            lds_barrier();
-            Own p1 = own;
-            if (p3) {
-                const Own zin = load_own(L::Z, 1);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) p1.v[s] = own.v[s] + zin.v[s];
-            }
-            store_own(L::XP, p1);
-        }
-        float eta = uniform(sum_red(red_e));                  // (read before the barrier below: the next write of red_e is two barriers away)
+        // ---- setup: r = gamma - S lambda0 ; r~ = Pinv r ; eta = r . r~   (p = r~ is formed by the first S half: beta = 0) ----
+        if constexpr (!P) (void)half(std::integral_constant<int, 0>{}, PB(0), 0, 0, 0, false, 0.f, L::US, L::ZS, red_v, 0);
         lds_barrier();
+        if constexpr (P) (void)half(std::integral_constant<int, 1>{}, RB(0), RB(1), L::US, L::ZS, true, 1.f, L::RT, L::ZP, red_e, 8);
+        cr = 1;
+        lds_barrier();
+        float eta = uniform(sum_red(red_e));
         // every matrix load has been consumed on the waves that ran a setup pass; say so, or the compiler keeps vmcnt waits inside the loop
         __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
         if (fabsf(eta) < a.exit_tol) { max_iter_exit = 0; return; }
@@ -325,85 +391,56 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
             prof_on = b == 0 && it == 20;
 #endif
             if constexpr (!P) {
-                // upsilon = S p ; v = p . upsilon
-                const Own own = pass(L::XP, red_v, 0);
-                MPCG_STAMP(4);
-                lds_barrier();
+                // p = r~ + beta p ; upsilon = S p ; v = p . upsilon
+                const Own pk = half(std::integral_constant<int, 2>{}, PB(cp), PB(cp ^ 1), L::RT, L::ZP, p3, beta, L::US, L::ZS, red_v, 0);
                 MPCG_STAMP(5);
-                // alpha = eta / v ; r -= alpha upsilon (own entries)
-                const Own zin = load_own(L::Z, 1), cur = load_own(L::XR, 0);
+                lds_barrier();
+                MPCG_STAMP(6);
+                // alpha = eta / v ; lambda += alpha p (own entries) — while the Pinv half runs
+                const Own cur = load_own(L::LAM, 0);
                 const float alpha = uniform(eta / sum_red(red_v));
                 Own nw;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) nw.v[s] = cur.v[s] - alpha * (own.v[s] + zin.v[s]);
-                store_own(L::XR, nw);
-                MPCG_STAMP(6);
-                lds_barrier();
+                for (int s = 0; s < 4; ++s) nw.v[s] = cur.v[s] + alpha * pk.v[s];
+                store_own(L::LAM, nw);
                 MPCG_STAMP(7);
-                lds_barrier();                              // (the Pinv pass)
-                MPCG_STAMP(13);
-                // eta' ; exit test
-                const float eta_new = uniform(sum_red(red_e));
-                iters = (uint32_t)(it + 1);
-                if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
-                eta = eta_new;
-                MPCG_STAMP(14);
                 lds_barrier();
                 MPCG_STAMP(15);
             } else {
-                MPCG_STAMP(4);
-                lds_barrier();                              // (the S pass)
                 MPCG_STAMP(5);
-                // alpha ; lambda += alpha p (own entries)
-                {
-                    const Own pk = load_own(L::XP, 0), cur = load_own(L::LAM, 0);
-                    const float alpha = uniform(eta / sum_red(red_v));
-                    Own nw;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) nw.v[s] = cur.v[s] + alpha * pk.v[s];
-                    store_own(L::LAM, nw);
-                }
+                lds_barrier();
                 MPCG_STAMP(6);
-                lds_barrier();
-                MPCG_STAMP(7);
-                // r~ = Pinv r ; eta' = r . r~
-                const Own own = pass(L::XR, red_e, 8);
-                MPCG_STAMP(12);
-                lds_barrier();
-                MPCG_STAMP(13);
-                // eta' ; exit test ; p = r~ + (eta'/eta) p (own entries)
-                Own zin;
-                if (p3) zin = load_own(L::Z, 1);
-                const Own pold = load_own(L::XP, 0);
-                const float eta_new = uniform(sum_red(red_e));
-                iters = (uint32_t)(it + 1);
-                if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
-                const float beta = uniform(eta_new / eta);
-                Own pn;
-                if (p3) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) pn.v[s] = (own.v[s] + zin.v[s]) + beta * pold.v[s];
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) pn.v[s] = own.v[s] + beta * pold.v[s];
-                }
-                store_own(L::XP, pn);
-                eta = eta_new;
+                // alpha = eta / v ; r -= alpha upsilon ; r~ = Pinv r ; eta' = r . r~
+                const float alpha = uniform(eta / sum_red(red_v));
+                (void)half(std::integral_constant<int, 1>{}, RB(cr), RB(cr ^ 1), L::US, L::ZS, true, alpha, L::RT, L::ZP, red_e, 8);
                 MPCG_STAMP(14);
                 lds_barrier();
                 MPCG_STAMP(15);
             }
+            cp ^= 1; cr ^= 1;
+            // eta' ; exit test ; beta
+            const float eta_new = uniform(sum_red(red_e));
+            iters = (uint32_t)(it + 1);
+            if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; p_pending = false; break; }     // (the reference leaves p as it is on this exit)
+            beta = uniform(eta_new / eta);
+            eta = eta_new;
         }
     };
     if (isP) run_role(std::true_type{}); else run_role(std::false_type{});
 
     // ---- write back ----
     lds_barrier();
+    const int XPf = PB(cp), XRf = RB(cr);                      // (the reference leaves p and r of the last completed update in d_p / d_r)
     for (int e = tid; e < N * NS; e += NTHR) {
         const int kk = e / NS, i = e - kk * NS;
         lam_g[e] = lds[L::LAM + L::at(kk, i)];
-        if (a.r_out) a.r_out[(size_t)b * vstride + e] = lds[L::XR + L::at(kk, i)];
-        if (a.p_out) a.p_out[(size_t)b * vstride + e] = lds[L::XP + L::at(kk, i)];
+        if (a.r_out) a.r_out[(size_t)b * vstride + e] = lds[XRf + L::at(kk, i)];
+        if (a.p_out) {
+            // p of the last completed update; when the loop ended without a tolerance exit that update is still pending: p = r~ + beta p
+            float pv = lds[XPf + L::at(kk, i)];
+            if (p_pending) pv = (lds[L::RT + L::at(kk, i)] + (p3 ? lds[L::ZP + L::at(kk + 1, i)] : 0.f)) + beta * pv;
+            a.p_out[(size_t)b * vstride + e] = pv;
+        }
     }
     if (tid == 0) {
         a.iters[b] = iters;
