@@ -26,8 +26,9 @@
 // NEXT pass form their operand themselves, from what the previous pass published and the scalar that pass's inner product gives,
 //     Pinv pass:  r_new = r_old - alpha (US + ZS<<1)         S pass:  p_new = (RT + ZP<<1) + beta p_old
 // (US / RT = the merged row halves, ZS / ZP = the z vectors, <<1 = knot k+1's) — for the 14 entries of knot k and the own 8 of knot
-// k-1, 33 ds_read_b64 instead of 11 — with the very operations, hence the very bits, every other reader of that entry uses; each
-// lane publishes its own 8 entries of the new vector into the other half of a double buffer (the old one is still being read).
+// k-1 — with the very operations, hence the very bits, every other holder of that entry uses.  The iterate vectors p and r therefore
+// never exist in LDS inside the loop: every lane carries its 8 + 8 entries (knot k, knot k-1) in registers from one half to the next,
+// fetches only US / ZS (RT / ZP) — 16 ds_read_b64 — and gets the remaining 6 entries of knot k from the partner lane by DPP.
 // lambda += alpha p is done by the S lanes while the Pinv pass runs.  Per iteration: S half | barrier | Pinv half | barrier.
 // Inner product without the assembled vector: x^T M x = sum_k x_k^T (D_k x_k + L_k x_{k-1}) + x_{k-1}^T (L_k^T x_k); the lane has
 // both factors of both terms in registers.
@@ -50,8 +51,9 @@ template <int NWR> struct LpkLds {
     static constexpr int KN = NMAX + 4;                        // knot slots per row pair: NMAX + 2 rounded up to 4 (mod 8)
     static_assert(KN % 8 == 4, "row pairs q and q + 4 must sit 32 banks apart");
     static constexpr int VS = 7 * KN * 2;                      // floats per vector
-    // p and r double-buffered (P0 P1, R0 R1) | US, ZS: what the S pass publishes | RT, ZP: the Pinv pass | lambda | wave partials
-    static constexpr int P0 = 0, R0 = 2 * VS, US = 4 * VS, ZS = 5 * VS, RT = 6 * VS, ZP = 7 * VS, LAM = 8 * VS, RED = 9 * VS, MX = RED + NW, NPARK = 3, TOTAL = MX + NPARK * 2 * NW * 64;
+    // P0, R0: staging of lambda0 / gamma, at the end p and r for d_p / d_r (inside the loop p and r live in registers only) |
+    // US, ZS: what the S pass publishes | RT, ZP: the Pinv pass | lambda | wave partials
+    static constexpr int P0 = 0, R0 = VS, US = 2 * VS, ZS = 3 * VS, RT = 4 * VS, ZP = 5 * VS, LAM = 6 * VS, RED = 7 * VS, MX = RED + NW, NPARK = 3, TOTAL = MX + NPARK * 2 * NW * 64;
     // MX: NPARK matrix register pairs per lane parked in LDS (lane-private float2 slots, [pair][thread]: conflict-free): the register file
     // holds 196 matrix registers + the working set of a half-iteration only just; left to the compiler the overflow goes to SCRATCH, whose
     // reloads (global-memory latency, three per pass) cost more than the whole FMA stream
@@ -228,54 +230,60 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
         }
     };
 
-    // One half-iteration of this wave's matrix.
-    //   MODE 0: the operand is the vector at XOLD as it stands (setup product S lambda0);
-    //   MODE 1: operand = XOLD - c (T + Z<<1)          (Pinv half: r_new, c = alpha; setup: c = 1)
-    //   MODE 2: operand = (T + Z<<1) + c XOLD          (S half: p_new, c = beta; first iteration: c = 0);  useZ = false: T alone (block-Jacobi r~)
-    // The lane forms the operand for knot k (all 14 entries, its slot order) and knot k-1 (its own 8 entries), publishes its own
-    // entries of knot k to XNEW (MODE != 0), runs the pass, publishes the merged own row pairs to TOUT and z to ZOUT, the wave's
-    // share of x^T M x to red[wl].  Returns the own entries of the operand (the S lanes' lambda update needs p).
-    auto half = [&](auto mode_tag, int XOLD, int XNEW, int T, int Z, bool useZ, float c, int TOUT, int ZOUT, float* red, int pb) -> Own {
+    // The operand loads of a half-iteration, requested as soon as the barrier in front of it is passed — BEFORE the scalar of the update
+    // (alpha / beta: LDS read of the partials, three adds, a 13-instruction IEEE division, the exit test) is worked out: that chain is
+    // ~300 cycles of dependent latency and the loads do not depend on it.  Own row pairs (register slots 0..3) of knot k and of knot k-1
+    // of the two published vectors the operand is formed from: 16 volatile ds_read_b64.
+    struct Fetch { f2 t[4], z[4], gt[4], gz[4]; };
+    auto fetch = [&](int T, int Z) -> Fetch {
+        const float* xt = lds + T;
+        const float* xz = lds + Z + 2;
+        Fetch f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { f.t[s] = lds_ld64(xt + bA + K2 * s); f.z[s] = lds_ld64(xz + bA + K2 * s); }
+        f.t[3] = lds_ld64(xt + b0 + 3 * K2); f.z[3] = lds_ld64(xz + b0 + 3 * K2);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { f.gt[s] = lds_ld64(xt - 2 + bA + K2 * s); f.gz[s] = lds_ld64(xz - 2 + bA + K2 * s); }
+        f.gt[3] = lds_ld64(xt - 2 + b0 + 3 * K2); f.gz[3] = lds_ld64(xz - 2 + b0 + 3 * K2);
+        return f;
+    };
+    struct Vec { Own k, m; };                                  // a lane's copy of a vector: its own row pairs of knot k and of knot k-1
+
+    // One half-iteration of this wave's matrix.  `old` = the lane's register copy of the vector being updated (r or p).
+    //   MODE 0: the operand is `old` as it stands (setup product S lambda0);
+    //   MODE 1: operand = old - c (T + Z<<1)          (Pinv half: r_new, c = alpha; setup: c = 1)
+    //   MODE 2: operand = (T + Z<<1) + c old          (S half: p_new, c = beta; first iteration: c = 0)
+    // (block-Jacobi: the Pinv waves never write ZP, it stays zero.)  The lane forms its OWN row pairs of the operand for knot k and for
+    // knot k-1, takes the other three pairs of knot k from the partner lane's registers (DPP), runs the pass, publishes the merged own
+    // row pairs to TOUT and z to ZOUT, the wave's share of x^T M x to red[wl].  Returns the operand (= the updated vector) for the next half.
+    auto half = [&](auto mode_tag, const Fetch& f, const Vec& old, float c, int TOUT, int ZOUT, float* red, int pb) -> Vec {
         constexpr int MODE = decltype(mode_tag)::value;
         MPCG_STAMP(pb + 0);
-        // Operand: every lane forms its OWN row pairs (register slots 0..3) of knot k and of knot k-1 — 24 loads, all requested up front —
-        // and takes slots 4..6 of knot k (the partner lane's own pairs 0..2) from the partner's registers by DPP.
         f2 xk[7];
         Own om;                                                  // knot k-1, own entries
-        {
-            const float* xo = lds + XOLD;
-            if constexpr (MODE == 0) {
-                const Own a_ = load_own(XOLD, 0);
-                om = load_own(XOLD, -1);
+        if constexpr (MODE == 0) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) xk[s] = a_.v[s];
-            } else {
-                const float* xt = lds + T;
-                const float* xz = lds + Z + 2;
-                f2 t[4], z[4], o[4], gt[4], gz[4], go[4];
+            for (int s = 0; s < 4; ++s) { xk[s] = old.k.v[s]; om.v[s] = old.m.v[s]; }
+        } else {
 #pragma unroll
-                for (int s = 0; s < 3; ++s) { t[s] = lds_ld64(xt + bA + K2 * s); z[s] = lds_ld64(xz + bA + K2 * s); o[s] = lds_ld64(xo + bA + K2 * s); }
-                t[3] = lds_ld64(xt + b0 + 3 * K2); z[3] = lds_ld64(xz + b0 + 3 * K2); o[3] = lds_ld64(xo + b0 + 3 * K2);
+            for (int s = 0; s < 4; ++s) { const f2 u = f.t[s] + f.z[s]; xk[s] = MODE == 1 ? old.k.v[s] - c * u : u + c * old.k.v[s]; }
 #pragma unroll
-                for (int s = 0; s < 3; ++s) { gt[s] = lds_ld64(xt - 2 + bA + K2 * s); gz[s] = lds_ld64(xz - 2 + bA + K2 * s); go[s] = lds_ld64(xo - 2 + bA + K2 * s); }
-                gt[3] = lds_ld64(xt - 2 + b0 + 3 * K2); gz[3] = lds_ld64(xz - 2 + b0 + 3 * K2); go[3] = lds_ld64(xo - 2 + b0 + 3 * K2);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { const f2 u = t[s] + z[s]; xk[s] = MODE == 1 ? o[s] - c * u : u + c * o[s]; }
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { const f2 u = gt[s] + gz[s]; om.v[s] = MODE == 1 ? go[s] - c * u : u + c * go[s]; }
-            }
-#pragma unroll
-            for (int s = 0; s < 3; ++s) xk[4 + s] = f2{dpp_partner(xk[s].x), dpp_partner(xk[s].y)};
+            for (int s = 0; s < 4; ++s) { const f2 u = f.gt[s] + f.gz[s]; om.v[s] = MODE == 1 ? old.m.v[s] - c * u : u + c * old.m.v[s]; }
         }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) xk[4 + s] = f2{dpp_partner(xk[s].x), dpp_partner(xk[s].y)};
         Own me;
 #pragma unroll
         for (int s = 0; s < 4; ++s) me.v[s] = xk[s];
-        if constexpr (MODE != 0) store_own(XNEW, me);
         MPCG_STAMP(pb + 1);
         f2 acc[7];
         float cterm = 0.f;
         const float xk6 = h ? xk[3].y : xk[3].x;
+#if defined(MPCG_ABLATE_LPK) && (MPCG_ABLATE_LPK & 1)     // (timing experiments only, tools/lpk_ablate.sh: results are wrong with any bit set)
+        if (false) {
+#else
         if (hasL) {
+#endif
             // transposed: z[j] = sum over row pairs of L[pair][column j] (.) x_k[pair]; four + three independent chains (register budget)
             f2 z2[3];
             float z6;
@@ -336,6 +344,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
 #pragma unroll
         for (int i = 0; i < L::NPARK; ++i) pk_[i] = lds_ld64(reinterpret_cast<const float*>(park + i * NTHR));
         // direct, diagonal columns
+#if !(defined(MPCG_ABLATE_LPK) && (MPCG_ABLATE_LPK & 2))
 #pragma unroll
         for (int j = 1; j < 6; ++j) {
             const float xs = (j & 1) ? xk[j >> 1].y : xk[j >> 1].x;
@@ -346,6 +355,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
         for (int s = 0; s < 4; ++s) acc[s] = __builtin_elementwise_fma(Md[s][6], f2{xk6, xk6}, acc[s]);
 #pragma unroll
         for (int i = 0; i < L::NPARK; ++i) acc[4 + i] = __builtin_elementwise_fma(pk_[i], f2{xk6, xk6}, acc[4 + i]);
+#endif
         MPCG_STAMP(pb + 3);
         // merge the two column halves: own slot s + the partner's slot (4, 5, 6, 3)[s]
         Own o;
@@ -360,77 +370,91 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
         d0 = __builtin_elementwise_fma(o.v[2], me.v[2], d0);
         const f2 d3 = o.v[3] * me.v[3];
         const f2 dd = d0 + d1;
+#if defined(MPCG_ABLATE_LPK) && (MPCG_ABLATE_LPK & 4)
+        const float part = ((dd.x + dd.y) + (h ? 0.f : d3.x + d3.y)) + cterm;
+#else
         const float part = wave_fold(((dd.x + dd.y) + (h ? 0.f : d3.x + d3.y)) + cterm);
+#endif
         if (lane == 0) red[wl] = part;
         MPCG_STAMP(pb + 4);
-        return me;
+        return Vec{me, om};
     };
 
     // The S waves and the Pinv waves run the same barrier sequence through two SEPARATE code paths (the role is wave-uniform).
     uint32_t iters = 0;
     uint32_t max_iter_exit = 1;
-    int cp = 0, cr = 0;                                        // halves of the double buffers that hold the current p / r
     float beta = 0.f;                                          // scalar of the NEXT p update (the S half applies it)
-    bool p_pending = true;                                     // that update has not been applied to the buffer (write-back of d_p does it)
-    auto PB = [&](int c_) { return L::P0 + c_ * L::VS; };
-    auto RB = [&](int c_) { return L::R0 + c_ * L::VS; };
+    bool p_pending = true;                                     // that update has not been applied to p (write-back of d_p does it)
     auto run_role = [&](auto role_tag) {
         constexpr bool P = decltype(role_tag)::value;
         // ---- setup: r = gamma - S lambda0 ; r~ = Pinv r ; eta = r . r~   (p = r~ is formed by the first S half: beta = 0) ----
-        if constexpr (!P) (void)half(std::integral_constant<int, 0>{}, PB(0), 0, 0, 0, false, 0.f, L::US, L::ZS, red_v, 0);
+        Fetch f;
+        Vec x;                                                   // S waves: p;  Pinv waves: r
+        x.k = load_own(P ? L::R0 : L::P0, 0);
+        x.m = load_own(P ? L::R0 : L::P0, -1);
+        if constexpr (!P) (void)half(std::integral_constant<int, 0>{}, f, x, 0.f, L::US, L::ZS, red_v, 0);
         lds_barrier();
-        if constexpr (P) (void)half(std::integral_constant<int, 1>{}, RB(0), RB(1), L::US, L::ZS, true, 1.f, L::RT, L::ZP, red_e, 8);
-        cr = 1;
+        if constexpr (P) {
+            f = fetch(L::US, L::ZS);
+            x = half(std::integral_constant<int, 1>{}, f, x, 1.f, L::RT, L::ZP, red_e, 8);
+        }
         lds_barrier();
+        if constexpr (!P) f = fetch(L::RT, L::ZP);
         float eta = uniform(sum_red(red_e));
         // every matrix load has been consumed on the waves that ran a setup pass; say so, or the compiler keeps vmcnt waits inside the loop
         __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
-        if (fabsf(eta) < a.exit_tol) { max_iter_exit = 0; return; }
-        for (int it = 0; it < a.max_iter; ++it) {
+        if (fabsf(eta) < a.exit_tol) {
+            max_iter_exit = 0;
+        } else {
+            for (int it = 0; it < a.max_iter; ++it) {
 #ifdef MPCG_PROF
-            prof_on = b == 0 && it == 20;
+                prof_on = b == 0 && it == 20;
 #endif
-            if constexpr (!P) {
-                // p = r~ + beta p ; upsilon = S p ; v = p . upsilon
-                const Own pk = half(std::integral_constant<int, 2>{}, PB(cp), PB(cp ^ 1), L::RT, L::ZP, p3, beta, L::US, L::ZS, red_v, 0);
-                MPCG_STAMP(5);
-                lds_barrier();
-                MPCG_STAMP(6);
-                // alpha = eta / v ; lambda += alpha p (own entries) — while the Pinv half runs
-                const Own cur = load_own(L::LAM, 0);
-                const float alpha = uniform(eta / sum_red(red_v));
-                Own nw;
+                if constexpr (!P) {
+                    // p = r~ + beta p ; upsilon = S p ; v = p . upsilon
+                    x = half(std::integral_constant<int, 2>{}, f, x, beta, L::US, L::ZS, red_v, 0);
+                    MPCG_STAMP(5);
+                    lds_barrier();
+                    MPCG_STAMP(6);
+                    // alpha = eta / v ; lambda += alpha p (own entries) — while the Pinv half runs
+                    const Own cur = load_own(L::LAM, 0);
+                    const float alpha = uniform(eta / sum_red(red_v));
+                    Own nw;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) nw.v[s] = cur.v[s] + alpha * pk.v[s];
-                store_own(L::LAM, nw);
-                MPCG_STAMP(7);
-                lds_barrier();
-                MPCG_STAMP(15);
-            } else {
-                MPCG_STAMP(5);
-                lds_barrier();
-                MPCG_STAMP(6);
-                // alpha = eta / v ; r -= alpha upsilon ; r~ = Pinv r ; eta' = r . r~
-                const float alpha = uniform(eta / sum_red(red_v));
-                (void)half(std::integral_constant<int, 1>{}, RB(cr), RB(cr ^ 1), L::US, L::ZS, true, alpha, L::RT, L::ZP, red_e, 8);
-                MPCG_STAMP(14);
-                lds_barrier();
-                MPCG_STAMP(15);
+                    for (int s = 0; s < 4; ++s) nw.v[s] = cur.v[s] + alpha * x.k.v[s];
+                    store_own(L::LAM, nw);
+                    MPCG_STAMP(7);
+                    lds_barrier();
+                    MPCG_STAMP(15);
+                    f = fetch(L::RT, L::ZP);                    // the next S half's operand loads fly during the scalar chain below
+                } else {
+                    MPCG_STAMP(5);
+                    lds_barrier();
+                    MPCG_STAMP(6);
+                    // alpha = eta / v ; r -= alpha upsilon ; r~ = Pinv r ; eta' = r . r~
+                    f = fetch(L::US, L::ZS);
+                    const float alpha = uniform(eta / sum_red(red_v));
+                    x = half(std::integral_constant<int, 1>{}, f, x, alpha, L::RT, L::ZP, red_e, 8);
+                    MPCG_STAMP(14);
+                    lds_barrier();
+                    MPCG_STAMP(15);
+                }
+                // eta' ; exit test ; beta
+                const float eta_new = uniform(sum_red(red_e));
+                iters = (uint32_t)(it + 1);
+                if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; p_pending = false; break; }     // (the reference leaves p as it is on this exit)
+                beta = uniform(eta_new / eta);
+                eta = eta_new;
             }
-            cp ^= 1; cr ^= 1;
-            // eta' ; exit test ; beta
-            const float eta_new = uniform(sum_red(red_e));
-            iters = (uint32_t)(it + 1);
-            if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; p_pending = false; break; }     // (the reference leaves p as it is on this exit)
-            beta = uniform(eta_new / eta);
-            eta = eta_new;
         }
+        // the vector this role carries, for d_p / d_r (the staging buffers are free since the setup)
+        store_own(P ? L::R0 : L::P0, x.k);
     };
     if (isP) run_role(std::true_type{}); else run_role(std::false_type{});
 
     // ---- write back ----
     lds_barrier();
-    const int XPf = PB(cp), XRf = RB(cr);                      // (the reference leaves p and r of the last completed update in d_p / d_r)
+    constexpr int XPf = L::P0, XRf = L::R0;                    // (the reference leaves p and r of the last completed update in d_p / d_r)
     for (int e = tid; e < N * NS; e += NTHR) {
         const int kk = e / NS, i = e - kk * NS;
         lam_g[e] = lds[L::LAM + L::at(kk, i)];
