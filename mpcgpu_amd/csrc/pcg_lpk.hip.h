@@ -79,9 +79,10 @@ __device__ __forceinline__ f2 lds_ld64(const float* p) { return *(lds_cv_f2*)(p)
 __device__ __forceinline__ float uniform(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
-// (alpha and beta are IEEE divisions: v_rcp_f32 + multiply is ~100 cycles shorter on the critical path of a half-iteration, but v_rcp_f32
-//  has no denormal support — an over-iterated, exactly converged system (p^T S p underflowing) then turns lambda into inf/NaN where the
-//  correctly rounded quotient stays finite: tests/test_gpu_lpk.py, N = 2, 30 fixed iterations.)
+// (alpha and beta are plain IEEE divisions.  v_rcp_f32 + multiply has no denormal support — an over-iterated, exactly converged system
+//  turns lambda into inf / NaN where the correctly rounded quotient stays finite, tests/test_gpu_lpk.py N = 2 — and guarded by a range
+//  test it measured SLOWER than the 13-instruction division, whose latency is covered by the operand loads issued in front of it:
+//  one trajectory 0.318 vs 0.301 ms.)
 // value of `v` in the partner lane (lane ^ 1): DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ float dpp_partner(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
