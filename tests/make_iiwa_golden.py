@@ -112,6 +112,25 @@ def main():
             scen.append(dict(name=name, xu=xu.astype(np.float32), goals=goals.astype(np.float32), xs=xs.astype(np.float32), G=G32, C=C32, g=g32, c=c32,
                              S=S.astype(np.float32), Pinv=P.astype(np.float32), gamma=gam.astype(np.float32), cond=cond,
                              iters_ss_1e4=stats["ss_tol0.0001"][0]))
+        if N == 128:
+            # two of the N = 128 windows (cond(-S) ~ 1e7: the regime bench.py's iiwa_run reports) with float64 answers made HERE by dense numpy
+            # (tests/make_golden.py:dense_pcg — no code shared with oracle/ or the kernels): iterate after K iterations from a cold and from an
+            # MPC-style warm start (the direct solution of a slightly different right-hand side), direct solution
+            from make_golden import dense_pcg
+            flat = {}
+            for i, sc in enumerate(scen[:2]):
+                S64, P64, g64 = (sc[k_].astype(np.float64) for k_ in ("S", "Pinv", "gamma"))
+                Sd, Pd = synth.bd_to_dense(S64, N), synth.bd_to_dense(P64, N)
+                lam_star = np.linalg.solve(Sd, g64)
+                warm = np.linalg.solve(Sd, g64 * (1 + 0.02 * rng.standard_normal(g64.shape)))      # previous SQP iterate's multipliers
+                for k_ in ("S", "Pinv", "gamma", "cond"):
+                    flat[f"s{i}_{k_}"] = sc[k_]
+                flat[f"s{i}_lam_direct"] = lam_star
+                flat[f"s{i}_lam_warm0"] = warm.astype(np.float32)
+                for K in (10, 40):
+                    flat[f"s{i}_lam_cold_K{K}"] = dense_pcg(Sd, Pd, g64, np.zeros(n * N), K)[0]
+                    flat[f"s{i}_lam_warm_K{K}"] = dense_pcg(Sd, Pd, g64, warm.astype(np.float32).astype(np.float64), K)[0]
+            np.savez_compressed(os.path.join(ROOT, "tests", "golden", "iiwa_kkt_N128.npz"), **flat)
         if N == 32:
             flat = {}
             for i, sc in enumerate(scen):

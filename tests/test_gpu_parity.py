@@ -378,11 +378,12 @@ def test_resident_row_variants_bitwise_equal_streaming(P, N, waves, reg_rows, ld
         assert not resident and len(kernels_run) == 2, kernels_run
 
 
+@pytest.mark.parametrize("N,B", [(37, 5), (512, 3)])
 @pytest.mark.parametrize("cols", [3, 1])
-def test_spmv_mfma_experiment_matches_valu_kernel(P, orc, cols):
+def test_spmv_mfma_experiment_matches_valu_kernel(P, orc, cols, N, B):
     """BASELINE config 5's MFMA block-GEMV (v_mfma_f32_16x16x4_f32, blocks padded 14->16 in registers):
-    same result as the VALU kernel up to fp32 summation order, unwritten blocks never read."""
-    N, B = 37, 5
+    same result as the VALU kernel up to fp32 summation order, unwritten blocks never read.  N = 512 is config 5 as written
+    ("IIWA-14 N=512 long-horizon, MFMA per-knot block GEMV on"), N = 37 the ragged case."""
     k = synth.make_kkt(N, B, 9)
     S, _, _ = synth.form_schur(k, poison_unused=True)
     x = np.random.default_rng(3).normal(size=(B, n * N)).astype(np.float32)
@@ -391,7 +392,7 @@ def test_spmv_mfma_experiment_matches_valu_kernel(P, orc, cols):
     sol.set_option("spmv_mfma", 1)
     y1 = sol.bt_spmv(dev(S), dev(x), cols=cols).cpu().numpy()
     assert np.isfinite(y1).all() and relinf(y1, y0) < 5e-6
-    for b in (0, 4):
+    for b in (0, B - 1):
         assert relinf(y1[b], orc.bt_spmv(np.nan_to_num(S[b]).astype(np.float64), x[b], N, cols=cols)) < 5e-6
 
 
