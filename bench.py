@@ -636,11 +636,11 @@ def main():
                                             "us_per_pcg_iter": ms1 * 1e3 / max(int(i1.item()), 1),
                                             "kernel_family": sol1.get_option("last_kernel_family"), "kernel_waves": sol1.get_option("last_kernel_waves")}
 
-    if extras and rank == 0 and world == 1 and not lean:
+    if extras and rank == 0 and world == 1:
         # horizons one CU cannot hold (BASELINE config 5's N = 512, and N = 256): the clustered lane-per-block kernel, fixed
         # iteration counts = the reference's caps (settings.cuh:123-139); 256 resident systems tiled to the batch
         lh = {}
-        for Nl in (256, 512):
+        for Nl in ((512,) if lean else (256, 512)):          # (--profile-lean: only the streaming leg below)
             sl = PcgSolver(Nl, max_batch=B, device=local_rank)
             S0, P0, g0 = build_inputs(sl, Nl, 32, seed0, "ss", dev, chunk=32)
             rep = (B + 31) // 32
@@ -654,13 +654,15 @@ def main():
             def run_b(nb):
                 ll[:nb].zero_()
                 sl.solve(Sl[:nb], Pl[:nb], gl[:nb], ll[:nb], cl, "ss", iters=il[:nb], exits=xl[:nb])
-            ms_b = timed(lambda: run_b(B), 5, warm=1)
-            its = int(il.sum().item())
-            ms_1 = timed(lambda: run_b(1), 15, warm=3)
-            assert int(xl.max().item()) <= 1, "a cluster gave up"
-            lh[f"N{Nl}"] = {"pcg_iters_per_solve": synth.pcg_max_iter(Nl), "batch": B, "kernel_ms": ms_b, "pcg_iterations_per_sec": its / (ms_b * 1e-3),
-                            "ms_one_trajectory": ms_1, "us_per_pcg_iter_one_trajectory": ms_1 * 1e3 / synth.pcg_max_iter(Nl),
-                            "kernel_family": sl.get_option("last_kernel_family"), "members_per_trajectory": sl.get_option("last_kernel_cluster")}
+            if not lean:
+                ms_b = timed(lambda: run_b(B), 5, warm=1)
+                its = int(il.sum().item())
+                ms_1 = timed(lambda: run_b(1), 15, warm=3)
+                assert int(xl.max().item()) <= 1, "a cluster gave up"
+                lh[f"N{Nl}"] = {"pcg_iters_per_solve": synth.pcg_max_iter(Nl), "batch": B, "kernel_ms": ms_b, "pcg_iterations_per_sec": its / (ms_b * 1e-3),
+                                "ms_one_trajectory": ms_1, "us_per_pcg_iter_one_trajectory": ms_1 * 1e3 / synth.pcg_max_iter(Nl),
+                                "kernel_family": sl.get_option("last_kernel_family"), "members_per_trajectory": sl.get_option("last_kernel_cluster"),
+                                "cluster_fixups": sl.get_option("cluster_fixups")}
             if Nl == 512:
                 # ---- the PCG solve as an HBM stream: nothing resident (pcg_traj_kernel<16,0,2>), every block re-read every iteration.
                 # One workgroup per CU (115 KB of LDS at N=512), so the LIVE matrices are 256 x 2.41 MB = 616 MB >> the 256 MiB Infinity Cache
@@ -690,7 +692,8 @@ def main():
                     out["roofline_pcg_streaming"]["traffic_source"] = src
                 del ss
             del Sl, Pl, gl, ll, sl
-        out["long_horizon"] = lh
+        if lh:
+            out["long_horizon"] = lh
 
     if extras and rank == 0 and world == 1 and not lean and args.scaling == "weak":
         # ---- what scaling to expect (measured here on one GPU, the multi-GPU curve itself is the driver's to measure) ----

@@ -13,16 +13,22 @@ out = {"source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_S
 for name, k in pmc.items():
     if "hbm_traffic_bytes_per_launch" not in k:
         continue
-    if "pcg_lpb_kernel" in name:
+    if "pcg_lpk_kernel" in name:
+        key = f"pcg_lpk_kernel|N{N}_B{B}_{pc}_it{mi}_tol{float(tol):g}"
+    elif "pcg_lpb_kernel" in name:
         key = f"pcg_lpb_kernel|N{N}_B{B}_{pc}_it{mi}_tol{float(tol):g}"
     elif "bt_spmv_kernel" in name:
         key = f"bt_spmv_kernel|N{N}_B{spB}"
     elif "pcg_traj_kernel<16, 0, 2" in name:
-        key = f"pcg_traj_kernel<16,0,2>|N{N}_B{max(int(B), 4096)}_{pc}_it{mi}_tol{float(tol):g}"
+        key = f"pcg_traj_kernel<16,0,2>|N512_B{B}_ss_it67_tol0"          # bench.py's streaming leg: N = 512, batch B, 67 fixed iterations
     else:
         continue
     out["kernels"][key] = {"kernel": name, "hbm_traffic_bytes_per_launch": k["hbm_traffic_bytes_per_launch"],
                            "fetch_bytes_corrected": k["fetch_bytes_corrected"], "write_bytes": k["write_bytes"],
                            "launches_averaged": k["FETCH_SIZE"]["launches"]}
+    # VALU pipe activity of the same kernel from the SQ pass.  Counters are per shader engine (8 CUs x 4 SIMDs = 32 SIMDs);
+    # SQ_ACTIVE_INST_VALU counts quad-cycles, SQ_BUSY_CYCLES cycles (MI355X_MICROARCH.md): active = 4 x ACTIVE / (32 x BUSY)
+    if "SQ_ACTIVE_INST_VALU" in k and "SQ_BUSY_CYCLES" in k and k["SQ_BUSY_CYCLES"]["avg"]:
+        out["kernels"][key]["valu_active_frac"] = k["SQ_ACTIVE_INST_VALU"]["avg"] / (8.0 * k["SQ_BUSY_CYCLES"]["avg"])
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
