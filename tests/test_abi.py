@@ -41,16 +41,16 @@ def test_version_and_lds_size(hiplib):
     assert hiplib.mpcg_abi_version() == 1
     assert b"gfx950" in hiplib.mpcg_build_info()
     # = the dynamic LDS of the launch a default batch-1 solve makes.  64 < N <= 128: the lane-pair-per-knot kernel, whose
-    # layout is compile-time per wave count (64 or 128 knots): p, r, lambda, z of NMAX + 2 knot slots of 16 floats, one
-    # partial per wave
+    # layout is compile-time per wave count (64 or 128 knots): seven pair-major vectors of 7 x (NMAX + 4) float2, one partial per
+    # wave, three parked matrix pairs per lane
     r4 = lambda x: (x + 3) & ~3
-    lpk = lambda nmax, nw: 4 * (4 * (nmax + 2) * 16 + nw)
+    lpk = lambda nmax, nw: 4 * (7 * 7 * (nmax + 4) * 2 + nw + 3 * 2 * nw * 64)
     # N <= 64: the row-per-lane kernel of a batch-1 call — six vectors padded by a knot either side + 2 partials per wave (4 waves
     # for N <= 16, else 8), DESIGN.md §3.1e
     for N in (2, 16, 32, 48, 64):
         assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (6 * r4((N + 2) * 14) + r4(2 * (4 if N <= 16 else 8)))
     for N in (65, 128):
-        assert hiplib.mpcg_pcg_lds_bytes(14, N) == lpk(128, 8) == 33312
+        assert hiplib.mpcg_pcg_lds_bytes(14, N) == lpk(128, 8) == 64064
     # N > 128: a member of the clustered lane-per-block kernel — six vectors of 128 + 2 knot slots, partials, broadcast cell, hand-off tables (§3.1d)
     for N in (129, 256, 512):
         assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (6 * r4(130 * 14) + r4(16) + 4 + 3 * 64) == 44528
