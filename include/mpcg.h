@@ -222,9 +222,10 @@ int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, flo
  *   X_const [nj*36] spatial transforms parent -> link, I_spatial [nj*36] spatial inertias, Xhom_const [nj*16] homogeneous
  *   transforms link -> parent.  mpcgpu_amd/data/iiwa14_model.json carries the KUKA iiwa 14 in exactly this form.
  * The cost is the reference's end-effector tracking cost: 1/2 |ee(q_k) - goal_k|^2 (xyz of d_eePos_traj [batch][N][6]) +
- * 1/2 qd_cost |qd|^2 + 1/2 r_cost |u|^2 with its Gauss-Newton Hessian.  Derivatives of the inverse dynamics are central
- * differences in float64 on the device (agreement with the float64 host restatement mpcgpu_amd/iiwa.py: ~1e-7 after
- * rounding to float), not GRiD's analytic recursion.  num_joints = 7 is the compiled specialisation. */
+ * 1/2 qd_cost |qd|^2 + 1/2 r_cost |u|^2 with its Gauss-Newton Hessian.  Derivatives of the inverse dynamics are one-sided
+ * differences in float64 on the device, (ID(. + h e_j) - u) / h with h = 3e-8 — the nominal value needs no evaluation, ID(q, qd, qdd) = u
+ * because qdd = Minv (u - c) — agreement of A, B with the float64 central-difference host restatement mpcgpu_amd/iiwa.py: ~2e-7, the
+ * rounding of the float outputs; not GRiD's analytic recursion.  num_joints = 7 is the compiled specialisation. */
 typedef struct mpcg_plant mpcg_plant;
 int mpcg_plant_create(mpcg_plant **out, int device, uint32_t num_joints, const double *X_const, const double *I_spatial,
                       const double *Xhom_const, const int32_t *X_trig_idx, const double *X_trig_coef, const int32_t *X_trig_j,

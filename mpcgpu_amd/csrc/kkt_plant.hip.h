@@ -10,12 +10,15 @@
 //     round 0  lanes 0..6: columns of the joint-space inertia matrix M = ID(q, 0, e_j);  lane 7: bias c = ID(q, qd, 0)
 //              then lanes 0..6: column j of Minv by a Cholesky solve (7x7, redundantly factorised per lane);  qdd = Minv (u - c)
 //     round 1  lanes 0..6: ID(q + h e_j, qd, qdd), lanes 7..13: ID(q, qd + h e_j, qdd);  lane 14: forward kinematics, end-effector
-//              position and geometric Jacobian z_j x (p_ee - p_j)
-//     round 2  the same at - h; every lane stores tau(+h) - tau(-h): central differences of the inverse dynamics
+//              position and geometric Jacobian z_j x (p_ee - p_j).  Every lane stores tau(+h) - u: ONE-SIDED differences of the
+//              inverse dynamics — the nominal value is known without evaluating it, ID(q, qd, qdd) = u because qdd = Minv (u - c)
+//              (round 3; rounds 1 and 2 used to be the central pair +-h: a third of the kernel's recursion time for accuracy the
+//              float outputs cannot hold — with h = 3e-8 in float64 the entries of A differ from the central-difference values by
+//              1.3e-7, the rounding of a float near 1).
 //     phase 4  dqdd/d(q,qd) = -Minv dID,  A, B, integrator defect, Gauss-Newton cost blocks, written as float in the
 //              reference's dense layouts (column-major blocks, C = -A, -B).
-// Arithmetic is float64 inside (h = 1e-6 central differences are exact to ~1e-9 there; the MI355X has the fp64 rate
-// to spare: the whole kernel is ~60 kflop per knot), results are rounded to float on the way out.
+// Arithmetic is float64 inside (the difference quotients need it; the MI355X has the fp64 rate to spare: the whole kernel is
+// ~40 kflop per knot), results are rounded to float on the way out.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -157,7 +160,7 @@ constexpr int KKT_THREADS = KKT_LANES;
 constexpr int KKT_ITEMS = 4;             // (trajectory, knot) pairs per wavefront: 16 lanes each
 constexpr int KKT_GL = KKT_LANES / KKT_ITEMS;
 constexpr int KKT_KIN_LANE = 2 * PJ;     // lane of a group after the 14 finite-difference tasks: forward kinematics + Jacobian
-constexpr double KKT_FD_H = 1e-6;
+constexpr double KKT_FD_H = 3e-8;             // one-sided difference step (truncation h/2 |f''| ~ roundoff eps |f| / h in float64)
 
 struct KktItemLds {                      // per-knot scratch in LDS (2.1 KB; LDS capacity is what bounds the resident wavefronts per CU)
     double M[PJ][PJ], Minv[PJ][PJ], Bias[PJ], Qdd[PJ];
@@ -166,7 +169,7 @@ struct KktItemLds {                      // per-knot scratch in LDS (2.1 KB; LDS
     double Dqd[PJ][PJ];
     double J[3][PJ], Ee[3], Gq[PJ], Gq1[PJ];
     double Xq[2 * PJ], U[PJ];            // [q; qd], u of this knot
-    double Sc[3][2][PJ];                 // sin / cos of q, q + h e_j, q - h e_j
+    double Sc[2][2][PJ];                 // sin / cos of q, q + h e_j
 };
 
 __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a) {
@@ -188,38 +191,32 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
         const float* xu = a.xu + (size_t)b * ((size_t)(n + m) * N - m) + (size_t)k * (n + m);      // x_k, u_k, x_{k+1}
         if (l < n) I.Xq[l] = (double)xu[l];
         if (l < m) I.U[l] = (double)xu[n + l];
-        // sin / cos table, two sweeps through one sincos: lanes 0..13 -> q_j and q_j + h, then lanes 0..6 -> q_j - h
-#pragma nounroll
-        for (int c = 0; c < 2; ++c) {
-            const int v = c == 0 ? l / PJ : 2, j = l % PJ;
-            if (l < (c == 0 ? 2 * PJ : PJ)) {
+        // sin / cos table through one sincos: lanes 0..13 -> q_j and q_j + h
+        {
+            const int v = l / PJ, j = l % PJ;
+            if (l < 2 * PJ) {
                 double sn_, cs_;
-                sincos((double)xu[j] + (v == 0 ? 0.0 : v == 1 ? KKT_FD_H : -KKT_FD_H), &sn_, &cs_);
+                sincos((double)xu[j] + (v == 0 ? 0.0 : KKT_FD_H), &sn_, &cs_);
                 I.Sc[v][0][j] = sn_;
                 I.Sc[v][1][j] = cs_;
             }
         }
         __syncthreads();
-        // ---- three rounds through ONE instance of the recursion (a runtime loop: a second inlined copy doubles the register
+        // ---- two rounds through ONE instance of the recursion (a runtime loop: a second inlined copy doubles the register
         //      pressure).  Round 0: lanes 0..6 inertia-matrix columns ID(q, 0, e_l), lane 7 bias ID(q, qd, 0), then Minv and qdd.
-        //      Round 1: lanes 0..6 ID(q + h e_j, qd, qdd), 7..13 ID(q, qd + h e_j, qdd); lane 14: kinematics.  Round 2: the same at - h;
-        //      the lane keeps tau(+h) in registers and stores the difference. ----
-        double tp[PJ];
-#pragma unroll
-        for (int i = 0; i < PJ; ++i) tp[i] = 0.0;
+        //      Round 1: lanes 0..6 ID(q + h e_j, qd, qdd), 7..13 ID(q, qd + h e_j, qdd), each minus the nominal torque u; lane 14: kinematics. ----
 #pragma nounroll
-        for (int round = 0; round < 3; ++round) {
+        for (int round = 0; round < 2; ++round) {
             const bool fd = round > 0;
             if (l < (fd ? 2 * PJ : PJ + 1)) {
                 const int kind = l / PJ, jj = l - kind * PJ;            // fd: kind 0 perturbs q_jj, kind 1 qd_jj
                 rnea(P, fl, &I.Sc[0][0][0], (fd && kind == 0) ? jj : -1, round, I.Xq + PJ, (fd || l == PJ) ? 1.0 : 0.0,
-                     (fd && kind == 1) ? jj : -1, round == 1 ? KKT_FD_H : -KKT_FD_H, fd ? I.Qdd : nullptr, l);
+                     (fd && kind == 1) ? jj : -1, KKT_FD_H, fd ? I.Qdd : nullptr, l);
 #pragma unroll
                 for (int i = 0; i < PJ; ++i) {
                     const double t = fl[RN_TAU(i)];
                     if (round == 0) { if (l < PJ) I.M[i][l] = t; else I.Bias[i] = t; }
-                    else if (round == 1) tp[i] = t;
-                    else fl[i] = tp[i] - t;                          // (the sweep is over: the record is free)
+                    else fl[i] = t - I.U[i];                         // ID(. + h e_j) - ID(.) with ID(q, qd, qdd) = u  (the sweep is over: the record is free)
                 }
             } else if (round == 1 && l == KKT_KIN_LANE) {
                 // forward kinematics; joint origins and axes wait in this lane's (otherwise unused) record
@@ -258,7 +255,8 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
             if (round == 0) {
                 // Minv (column l through a Cholesky solve of the symmetrised M), qdd = Minv (u - bias)
                 if (l < PJ) {
-                    double Lm[PJ][PJ];
+                    // (one reciprocal per pivot: float64 division and sqrt are ~25-instruction sequences, the textbook form has 42 + 14 divisions)
+                    double Lm[PJ][PJ], rd[PJ];
 #pragma unroll
                     for (int i = 0; i < PJ; ++i)
 #pragma unroll
@@ -266,7 +264,8 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
                             double sv = 0.5 * (I.M[i][jj] + I.M[jj][i]);
 #pragma unroll
                             for (int t = 0; t < jj; ++t) sv -= Lm[i][t] * Lm[jj][t];
-                            Lm[i][jj] = (i == jj) ? sqrt(sv) : sv / Lm[jj][jj];
+                            if (i == jj) { Lm[i][i] = sqrt(sv); rd[i] = 1.0 / Lm[i][i]; }
+                            else Lm[i][jj] = sv * rd[jj];
                         }
                     double y[PJ];
 #pragma unroll
@@ -274,14 +273,14 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
                         double sv = (i == l) ? 1.0 : 0.0;
 #pragma unroll
                         for (int t = 0; t < i; ++t) sv -= Lm[i][t] * y[t];
-                        y[i] = sv / Lm[i][i];
+                        y[i] = sv * rd[i];
                     }
 #pragma unroll
                     for (int i = PJ - 1; i >= 0; --i) {
                         double sv = y[i];
 #pragma unroll
                         for (int t = i + 1; t < PJ; ++t) sv -= Lm[t][i] * y[t];
-                        y[i] = sv / Lm[i][i];
+                        y[i] = sv * rd[i];
                     }
 #pragma unroll
                     for (int i = 0; i < PJ; ++i) I.Minv[i][l] = y[i];
@@ -305,8 +304,8 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
                 sq += I.Minv[i][t] * sF[gi * KKT_GL + j][t];
                 sd += I.Minv[i][t] * sF[gi * KKT_GL + PJ + j][t];
             }
-            I.M[i][j] = -sq / (2 * KKT_FD_H);                 // dqdd/dq
-            I.Dqd[i][j] = -sd / (2 * KKT_FD_H);
+            I.M[i][j] = -sq / KKT_FD_H;                       // dqdd/dq
+            I.Dqd[i][j] = -sd / KKT_FD_H;
         }
         if (l < PJ) {
             const float* goal = a.eePos_traj + ((size_t)b * N + k) * 6;
