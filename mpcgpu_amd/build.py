@@ -100,6 +100,22 @@ def build_mpcsim_demo(force: bool = False, verbose: bool = False):
     return DEMO_BINS
 
 
+MULTI_SRC = os.path.join(_ROOT, "examples", "multi_gpu_pcg.cpp")
+MULTI_BIN = os.path.join(_ROOT, "examples", "multi_gpu_pcg")
+
+
+def build_multi_gpu(force: bool = False, verbose: bool = False) -> str:
+    """The native multi-device driver: C++ host threads (one per GPU) over the C ABI + one RCCL all-gather."""
+    deps = [MULTI_SRC, LIB_PATH, os.path.join(_ROOT, "include", "mpcg.h")]
+    if force or not os.path.exists(MULTI_BIN) or any(os.path.getmtime(d) > os.path.getmtime(MULTI_BIN) for d in deps):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", MULTI_SRC, "-L" + _HERE, "-lmpcg_hip", "-lrccl", "-lpthread",
+               "-Wl,-rpath,$ORIGIN/../mpcgpu_amd", "-o", MULTI_BIN]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return MULTI_BIN
+
+
 UTILS_SRC = os.path.join(_ROOT, "examples", "bd_utils_probe.cpp")
 UTILS_BIN = os.path.join(_ROOT, "examples", "bd_utils_probe")
 
@@ -121,3 +137,4 @@ if __name__ == "__main__":
     print(build_chain_example(force="--force" in sys.argv, verbose=True))
     print(build_mpcsim_demo(force="--force" in sys.argv, verbose=True))
     print(build_utils_probe(force="--force" in sys.argv, verbose=True))
+    print(build_multi_gpu(force="--force" in sys.argv, verbose=True))

@@ -65,3 +65,23 @@ def test_self_launched_two_ranks_solve_on_the_gpu():
     assert out["n_gpus"] == 2 and out["self_launched"] is True and out["scaling"] == "strong"
     assert out["results_gather"]["trajectories"] == 96 and out["results_gather"]["consistent_with_allreduce_sum"] is True
     assert len(out["per_rank_kernel_ms"]) == 2 and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_native_multi_device_driver():
+    """examples/multi_gpu_pcg.cpp: C++ host threads (one per device) over the C ABI + one RCCL all-gather in a single-process
+    communicator — on every device of the box (one here, eight on the scaling node), weak and strong partitioning; asking for more
+    devices than there are is refused."""
+    import torch
+    from mpcgpu_amd import build
+    exe = build.MULTI_BIN if os.path.exists(build.MULTI_BIN) else build.build_multi_gpu()
+    nd = torch.cuda.device_count()
+    for extra, total in ((["--batch", "40"], 40 * nd), (["--batch", "37", "--strong"], 37)):
+        r = subprocess.run([exe, "--knots", "64", "--steps", "2", "--warmup", "1", *extra], capture_output=True, text=True, timeout=600, env=_clean_env())
+        assert r.returncode == 0, r.stdout + r.stderr
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+        assert out["n_gpus"] == nd and out["global_batch"] == total and out["value"] > 0 and len(out["per_device_ms_per_step"]) == nd
+        assert out["results_gather"]["consistent_with_shard_sums"] is True and out["results_gather"]["trajectories"] == total
+        assert 0 < out["mean_pcg_iters"] <= 167
+    r = subprocess.run([exe, "--gpus", str(nd + 1)], capture_output=True, text=True, timeout=120, env=_clean_env())
+    assert r.returncode == 2 and "refusing to run fewer" in r.stderr
