@@ -1,0 +1,154 @@
+// mpcsim_iiwa_demo.cpp — simulateMPC -> sqpSolvePcg | sqpSolveQdldl (the reference's entry-point chain, include/mpcsim.cuh:147, :267-269,
+// compile-time LINSYS_SOLVE switch :21-25) over THIS repo's shim headers on a REAL window of the reference's precomputed trajectory
+// (examples/trajfiles/0_0_traj.csv / 0_0_eepos.traj; first 400 rows in mpcgpu_amd/data/iiwa_traj_0_0.f32), with
+//   * the library's own generate_kkt_submatrices as the KKT stage (mpcgpu_compat::use_mpcg_generate_kkt: IIWA-14 dynamics, tracking
+//     cost and Euler integrator on the device, robot model = mpcg_plant_create_iiwa14, the reference's initializeDynamicsConstMem);
+//   * the stages that stay plug points registered here in their simplest form: the full step alpha = -1 instead of the merit-function
+//     line search (include/pcg/sqp.cuh:265-353), and a horizon shift without plant noise instead of simple_simulate (include/mpcsim.cuh:288-341).
+// The start state is the trajectory's, perturbed; the program reports the constraint violation (integrator defect + initial-state
+// residual: the `c` of the KKT system) before the first and after the last SQP iteration of every control step, the linear-system
+// iterations and times, and fails if the violation does not come down (full steps without a merit function and an |eta| exit test that is
+// loose at cond 1e6 make that a slow descent with PCG — 5.7e-2 -> 3.6e-2 over three control steps — and a faster one with the direct LDL^T: 1.8e-2).
+//   hipcc --offload-arch=gfx950 -O2 -DLINSYS_SOLVE=1 -Iinclude examples/mpcsim_iiwa_demo.cpp -Lmpcgpu_amd -lmpcg_hip      (and -DLINSYS_SOLVE=0)
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#define STATE_SIZE 14
+#define KNOT_POINTS 32
+#define PCG_MAX_ITER 3000         // (the reference's cap of 173, include/common/settings.cuh:127, presupposes its merit-function line search:
+                                  //  an inexact lambda with FULL steps diverges on these systems — measured: violation 5.7e-2 -> 1e3 in three control steps)
+#include "mpcsim.cuh"
+
+typedef float T;
+static const int n = 14, m = 7, N = KNOT_POINTS, ROWW = 27;      // a row of the data file: x (14), u (7), end-effector pose (6)
+
+__global__ void axpy_kernel(T* y, const T* x, T a, int count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < count) y[i] += a * x[i];
+}
+
+static std::vector<T> load_rows(const std::string& exe) {
+    const std::string dir = exe.substr(0, exe.find_last_of('/') + 1);
+    for (const std::string& p : {dir + "../mpcgpu_amd/data/iiwa_traj_0_0.f32", std::string("mpcgpu_amd/data/iiwa_traj_0_0.f32")}) {
+        if (FILE* f = fopen(p.c_str(), "rb")) {
+            std::vector<T> v(400 * ROWW);
+            const size_t got = fread(v.data(), sizeof(T), v.size(), f);
+            fclose(f);
+            if (got == v.size()) return v;
+        }
+    }
+    fprintf(stderr, "cannot read mpcgpu_amd/data/iiwa_traj_0_0.f32\n");
+    exit(1);
+}
+
+int main(int, char** argv) {
+    const uint32_t state_size = n, control_size = m, knot_points = N;
+    const size_t gsz = (size_t)(n + m) * N - m;
+    const std::vector<T> rows = load_rows(argv[0]);
+    int t0 = 0, steps_done = 0;
+    const int control_steps = 3;
+
+    mpcg_plant* plant = nullptr;
+    if (mpcg_plant_create_iiwa14(&plant, -1) != MPCG_OK) { fprintf(stderr, "mpcg_plant_create_iiwa14: %s\n", mpcg_last_error(nullptr)); return 1; }
+    mpcgpu_compat::use_mpcg_generate_kkt<T>(plant, /*QD_COST*/ 1e-4f, /*R_COST*/ 1e-4f);       // include/common/settings.cuh:84-94
+    auto& st = mpcgpu_compat::stages<T>();
+    st.sqp_max_iter = 4;
+    st.const_update_freq = false;         // CONST_UPDATE_FREQ = 0: a fixed number of SQP iterations per control step (the time box: mpcsim_shim_demo)
+
+    // window [t0, t0 + N) of the trajectory: iterate xu, goals = the end-effector poses of the same rows
+    auto window = [&](int t, std::vector<T>& xu, std::vector<T>& goals) {
+        xu.assign(gsz, 0.f); goals.assign(6 * N, 0.f);
+        for (int k = 0; k < N; ++k) {
+            const T* r = &rows[(size_t)(t + k) * ROWW];
+            for (int i = 0; i < n; ++i) xu[(size_t)k * (n + m) + i] = r[i];
+            if (k < N - 1) for (int i = 0; i < m; ++i) xu[(size_t)k * (n + m) + n + i] = r[n + i];
+            for (int i = 0; i < 6; ++i) goals[6 * k + i] = r[n + m + i];
+        }
+    };
+    std::vector<T> xu0, goals0, xs0(n);
+    window(t0, xu0, goals0);
+    unsigned s = 99u;
+    auto rnd = [&s]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (int i = 0; i < n; ++i) xs0[i] = xu0[i] + 0.04f * rnd();        // the measured state is off the plan: c_0 != 0
+    for (size_t e = n; e < gsz; ++e) xu0[e] += 0.02f * rnd();             // and the plan is off the dynamics
+
+    // violation of the constraints at an iterate = max |c| of the KKT system there (one more call of the KKT stage)
+    T *d_G, *d_C, *d_g, *d_c;
+    gpuErrchk(hipMalloc(&d_G, ((size_t)(n * n + m * m) * N - m * m) * sizeof(T)));
+    gpuErrchk(hipMalloc(&d_C, (size_t)(n * n + n * m) * (N - 1) * sizeof(T)));
+    gpuErrchk(hipMalloc(&d_g, gsz * sizeof(T)));
+    gpuErrchk(hipMalloc(&d_c, (size_t)n * N * sizeof(T)));
+    auto violation = [&](T* d_goal, T* d_xs, T* d_xu) {
+        st.generate_kkt(state_size, control_size, knot_points, d_G, d_C, d_g, d_c, st.dynmem, 1.0f / 64, d_goal, d_xs, d_xu);
+        std::vector<T> c((size_t)n * N);
+        gpuErrchk(hipMemcpy(c.data(), d_c, c.size() * sizeof(T), hipMemcpyDeviceToHost));
+        double v = 0;
+        for (T x : c) v = fmax(v, fabs((double)x));
+        return v;
+    };
+
+    std::vector<double> viol_before, viol_after;
+    T* d_xs_ptr = nullptr;
+    bool first_of_step = true;
+    // alpha = -1 (include/pcg/sqp.cuh:317, :332): the full Gauss-Newton step, no merit function
+    st.globalize_and_step = [&](uint32_t, uint32_t, uint32_t, T* d_xu, T* d_dz, T&, T, uint32_t) {
+        hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((gsz + 255) / 256)), dim3(256), 0, 0, d_xu, d_dz, (T)-1, (int)gsz);
+        gpuErrchk(hipGetLastError());
+        return true;
+    };
+    // horizon shift by one knot: the plant follows the plan exactly (no noise), goals move along the reference trajectory
+    st.simulate_and_shift = [&](uint32_t, uint32_t, uint32_t, T* d_xs, T* d_xu, T* d_lambda, T* d_goal, double, bool& done) {
+        viol_after.push_back(violation(d_goal, d_xs, d_xu));
+        std::vector<T> xu(gsz), lam((size_t)n * N), xs(n), nxt_xu, nxt_goals;
+        gpuErrchk(hipMemcpy(xu.data(), d_xu, gsz * sizeof(T), hipMemcpyDeviceToHost));
+        gpuErrchk(hipMemcpy(lam.data(), d_lambda, lam.size() * sizeof(T), hipMemcpyDeviceToHost));
+        ++t0;
+        window(t0, nxt_xu, nxt_goals);
+        for (int i = 0; i < n; ++i) xs[i] = xu[(size_t)(n + m) + i];                       // new start state = planned x_1
+        for (int k = 0; k + 1 < N; ++k) {                                                  // just_shift: iterate and multipliers move up one knot
+            for (int i = 0; i < n + (k + 2 < N ? m : 0); ++i) xu[(size_t)k * (n + m) + i] = xu[(size_t)(k + 1) * (n + m) + i];
+            for (int i = 0; i < n; ++i) lam[(size_t)k * n + i] = lam[(size_t)(k + 1) * n + i];
+        }
+        for (int i = 0; i < m; ++i) xu[(size_t)(N - 2) * (n + m) + n + i] = nxt_xu[(size_t)(N - 2) * (n + m) + n + i];    // last control and knot from the reference plan
+        for (int i = 0; i < n; ++i) xu[(size_t)(N - 1) * (n + m) + i] = nxt_xu[(size_t)(N - 1) * (n + m) + i];
+        gpuErrchk(hipMemcpy(d_xu, xu.data(), gsz * sizeof(T), hipMemcpyHostToDevice));
+        gpuErrchk(hipMemcpy(d_lambda, lam.data(), lam.size() * sizeof(T), hipMemcpyHostToDevice));
+        gpuErrchk(hipMemcpy(d_xs, xs.data(), n * sizeof(T), hipMemcpyHostToDevice));
+        gpuErrchk(hipMemcpy(d_goal, nxt_goals.data(), nxt_goals.size() * sizeof(T), hipMemcpyHostToDevice));
+        viol_before.push_back(violation(d_goal, d_xs, d_xu));
+        done = ++steps_done >= control_steps;
+        double err = 0;                                                                    // tracking error: end-effector goal vs plan is evaluated by the cost; report |x_s - reference state|
+        for (int i = 0; i < n; ++i) err += fabs((double)xs[i] - (double)rows[(size_t)t0 * ROWW + i]);
+        return (T)err;
+    };
+    (void)d_xs_ptr; (void)first_of_step;
+
+    T *d_xu_traj, *d_eePos_traj, *d_xs;
+    gpuErrchk(hipMalloc(&d_xu_traj, gsz * sizeof(T)));
+    gpuErrchk(hipMalloc(&d_eePos_traj, 6 * N * sizeof(T)));
+    gpuErrchk(hipMalloc(&d_xs, n * sizeof(T)));
+    gpuErrchk(hipMemcpy(d_xu_traj, xu0.data(), gsz * sizeof(T), hipMemcpyHostToDevice));
+    gpuErrchk(hipMemcpy(d_eePos_traj, goals0.data(), goals0.size() * sizeof(T), hipMemcpyHostToDevice));
+    gpuErrchk(hipMemcpy(d_xs, xs0.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    const double v0 = violation(d_eePos_traj, d_xs, d_xu_traj);
+
+    auto res = simulateMPC<T, toplevel_return_type>(state_size, control_size, knot_points, /*traj_steps*/ 400, 1.0f / 64, d_eePos_traj, d_xu_traj, d_xs,
+                                                    0, 0, 0, (T)1e-7, std::string("iiwa_demo"));
+    const std::vector<toplevel_return_type>& linsys_times = std::get<0>(res);
+    const std::vector<linsys_t>& tracking = std::get<1>(res);
+    double mean_us = 0;
+    for (double t : linsys_times) mean_us += t;
+    mean_us /= linsys_times.empty() ? 1 : linsys_times.size();
+    // the first control step starts from the perturbed plan (violation v0); later steps from a shifted, already feasible one
+    const bool ok = steps_done == control_steps && linsys_times.size() == (size_t)(control_steps * st.sqp_max_iter) && std::isfinite(viol_after.back()) &&
+                    viol_after[0] < v0 && viol_after[1] < v0 && viol_after.back() < 0.8 * v0 && std::isfinite((double)tracking.back());
+    printf("{\"linsys_solve\": %d, \"window\": \"reference trajectory 0_0, rows %d..%d, N = %d\", \"kkt_stage\": \"mpcg_generate_kkt (library default)\", "
+           "\"control_steps\": %d, \"linsolves\": %zu, \"mean_linsys_us\": %.1f, \"violation_start\": %.3e, \"violation_after_step\": [",
+           LINSYS_SOLVE, 0, t0 + N - 1, N, steps_done, linsys_times.size(), mean_us, v0);
+    for (size_t i = 0; i < viol_after.size(); ++i) printf("%s%.3e", i ? ", " : "", viol_after[i]);
+    printf("], \"state_error_last\": %.4f, \"ok\": %s}\n", (double)tracking.back(), ok ? "true" : "false");
+    mpcg_plant_destroy(plant);
+    return ok ? 0 : 1;
+}

@@ -35,6 +35,9 @@ struct sqp_stages {
     // done when the reference trajectory is exhausted.
     std::function<T(uint32_t state_size, uint32_t control_size, uint32_t knot_points, T* d_xs, T* d_xu, T* d_lambda,
                     T* d_eePos_goal, double sqp_solve_time_us, bool& done)> simulate_and_shift;
+    // d_dynMem_const of the reference (gato_plant::initializeDynamicsConstMem<T>(), include/mpcsim.cuh:194): handed to every SQP call by
+    // simulateMPC and on to the generate_kkt stage.  With the library's own stage (use_mpcg_generate_kkt below) it is an mpcg_plant*.
+    void* dynmem = nullptr;
     uint32_t sqp_max_iter = 20;          // SQP_MAX_ITER with TIME_LINSYS (include/common/settings.cuh:152-158)
     // The SQP time box (include/common/settings.cuh:56-58 CONST_UPDATE_FREQ = 1, :161-163 SQP_MAX_TIME_US = 2000): with
     // const_update_freq the loop is left as soon as sqpTimecheck() — wall time since the start of the call, allocation included,
@@ -48,6 +51,24 @@ inline sqp_stages<T>& stages() {
     static sqp_stages<T> s;
     return s;
 }
+
+// The library's own generate_kkt_submatrices (mpcg_generate_kkt: IIWA-14 dynamics, tracking cost, Euler integrator on the device) as the
+// generate_kkt stage — the default when an mpcg_plant is supplied; merit function / line search and the plant simulation stay plug points.
+// qd_cost / r_cost: QD_COST / R_COST of include/common/settings.cuh:84-94.  Needs gbd_pcg_compat/gpu_pcg.cuh (handle cache) before this header.
+#ifdef MPCG_H
+template <typename T>
+inline void use_mpcg_generate_kkt(mpcg_plant* plant, float qd_cost, float r_cost) {
+    auto& st = stages<T>();
+    st.dynmem = plant;
+    st.generate_kkt = [qd_cost, r_cost](uint32_t state_size, uint32_t control_size, uint32_t knot_points, T* d_G_dense, T* d_C_dense, T* d_g, T* d_c,
+                                         void* d_dynMem_const, float timestep, T* d_eePos_traj, T* d_xs, T* d_xu) {
+        mpcg_handle* h = mpcg_compat::handle_for(state_size, knot_points);
+        if (mpcg_generate_kkt(h, static_cast<const mpcg_plant*>(d_dynMem_const), control_size, timestep, d_eePos_traj, d_xs, d_xu, qd_cost, r_cost,
+                              d_G_dense, d_C_dense, d_g, d_c, 1, /*stream*/ nullptr) != MPCG_OK)
+            mpcg_compat::die("generate_kkt_submatrices", h);
+    };
+}
+#endif
 
 inline void require_stage(bool present, const char* which) {
     if (!present) {

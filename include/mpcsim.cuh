@@ -57,7 +57,7 @@ std::tuple<std::vector<toplevel_return_type>, std::vector<linsys_t>, linsys_t> s
     gpuErrchk(hipMemset(d_lambda, 0, state_size * knot_points * sizeof(T)));
     gpuErrchk(hipMemcpy(d_eePos_goal, d_eePos_traj, 6 * knot_points * sizeof(T), hipMemcpyDeviceToDevice));
     gpuErrchk(hipMemcpy(d_xu, d_xu_traj, traj_len * sizeof(T), hipMemcpyDeviceToDevice));
-    void* d_dynmem = nullptr;      // gato_plant::initializeDynamicsConstMem<T>() in the reference: owned by the registered stages here
+    void* d_dynmem = st.dynmem;    // gato_plant::initializeDynamicsConstMem<T>() in the reference (:194): the registered stages' model (an mpcg_plant* with the library's own generate_kkt stage)
 
     T rho = 1e-3, rho_reset = 1e-3;                                                  // (:219)
 #if LINSYS_SOLVE == 1

@@ -50,6 +50,7 @@ SYMBOLS = {
     "mpcg_block_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "mpcg_plant_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "mpcg_plant_create_iiwa14": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "mpcg_plant_destroy": (C.c_int, [C.c_void_p]),
     "mpcg_generate_kkt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libmpcg_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "mpcg_capi.hip")]
-DEPS = SOURCES + [os.path.join(_HERE, "csrc", f) for f in ("pcg_kernels.hip.h", "pcg_lpb.hip.h", "pcg_lpk.hip.h", "pcg_lpb_cluster.hip.h", "pcg_rpl.hip.h", "schur_kernels.hip.h", "schur_dpp.hip.h", "block_solve.hip.h", "pcg_f64.hip.h", "ldl_host.hpp", "kkt_plant.hip.h")] + [
+DEPS = SOURCES + [os.path.join(_HERE, "csrc", f) for f in ("pcg_kernels.hip.h", "pcg_lpb.hip.h", "pcg_lpk.hip.h", "pcg_lpb_cluster.hip.h", "pcg_rpl.hip.h", "schur_kernels.hip.h", "schur_dpp.hip.h", "block_solve.hip.h", "pcg_f64.hip.h", "ldl_host.hpp", "kkt_plant.hip.h", "iiwa14_model.inc")] + [
     os.path.join(_ROOT, "include", "mpcg.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -100,6 +100,25 @@ def build_mpcsim_demo(force: bool = False, verbose: bool = False):
     return DEMO_BINS
 
 
+IIWA_DEMO_SRC = os.path.join(_ROOT, "examples", "mpcsim_iiwa_demo.cpp")
+IIWA_DEMO_BINS = {1: os.path.join(_ROOT, "examples", "mpcsim_iiwa_demo_pcg"), 0: os.path.join(_ROOT, "examples", "mpcsim_iiwa_demo_qdldl")}
+
+
+def build_iiwa_demo(force: bool = False, verbose: bool = False):
+    """simulateMPC over the shim headers on a real window of the reference trajectory, KKT stage = the library's mpcg_generate_kkt;
+    -DLINSYS_SOLVE=1 and =0."""
+    inc = os.path.join(_ROOT, "include")
+    deps = [IIWA_DEMO_SRC, LIB_PATH] + [os.path.join(inc, f) for f in ("mpcsim.cuh", "pcg/sqp.cuh", "qdldl/sqp.cuh", "mpcgpu_compat/sqp_stages.cuh")]
+    for sel, exe in IIWA_DEMO_BINS.items():
+        if force or not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", f"-DLINSYS_SOLVE={sel}", "-I" + inc, IIWA_DEMO_SRC, "-L" + _HERE, "-lmpcg_hip",
+                   "-Wl,-rpath,$ORIGIN/../mpcgpu_amd", "-o", exe]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    return IIWA_DEMO_BINS
+
+
 MULTI_SRC = os.path.join(_ROOT, "examples", "multi_gpu_pcg.cpp")
 MULTI_BIN = os.path.join(_ROOT, "examples", "multi_gpu_pcg")
 
@@ -138,3 +157,4 @@ if __name__ == "__main__":
     print(build_mpcsim_demo(force="--force" in sys.argv, verbose=True))
     print(build_utils_probe(force="--force" in sys.argv, verbose=True))
     print(build_multi_gpu(force="--force" in sys.argv, verbose=True))
+    print(build_iiwa_demo(force="--force" in sys.argv, verbose=True))

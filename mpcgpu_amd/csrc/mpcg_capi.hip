@@ -1210,6 +1210,15 @@ int mpcg_plant_create(mpcg_plant** out, int device, uint32_t num_joints, const d
     return MPCG_OK;
 }
 
+// The KUKA LBR iiwa 14 the reference is built for, from the tables compiled into the library (csrc/iiwa14_model.inc): what
+// gato_plant::initializeDynamicsConstMem<T>() returns in the reference (include/dynamics/iiwa/iiwa_eepos_plant.cuh:63-66).
+#include "iiwa14_model.inc"
+int mpcg_plant_create_iiwa14(mpcg_plant** out, int device) {
+    return mpcg_plant_create(out, device, 7, kIiwa14_X_const, kIiwa14_I, kIiwa14_Xhom_const, kIiwa14_X_trig_idx, kIiwa14_X_trig_coef, kIiwa14_X_trig_j,
+                             (uint32_t)(sizeof(kIiwa14_X_trig_idx) / sizeof(int32_t)), kIiwa14_Xhom_trig_idx, kIiwa14_Xhom_trig_coef, kIiwa14_Xhom_trig_j,
+                             (uint32_t)(sizeof(kIiwa14_Xhom_trig_idx) / sizeof(int32_t)));
+}
+
 int mpcg_plant_destroy(mpcg_plant* p) {
     if (p && p->d) { (void)hipSetDevice(p->device); (void)hipFree(p->d); }
     delete p;

@@ -116,11 +116,11 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
     const bool hasL = !isP || p3;                          // wave-uniform: block-Jacobi has no off-diagonal Pinv blocks
     const bool valid = k < N;
     // float indices inside a vector (add the vector's offset; K2 = floats between consecutive row pairs):
-    //   register slots 0..2 -> pairs 4h + s: bA + K2 s | slot 3 -> pair 3: b0 + 3 K2 | slots 4..6 -> pairs 4 (1 - h) + s - 4: bB + K2 (s - 4)
+    //   register slots 0..2 -> pairs 4h + s: bA + K2 s | slot 3 -> pair 3: b0 + 3 K2   (slots 4..6 = the partner lane's pairs: by DPP, never from LDS)
     //   knot k - 1: subtract 2; knot k + 1: add 2
     constexpr int KN = L::KN, K2 = 2 * KN;
     const int b0 = 2 * (k + 1);
-    const int bA = b0 + (h ? 4 * K2 : 0), bB = b0 + (h ? 0 : 4 * K2);
+    const int bA = b0 + (h ? 4 * K2 : 0);
 
     // ---- matrix registers: seven columns of D_k and L_k (lane 0: columns 0..6; lane 1: 8..13, 7), row pairs in this lane's slot order ----
     f2 Md[7][7], Ml[7][7];                                 // [slot][j]

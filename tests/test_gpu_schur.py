@@ -304,3 +304,22 @@ def test_qdldl_twin_on_device_buffers(orc):
         assert relinf(lam.cpu().numpy(), exact) < 5e-2                    # float LDL^T at cond ~1e5
         assert relinf(lam_gpu[b].cpu().numpy(), exact) < 5e-2                  # fp32 block elimination, same conditioning
         np.testing.assert_array_equal(lam.cpu().numpy(), q.solve_host(val[b].cpu().numpy(), gam[b].cpu().numpy()))
+
+
+def test_mpcsim_on_a_real_trajectory_window_with_the_library_kkt_stage():
+    """examples/mpcsim_iiwa_demo.cpp: simulateMPC -> sqpSolvePcg | sqpSolveQdldl over the shim headers on rows 0.. of the reference's
+    0_0 trajectory, the KKT stage being the library's own mpcg_generate_kkt (mpcgpu_compat::use_mpcg_generate_kkt with
+    mpcg_plant_create_iiwa14); full steps stand in for the merit-function line search.  The constraint violation of the perturbed
+    start must come down over three control steps, with both linear-system solvers."""
+    import json
+    import os
+    import subprocess
+    from mpcgpu_amd import build
+    bins = build.IIWA_DEMO_BINS if all(os.path.exists(p) for p in build.IIWA_DEMO_BINS.values()) else build.build_iiwa_demo()
+    outs = {}
+    for sel, exe in bins.items():
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, (sel, r.stdout + r.stderr)
+        o = outs[sel] = json.loads(r.stdout.strip().splitlines()[-1])
+        assert o["ok"] is True and o["linsys_solve"] == sel and o["control_steps"] == 3 and o["linsolves"] == 12
+        assert o["violation_start"] > 1e-2 and max(o["violation_after_step"]) < o["violation_start"] and o["violation_after_step"][-1] < 0.8 * o["violation_start"]
