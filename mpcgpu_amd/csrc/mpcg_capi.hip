@@ -11,6 +11,7 @@
 #include "pcg_kernels.hip.h"
 #include "pcg_lpb.hip.h"
 #include "pcg_lpk.hip.h"
+#include "pcg_lpk_cluster.hip.h"
 #include "pcg_lpb_cluster.hip.h"
 #include "pcg_rpl.hip.h"
 #include "schur_kernels.hip.h"
@@ -36,7 +37,7 @@ struct PcgKnobs {
 };
 
 // What the last solve on this handle actually launched (read-only "last_kernel_*" options; tests assert on it).
-enum { FAM_NONE = -1, FAM_TRAJ = 0, FAM_CLUSTER = 1, FAM_LPB = 2, FAM_GENERIC = 3, FAM_LPBC = 4, FAM_RPL = 5, FAM_LPK = 6 };
+enum { FAM_NONE = -1, FAM_TRAJ = 0, FAM_CLUSTER = 1, FAM_LPB = 2, FAM_GENERIC = 3, FAM_LPBC = 4, FAM_RPL = 5, FAM_LPK = 6, FAM_LPKC = 7 };
 struct LastKernel { int family = FAM_NONE, waves = 0, reg_rows = 0, lds_rows = 0, stream_bufs = 0, cluster = 0, lds_bytes = 0, lds_extra = 0; };
 
 struct mpcg_handle {
@@ -56,6 +57,7 @@ struct mpcg_handle {
     int cluster_adj = 1;      // lane order of the cluster kernel (1: blocks of a row in adjacent lanes)
     int cluster = -1;         // workgroups per trajectory for the cluster kernel: 0 off, -1 auto, G > 0 forced
     int cluster_lpb = -1;     // clustered lane-per-block kernel (pcg_lpb_cluster.hip.h) instead of the row-triple cluster kernel: -1 auto (on), 0 off, 1 on
+    int cluster_lpk = -1;     // clustered lane-PAIR kernel (pcg_lpk_cluster.hip.h) where the clustered lane-per-block kernel would run: -1 auto (on), 0 off, 1 on
     int cluster_l2 = 1;       // clustered lane-per-block kernel: 1 = L2-resident hand-offs when a cluster's members share an XCD, 0 = always write-through
     int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
     int check_symmetry = 0;   // debug: 1 = every solve that would run a lower-triangle kernel first verifies block symmetry of S and Pinv (synchronises)
@@ -235,6 +237,10 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "cluster_fixup")) { h->cluster_fixup = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_l2")) { h->cluster_l2 = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "check_symmetry")) { h->check_symmetry = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "cluster_lpk")) {
+        if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "cluster_lpk must be -1 (auto), 0 or 1");
+        h->cluster_lpk = value; return MPCG_OK;
+    }
     if (!strcmp(key, "cluster_lpb")) {
         if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "cluster_lpb must be -1 (auto), 0 or 1");
         h->cluster_lpb = value; return MPCG_OK;
@@ -269,6 +275,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "cluster_lpb")) { *value = h->cluster_lpb; return MPCG_OK; }
     if (!strcmp(key, "cluster_l2")) { *value = h->cluster_l2; return MPCG_OK; }
     if (!strcmp(key, "check_symmetry")) { *value = h->check_symmetry; return MPCG_OK; }
+    if (!strcmp(key, "cluster_lpk")) { *value = h->cluster_lpk; return MPCG_OK; }
     if (!strcmp(key, "last_symmetry_violations")) { *value = h->last_sym_violations; return MPCG_OK; }
     if (!strcmp(key, "schur_dpp")) { *value = h->schur_dpp; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
@@ -626,7 +633,7 @@ static int lpbc_members(const mpcg_handle* h, int nmax) {
 }
 // scratch of the clustered lane-per-block kernel: [queue: one 128-byte line][flags: one line per trajectory of the call = members that
 // finished it][cells: 1 KB per member of the launch] — what a call uses is contiguous, so one small fill precedes every launch
-template <int NWR>
+template <int NWR, bool LPK>
 static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
     constexpr int per_cu = NWR == 2 ? 1 : 2;
     const int G = lpbc_members(h, 64 * NWR);
@@ -638,8 +645,9 @@ static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, h
     const int xcd_slots = per_cu * (h->num_cus / 8);
     const uint32_t resident = h->num_cus >= 8 && xcd_slots >= G ? (uint32_t)(8 * (xcd_slots / G)) : (uint32_t)(per_cu * h->num_cus / G);
     const uint32_t clusters = batch < resident ? batch : resident;
-    const size_t lds = pcg_lpbc_lds_floats(4 * NWR) * sizeof(float);
-    auto kern = pcg_lpbc_kernel<NWR>;
+    const size_t lds = (LPK ? pcg_lpkc_lds_floats(4 * NWR) : pcg_lpbc_lds_floats(4 * NWR)) * sizeof(float);
+    void (*kern)(ClusterArgs);
+    if constexpr (LPK) kern = pcg_lpkc_kernel<NWR>; else kern = pcg_lpbc_kernel<NWR>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PcgKnobs kf = h->k;
@@ -670,17 +678,18 @@ static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, h
         const int rc = h->N <= kLpbMaxN ? launch_lpb(h, c, batch, st) : launch_traj(h, kf, c, batch, st, 4, /*record=*/false);
         if (rc != MPCG_OK) return rc;
     }
-    h->last = LastKernel{FAM_LPBC, 4 * NWR, 0, 0, 0, G, (int)lds, 0};
+    h->last = LastKernel{LPK ? FAM_LPKC : FAM_LPBC, 4 * NWR, 0, 0, 0, G, (int)lds, 0};
     return MPCG_OK;
 }
 static int try_launch_lpbc(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
     if (h->cluster_lpb == 0) return 1;
-    if (h->cluster <= 0 && h->N <= kLpbMaxN) return 1;   // one CU holds it: pcg_lpb_kernel
+    if (h->cluster <= 0 && h->N <= kLpbMaxN) return 1;   // one CU holds it: pcg_lpk_kernel / pcg_lpb_kernel
+    const bool lpk = h->cluster_lpk != 0;                // round 3: the lane-pair arithmetic inside the same hand-off machinery
     if (h->cluster_waves == 4) {
-        const int rc = try_launch_lpbc_t<1>(h, a, batch, st);
+        const int rc = lpk ? try_launch_lpbc_t<1, true>(h, a, batch, st) : try_launch_lpbc_t<1, false>(h, a, batch, st);
         if (rc != 1) return rc;
     }
-    return try_launch_lpbc_t<2>(h, a, batch, st);
+    return lpk ? try_launch_lpbc_t<2, true>(h, a, batch, st) : try_launch_lpbc_t<2, false>(h, a, batch, st);
 }
 
 static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
@@ -809,7 +818,7 @@ static size_t default_launch_lds_bytes(uint32_t N, int num_cus) {
     }
     mpcg_handle tmp;
     tmp.N = N; tmp.n = NS; tmp.num_cus = num_cus;
-    if (lpbc_members(&tmp, 128) > 0) return pcg_lpbc_lds_floats(8) * sizeof(float);      // clustered lane-per-block kernel
+    if (lpbc_members(&tmp, 128) > 0) return pcg_lpkc_lds_floats(8) * sizeof(float);      // clustered lane-pair kernel
     const int ntr = ((int)N + 2) / 3;
     const int G = (ntr + 23) / 24;                       // 8-wave cluster members, 3 register triples per wave and matrix
     if (G >= 2 && G <= num_cus) {

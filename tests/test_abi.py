@@ -51,9 +51,9 @@ def test_version_and_lds_size(hiplib):
         assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (6 * r4((N + 2) * 14) + r4(2 * (4 if N <= 16 else 8)))
     for N in (65, 128):
         assert hiplib.mpcg_pcg_lds_bytes(14, N) == lpk(128, 8) == 64064
-    # N > 128: a member of the clustered lane-per-block kernel — six vectors of 128 + 2 knot slots, partials, broadcast cell, hand-off tables (§3.1d)
+    # N > 128: a member of the clustered lane-pair kernel — the same seven vectors, broadcast cell, hand-off tables (5 x 64), parked pairs (§3.1g)
     for N in (129, 256, 512):
-        assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (6 * r4(130 * 14) + r4(16) + 4 + 3 * 64) == 44528
+        assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (7 * 7 * 132 * 2 + 4 + 5 * 64 + 3 * 2 * 8 * 64) == 65328
     assert hiplib.mpcg_pcg_lds_bytes_f64(14, 32) == 8 * (6 * r4((32 + 2) * 14) + 16)          # N <= 32: the row-per-lane kernel in double
     assert hiplib.mpcg_pcg_lds_bytes_f64(14, 64) == 8 * ((64 + 2) * 14 * 2 + 64 * 14 * 2 + 8)   # beyond: the generic streaming kernel
     assert hiplib.mpcg_pcg_lds_bytes(12, 128) == 4 * (2 * 130 * 12 + 2 * 128 * 12 + 8)   # n != 14: the generic kernel's vectors

@@ -20,7 +20,7 @@ def dev(a):
 @pytest.mark.parametrize("N,G,B", [(128, 2, 3), (200, 3, 2), (256, 4, 2), (512, 8, 2), (512, 16, 1), (64, 2, 1),
                                    (512, -411, 40), (256, -406, 70)])      # G < 0: 4-wave members, -(400 + G), two per CU
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
-@pytest.mark.parametrize("lpbc", [1, 0])       # 1: clustered lane-per-block kernel (family 4), 0: row-triple cluster kernel (family 1)
+@pytest.mark.parametrize("lpbc", [1, 0])       # 1: clustered register-resident kernel (round 3: lane-pair, family 7), 0: row-triple cluster kernel (family 1)
 def test_cluster_matches_oracle_and_single_workgroup(orc, N, G, B, pc, lpbc):
     from mpcgpu_amd import PcgSolver, pcg_config
     waves4 = G < 0
@@ -43,7 +43,7 @@ def test_cluster_matches_oracle_and_single_workgroup(orc, N, G, B, pc, lpbc):
             out[(mode, K)] = (lam.cpu().numpy(), it.cpu().numpy().astype(np.int64), ex.cpu().numpy())
             if mode == "cluster":                      # the kernel under test really ran
                 # (the clustered lane-per-block kernel takes up to 8 members; beyond, the row-triple cluster kernel runs)
-                assert sol.get_option("last_kernel_family") == (4 if lpbc and G <= 8 else 1) and sol.get_option("last_kernel_cluster") == G
+                assert sol.get_option("last_kernel_family") == (7 if lpbc and G <= 8 else 1) and sol.get_option("last_kernel_cluster") == G
                 assert sol.get_option("last_kernel_waves") == (4 if waves4 else 8)
         if mode == "cluster":      # deterministic: bitwise identical on a second run
             lam = dev(lam0)

@@ -275,7 +275,7 @@ def test_cluster_falls_back_when_peers_are_not_resident(P, orc):
     with torch.cuda.stream(s2):
         it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
     torch.cuda.synchronize()
-    assert sol.get_option("last_kernel_family") == 4 and sol.get_option("last_kernel_cluster") == 2
+    assert sol.get_option("last_kernel_family") == 7 and sol.get_option("last_kernel_cluster") == 2
     assert int(it.item()) == K and int(ex.item()) == 1, (it, ex)
     Sz, Pz = np.nan_to_num(S[0]), np.nan_to_num(Pinv[0])
     r64 = orc.pcg(Sz.astype(np.float64), Pz.astype(np.float64), g[0].astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")

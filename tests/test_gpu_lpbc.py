@@ -1,5 +1,6 @@
-"""GPU: the clustered lane-per-block kernel (pcg_lpb_cluster.hip.h), the default for fp32 horizons beyond 128 knots:
-G = ceil(N / 128) workgroups per trajectory, one hand-off per matrix pass.  tests/test_gpu_cluster.py runs it with forced
+"""GPU: the clustered register-resident kernels for fp32 horizons beyond 128 knots — round 3's clustered lane-PAIR kernel
+(pcg_lpk_cluster.hip.h, the default: family 7) and round 2's clustered lane-per-block kernel (pcg_lpb_cluster.hip.h, "cluster_lpk" = 0:
+family 4), every test on both: G = ceil(N / 128) workgroups per trajectory, one hand-off per matrix pass.  tests/test_gpu_cluster.py runs it with forced
 member counts next to the row-triple cluster kernel; here: the automatic policy on ragged horizons, batches that need several
 launches, determinism and batch-composition independence."""
 import numpy as np
@@ -17,10 +18,16 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+@pytest.fixture(params=["lpkc", "lpbc"])
+def kern(request):
+    """(value of the "cluster_lpk" option, expected "last_kernel_family")"""
+    return (-1, 7) if request.param == "lpkc" else (0, 4)
+
+
 @pytest.mark.parametrize("N", [129, 131, 255, 257, 300, 512, 640])
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
 @pytest.mark.parametrize("l2", [1, 0])
-def test_auto_policy_ragged_horizons_vs_oracle(orc, N, pc, l2):
+def test_auto_policy_ragged_horizons_vs_oracle(orc, kern, N, pc, l2):
     """Default handle, no knobs: N > 128 runs family 4 with G = ceil(N / 128) members of floor/ceil(N / G) knots."""
     from mpcgpu_amd import PcgSolver, pcg_config
     B = 2
@@ -28,14 +35,15 @@ def test_auto_policy_ragged_horizons_vs_oracle(orc, N, pc, l2):
     S, Pinv, g = synth.form_schur(k, poison_unused=True)
     lam0 = np.random.default_rng(N).normal(0, 0.2, (B, n * N)).astype(np.float32)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("cluster_lpk", kern[0])
     sol.set_option("cluster_l2", l2)               # 1 (default): L2-resident hand-offs inside an XCD; 0: write-through hand-offs
     dS, dP, dg = dev(S), dev(Pinv), dev(g)
     for K in (2, 25):
         lam = dev(lam0)
         it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), pc)
         torch.cuda.synchronize()
-        assert sol.get_option("last_kernel_family") == 4 and sol.get_option("last_kernel_cluster") == (N + 127) // 128
-        assert sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes(14, N)
+        assert sol.get_option("last_kernel_family") == kern[1] and sol.get_option("last_kernel_cluster") == (N + 127) // 128
+        assert kern[1] != 7 or sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes(14, N)
         assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all()
         for t in range(B):
             Sz, Pz = np.nan_to_num(S[t]), np.nan_to_num(Pinv[t])
@@ -44,7 +52,7 @@ def test_auto_policy_ragged_horizons_vs_oracle(orc, N, pc, l2):
             assert relinf(lam.cpu().numpy()[t], r64["lam"]) <= max(2e-5 if K == 2 else 1e-3, 4 * band)
 
 
-def test_full_batch_in_several_launches_is_deterministic_and_composition_independent(orc):
+def test_full_batch_in_several_launches_is_deterministic_and_composition_independent(orc, kern):
     """N = 256, 300 trajectories: 128 clusters fit the chip, so the call is three launches (128 + 128 + 44), each followed by its
     fix-up launch.  Same answer twice, the same answer for a sub-batch, tolerance exits and counts like the CPU restatement."""
     from mpcgpu_amd import PcgSolver, pcg_config
@@ -53,6 +61,7 @@ def test_full_batch_in_several_launches_is_deterministic_and_composition_indepen
     S, Pinv, g = synth.form_schur(k, poison_unused=True)
     dS, dP, dg = dev(S), dev(Pinv), dev(g)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("cluster_lpk", kern[0])
     cfg = pcg_config(pcg_exit_tol=1e-4, pcg_max_iter=60)
     runs = []
     for _ in range(2):
@@ -60,7 +69,7 @@ def test_full_batch_in_several_launches_is_deterministic_and_composition_indepen
         it, ex = sol.solve(dS, dP, dg, lam, cfg, "ss")
         torch.cuda.synchronize()
         runs.append((lam.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy()))
-    assert sol.get_option("last_kernel_family") == 4 and sol.get_option("last_kernel_cluster") == 2
+    assert sol.get_option("last_kernel_family") == kern[1] and sol.get_option("last_kernel_cluster") == 2
     np.testing.assert_array_equal(runs[0][0], runs[1][0])
     np.testing.assert_array_equal(runs[0][1], runs[1][1])
     assert (runs[0][2] <= 1).all() and (runs[0][1] <= 60).all()          # no cluster gave up (flag 2 / 0xFFFFFFFF)
@@ -77,18 +86,19 @@ def test_full_batch_in_several_launches_is_deterministic_and_composition_indepen
         assert rel_residual(S[t], g[t], runs[0][0][t], N) <= 2 * rel_residual(S[t], g[t], r32["lam"], N) + 1e-6
 
 
-def test_warm_start_and_zero_iterations():
+def test_warm_start_and_zero_iterations(kern):
     """lambda in/out: a second call starting from the converged lambda exits at once with 0 iterations and leaves lambda alone."""
     from mpcgpu_amd import PcgSolver, pcg_config
     N, B = 384, 3
     k = synth.make_kkt(N, B, 5)
     S, Pinv, g = synth.form_schur(k)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("cluster_lpk", kern[0])
     dS, dP, dg = dev(S), dev(Pinv), dev(g)
     lam = torch.zeros(B, n * N, device="cuda")
     it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=1e-2, pcg_max_iter=2000), "ss")
     torch.cuda.synchronize()
-    assert sol.get_option("last_kernel_family") == 4 and (ex.cpu().numpy() == 0).all() and (it.cpu().numpy() > 0).all()
+    assert sol.get_option("last_kernel_family") == kern[1] and (ex.cpu().numpy() == 0).all() and (it.cpu().numpy() > 0).all()
     before = lam.clone()
     it2, ex2 = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=1e-2, pcg_max_iter=2000), "ss")
     torch.cuda.synchronize()
@@ -96,7 +106,7 @@ def test_warm_start_and_zero_iterations():
     assert torch.equal(lam, before)
 
 
-def test_options_round_trip_and_selection():
+def test_options_round_trip_and_selection(kern):
     """cluster_lpb: -1 auto (on) / 0 (row-triple cluster kernel) / 1; invalid values are refused and leave the handle usable."""
     from mpcgpu_amd import PcgSolver, pcg_config
     from mpcgpu_amd._lib import MpcgError
@@ -104,6 +114,8 @@ def test_options_round_trip_and_selection():
     k = synth.make_kkt(N, 1, 2)
     S, Pinv, g = synth.form_schur(k)
     sol = PcgSolver(N, max_batch=1)
+    assert sol.get_option("cluster_lpk") == -1
+    sol.set_option("cluster_lpk", kern[0])
     assert sol.get_option("cluster_lpb") == -1 and sol.get_option("cluster_fixup") == 1
     with pytest.raises(MpcgError):
         sol.set_option("cluster_lpb", 2)
@@ -115,7 +127,7 @@ def test_options_round_trip_and_selection():
         it, ex = sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=7), "ss")
         torch.cuda.synchronize()
         fam[v] = (sol.get_option("last_kernel_family"), int(it.item()), lam.cpu().numpy())
-    assert fam[-1][0] == 4 and fam[1][0] == 4 and fam[0][0] == 1 and all(f[1] == 7 for f in fam.values())
+    assert fam[-1][0] == kern[1] and fam[1][0] == kern[1] and fam[0][0] == 1 and all(f[1] == 7 for f in fam.values())
     np.testing.assert_array_equal(fam[-1][2], fam[1][2])
     # hand-offs through the XCD's L2 (default, when the members of a cluster share an XCD) or write-through: same arithmetic, same bits
     assert sol.get_option("cluster_l2") == 1
@@ -123,6 +135,6 @@ def test_options_round_trip_and_selection():
     lam = torch.zeros(1, n * N, device="cuda")
     sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=7), "ss")
     torch.cuda.synchronize()
-    assert sol.get_option("last_kernel_family") == 4
+    assert sol.get_option("last_kernel_family") == kern[1]
     np.testing.assert_array_equal(lam.cpu().numpy(), fam[1][2])
     assert relinf(fam[0][2][0], fam[1][2][0]) <= 2e-3          # two kernels, same PCG, 7 iterations: fp32 round-off of the products and inner products
