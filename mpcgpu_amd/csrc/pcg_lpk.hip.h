@@ -222,13 +222,13 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
         o.v[3] = *reinterpret_cast<const f2*>(x + b0 + 3 * K2);
         return o;
     };
+    // (no `k < N` predicate: a lane beyond the horizon holds all-zero blocks — its products, its z and its copies of the vectors are exact
+    //  zeros, and its knot slots exist (NMAX + 4 of them) — so it may write them; three exec-mask branches less per half-iteration)
     auto store_own = [&](int X, const Own& o) {
-        if (valid) {
-            float* x = lds + X;
+        float* x = lds + X;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) *reinterpret_cast<f2*>(x + bA + K2 * s) = o.v[s];
-            *reinterpret_cast<f2*>(x + b0 + 3 * K2) = o.v[3];
-        }
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<f2*>(x + bA + K2 * s) = o.v[s];
+        *reinterpret_cast<f2*>(x + b0 + 3 * K2) = o.v[3];
     };
 
     // The operand loads of a half-iteration, requested as soon as the barrier in front of it is passed — BEFORE the scalar of the update
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
                 z6 = t[2].x + t[2].y;
             }
             const float xm6 = h ? om.v[3].y : om.v[3].x;        // x_{k-1} at this lane's seventh column (entry 6 + h)
-            if (valid) {                                         // z belongs to knot k-1's vector: entries of this lane's columns
+            {                                                    // z belongs to knot k-1's vector: entries of this lane's columns
                 float* zo = lds + ZOUT;
 #pragma unroll
                 for (int s = 0; s < 3; ++s) *reinterpret_cast<f2*>(zo + bA + K2 * s) = z2[s];
