@@ -888,10 +888,33 @@ int mpcg_check_pcg_occupancy(mpcg_handle* h, uint32_t* resident_trajectories) {
         auto kern = pcg_generic_kernel<float, 0>;
         if (lds > 48 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, F64_THREADS, lds));
+    } else if (use_rpl(h, 4, h->max_batch)) {
+        // mirrors launch_pcg for a throughput-sized call (batch = max_batch): the row-per-lane kernel in the shape that call would take
+        int nw, rho;
+        rpl_shape(h, h->max_batch, &nw, &rho);
+        const size_t lds = pcg_rpl_lds_floats((int)h->N, nw) * sizeof(float);
+#define X(NW_, RHO_) if (nw == NW_ && rho == RHO_) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_rpl_kernel<NW_, RHO_, true>, NW_ * 64, lds));
+        MPCG_RPL_VARIANTS(X)
+#undef X
     } else if (use_lpb(h, 4)) {
-        const size_t lds = pcg_lpb_lds_floats((int)h->N, h->N <= 64 ? 4 : 8) * sizeof(float);
-        if (h->N <= 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpb_kernel<1>, 256, lds));
-        else HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpb_kernel<2>, 512, lds));
+        if (prefer_lpk(h)) {
+            const size_t lds = pcg_lpk_lds_floats(h->N <= 64 ? 4 : 8) * sizeof(float);
+            if (h->N <= 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpk_kernel<1>, 256, lds));
+            else {
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_lpk_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpk_kernel<2>, 512, lds));
+            }
+        } else {
+            const size_t lds = pcg_lpb_lds_floats((int)h->N, h->N <= 64 ? 4 : 8) * sizeof(float);
+            if (h->N <= 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpb_kernel<1>, 256, lds));
+            else HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpb_kernel<2>, 512, lds));
+        }
+    } else if (h->auto_cfg && h->cluster != 0 && h->cluster_lpb != 0 && h->N > kLpbMaxN && lpbc_members(h, 128) > 0) {
+        // clustered kernels: resident CLUSTERS (= trajectories in flight), sized per XCD as try_launch_lpbc_t does
+        const int G = lpbc_members(h, 128);
+        const int xcd_slots = h->num_cus / 8;
+        *resident_trajectories = h->num_cus >= 8 && xcd_slots >= G ? (uint32_t)(8 * (xcd_slots / G)) : (uint32_t)(h->num_cus / G);
+        return MPCG_OK;
     } else {
         PcgKnobs k = h->k;
         if (h->auto_cfg) choose_auto(h, k, h->max_batch, 4);

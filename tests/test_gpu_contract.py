@@ -112,3 +112,51 @@ def test_fixup_counter_counts_abandoned_trajectories():
     assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all() and np.isfinite(lam.cpu().numpy()).all()
     if fixed == 0:       # the clusters found their CUs anyway: same bits as the undisturbed solve
         assert torch.equal(lam, lam_ref)
+
+
+def test_check_pcg_occupancy_mirrors_the_launch_policy():
+    """checkPcgOccupancy (reference examples/track_iiwa_pcg.cu:24) reports the residency of the kernel a throughput-sized call really
+    launches: row-per-lane kernel for N <= 32, lane-pair kernel up to 128 (one workgroup per CU at N > 64, two below),
+    clusters per XCD beyond."""
+    from mpcgpu_amd import PcgSolver
+    ncu = PcgSolver(32, max_batch=1).get_option("num_cus")
+    assert PcgSolver(32, max_batch=4096).checkPcgOccupancy() >= 2 * ncu          # 4 waves x 2 slots: at least two workgroups per CU
+    assert PcgSolver(128, max_batch=1024).checkPcgOccupancy() == ncu             # 8 waves x 254 registers: one trajectory per CU
+    assert PcgSolver(64, max_batch=2048).checkPcgOccupancy() == 2 * ncu
+    assert PcgSolver(256, max_batch=1024).checkPcgOccupancy() == ncu // 2        # 2-member clusters
+    assert PcgSolver(384, max_batch=1024).checkPcgOccupancy() == 8 * ((ncu // 8) // 3)
+    assert PcgSolver(512, max_batch=1024).checkPcgOccupancy() == ncu // 4
+
+
+@pytest.mark.parametrize("N", [32, 64])
+def test_kernel_family_depends_on_batch_and_can_be_pinned(orc, N):
+    """include/mpcg.h: which family serves a call depends on knot_points AND batch; families sum the inner products in different orders, so a
+    trajectory solved alone and inside a large batch agrees to the fp32 band, not bit for bit — unless the family is pinned."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    K, Bbig = 25, 600
+    k = synth.make_kkt(N, 4, 77 + N)
+    S, Pinv, g = synth.form_schur(k, precond="ss")
+    rep = Bbig // 4
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+
+    def run(B, opts):
+        sol = PcgSolver(N, max_batch=B)
+        for k_, v_ in opts.items():
+            sol.set_option(k_, v_)
+        lam = torch.zeros(B, n * N, device="cuda")
+        r = B // 4
+        sol.solve(dev(np.tile(S, (r, 1))), dev(np.tile(Pinv, (r, 1))), dev(np.tile(g, (r, 1))), lam, cfg, "ss")
+        torch.cuda.synchronize()
+        return lam.cpu().numpy()[:4], sol.get_option("last_kernel_family"), sol.get_option("last_kernel_waves")
+    small, fam_s, w_s = run(4, {})
+    big, fam_b, w_b = run(Bbig, {})
+    assert (fam_s, w_s) != (fam_b, w_b)                    # N = 32: 8 x 1 vs 4 x 2 row-per-lane shapes; N = 64: row-per-lane vs lane-pair kernel
+    for t in range(4):
+        ref = orc.pcg(S[t].astype(np.float64), Pinv[t].astype(np.float64), g[t].astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")["lam"]
+        band = fp32_band(orc, S[t], Pinv[t], g[t], np.zeros(n * N), N, K, "ss", ref, trials=2)
+        assert relinf(small[t], ref) <= max(1e-3, 4 * band) and relinf(big[t], ref) <= max(1e-3, 4 * band)
+    pin = {"pcg_rpl": 1, "rpl_waves": 8} if N == 32 else {"pcg_lpk": 1}
+    a_, fa, _ = run(4, pin)
+    b_, fb, _ = run(Bbig, pin)
+    assert fa == fb
+    np.testing.assert_array_equal(a_, b_)                  # pinned: bit-identical whatever the batch
