@@ -15,7 +15,7 @@
  *   - BLOCK SYMMETRY (precondition of the PCG entry points).  PCG needs symmetric S and Pinv, and the reference's are: it writes
  *     S[k,right] as the transposed copy of S[k+1,left] (include/pcg/linsys_setup.cuh:536-557, bit for bit) and forms the symmetric-stair
  *     Pinv[k,right] / Pinv[k+1,left] as the same product twice (:97-136, equal to ~1e-7 relative).  The register-resident kernels that
- *     serve fp32 horizons above 32 knots by default ("last_kernel_family" 2, 4 and 6) READ ONLY THE LEFT AND DIAGONAL block columns and
+ *     serve fp32 horizons above 32 knots by default ("last_kernel_family" 2, 4, 6 and 7) READ ONLY THE LEFT AND DIAGONAL block columns and
  *     apply L_{k+1}^T where the reference's kernel reads block (k,right); the right blocks of d_S / d_Pinv may hold anything (tests
  *     poison them with NaN).  On the reference's matrices the results agree to fp32 round-off of the products (~1e-7 of |Pinv| per
  *     apply; bit-identical for S).  A caller whose Pinv is NOT block-symmetric gets the solve of its symmetrised lower triangle from
@@ -278,7 +278,10 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * "cluster_waves" (waves per cluster member: 8 = one member per CU, 4 = two per CU, -1 by horizon and batch),
  * "pcg_rpl" (-1 auto / 0 / 1: the row-per-lane kernel for knot_points <= 64 — a DPP row per knot, vectors in registers; automatic for
  * knot_points <= 32 and for calls of at most one trajectory per CU up to 64), "rpl_waves" (its wavefronts per trajectory: 0 auto, 4, 8, 16),
- * "pcg_lpb" (-1 auto / 0 / 1: the lane-per-block kernel, knot_points <= 128),
+ * "pcg_lpk" (-1 auto / 0 / 1: the lane-pair-per-knot kernel, knot_points <= 128 — round 3's default for 36 < knot_points <= 128),
+ * "pcg_lpb" (-1 auto / 0 / 1: the lane-per-block kernel, knot_points <= 128 — round 2's default; 1 selects it instead of the lane-pair kernel),
+ * "cluster_lpk" (-1 auto (on) / 0 / 1: the clustered lane-pair kernel where a clustered register-resident kernel runs; 0: the clustered
+ * lane-per-block kernel),
  * "cluster_lpb" (-1 auto / 0 / 1: the clustered lane-per-block kernel — members of up to 128 knots, everything in registers, one
  * hand-off per matrix pass — instead of the row-triple cluster kernel; default on), "cluster_l2" (1, default: its hand-offs stay in
  * the XCD's L2 when all members of a cluster run on one XCD, which the kernel verifies; 0: always write-through), "cluster_fixup" (1: trajectories whose cluster
@@ -289,7 +292,8 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * read-only: "cluster_fixups" (trajectories re-solved by fix-up launches since mpcg_create because their cluster gave up after the bounded
  * spin — each costs 1.5-4.5 ms of spinning; blocking 8-byte D2H read), "last_symmetry_violations", "num_cus", "pcg_resident" (1 if the current configuration streams nothing inside the PCG loop),
  * "last_kernel_family" (kernel of the last solve: 0 single-workgroup row-pair, 1 row-triple cluster, 2 lane-per-block, 3 generic,
- * 4 clustered lane-per-block, 5 row-per-lane), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
+ * 4 clustered lane-per-block, 5 row-per-lane, 6 lane-pair-per-knot, 7 clustered lane-pair),
+ * "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
  * WHICH kernel family serves a call depends on knot_points AND on the call's batch (e.g. 32 < N <= 64: row-per-lane kernel up to one
  * trajectory per CU, lane-pair / lane-per-block kernel beyond; N <= 32: 8 waves x 1 slot or 4 x 2 by batch).  Families sum the inner
  * products in different orders, so the SAME trajectory solved alone and inside a large batch may differ in the last fp32 bits (and, near
