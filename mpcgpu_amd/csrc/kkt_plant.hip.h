@@ -4,21 +4,27 @@
 // _lastblock :392-411) and the Euler integrator (include/common/integrator.cuh:56-104, 143-162).  SURVEY.md §8f row 4.
 //
 // The reference runs GRiD-generated, robot-specific code (10 k lines of unrolled recursions) with one thread block per
-// knot.  Here the robot is DATA (struct PlantDev: spatial transforms as constant + sin + cos parts, spatial inertias,
-// homogeneous transforms) and the algorithms are the generic ones, mapped for a 64-wide wavefront:
-//   one wavefront per FOUR (trajectory, knot) pairs, 16 lanes each; a lane runs a whole recursive Newton-Euler pass:
-//     round 0  lanes 0..6: columns of the joint-space inertia matrix M = ID(q, 0, e_j);  lane 7: bias c = ID(q, qd, 0)
-//              then lanes 0..6: column j of Minv by a Cholesky solve (7x7, redundantly factorised per lane);  qdd = Minv (u - c)
-//     round 1  lanes 0..6: ID(q + h e_j, qd, qdd), lanes 7..13: ID(q, qd + h e_j, qdd);  lane 14: forward kinematics, end-effector
-//              position and geometric Jacobian z_j x (p_ee - p_j).  Every lane stores tau(+h) - u: ONE-SIDED differences of the
-//              inverse dynamics — the nominal value is known without evaluating it, ID(q, qd, qdd) = u because qdd = Minv (u - c)
-//              (round 3; rounds 1 and 2 used to be the central pair +-h: a third of the kernel's recursion time for accuracy the
-//              float outputs cannot hold — with h = 3e-8 in float64 the entries of A differ from the central-difference values by
-//              1.3e-7, the rounding of a float near 1).
-//     phase 4  dqdd/d(q,qd) = -Minv dID,  A, B, integrator defect, Gauss-Newton cost blocks, written as float in the
-//              reference's dense layouts (column-major blocks, C = -A, -B).
-// Arithmetic is float64 inside (the difference quotients need it; the MI355X has the fp64 rate to spare: the whole kernel is
-// ~40 kflop per knot), results are rounded to float on the way out.
+// knot.  Here the robot is DATA (struct PlantDev: the constant "tree" part of every joint's spatial transform — the joint rotation
+// about its z axis is applied in the kernel — and the spatial inertias) and the algorithms are the generic ones, mapped for a
+// 64-wide wavefront:
+//   one wavefront per FOUR (trajectory, knot) pairs, 16 lanes each; a lane runs a whole recursive Newton-Euler pass, and every
+//   quantity the knot needs falls out of TWO such rounds:
+//     round 0  lanes 0..6: columns of the joint-space inertia matrix M = ID(q, 0, e_j) — and, for free, column j of the body
+//              Jacobian of the last link (its spatial acceleration at the end of the forward sweep);  lane 7: bias c = ID(q, qd, 0);
+//              lanes 8..10: the same sweep started from a unit angular base acceleration e_x / e_y / e_z — the last link's
+//              acceleration is then [R e_i ; R (e_i x p)]: the POSE of the end effector (R world -> link, p its origin), i.e. the
+//              forward kinematics and the geometric Jacobian cost no sweep of their own (round 2 ran them in a separate lane:
+//              a divergent branch the wavefront paid for in full);
+//              then lanes 0..6: column j of Minv by a Cholesky solve (7x7, redundantly factorised per lane), qdd_j = Minv_j (u - c),
+//              the end-effector Jacobian column and the cost gradient entry.
+//     round 1  lanes 0..6: ID(q + h e_j, qd, qdd), lanes 7..13: ID(q, qd + h e_j, qdd): ONE-SIDED differences of the inverse
+//              dynamics — the nominal value is known without evaluating it, ID(q, qd, qdd) = u because qdd = Minv (u - c)
+//              (with h = 3e-8 in float64 the entries of A differ from central-difference values by 1.3e-7, the rounding of a float
+//              near 1); each lane turns its difference into ITS column of dqdd/d(q, qd) = -Minv dID in registers and writes its column
+//              of A (and of Q, B, R) as float in the reference's dense layouts (column-major blocks, C = -A, -B).
+// Arithmetic is float64 inside (the difference quotients need it; fp64 FMA is full rate on the MI355X), results are rounded to float
+// on the way out.  LDS is what bounds the resident wavefronts: 19.9 KB per wavefront = EIGHT per CU (two per SIMD, round 3; 30 KB =
+// five before), which is what hides the dependent-issue latency of the recursion.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,15 +33,25 @@ namespace mpcg {
 
 constexpr int PJ = 7;                    // joints of the compiled specialisation (state 2 PJ, control PJ)
 constexpr int KKT_LANES = 64;            // one wavefront per KKT_ITEMS (trajectory, knot) pairs
-constexpr int RN_ROWS = 6 * PJ + 1;        // record: link forces [PJ][6] (+1: an odd row count = conflict-free 8-byte accesses at lane stride)
-__host__ __device__ constexpr int RN_TAU(int k) { return 6 * k + 2; }             // tau_k overwrites row 2 of link k's force once consumed
+constexpr int KKT_THREADS = KKT_LANES;
+constexpr int KKT_ITEMS = 4;             // (trajectory, knot) pairs per wavefront: 16 lanes each
+constexpr int KKT_GL = KKT_LANES / KKT_ITEMS;
+constexpr int KKT_RL = 2 * PJ;           // lanes of a group that own a record (the other two never run the recursion)
+#ifndef KKT_ABLATE
+#define KKT_ABLATE 0      // timing experiments only (tools/kkt_ablate.sh): 1 no round-1 recursion, 2 no Cholesky, 4 no sincos, 8 no output stores, 16 no round-0 recursion
+#endif
+constexpr double KKT_FD_H = 3e-8;        // one-sided difference step (truncation h/2 |f''| ~ roundoff eps |f| / h in float64)
+// Per-lane record of the recursion in LDS: the forces of links 0..5 wait there for the backward sweep (the last link's stays in
+// registers), 6 rows each; tau_k overwrites row 2 of link k's force once that is consumed, tau_6 takes the 37th row (an odd row
+// count = conflict-free 8-byte accesses at lane stride).
+constexpr int RN_ROWS = 6 * (PJ - 1) + 1;
+__host__ __device__ constexpr int RN_TAU(int k) { return k < PJ - 1 ? 6 * k + 2 : 6 * (PJ - 1); }
+constexpr int RN_AW = 3, RN_AU = 9;      // rows (3 each) where a lane leaves the last link's acceleration after round 0 (consumed force rows)
 
-struct PlantDev {                        // all row-major 3x3 unless noted
-    double E0[PJ][9], Es[PJ][9], Ec[PJ][9];      // rotation block of X_k(q_k) = E0 + Es sin q_k + Ec cos q_k
-    double B0[PJ][9], Bs[PJ][9], Bc[PJ][9];      // lower-left block of X_k (= -E r x)
-    double I[PJ][36];                            // spatial inertia, row-major 6x6
-    double R0[PJ][9], Rs[PJ][9], Rc[PJ][9];      // rotation of the homogeneous transform link k -> parent
-    double p[PJ][3];                             // its translation
+// X_k(q_k) = blkdiag(Rz, Rz) [[ET, 0], [BT, ET]],  Rz(q) = [[c, s, 0], [-s, c, 0], [0, 0, 1]]  (row-major 3x3 blocks)
+struct PlantDev {
+    double ET[PJ][9], BT[PJ][9];
+    double I[PJ][36];                            // spatial inertia, row-major 6x6 (symmetric: the upper triangle is read)
 };
 
 struct KktArgs {
@@ -56,58 +72,67 @@ typedef const __attribute__((address_space(4))) double cdouble;
 struct PlantC {
     cdouble* base;
     __device__ __forceinline__ cdouble* at(size_t byte_off, int k, int per) const { return base + byte_off / sizeof(double) + (size_t)k * per; }
-    __device__ __forceinline__ cdouble* E0(int k) const { return at(offsetof(PlantDev, E0), k, 9); }
-    __device__ __forceinline__ cdouble* Es(int k) const { return at(offsetof(PlantDev, Es), k, 9); }
-    __device__ __forceinline__ cdouble* Ec(int k) const { return at(offsetof(PlantDev, Ec), k, 9); }
-    __device__ __forceinline__ cdouble* B0(int k) const { return at(offsetof(PlantDev, B0), k, 9); }
-    __device__ __forceinline__ cdouble* Bs(int k) const { return at(offsetof(PlantDev, Bs), k, 9); }
-    __device__ __forceinline__ cdouble* Bc(int k) const { return at(offsetof(PlantDev, Bc), k, 9); }
+    __device__ __forceinline__ cdouble* ET(int k) const { return at(offsetof(PlantDev, ET), k, 9); }
+    __device__ __forceinline__ cdouble* BT(int k) const { return at(offsetof(PlantDev, BT), k, 9); }
     __device__ __forceinline__ cdouble* I(int k) const { return at(offsetof(PlantDev, I), k, 36); }
-    __device__ __forceinline__ cdouble* R0(int k) const { return at(offsetof(PlantDev, R0), k, 9); }
-    __device__ __forceinline__ cdouble* Rs(int k) const { return at(offsetof(PlantDev, Rs), k, 9); }
-    __device__ __forceinline__ cdouble* Rc(int k) const { return at(offsetof(PlantDev, Rc), k, 9); }
-    __device__ __forceinline__ cdouble* p(int k) const { return at(offsetof(PlantDev, p), k, 3); }
 };
 
-__device__ __forceinline__ void mat3(double (&M)[9], cdouble* c0, cdouble* cs, cdouble* cc, double s, double c) {
-#pragma unroll
-    for (int e = 0; e < 9; ++e) M[e] = c0[e] + cs[e] * s + cc[e] * c;
-}
+struct KktItemLds {                      // per-knot scratch in LDS (840 B)
+    double Minv[PJ][PJ];
+    double Qdd[PJ];
+    double Xq[2 * PJ], U[PJ];            // [q; qd], u of this knot
+    double Sc[2][PJ];                    // sin / cos of q
+    double Gq[PJ], Gq1[PJ];              // J^T (ee - goal_k), J^T (ee - goal_{k+1})
+};
 
-// tau = ID(q, qd, qdd) without gravity (gato_plant::GRAVITY = 0, iiwa_eepos_plant.cuh:53).  Inputs, the link forces that wait
-// for the backward sweep, sin / cos and the result all live in this lane's column `fl` of an LDS record (rows RN_*), and both
-// sweeps are RUNTIME loops over the joints.  Measured alternatives on gfx950 (hipcc 7.2): everything in registers with unrolled
-// sweeps = 3.4 KB of scratch per lane (the 84 force registers, plus the seven E_k / B_k pairs the compiler keeps from the
-// forward sweep for the backward one instead of recomputing them: 252 doubles); plain (non-volatile) LDS accesses get
-// store-forwarded back into registers.  This form compiles one joint body in ~225 registers without scratch; the record (LDS capacity)
-// is then what bounds the resident wavefronts per CU.
-//   sin / cos of the joint angles come from a table sc[variant][2][PJ] shared by the lanes (variant 0: q, 1: q + h e_j, 2: q - h e_j;
-//   ONE sincos call per knot fills it — every recursion used to recompute all seven, 29 % of the kernel's VALU instructions):
-//   joint k uses variant (k == sj ? sv : 0).
-//   qd_k = qdscale * xqd[k] + (k == prow ? ph : 0)   (xqd shared by the lanes),   qdd_k = qdd ? qdd[k] : (k == unit ? 1 : 0)
-__device__ __forceinline__ void rnea(const PlantC& P, volatile double* fl, const double* sc, int sj, int sv, const double* xqd, double qdscale,
-                                     int prow, double ph, const double* qdd, int unit) {
+// LDS is addressed through explicit address-space pointers: through generic pointers the accesses become flat loads whose 64-bit
+// addresses (one per record row touched) the compiler hoists out of the knot loop and spills.
+typedef __attribute__((address_space(3))) volatile double kkt_lds_vd;
+typedef __attribute__((address_space(3))) KktItemLds kkt_lds_item;
+
+struct RneaTask {                        // what this lane's recursion evaluates
+    int sj;                              // joint whose angle is q + h (-1: none): (sin, cos) -> (s + h c, c - h s), exact to h^2 / 2 = 4.5e-16
+    int pj;                              // joint whose velocity is qd + h (-1: none)
+    double qdscale;                      // 0: qd = 0, 1: qd of the knot
+    bool knot_qdd;                       // qdd of the knot (round 1) / unit vector e_unit (round 0)
+    int unit;
+    int base;                            // unit angular base acceleration e_base (-1: none)
+};
+
+// tau = ID(q, qd, qdd) without gravity (gato_plant::GRAVITY = 0, iiwa_eepos_plant.cuh:53).  The link forces that wait for the backward
+// sweep live in this lane's record `fl` (rows RN_*), and both sweeps are RUNTIME loops over the joints.  Measured alternatives on
+// gfx950 (hipcc 7.2): everything in registers with unrolled sweeps = 3.4 KB of scratch per lane (the 84 force registers, plus the
+// transforms the compiler keeps from the forward sweep for the backward one, plus 840 hoisted table loads); plain (non-volatile)
+// LDS accesses get store-forwarded back into registers.  The joint transform is applied as the constant tree part (operands straight
+// from scalar registers: one SGPR pair per FMA is what the ISA allows, so forming E(q) = E0 + Es sin + Ec cos first, as rounds 1-2 did,
+// cost three instructions per matrix entry and sweep) followed by the rotation about z: 4 instructions per 3-vector.
+// Returns the last link's spatial acceleration (aw, au) in its own frame.
+__device__ __forceinline__ void rnea(const PlantC& P, kkt_lds_vd* fl, kkt_lds_item* I, const RneaTask t, double (&aw_out)[3], double (&au_out)[3]) {
     double vw[3] = {0, 0, 0}, vu[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, au[3] = {0, 0, 0};
+    if (t.base >= 0) aw[t.base] = 1.0;
+    double f[6] = {0, 0, 0, 0, 0, 0};
 #pragma nounroll
     for (int kv = 0; kv < PJ; ++kv) {
         const int k = __builtin_amdgcn_readfirstlane(kv);    // uniform by construction; said so, the model tables come through s_load
-        const double qdk = qdscale * xqd[k] + (k == prow ? ph : 0.0);
-        const double qddk = qdd ? qdd[k] : (k == unit ? 1.0 : 0.0);
-        const double* sck = sc + (k == sj ? sv : 0) * (2 * PJ) + k;
-        const double sn = sck[0], cs = sck[PJ];
-        double E[9], B[9];
-        mat3(E, P.E0(k), P.Es(k), P.Ec(k), sn, cs);
-        mat3(B, P.B0(k), P.Bs(k), P.Bc(k), sn, cs);
-        double w[3], u[3], bw[3], bu[3];
+        const double qdk = t.qdscale * I->Xq[PJ + k] + (k == t.pj ? KKT_FD_H : 0.0);
+        const double qddk = t.knot_qdd ? I->Qdd[k] : (k == t.unit ? 1.0 : 0.0);
+        double sn = I->Sc[0][k], cs = I->Sc[1][k];
+        if (k == t.sj) { const double s0 = sn; sn = s0 + KKT_FD_H * cs; cs = cs - KKT_FD_H * s0; }
+        cdouble* E = P.ET(k);
+        cdouble* B = P.BT(k);
+        double tw[3], tu[3], sw[3], su[3];                   // tree part of v = X v_parent, a = X a_parent
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {                    // v = X v_parent, a = X a_parent
-            w[r] = E[3 * r] * vw[0] + E[3 * r + 1] * vw[1] + E[3 * r + 2] * vw[2];
-            u[r] = B[3 * r] * vw[0] + B[3 * r + 1] * vw[1] + B[3 * r + 2] * vw[2] + E[3 * r] * vu[0] + E[3 * r + 1] * vu[1] + E[3 * r + 2] * vu[2];
-            bw[r] = E[3 * r] * aw[0] + E[3 * r + 1] * aw[1] + E[3 * r + 2] * aw[2];
-            bu[r] = B[3 * r] * aw[0] + B[3 * r + 1] * aw[1] + B[3 * r + 2] * aw[2] + E[3 * r] * au[0] + E[3 * r + 1] * au[1] + E[3 * r + 2] * au[2];
+        for (int r = 0; r < 3; ++r) {
+            tw[r] = E[3 * r] * vw[0] + E[3 * r + 1] * vw[1] + E[3 * r + 2] * vw[2];
+            tu[r] = B[3 * r] * vw[0] + B[3 * r + 1] * vw[1] + B[3 * r + 2] * vw[2] + E[3 * r] * vu[0] + E[3 * r + 1] * vu[1] + E[3 * r + 2] * vu[2];
+            sw[r] = E[3 * r] * aw[0] + E[3 * r + 1] * aw[1] + E[3 * r + 2] * aw[2];
+            su[r] = B[3 * r] * aw[0] + B[3 * r + 1] * aw[1] + B[3 * r + 2] * aw[2] + E[3 * r] * au[0] + E[3 * r + 1] * au[1] + E[3 * r + 2] * au[2];
         }
-        w[2] += qdk;                                     // + S qd, S = e_z (angular)
-        bw[2] += qddk;
+        double w[3], u[3], bw[3], bu[3];                     // joint rotation about z
+        w[0] = cs * tw[0] + sn * tw[1]; w[1] = cs * tw[1] - sn * tw[0]; w[2] = tw[2] + qdk;       // + S qd, S = e_z (angular)
+        u[0] = cs * tu[0] + sn * tu[1]; u[1] = cs * tu[1] - sn * tu[0]; u[2] = tu[2];
+        bw[0] = cs * sw[0] + sn * sw[1]; bw[1] = cs * sw[1] - sn * sw[0]; bw[2] = sw[2] + qddk;
+        bu[0] = cs * su[0] + sn * su[1]; bu[1] = cs * su[1] - sn * su[0]; bu[2] = su[2];
         // + v x (S qd): column 2 of crm(v) times qd
         bw[0] += w[1] * qdk; bw[1] -= w[0] * qdk;
         bu[0] += u[1] * qdk; bu[1] -= u[0] * qdk;
@@ -119,68 +144,75 @@ __device__ __forceinline__ void rnea(const PlantC& P, volatile double* fl, const
         for (int r = 0; r < 6; ++r) {
             double sa = 0, sv = 0;
 #pragma unroll
-            for (int cc_ = 0; cc_ < 6; ++cc_) { sa += Ik[6 * r + cc_] * a6[cc_]; sv += Ik[6 * r + cc_] * v6[cc_]; }
+            for (int cc_ = 0; cc_ < 6; ++cc_) {
+                const double ik = Ik[r <= cc_ ? 6 * r + cc_ : 6 * cc_ + r];
+                sa += ik * a6[cc_]; sv += ik * v6[cc_];
+            }
             Ia[r] = sa; Iv[r] = sv;
         }
         // crf(v) h = [w x n + u x l ; w x l],  h = [n; l]
-        volatile double* f = fl + k * 6;
         f[0] = Ia[0] + (w[1] * Iv[2] - w[2] * Iv[1]) + (u[1] * Iv[5] - u[2] * Iv[4]);
         f[1] = Ia[1] + (w[2] * Iv[0] - w[0] * Iv[2]) + (u[2] * Iv[3] - u[0] * Iv[5]);
         f[2] = Ia[2] + (w[0] * Iv[1] - w[1] * Iv[0]) + (u[0] * Iv[4] - u[1] * Iv[3]);
         f[3] = Ia[3] + (w[1] * Iv[5] - w[2] * Iv[4]);
         f[4] = Ia[4] + (w[2] * Iv[3] - w[0] * Iv[5]);
         f[5] = Ia[5] + (w[0] * Iv[4] - w[1] * Iv[3]);
+        if (k < PJ - 1) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) fl[6 * k + r] = f[r];
+        }
 #pragma unroll
         for (int r = 0; r < 3; ++r) { vw[r] = w[r]; vu[r] = u[r]; aw[r] = bw[r]; au[r] = bu[r]; }
     }
-    double fc[6];                                        // force of the link being folded into its parent
 #pragma unroll
-    for (int r = 0; r < 6; ++r) fc[r] = fl[(PJ - 1) * 6 + r];   // tau_6 = row 2 of the last link's force: already in place
+    for (int r = 0; r < 3; ++r) { aw_out[r] = aw[r]; au_out[r] = au[r]; }
+    fl[RN_TAU(PJ - 1)] = f[2];                               // tau_6; f = force of the link being folded into its parent
 #pragma nounroll
-    for (int kv = PJ - 1; kv >= 1; --kv) {               // f_parent += X^T f = [E^T n + B^T l ; E^T l]
+    for (int kv = PJ - 1; kv >= 1; --kv) {                   // f_parent += X^T f = Xtree^T blkdiag(Rz^T, Rz^T) [n; l] = [ET^T n' + BT^T l' ; ET^T l']
         const int k = __builtin_amdgcn_readfirstlane(kv);
-        const double* sck = sc + (k == sj ? sv : 0) * (2 * PJ) + k;
-        const double sk = sck[0], ck = sck[PJ];
-        double E[9], B[9];
-        mat3(E, P.E0(k), P.Es(k), P.Ec(k), sk, ck);
-        mat3(B, P.B0(k), P.Bs(k), P.Bc(k), sk, ck);
+        double sn = I->Sc[0][k], cs = I->Sc[1][k];
+        if (k == t.sj) { const double s0 = sn; sn = s0 + KKT_FD_H * cs; cs = cs - KKT_FD_H * s0; }
+        cdouble* E = P.ET(k);
+        cdouble* B = P.BT(k);
+        const double n0 = cs * f[0] - sn * f[1], n1 = sn * f[0] + cs * f[1], n2 = f[2];
+        const double l0 = cs * f[3] - sn * f[4], l1 = sn * f[3] + cs * f[4], l2 = f[5];
         double fp[6];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            fp[r] = fl[(k - 1) * 6 + r] + E[r] * fc[0] + E[3 + r] * fc[1] + E[6 + r] * fc[2] + B[r] * fc[3] + B[3 + r] * fc[4] + B[6 + r] * fc[5];
-            fp[3 + r] = fl[(k - 1) * 6 + 3 + r] + E[r] * fc[3] + E[3 + r] * fc[4] + E[6 + r] * fc[5];
+            fp[r] = fl[6 * (k - 1) + r] + E[r] * n0 + E[3 + r] * n1 + E[6 + r] * n2 + B[r] * l0 + B[3 + r] * l1 + B[6 + r] * l2;
+            fp[3 + r] = fl[6 * (k - 1) + 3 + r] + E[r] * l0 + E[3 + r] * l1 + E[6 + r] * l2;
         }
 #pragma unroll
-        for (int r = 0; r < 6; ++r) fc[r] = fp[r];
-        fl[RN_TAU(k - 1)] = fc[2];                       // (link k-1's own force row 2: consumed just above)
+        for (int r = 0; r < 6; ++r) f[r] = fp[r];
+        fl[RN_TAU(k - 1)] = f[2];                            // (link k-1's own force row 2: consumed just above)
     }
 }
 
-constexpr int KKT_THREADS = KKT_LANES;
-constexpr int KKT_ITEMS = 4;             // (trajectory, knot) pairs per wavefront: 16 lanes each
-constexpr int KKT_GL = KKT_LANES / KKT_ITEMS;
-constexpr int KKT_KIN_LANE = 2 * PJ;     // lane of a group after the 14 finite-difference tasks: forward kinematics + Jacobian
-constexpr double KKT_FD_H = 3e-8;             // one-sided difference step (truncation h/2 |f''| ~ roundoff eps |f| / h in float64)
-
-struct KktItemLds {                      // per-knot scratch in LDS (2.1 KB; LDS capacity is what bounds the resident wavefronts per CU)
-    double M[PJ][PJ], Minv[PJ][PJ], Bias[PJ], Qdd[PJ];
-    // (the central differences ID(. + h e_j) - ID(. - h e_j) wait in rows 0..6 of the finished recursion's record of lane j / 7 + j;
-    //  dqdd/dq overwrites M, which is dead after the Cholesky factorisation)
-    double Dqd[PJ][PJ];
-    double J[3][PJ], Ee[3], Gq[PJ], Gq1[PJ];
-    double Xq[2 * PJ], U[PJ];            // [q; qd], u of this knot
-    double Sc[2][2][PJ];                 // sin / cos of q, q + h e_j
-};
+// Output staging (floats, in the group's records once the last sweep is over): [Q R | Q_last] [-A -B] [q r | q_last] [c_0] [c_{k+1}]
+typedef __attribute__((address_space(3))) float kkt_lds_f;
+constexpr int ST_G = 0, ST_Q1 = ST_G + 14 * 14 + 7 * 7, ST_C = ST_Q1 + 14 * 14, ST_g = ST_C + 14 * 14 + 14 * 7, ST_g1 = ST_g + 21, ST_c0 = ST_g1 + 14,
+              ST_c1 = ST_c0 + 14, ST_END = ST_c1 + 14;
+static_assert(ST_END * sizeof(float) <= KKT_RL * RN_ROWS * sizeof(double), "staging fits the group's records");
+template <int LEN>
+__device__ __forceinline__ void kkt_copy_out(float* dst, kkt_lds_f* src, int l) {
+#pragma unroll
+    for (int e = 0; e + KKT_GL <= LEN; e += KKT_GL) dst[e + l] = src[e + l];
+    if (LEN % KKT_GL != 0 && l < LEN % KKT_GL) dst[LEN - LEN % KKT_GL + l] = src[LEN - LEN % KKT_GL + l];
+}
 
 __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a) {
     constexpr int n = 2 * PJ, m = PJ, nn = n * n, mm = m * m, nm = n * m;
     __shared__ KktItemLds sI[KKT_ITEMS];
-    __shared__ double sF[KKT_LANES][RN_ROWS];               // per-lane record of the recursion: link forces (22 KB)
-    // The model tables are read with RUNTIME joint indices.  With compile-time indices (unrolled sweeps) all 840 doubles are
+    __shared__ double sF[KKT_ITEMS * KKT_RL][RN_ROWS];      // the recursion records (16.6 KB)
+    static_assert(sizeof(KktItemLds) * KKT_ITEMS + sizeof(double) * KKT_ITEMS * KKT_RL * RN_ROWS <= 20480, "eight wavefronts per CU");
+    // The model tables are read with RUNTIME joint indices.  With compile-time indices (unrolled sweeps) all table entries are
     // loop-invariant loads that the compiler hoists into registers: 512 VGPR + AGPR and scratch.
     const int lane = threadIdx.x, gi = lane / KKT_GL, l = lane - gi * KKT_GL;
-    KktItemLds& I = sI[gi];
-    volatile double* fl = &sF[lane][0];
+    kkt_lds_item* I = (kkt_lds_item*)&sI[gi];
+    kkt_lds_vd* recs = (kkt_lds_vd*)&sF[gi * KKT_RL][0];
+    auto rec = [&](int j) -> kkt_lds_vd* { return recs + j * RN_ROWS; };                // record of lane j of this group
+    kkt_lds_vd* fl = rec(l < KKT_RL ? l : 0);                // (lanes 14, 15 never touch theirs)
+    kkt_lds_f* st = (kkt_lds_f*)&sF[gi * KKT_RL][0];
     const PlantC P{reinterpret_cast<cdouble*>(reinterpret_cast<unsigned long long>(a.plant))};
     const int N = a.N;
     const long total = (long)a.batch * (N - 1);
@@ -189,177 +221,158 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
         const long item = live ? base + gi : total - 1;
         const int b = (int)(item / (N - 1)), k = (int)(item - (long)b * (N - 1));
         const float* xu = a.xu + (size_t)b * ((size_t)(n + m) * N - m) + (size_t)k * (n + m);      // x_k, u_k, x_{k+1}
-        if (l < n) I.Xq[l] = (double)xu[l];
-        if (l < m) I.U[l] = (double)xu[n + l];
-        // sin / cos table through one sincos: lanes 0..13 -> q_j and q_j + h
-        {
-            const int v = l / PJ, j = l % PJ;
-            if (l < 2 * PJ) {
-                double sn_, cs_;
-                sincos((double)xu[j] + (v == 0 ? 0.0 : KKT_FD_H), &sn_, &cs_);
-                I.Sc[v][0][j] = sn_;
-                I.Sc[v][1][j] = cs_;
-            }
+        if (l < n) I->Xq[l] = (double)xu[l];
+        if (l < m) {
+            I->U[l] = (double)xu[n + l];
+            double sn_, cs_;
+            if (KKT_ABLATE & 4) { sn_ = (double)xu[l]; cs_ = 1.0 - sn_; } else
+            sincos((double)xu[l], &sn_, &cs_);
+            I->Sc[0][l] = sn_;
+            I->Sc[1][l] = cs_;
         }
         __syncthreads();
-        // ---- two rounds through ONE instance of the recursion (a runtime loop: a second inlined copy doubles the register
-        //      pressure).  Round 0: lanes 0..6 inertia-matrix columns ID(q, 0, e_l), lane 7 bias ID(q, qd, 0), then Minv and qdd.
-        //      Round 1: lanes 0..6 ID(q + h e_j, qd, qdd), 7..13 ID(q, qd + h e_j, qdd), each minus the nominal torque u; lane 14: kinematics. ----
-#pragma nounroll
-        for (int round = 0; round < 2; ++round) {
-            const bool fd = round > 0;
-            if (l < (fd ? 2 * PJ : PJ + 1)) {
-                const int kind = l / PJ, jj = l - kind * PJ;            // fd: kind 0 perturbs q_jj, kind 1 qd_jj
-                rnea(P, fl, &I.Sc[0][0][0], (fd && kind == 0) ? jj : -1, round, I.Xq + PJ, (fd || l == PJ) ? 1.0 : 0.0,
-                     (fd && kind == 1) ? jj : -1, KKT_FD_H, fd ? I.Qdd : nullptr, l);
+        // ---- round 0: lanes 0..6 inertia-matrix columns ID(q, 0, e_l), lane 7 bias ID(q, qd, 0), lanes 8..10 the pose sweeps ----
+        double a6w[3], a6u[3];
+        if (l < PJ + 4) {
+            RneaTask t;
+            t.sj = -1; t.pj = -1; t.qdscale = (l == PJ) ? 1.0 : 0.0; t.knot_qdd = false; t.unit = l < PJ ? l : -1; t.base = l > PJ ? l - PJ - 1 : -1;
+            if (!(KKT_ABLATE & 16)) rnea(P, fl, I, t, a6w, a6u);
 #pragma unroll
-                for (int i = 0; i < PJ; ++i) {
-                    const double t = fl[RN_TAU(i)];
-                    if (round == 0) { if (l < PJ) I.M[i][l] = t; else I.Bias[i] = t; }
-                    else fl[i] = t - I.U[i];                         // ID(. + h e_j) - ID(.) with ID(q, qd, qdd) = u  (the sweep is over: the record is free)
-                }
-            } else if (round == 1 && l == KKT_KIN_LANE) {
-                // forward kinematics; joint origins and axes wait in this lane's (otherwise unused) record
-                double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pos[3] = {0, 0, 0};
-#pragma nounroll
-                for (int jv = 0; jv < PJ; ++jv) {
-                    const int jn = __builtin_amdgcn_readfirstlane(jv);
-                    double H[9];
-                    const double s_ = I.Sc[0][0][jn], c_ = I.Sc[0][1][jn];
-                    mat3(H, P.R0(jn), P.Rs(jn), P.Rc(jn), s_, c_);
-                    double Rn[9];
-                    cdouble* pj = P.p(jn);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        pos[r] += R[3 * r] * pj[0] + R[3 * r + 1] * pj[1] + R[3 * r + 2] * pj[2];
-#pragma unroll
-                        for (int cc_ = 0; cc_ < 3; ++cc_) Rn[3 * r + cc_] = R[3 * r] * H[cc_] + R[3 * r + 1] * H[3 + cc_] + R[3 * r + 2] * H[6 + cc_];
-                    }
-#pragma unroll
-                    for (int e = 0; e < 9; ++e) R[e] = Rn[e];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) { fl[jn * 6 + r] = pos[r]; fl[jn * 6 + 3 + r] = R[3 * r + 2]; }
-                }
-#pragma unroll
-                for (int r = 0; r < 3; ++r) I.Ee[r] = pos[r];
-#pragma nounroll
-                for (int jn = 0; jn < PJ; ++jn) {
-                    const double d0 = pos[0] - fl[jn * 6 + 0], d1 = pos[1] - fl[jn * 6 + 1], d2 = pos[2] - fl[jn * 6 + 2];
-                    const double z0 = fl[jn * 6 + 3], z1 = fl[jn * 6 + 4], z2 = fl[jn * 6 + 5];
-                    I.J[0][jn] = z1 * d2 - z2 * d1;
-                    I.J[1][jn] = z2 * d0 - z0 * d2;
-                    I.J[2][jn] = z0 * d1 - z1 * d0;
-                }
-            }
-            __syncthreads();
-            if (round == 0) {
-                // Minv (column l through a Cholesky solve of the symmetrised M), qdd = Minv (u - bias)
-                if (l < PJ) {
-                    // (one reciprocal per pivot: float64 division and sqrt are ~25-instruction sequences, the textbook form has 42 + 14 divisions)
-                    double Lm[PJ][PJ], rd[PJ];
-#pragma unroll
-                    for (int i = 0; i < PJ; ++i)
-#pragma unroll
-                        for (int jj = 0; jj <= i; ++jj) {
-                            double sv = 0.5 * (I.M[i][jj] + I.M[jj][i]);
-#pragma unroll
-                            for (int t = 0; t < jj; ++t) sv -= Lm[i][t] * Lm[jj][t];
-                            if (i == jj) { Lm[i][i] = sqrt(sv); rd[i] = 1.0 / Lm[i][i]; }
-                            else Lm[i][jj] = sv * rd[jj];
-                        }
-                    double y[PJ];
-#pragma unroll
-                    for (int i = 0; i < PJ; ++i) {
-                        double sv = (i == l) ? 1.0 : 0.0;
-#pragma unroll
-                        for (int t = 0; t < i; ++t) sv -= Lm[i][t] * y[t];
-                        y[i] = sv * rd[i];
-                    }
-#pragma unroll
-                    for (int i = PJ - 1; i >= 0; --i) {
-                        double sv = y[i];
-#pragma unroll
-                        for (int t = i + 1; t < PJ; ++t) sv -= Lm[t][i] * y[t];
-                        y[i] = sv * rd[i];
-                    }
-#pragma unroll
-                    for (int i = 0; i < PJ; ++i) I.Minv[i][l] = y[i];
-                }
-                __syncthreads();
-                if (l < PJ) {
-                    double sv = 0;
-#pragma unroll
-                    for (int jj = 0; jj < PJ; ++jj) sv += I.Minv[l][jj] * (I.U[jj] - I.Bias[jj]);
-                    I.Qdd[l] = sv;
-                }
-                __syncthreads();
-            }
+            for (int r = 0; r < 3; ++r) { fl[RN_AW + r] = a6w[r]; fl[RN_AU + r] = a6u[r]; }
         }
-        // ---- phase 4a: dqdd = -Minv dID ; cost gradient pieces ----
-        for (int pi = l; pi < PJ * PJ; pi += KKT_GL) {
-            const int i = pi / PJ, j = pi - i * PJ;
-            double sq = 0, sd = 0;
+        __syncthreads();
+        // ---- Minv (column l through a Cholesky solve of the symmetrised M), qdd_l = Minv_l . (u - bias)  (Minv is symmetric: row l = column l),
+        //      end-effector position, Jacobian column l, cost gradient entries ----
+        if (l < PJ && !(KKT_ABLATE & 2)) {
+            // (one reciprocal per pivot: float64 division and sqrt are ~25-instruction sequences, the textbook form has 42 + 14 divisions)
+            double Lm[PJ][PJ], rd[PJ];
 #pragma unroll
-            for (int t = 0; t < PJ; ++t) {
-                sq += I.Minv[i][t] * sF[gi * KKT_GL + j][t];
-                sd += I.Minv[i][t] * sF[gi * KKT_GL + PJ + j][t];
+            for (int i = 0; i < PJ; ++i)
+#pragma unroll
+                for (int jj = 0; jj <= i; ++jj) {
+                    double sv = 0.5 * (rec(jj)[RN_TAU(i)] + rec(i)[RN_TAU(jj)]);      // M[i][jj] = tau_i of lane jj
+#pragma unroll
+                    for (int t = 0; t < jj; ++t) sv -= Lm[i][t] * Lm[jj][t];
+                    if (i == jj) { Lm[i][i] = sqrt(sv); rd[i] = 1.0 / Lm[i][i]; }
+                    else Lm[i][jj] = sv * rd[jj];
+                }
+            double y[PJ];
+#pragma unroll
+            for (int i = 0; i < PJ; ++i) {
+                double sv = (i == l) ? 1.0 : 0.0;
+#pragma unroll
+                for (int t = 0; t < i; ++t) sv -= Lm[i][t] * y[t];
+                y[i] = sv * rd[i];
             }
-            I.M[i][j] = -sq / KKT_FD_H;                       // dqdd/dq
-            I.Dqd[i][j] = -sd / KKT_FD_H;
-        }
-        if (l < PJ) {
+#pragma unroll
+            for (int i = PJ - 1; i >= 0; --i) {
+                double sv = y[i];
+#pragma unroll
+                for (int t = i + 1; t < PJ; ++t) sv -= Lm[t][i] * y[t];
+                y[i] = sv * rd[i];
+            }
+            double qdd = 0;
+#pragma unroll
+            for (int i = 0; i < PJ; ++i) {
+                I->Minv[i][l] = y[i];
+                qdd += y[i] * (I->U[i] - rec(PJ)[RN_TAU(i)]);          // bias_i = tau_i of lane 7
+            }
+            I->Qdd[l] = qdd;
+            // pose of the last link from the three base-acceleration sweeps (lanes 8..10): their final acceleration is [W_i ; V_i] =
+            // [R e_i ; R (e_i x p)], R = rotation world -> link.  Row i of R^T is W_i, so R^T x = (W_0.x, W_1.x, W_2.x);
+            // e_x x p = (0, -pz, py), e_y x p = (pz, 0, -px).
+            double W[3][3], V0[3], V1[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) W[i][r] = rec(PJ + 1 + i)[RN_AW + r];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { V0[r] = rec(PJ + 1)[RN_AU + r]; V1[r] = rec(PJ + 2)[RN_AU + r]; }
+            double ee[3], J[3];
+            ee[0] = -(W[2][0] * V1[0] + W[2][1] * V1[1] + W[2][2] * V1[2]);
+            ee[1] = W[2][0] * V0[0] + W[2][1] * V0[1] + W[2][2] * V0[2];
+            ee[2] = -(W[1][0] * V0[0] + W[1][1] * V0[1] + W[1][2] * V0[2]);
+            // Jacobian column l = R^T (linear velocity of the last link's origin for qd = e_l) = R^T au of this lane's own sweep
+#pragma unroll
+            for (int r = 0; r < 3; ++r) J[r] = W[r][0] * a6u[0] + W[r][1] * a6u[1] + W[r][2] * a6u[2];
             const float* goal = a.eePos_traj + ((size_t)b * N + k) * 6;
             double s0 = 0, s1 = 0;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                s0 += I.J[r][l] * (I.Ee[r] - (double)goal[r]);
-                s1 += I.J[r][l] * (I.Ee[r] - (double)goal[6 + r]);       // goal of knot k+1: used by the last block only
+                s0 += J[r] * (ee[r] - (double)goal[r]);
+                s1 += J[r] * (ee[r] - (double)goal[6 + r]);       // goal of knot k+1: used by the last block only
             }
-            I.Gq[l] = s0;
-            I.Gq1[l] = s1;
+            I->Gq[l] = s0;
+            I->Gq1[l] = s1;
         }
         __syncthreads();
-        // ---- phase 4b: outputs, float, the reference's dense layouts ----
-        if (live) {
+        // ---- round 1: lanes 0..6 ID(q + h e_l, qd, qdd), 7..13 ID(q, qd + h e_(l-7), qdd); each lane then owns column l of
+        //      [dqdd/dq, dqdd/dqd] = -Minv (ID(. + h e) - u) / h  and writes column l of A and Q (lanes 0..6: of B and R too) ----
+        if (l < n) {
+            RneaTask t;
+            t.sj = l < PJ ? l : -1; t.pj = l < PJ ? -1 : l - PJ; t.qdscale = 1.0; t.knot_qdd = true; t.unit = -1; t.base = -1;
+            if (!(KKT_ABLATE & 1)) rnea(P, fl, I, t, a6w, a6u);
+            double d[PJ], colv[PJ];
+#pragma unroll
+            for (int i = 0; i < PJ; ++i) d[i] = (fl[RN_TAU(i)] - I->U[i]) * (-1.0 / KKT_FD_H);
+            asm volatile("" ::: "memory");                // (the float staging stores below reuse the records: keep them behind these loads)
+#pragma unroll
+            for (int i = 0; i < PJ; ++i) {
+                double sv = 0;
+#pragma unroll
+                for (int tt = 0; tt < PJ; ++tt) sv += I->Minv[i][tt] * d[tt];
+                colv[i] = sv;
+            }
+            if (!(KKT_ABLATE & 8)) {
+                // The knot's outputs are STAGED in the group's (now free) records as float, in the order they have in memory, and
+                // copied out by all 16 lanes in 64-byte runs below.  Written straight from here — a lane per column, 14 lanes 56 bytes
+                // apart per store — the ~60 stores per lane were a fifth of the kernel's time (one cache line per lane and store).
+                const double dt = a.dt;
+                const double gql = l < PJ ? I->Gq[l] : 0.0, gq1l = l < PJ ? I->Gq1[l] : 0.0;
+                // column l (column-major):  A = I + dt [[0, I], [dqdd/dq, dqdd/dqd]],  Q = blkdiag(g g^T, QD I)
+#pragma unroll
+                for (int r = 0; r < n; ++r) {
+                    double av = (r == l) ? 1.0 : 0.0;
+                    if (r < PJ) av += (l == r + PJ) ? dt : 0.0;
+                    else av += dt * colv[r - PJ];
+                    st[ST_C + l * n + r] = (float)(-av);
+                    double qv, q1;
+                    if (r < PJ) { qv = I->Gq[r] * gql; q1 = I->Gq1[r] * gq1l; }
+                    else qv = q1 = (r == l) ? a.qd_cost : 0.0;
+                    st[ST_G + l * n + r] = (float)qv;
+                    st[ST_Q1 + l * n + r] = (float)q1;
+                }
+                if (l < m) {
+#pragma unroll
+                    for (int r = 0; r < n; ++r) st[ST_C + nn + l * n + r] = (float)(-(r < PJ ? 0.0 : dt * I->Minv[r - PJ][l]));      // B = dt [0; Minv]
+#pragma unroll
+                    for (int r = 0; r < m; ++r) st[ST_G + nn + l * m + r] = (float)(r == l ? a.r_cost : 0.0);
+                    st[ST_g + n + l] = (float)(a.r_cost * I->U[l]);
+                }
+                const double qdl = I->Xq[l < PJ ? l + PJ : l];              // qd_{l mod 7}
+                st[ST_g + l] = (float)(l < PJ ? gql : a.qd_cost * qdl);
+                st[ST_g1 + l] = (float)(l < PJ ? gq1l : a.qd_cost * qdl);  // last block only (evaluated at x_{N-2}: iiwa_eepos_plant.cuh:407)
+                // integrator defect c_{k+1} = x_{k+1} - (x_k + dt [qd; qdd]);  c_0 = x_0 - x_s
+                const double pred = l < PJ ? I->Xq[l] + dt * qdl : qdl + dt * I->Qdd[l - PJ];
+                st[ST_c1 + l] = (float)((double)xu[(n + m) + l] - pred);
+                if (k == 0) st[ST_c0 + l] = (float)((double)xu[l] - (double)a.xs[(size_t)b * n + l]);
+            }
+        }
+        __syncthreads();
+        if (live && !(KKT_ABLATE & 8)) {
             float* G = a.G + (size_t)b * ((size_t)(nn + mm) * N - mm) + (size_t)(nn + mm) * k;
             float* Cm = a.C + (size_t)b * (size_t)(nn + nm) * (N - 1) + (size_t)(nn + nm) * k;
             float* g = a.g + (size_t)b * ((size_t)(n + m) * N - m) + (size_t)(n + m) * k;
-            float* c = a.c + (size_t)b * (size_t)n * N;
-            const double dt = a.dt;
-            for (int e = l; e < nn; e += KKT_GL) {
-                const int col = e / n, r = e - col * n;                    // column-major
-                // A = I + dt [[0, I], [dqdd/dq, dqdd/dqd]]
-                double av = (r == col) ? 1.0 : 0.0;
-                if (r < PJ) av += (col == r + PJ) ? dt : 0.0;
-                else av += dt * (col < PJ ? I.M[r - PJ][col] : I.Dqd[r - PJ][col - PJ]);
-                Cm[e] = (float)(-av);
-                // Q = blkdiag(g g^T, QD I)
-                double qv = 0.0;
-                if (r < PJ && col < PJ) qv = I.Gq[r] * I.Gq[col];
-                else if (r == col) qv = a.qd_cost;
-                G[e] = (float)qv;
-                if (k == N - 2) {
-                    double q1 = 0.0;
-                    if (r < PJ && col < PJ) q1 = I.Gq1[r] * I.Gq1[col];
-                    else if (r == col) q1 = a.qd_cost;
-                    G[(nn + mm) + e] = (float)q1;
-                }
+            float* c = a.c + (size_t)b * (size_t)n * N + (size_t)n * (k + 1);
+            kkt_copy_out<nn + mm>(G, st + ST_G, l);
+            kkt_copy_out<nn + nm>(Cm, st + ST_C, l);
+            kkt_copy_out<n + m>(g, st + ST_g, l);
+            kkt_copy_out<n>(c, st + ST_c1, l);
+            if (k == N - 2) {                                 // the last block: Q_{N-1}, q_{N-1} follow R_{N-2}, r_{N-2} in memory
+                kkt_copy_out<nn>(G + nn + mm, st + ST_Q1, l);
+                kkt_copy_out<n>(g + n + m, st + ST_g1, l);
             }
-            for (int e = l; e < nm; e += KKT_GL) {
-                const int col = e / n, r = e - col * n;                    // B = dt [0; Minv]
-                Cm[nn + e] = (float)(-(r < PJ ? 0.0 : dt * I.Minv[r - PJ][col]));
-            }
-            for (int e = l; e < mm; e += KKT_GL) G[nn + e] = (float)((e % m == e / m) ? a.r_cost : 0.0);
-            if (l < n) {
-                const double qdl = I.Xq[l < PJ ? l + PJ : l];              // qd_{l mod 7}
-                g[l] = (float)(l < PJ ? I.Gq[l] : a.qd_cost * qdl);
-                if (k == N - 2) g[(n + m) + l] = (float)(l < PJ ? I.Gq1[l] : a.qd_cost * qdl);     // (evaluated at x_{N-2}: iiwa_eepos_plant.cuh:407)
-                // integrator defect c_{k+1} = x_{k+1} - (x_k + dt [qd; qdd])
-                const double pred = l < PJ ? I.Xq[l] + dt * qdl : qdl + dt * I.Qdd[l - PJ];
-                c[(size_t)n * (k + 1) + l] = (float)((double)xu[(n + m) + l] - pred);
-                if (k == 0) c[l] = (float)((double)xu[l] - (double)a.xs[(size_t)b * n + l]);
-            }
-            if (l < m) g[n + l] = (float)(a.r_cost * I.U[l]);
+            if (k == 0) kkt_copy_out<n>(c - n, st + ST_c0, l);
         }
         __syncthreads();
     }

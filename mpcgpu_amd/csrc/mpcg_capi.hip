@@ -1195,10 +1195,15 @@ int mpcg_plant_create(mpcg_plant** out, int device, uint32_t num_joints, const d
     PlantDev* hp = new (std::nothrow) PlantDev();
     if (!hp) return MPCG_ERR_NOMEM;
     memset(hp, 0, sizeof(PlantDev));
-    // tables are column-major (6x6 / 4x4), PlantDev is row-major 3x3 blocks
+    // The tables as given: X_k(q_k) = [[E, 0], [B, E]] with E = E0 + Es sin q_k + Ec cos q_k (likewise B), homogeneous transforms
+    // R = R0 + Rs sin + Rc cos and translation p.  Tables are column-major (6x6 / 4x4), these are row-major 3x3 blocks.
+    struct Given { double E0[PJ][9], Es[PJ][9], Ec[PJ][9], B0[PJ][9], Bs[PJ][9], Bc[PJ][9], R0[PJ][9], Rs[PJ][9], Rc[PJ][9], p[PJ][3]; };
+    Given* gv = new (std::nothrow) Given();
+    if (!gv) { delete hp; return MPCG_ERR_NOMEM; }
+    memset(gv, 0, sizeof(Given));
     auto place = [&](int k, int r, int c, double v, int which /*0 const, 1 sin, 2 cos*/) -> bool {
-        double(*E)[9] = which == 0 ? hp->E0 : (which == 1 ? hp->Es : hp->Ec);
-        double(*B)[9] = which == 0 ? hp->B0 : (which == 1 ? hp->Bs : hp->Bc);
+        double(*E)[9] = which == 0 ? gv->E0 : (which == 1 ? gv->Es : gv->Ec);
+        double(*B)[9] = which == 0 ? gv->B0 : (which == 1 ? gv->Bs : gv->Bc);
         if (r < 3 && c < 3) { E[k][3 * r + c] = v; return true; }
         if (r >= 3 && c < 3) { B[k][3 * (r - 3) + c] = v; return true; }
         return v == 0.0 || (r >= 3 && c >= 3);             // upper-right block must be zero; lower-right repeats E
@@ -1211,8 +1216,8 @@ int mpcg_plant_create(mpcg_plant** out, int device, uint32_t num_joints, const d
                 hp->I[k][6 * r + c] = I_spatial[k * 36 + c * 6 + r];
             }
         for (int c = 0; c < 3; ++c)
-            for (int r = 0; r < 3; ++r) hp->R0[k][3 * r + c] = Xhom_const[k * 16 + c * 4 + r];
-        for (int r = 0; r < 3; ++r) hp->p[k][r] = Xhom_const[k * 16 + 12 + r];
+            for (int r = 0; r < 3; ++r) gv->R0[k][3 * r + c] = Xhom_const[k * 16 + c * 4 + r];
+        for (int r = 0; r < 3; ++r) gv->p[k][r] = Xhom_const[k * 16 + 12 + r];
     }
     for (uint32_t t = 0; t < n_X_trig && ok; ++t) {
         const int idx = X_trig_idx[t], k = idx / 36, c = (idx % 36) / 6, r = idx % 6, j = X_trig_j[t];
@@ -1224,10 +1229,83 @@ int mpcg_plant_create(mpcg_plant** out, int device, uint32_t num_joints, const d
     for (uint32_t t = 0; t < n_Xhom_trig && ok; ++t) {
         const int idx = Xhom_trig_idx[t], k = idx / 16, c = (idx % 16) / 4, r = idx % 4, j = Xhom_trig_j[t];
         if (idx < 0 || k >= PJ || j < 0 || j >= 2 * PJ || j % PJ != k || r >= 3 || c >= 3) { ok = false; break; }
-        hp->R0[k][3 * r + c] = 0.0;
-        (j < PJ ? hp->Rs : hp->Rc)[k][3 * r + c] = Xhom_trig_coef[t];
+        gv->R0[k][3 * r + c] = 0.0;
+        (j < PJ ? gv->Rs : gv->Rc)[k][3 * r + c] = Xhom_trig_coef[t];
     }
-    if (!ok) { delete hp; return fail(nullptr, MPCG_ERR_INVALID, "mpcg_plant_create: tables do not describe a serial chain of revolute joints (X = [[E, 0], [B, E]], joint k depends on q_k)"); }
+    if (!ok) { delete hp; delete gv; return fail(nullptr, MPCG_ERR_INVALID, "mpcg_plant_create: tables do not describe a serial chain of revolute joints (X = [[E, 0], [B, E]], joint k depends on q_k)"); }
+    // The kernel applies X_k(q) as blkdiag(Rz, Rz) Xtree, Rz = [[c, s, 0], [-s, c, 0], [0, 0, 1]] (a revolute joint about its own z axis,
+    // the convention of GRiD's tables): row 0 = c T0 + s T1, row 1 = -s T0 + c T1, row 2 = T2 with T = E0 + Ec the transform at q = 0.
+    // Verify that the given constant / sin / cos parts have exactly that form.
+    double scale = 0.0;
+    for (int k = 0; k < PJ; ++k)
+        for (int e = 0; e < 9; ++e) {
+            hp->ET[k][e] = gv->E0[k][e] + gv->Ec[k][e];
+            hp->BT[k][e] = gv->B0[k][e] + gv->Bc[k][e];
+            scale = fmax(scale, fmax(fabs(hp->ET[k][e]), fabs(hp->BT[k][e])));
+        }
+    auto rotz_form = [&](const double* T, const double* c0, const double* cs, const double* cc) {
+        double worst = 0.0;
+        for (int c = 0; c < 3; ++c) {
+            worst = fmax(worst, fabs(cc[c] - T[c]) + fabs(cc[3 + c] - T[3 + c]) + fabs(cc[6 + c]));                 // cos part: rows 0, 1 of T
+            worst = fmax(worst, fabs(cs[c] - T[3 + c]) + fabs(cs[3 + c] + T[c]) + fabs(cs[6 + c]));                 // sin part: T1, -T0
+            worst = fmax(worst, fabs(c0[c]) + fabs(c0[3 + c]) + fabs(c0[6 + c] - T[6 + c]));                        // constant part: row 2
+        }
+        return worst;
+    };
+    double dev = 0.0;
+    for (int k = 0; k < PJ; ++k) {
+        dev = fmax(dev, rotz_form(hp->ET[k], gv->E0[k], gv->Es[k], gv->Ec[k]));
+        dev = fmax(dev, rotz_form(hp->BT[k], gv->B0[k], gv->Bs[k], gv->Bc[k]));
+    }
+    if (!(dev <= 1e-12 * fmax(scale, 1.0))) {
+        delete hp; delete gv;
+        return fail(nullptr, MPCG_ERR_UNSUPPORTED, "mpcg_plant_create: every joint must rotate about its own z axis, X_k(q) = blkdiag(Rz(q), Rz(q)) X_k(0) (the form of GRiD's tables)");
+    }
+    for (int k = 0; k < PJ; ++k)
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < r; ++c)
+                if (fabs(hp->I[k][6 * r + c] - hp->I[k][6 * c + r]) > 1e-12 * fmax(1.0, fabs(hp->I[k][6 * r + c]))) {
+                    delete hp; delete gv;
+                    return fail(nullptr, MPCG_ERR_INVALID, "mpcg_plant_create: spatial inertias must be symmetric");
+                }
+    // The end-effector position and Jacobian come out of the spatial transforms on the device (kkt_plant.hip.h, round 0); the reference
+    // takes them from the homogeneous transforms.  Both tables describe the same chain: check it at three configurations.
+    {
+        const double qs[3][PJ] = {{0, 0, 0, 0, 0, 0, 0}, {0.3, -0.7, 1.1, 0.5, -1.3, 0.9, 0.2}, {-2.1, 1.4, -0.6, 1.9, 0.8, -1.7, 2.5}};
+        double worst = 0.0;
+        for (int t = 0; t < 3; ++t) {
+            double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pos[3] = {0, 0, 0};
+            double W[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, V[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};       // motion vectors [e_i; 0] pushed through the chain
+            for (int k = 0; k < PJ; ++k) {
+                const double sn = sin(qs[t][k]), cs = cos(qs[t][k]);
+                double H[9], Rn[9];
+                for (int e = 0; e < 9; ++e) H[e] = gv->R0[k][e] + gv->Rs[k][e] * sn + gv->Rc[k][e] * cs;
+                for (int r = 0; r < 3; ++r) {
+                    pos[r] += R[3 * r] * gv->p[k][0] + R[3 * r + 1] * gv->p[k][1] + R[3 * r + 2] * gv->p[k][2];
+                    for (int c = 0; c < 3; ++c) Rn[3 * r + c] = R[3 * r] * H[c] + R[3 * r + 1] * H[3 + c] + R[3 * r + 2] * H[6 + c];
+                }
+                memcpy(R, Rn, sizeof(R));
+                for (int i = 0; i < 3; ++i) {
+                    double tw[3], tu[3];
+                    for (int r = 0; r < 3; ++r) {
+                        tw[r] = hp->ET[k][3 * r] * W[i][0] + hp->ET[k][3 * r + 1] * W[i][1] + hp->ET[k][3 * r + 2] * W[i][2];
+                        tu[r] = hp->BT[k][3 * r] * W[i][0] + hp->BT[k][3 * r + 1] * W[i][1] + hp->BT[k][3 * r + 2] * W[i][2] +
+                                hp->ET[k][3 * r] * V[i][0] + hp->ET[k][3 * r + 1] * V[i][1] + hp->ET[k][3 * r + 2] * V[i][2];
+                    }
+                    W[i][0] = cs * tw[0] + sn * tw[1]; W[i][1] = cs * tw[1] - sn * tw[0]; W[i][2] = tw[2];
+                    V[i][0] = cs * tu[0] + sn * tu[1]; V[i][1] = cs * tu[1] - sn * tu[0]; V[i][2] = tu[2];
+                }
+            }
+            const double ee[3] = {-(W[2][0] * V[1][0] + W[2][1] * V[1][1] + W[2][2] * V[1][2]), W[2][0] * V[0][0] + W[2][1] * V[0][1] + W[2][2] * V[0][2],
+                                  -(W[1][0] * V[0][0] + W[1][1] * V[0][1] + W[1][2] * V[0][2])};
+            for (int r = 0; r < 3; ++r) worst = fmax(worst, fabs(ee[r] - pos[r]));
+        }
+        if (!(worst <= 1e-9)) {
+            delete hp; delete gv;
+            return fail(nullptr, MPCG_ERR_INVALID, "mpcg_plant_create: the homogeneous transforms (Xhom) and the spatial transforms (X) describe different chains");
+        }
+    }
+    delete gv;
     mpcg_plant* pl = new (std::nothrow) mpcg_plant();
     if (!pl) { delete hp; return MPCG_ERR_NOMEM; }
     if (device < 0 && hipGetDevice(&device) != hipSuccess) { delete hp; delete pl; return fail(nullptr, MPCG_ERR_HIP, "mpcg_plant_create: no HIP device"); }

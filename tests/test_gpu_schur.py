@@ -309,8 +309,8 @@ def test_qdldl_twin_on_device_buffers(orc):
 def test_mpcsim_on_a_real_trajectory_window_with_the_library_kkt_stage():
     """examples/mpcsim_iiwa_demo.cpp: simulateMPC -> sqpSolvePcg | sqpSolveQdldl over the shim headers on rows 0.. of the reference's
     0_0 trajectory, the KKT stage being the library's own mpcg_generate_kkt (mpcgpu_compat::use_mpcg_generate_kkt with
-    mpcg_plant_create_iiwa14); full steps stand in for the merit-function line search.  The constraint violation of the perturbed
-    start must come down over three control steps, with both linear-system solvers."""
+    mpcg_plant_create_iiwa14) and the step stage the reference's line search (eight step lengths, rho adaptation) on a constraint-violation
+    merit.  The constraint violation of the perturbed start must come down and stay down over three control steps, with both linear-system solvers."""
     import json
     import os
     import subprocess
@@ -322,4 +322,5 @@ def test_mpcsim_on_a_real_trajectory_window_with_the_library_kkt_stage():
         assert r.returncode == 0, (sel, r.stdout + r.stderr)
         o = outs[sel] = json.loads(r.stdout.strip().splitlines()[-1])
         assert o["ok"] is True and o["linsys_solve"] == sel and o["control_steps"] == 3 and o["linsolves"] == 12
-        assert o["violation_start"] > 1e-2 and max(o["violation_after_step"]) < o["violation_start"] and o["violation_after_step"][-1] < 0.8 * o["violation_start"]
+        assert o["violation_start"] > 1e-2 and max(o["violation_after_step"]) < 0.6 * o["violation_start"]
+        assert len(o["line_search_exponents"]) == 12 and sum(p >= 0 for p in o["line_search_exponents"]) >= 6

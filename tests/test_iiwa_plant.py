@@ -78,3 +78,30 @@ def test_generate_kkt_matches_fixture_and_reference_structure(M, orc):
         r = orc.pcg(d[f"s{s}_S"], d[f"s{s}_Pinv"], d[f"s{s}_gamma"], np.zeros(n * N, np.float32), N, 5000, 1e-4, "ss")
         assert r["iters"] == int(d[f"s{s}_iters_ss_1e4"]) and r["iters"] <= synth.pcg_max_iter(N)          # inside the reference's cap of 173
         assert float(d[f"s{s}_cond"]) > 1e4                                                                # real systems are ill-conditioned
+
+
+def _tampered(kind):
+    import copy
+    m = copy.deepcopy(iiwa.Model())
+    if kind == "axis":                                       # a sin coefficient with the wrong sign: no longer Rz(q) X(0)
+        t = next(i for i, e in enumerate(m.X_trig) if e[2] < iiwa.NJ)
+        m.X_trig = list(m.X_trig)
+        m.X_trig[t] = (m.X_trig[t][0], -m.X_trig[t][1], m.X_trig[t][2])
+    elif kind == "xhom":                                     # link 3 is 1 cm longer in the homogeneous transforms only
+        m.Xhom_const = np.array(m.Xhom_const, dtype=np.float64, copy=True)
+        m.Xhom_const.reshape(-1)[3 * 16 + 12 + 1] += 0.01
+    elif kind == "inertia":
+        m.I = np.array(m.I, dtype=np.float64, copy=True)
+        m.I[2, 0, 4] += 1e-3
+    return m
+
+
+@pytest.mark.parametrize("kind,rc,word", [("axis", -2, "z axis"), ("xhom", -1, "different chains"), ("inertia", -1, "symmetric")])
+def test_plant_create_rejects_tables_the_kernel_cannot_use(kind, rc, word):
+    """mpcg_plant_create checks what the device kernel assumes (kkt_plant.hip.h): joints rotate about their own z axis, the homogeneous
+    transforms and the spatial transforms describe the same chain (the end effector comes out of the latter), symmetric inertias.
+    The checks run on the host before any device call: no GPU needed."""
+    from mpcgpu_amd import Plant, _lib
+    with pytest.raises(_lib.MpcgError) as e:
+        Plant(_tampered(kind), device=0)
+    assert e.value.code == rc and word in str(e.value), e.value

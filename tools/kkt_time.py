@@ -4,6 +4,9 @@ import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from mpcgpu_amd import _lib as _L
+if os.environ.get("AB_LIB"):                      # A/B against another build of the library (tools/_prof/ab/)
+    _L.LIB_PATH = os.environ["AB_LIB"]
 from mpcgpu_amd import PcgSolver, Plant, iiwa
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
