@@ -100,6 +100,11 @@ __device__ __forceinline__ float matvec(const float (&M)[NC], float v) {
 }
 // Gauss-Jordan on [A | I] without pivoting (include/utils/matrix.cuh:120-238), rows in lanes 0..NN-1:
 // A destroyed, I becomes A^-1.  lr = lane index inside the 16-lane row.
+// A pivot step updates every column of [A | I] independently of the others (only the pivot COLUMN, read before the step, couples
+// them), and without pivoting half of the 2 NN columns are structurally inert at every step: columns of A at or left of the pivot are
+// finished (nobody reads them again) and columns of I right of the pivot are still unit columns — the pivot row holds 0 there, so
+// the reference's update leaves them as they are (x - pcol * 0).  Skipping both halves the work (round 3) and changes no bit of A^-1
+// for finite inputs.
 template <int NN>
 __device__ __forceinline__ void invert(float (&A)[NN], float (&I)[NN], int lr) {
 #pragma unroll
@@ -110,14 +115,17 @@ __device__ __forceinline__ void invert(float (&A)[NN], float (&I)[NN], int lr) {
         const float pcol = A[P];
         const bool is_p = lr == P;
 #pragma unroll
-        for (int c = 0; c < NN; ++c) {
+        for (int c = P + 1; c < NN; ++c) {
             const float pa = A[c] * pinv;               // the pivot row's entry (meaningful in lane P)
-            const float pi = I[c] * pinv;
             const float ta = pcol * rbc<P>(pa);
-            const float ti = pcol * rbc<P>(pi);
             const float na = A[c] - ta;
-            const float ni = I[c] - ti;
             A[c] = is_p ? pa : na;
+        }
+#pragma unroll
+        for (int c = 0; c <= P; ++c) {
+            const float pi = I[c] * pinv;
+            const float ti = pcol * rbc<P>(pi);
+            const float ni = I[c] - ti;
             I[c] = is_p ? pi : ni;
         }
     });

@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
-"""Time mpcg_form_schur / mpcg_compute_dz on 128 trajectories x N=128."""
+"""Time mpcg_form_schur / mpcg_compute_dz on B trajectories x N knots (default 128 x 128):  time_schur.py [N [B]]"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from mpcgpu_amd import _lib as _L
+if os.environ.get("AB_LIB"):                      # A/B against another build of the library (tools/_prof/ab/)
+    _L.LIB_PATH = os.environ["AB_LIB"]
 from mpcgpu_amd import PcgSolver, synth
-N, B = 128, 128
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 sol = PcgSolver(N, max_batch=B)
 k = synth.make_kkt(N, B, 1)
 G, C, g, c = (torch.from_numpy(a).cuda() for a in synth.pack_kkt_dense(k, np.float32))
@@ -21,7 +25,7 @@ def t(fn, reps=6):
 for dpp in (0, 1):
     sol.set_option("schur_dpp", dpp)
     tag = "register/DPP kernels" if dpp else "LDS kernels"
-    print("form_schur (ss)   128 traj x 128 knots, %s: %.1f us" % (tag, t(lambda: sol.form_schur(G, C, g, c, 1e-3, "ss", S=S, Pinv=P, gamma=gm))))
-    print("form_schur (jac)  128 traj x 128 knots, %s: %.1f us" % (tag, t(lambda: sol.form_schur(G, C, g, c, 1e-3, "jacobi", S=S, Pinv=P, gamma=gm))))
+    print("form_schur (ss)   %d traj x %d knots, %s: %.1f us" % (B, N, tag, t(lambda: sol.form_schur(G, C, g, c, 1e-3, "ss", S=S, Pinv=P, gamma=gm))))
+    print("form_schur (jac)  %d traj x %d knots, %s: %.1f us" % (B, N, tag, t(lambda: sol.form_schur(G, C, g, c, 1e-3, "jacobi", S=S, Pinv=P, gamma=gm))))
 sol.form_schur(G, C, g, c, 1e-3, "ss", S=S, Pinv=P, gamma=gm)
-print("compute_dz        128 traj x 128 knots: %.1f us" % t(lambda: sol.compute_dz(G, C, g, lam)))
+print("compute_dz        %d traj x %d knots: %.1f us" % (B, N, t(lambda: sol.compute_dz(G, C, g, lam))))
