@@ -1197,7 +1197,7 @@ int mpcg_plant_create(mpcg_plant** out, int device, uint32_t num_joints, const d
     memset(hp, 0, sizeof(PlantDev));
     // The tables as given: X_k(q_k) = [[E, 0], [B, E]] with E = E0 + Es sin q_k + Ec cos q_k (likewise B), homogeneous transforms
     // R = R0 + Rs sin + Rc cos and translation p.  Tables are column-major (6x6 / 4x4), these are row-major 3x3 blocks.
-    struct Given { double E0[PJ][9], Es[PJ][9], Ec[PJ][9], B0[PJ][9], Bs[PJ][9], Bc[PJ][9], R0[PJ][9], Rs[PJ][9], Rc[PJ][9], p[PJ][3]; };
+    struct Given { double E0[PJ][9], Es[PJ][9], Ec[PJ][9], B0[PJ][9], Bs[PJ][9], Bc[PJ][9], R0[PJ][9], Rs[PJ][9], Rc[PJ][9], p[PJ][3], I[PJ][36]; };
     Given* gv = new (std::nothrow) Given();
     if (!gv) { delete hp; return MPCG_ERR_NOMEM; }
     memset(gv, 0, sizeof(Given));
@@ -1213,7 +1213,7 @@ int mpcg_plant_create(mpcg_plant** out, int device, uint32_t num_joints, const d
         for (int c = 0; c < 6; ++c)
             for (int r = 0; r < 6; ++r) {
                 ok = ok && place(k, r, c, X_const[k * 36 + c * 6 + r], 0);
-                hp->I[k][6 * r + c] = I_spatial[k * 36 + c * 6 + r];
+                gv->I[k][6 * r + c] = I_spatial[k * 36 + c * 6 + r];
             }
         for (int c = 0; c < 3; ++c)
             for (int r = 0; r < 3; ++r) gv->R0[k][3 * r + c] = Xhom_const[k * 16 + c * 4 + r];
@@ -1261,13 +1261,31 @@ int mpcg_plant_create(mpcg_plant** out, int device, uint32_t num_joints, const d
         delete hp; delete gv;
         return fail(nullptr, MPCG_ERR_UNSUPPORTED, "mpcg_plant_create: every joint must rotate about its own z axis, X_k(q) = blkdiag(Rz(q), Rz(q)) X_k(0) (the form of GRiD's tables)");
     }
-    for (int k = 0; k < PJ; ++k)
+    // Spatial inertias: the kernel multiplies with the rigid-body form [[Ibar, skew(h)], [skew(h)^T, m 1]] (ten numbers).
+    for (int k = 0; k < PJ; ++k) {
+        const double* Ik = gv->I[k];
+        double sc = 0.0, asym = 0.0;
         for (int r = 0; r < 6; ++r)
-            for (int c = 0; c < r; ++c)
-                if (fabs(hp->I[k][6 * r + c] - hp->I[k][6 * c + r]) > 1e-12 * fmax(1.0, fabs(hp->I[k][6 * r + c]))) {
-                    delete hp; delete gv;
-                    return fail(nullptr, MPCG_ERR_INVALID, "mpcg_plant_create: spatial inertias must be symmetric");
-                }
+            for (int c = 0; c < 6; ++c) { sc = fmax(sc, fabs(Ik[6 * r + c])); asym = fmax(asym, fabs(Ik[6 * r + c] - Ik[6 * c + r])); }
+        if (!(asym <= 1e-12 * fmax(1.0, sc))) {
+            delete hp; delete gv;
+            return fail(nullptr, MPCG_ERR_INVALID, "mpcg_plant_create: spatial inertias must be symmetric");
+        }
+        const double mass = Ik[6 * 3 + 3], h[3] = {Ik[6 * 2 + 4], Ik[6 * 0 + 5], Ik[6 * 1 + 3]};      // skew(h) = [[0, -hz, hy], [hz, 0, -hx], [-hy, hx, 0]]
+        const double sk[9] = {0, -h[2], h[1], h[2], 0, -h[0], -h[1], h[0], 0};
+        double devI = 0.0;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                devI = fmax(devI, fabs(Ik[6 * r + 3 + c] - sk[3 * r + c]));
+                devI = fmax(devI, fabs(Ik[6 * (3 + r) + 3 + c] - (r == c ? mass : 0.0)));
+            }
+        if (!(devI <= 1e-12 * fmax(1.0, sc))) {
+            delete hp; delete gv;
+            return fail(nullptr, MPCG_ERR_UNSUPPORTED, "mpcg_plant_create: spatial inertias must have the rigid-body form [[Ibar, skew(m c)], [skew(m c)^T, m 1]]");
+        }
+        const double ib[10] = {Ik[0], Ik[1], Ik[2], Ik[7], Ik[8], Ik[14], h[0], h[1], h[2], mass};
+        memcpy(hp->Ib[k], ib, sizeof(ib));
+    }
     // The end-effector position and Jacobian come out of the spatial transforms on the device (kkt_plant.hip.h, round 0); the reference
     // takes them from the homogeneous transforms.  Both tables describe the same chain: check it at three configurations.
     {

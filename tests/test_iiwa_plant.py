@@ -93,13 +93,18 @@ def _tampered(kind):
     elif kind == "inertia":
         m.I = np.array(m.I, dtype=np.float64, copy=True)
         m.I[2, 0, 4] += 1e-3
+    elif kind == "nonrigid":                                 # symmetric, but the mass block is not m * 1
+        m.I = np.array(m.I, dtype=np.float64, copy=True)
+        m.I[2, 3, 4] += 1e-3
+        m.I[2, 4, 3] += 1e-3
     return m
 
 
-@pytest.mark.parametrize("kind,rc,word", [("axis", -2, "z axis"), ("xhom", -1, "different chains"), ("inertia", -1, "symmetric")])
+@pytest.mark.parametrize("kind,rc,word", [("axis", -2, "z axis"), ("xhom", -1, "different chains"), ("inertia", -1, "symmetric"),
+                                          ("nonrigid", -2, "rigid-body form")])
 def test_plant_create_rejects_tables_the_kernel_cannot_use(kind, rc, word):
     """mpcg_plant_create checks what the device kernel assumes (kkt_plant.hip.h): joints rotate about their own z axis, the homogeneous
-    transforms and the spatial transforms describe the same chain (the end effector comes out of the latter), symmetric inertias.
+    transforms and the spatial transforms describe the same chain (the end effector comes out of the latter), symmetric inertias of the rigid-body form.
     The checks run on the host before any device call: no GPU needed."""
     from mpcgpu_amd import Plant, _lib
     with pytest.raises(_lib.MpcgError) as e:
