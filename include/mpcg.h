@@ -225,7 +225,11 @@ int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, flo
  * 1/2 qd_cost |qd|^2 + 1/2 r_cost |u|^2 with its Gauss-Newton Hessian.  Derivatives of the inverse dynamics are one-sided
  * differences in float64 on the device, (ID(. + h e_j) - u) / h with h = 3e-8 — the nominal value needs no evaluation, ID(q, qd, qdd) = u
  * because qdd = Minv (u - c) — agreement of A, B with the float64 central-difference host restatement mpcgpu_amd/iiwa.py: ~2e-7, the
- * rounding of the float outputs; not GRiD's analytic recursion.  num_joints = 7 is the compiled specialisation. */
+ * rounding of the float outputs; not GRiD's analytic recursion.  num_joints = 7 is the compiled specialisation.
+ * mpcg_plant_create checks what the device kernel relies on and returns MPCG_ERR_UNSUPPORTED / MPCG_ERR_INVALID otherwise: every joint
+ * rotates about its own z axis (X_k(q) = blkdiag(Rz(q), Rz(q)) X_k(0), the form of GRiD's tables), the spatial inertias are symmetric and of
+ * the rigid-body form [[Ibar, skew(m c)], [skew(m c)^T, m 1]], and Xhom describes the same chain as X (the end-effector position and
+ * Jacobian are taken from the spatial transforms on the device; Xhom is used for that consistency check only). */
 typedef struct mpcg_plant mpcg_plant;
 int mpcg_plant_create(mpcg_plant **out, int device, uint32_t num_joints, const double *X_const, const double *I_spatial,
                       const double *Xhom_const, const int32_t *X_trig_idx, const double *X_trig_coef, const int32_t *X_trig_j,
