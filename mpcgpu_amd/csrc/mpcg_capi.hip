@@ -53,6 +53,7 @@ struct mpcg_handle {
     int lpb = -1;             // lane-per-block kernel (pcg_lpb.hip.h): -1 auto (N <= 128, fp32, automatic configuration), 0 off, 1 forced
     int block_solve_wide = -1; // mpcg_block_solve: one trajectory per wavefront (1), four (0), by batch size (-1)
     int schur_dpp = 1;        // 1: register-resident Schur formation kernels (schur_dpp.hip.h), 0: the LDS versions
+    int schur_fma = 0;        // 1: the register-resident kernels compiled with floating-point contraction (fused multiply-adds): faster, not the oracle's bits
     int cluster_waves = -1;   // waves per cluster member: 8 (one member per CU), 4 (two per CU), -1 by batch size
     int cluster_adj = 1;      // lane order of the cluster kernel (1: blocks of a row in adjacent lanes)
     int cluster = -1;         // workgroups per trajectory for the cluster kernel: 0 off, -1 auto, G > 0 forced
@@ -246,6 +247,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
         h->cluster_lpb = value; return MPCG_OK;
     }
     if (!strcmp(key, "schur_dpp")) { h->schur_dpp = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "schur_fma")) { h->schur_fma = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
         if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");
         h->cluster = value; return MPCG_OK;
@@ -278,6 +280,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "cluster_lpk")) { *value = h->cluster_lpk; return MPCG_OK; }
     if (!strcmp(key, "last_symmetry_violations")) { *value = h->last_sym_violations; return MPCG_OK; }
     if (!strcmp(key, "schur_dpp")) { *value = h->schur_dpp; return MPCG_OK; }
+    if (!strcmp(key, "schur_fma")) { *value = h->schur_fma; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "spmv_mfma")) { *value = h->spmv_mfma; return MPCG_OK; }
     if (!strcmp(key, "num_cus")) { *value = h->num_cus; return MPCG_OK; }
@@ -1118,11 +1121,13 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
         // register-resident kernels, four knots per wave (schur_dpp.hip.h)
         long b4 = ((long)batch * (N - 1) + 3) / 4;
         if (b4 > cap) b4 = cap;
-        hipLaunchKernelGGL(form_schur_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);
+        if (h->schur_fma) hipLaunchKernelGGL(form_schur_dpp_kernel_fma, dim3((unsigned)b4), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(form_schur_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);
         HIP_TRY(h, hipGetLastError());
         b4 = ((long)batch * N + 3) / 4;
         if (b4 > cap) b4 = cap;
-        hipLaunchKernelGGL(complete_ss_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);
+        if (h->schur_fma) hipLaunchKernelGGL(complete_ss_dpp_kernel_fma, dim3((unsigned)b4), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(complete_ss_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);
         HIP_TRY(h, hipGetLastError());
     } else {
         hipLaunchKernelGGL((form_schur_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);

@@ -22,10 +22,12 @@ def t(fn, reps=6):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return float(np.median(ts[1:])) * 1e3
-for dpp in (0, 1):
-    sol.set_option("schur_dpp", dpp)
-    tag = "register/DPP kernels" if dpp else "LDS kernels"
+for dpp in (0, 1, 2):
+    sol.set_option("schur_dpp", 1 if dpp else 0)
+    sol.set_option("schur_fma", 1 if dpp == 2 else 0)
+    tag = ("register/DPP kernels, fused multiply-adds (schur_fma)" if dpp == 2 else "register/DPP kernels") if dpp else "LDS kernels"
     print("form_schur (ss)   %d traj x %d knots, %s: %.1f us" % (B, N, tag, t(lambda: sol.form_schur(G, C, g, c, 1e-3, "ss", S=S, Pinv=P, gamma=gm))))
     print("form_schur (jac)  %d traj x %d knots, %s: %.1f us" % (B, N, tag, t(lambda: sol.form_schur(G, C, g, c, 1e-3, "jacobi", S=S, Pinv=P, gamma=gm))))
+sol.set_option("schur_fma", 0)
 sol.form_schur(G, C, g, c, 1e-3, "ss", S=S, Pinv=P, gamma=gm)
 print("compute_dz        %d traj x %d knots: %.1f us" % (B, N, t(lambda: sol.compute_dz(G, C, g, lam))))
