@@ -295,6 +295,8 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * "check_symmetry" (debug, 0/1: see BLOCK SYMMETRY above),
  * read-only: "cluster_fixups" (trajectories re-solved by fix-up launches since mpcg_create because their cluster gave up after the bounded
  * spin — each costs 1.5-4.5 ms of spinning; blocking 8-byte D2H read), "last_symmetry_violations", "num_cus", "pcg_resident" (1 if the current configuration streams nothing inside the PCG loop),
+ * "schur_inplace" (-1 auto / 0 / 1: mpcg_form_schur's register-resident formation as three kernels with G inverted in place — Q and R once per
+ * knot, no scratch copy; automatic from batch * knot_points >= 16 x #CUs, smaller calls keep the two-kernel formation: one launch less; same bits),
  * "schur_fma" (0 / 1, default 0: mpcg_form_schur's register-resident kernels built with every rounded multiply + rounded add fused into one
  * multiply-add — ~12 % faster, results within 2e-4 of the default kernels' relative to the block scale instead of bit-identical to the oracle),
  * "last_kernel_family" (kernel of the last solve: 0 single-workgroup row-pair, 1 row-triple cluster, 2 lane-per-block, 3 generic,

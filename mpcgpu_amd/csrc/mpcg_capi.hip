@@ -53,6 +53,7 @@ struct mpcg_handle {
     int lpb = -1;             // lane-per-block kernel (pcg_lpb.hip.h): -1 auto (N <= 128, fp32, automatic configuration), 0 off, 1 forced
     int block_solve_wide = -1; // mpcg_block_solve: one trajectory per wavefront (1), four (0), by batch size (-1)
     int schur_dpp = 1;        // 1: register-resident Schur formation kernels (schur_dpp.hip.h), 0: the LDS versions
+    int schur_inplace = -1;   // register-resident Schur formation as three kernels with G inverted in place: -1 auto (throughput-sized calls), 0, 1
     int schur_fma = 0;        // 1: the register-resident kernels compiled with floating-point contraction (fused multiply-adds): faster, not the oracle's bits
     int cluster_waves = -1;   // waves per cluster member: 8 (one member per CU), 4 (two per CU), -1 by batch size
     int cluster_adj = 1;      // lane order of the cluster kernel (1: blocks of a row in adjacent lanes)
@@ -248,6 +249,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     }
     if (!strcmp(key, "schur_dpp")) { h->schur_dpp = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "schur_fma")) { h->schur_fma = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "schur_inplace")) { if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "schur_inplace must be -1 (auto), 0 or 1"); h->schur_inplace = value; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
         if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");
         h->cluster = value; return MPCG_OK;
@@ -281,6 +283,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "last_symmetry_violations")) { *value = h->last_sym_violations; return MPCG_OK; }
     if (!strcmp(key, "schur_dpp")) { *value = h->schur_dpp; return MPCG_OK; }
     if (!strcmp(key, "schur_fma")) { *value = h->schur_fma; return MPCG_OK; }
+    if (!strcmp(key, "schur_inplace")) { *value = h->schur_inplace; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "spmv_mfma")) { *value = h->spmv_mfma; return MPCG_OK; }
     if (!strcmp(key, "num_cus")) { *value = h->num_cus; return MPCG_OK; }
@@ -1101,7 +1104,10 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = (int)h->n, m = (int)control_size, N = (int)h->N;
     const size_t Gsz = (size_t)(n * n + m * m) * N - m * m;
-    const size_t need = Gsz * h->max_batch;
+    // Register-resident formation as three kernels with G inverted in place (schur_dpp.hip.h) once the call is large enough to be
+    // throughput-bound; small calls (one trajectory: the MPC loop's own case) keep the two-kernel formation, one launch less.
+    const bool inplace = h->schur_dpp && (h->schur_inplace == 1 || (h->schur_inplace < 0 && (long)batch * N >= (long)h->num_cus * 16));
+    const size_t need = inplace ? 0 : Gsz * h->max_batch;
     if (h->ginv_scratch_floats < need) {          // first call only (not stream-ordered: hipMalloc)
         if (h->ginv_scratch) HIP_TRY(h, hipFree(h->ginv_scratch));
         h->ginv_scratch = nullptr; h->ginv_scratch_floats = 0;
@@ -1117,7 +1123,26 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
     if (blocks > cap) blocks = cap;
     hipStream_t st = static_cast<hipStream_t>(stream);
     a.k0_only = 0;
-    if (h->schur_dpp) {
+    if (h->schur_dpp && inplace) {
+        a.Ginv_scratch = nullptr;
+        long b4 = ((long)batch * N + 3) / 4;
+        if (b4 > cap) b4 = cap;
+        if (h->schur_fma) hipLaunchKernelGGL(invert_g_dpp_kernel_fma, dim3((unsigned)b4), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(invert_g_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);
+        HIP_TRY(h, hipGetLastError());
+        if (N > 1) {
+            long b3 = ((long)batch * (N - 1) + 3) / 4;
+            if (b3 > cap) b3 = cap;
+            if (h->schur_fma) hipLaunchKernelGGL(form_schur_inv_dpp_kernel_fma, dim3((unsigned)b3), dim3(64), 0, st, a);
+            else hipLaunchKernelGGL(form_schur_inv_dpp_kernel, dim3((unsigned)b3), dim3(64), 0, st, a);
+            HIP_TRY(h, hipGetLastError());
+        }
+        if (a.ss) {
+            if (h->schur_fma) hipLaunchKernelGGL(complete_ss_dpp_kernel_fma, dim3((unsigned)b4), dim3(64), 0, st, a);
+            else hipLaunchKernelGGL(complete_ss_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);
+            HIP_TRY(h, hipGetLastError());
+        }
+    } else if (h->schur_dpp) {
         // register-resident kernels, four knots per wave (schur_dpp.hip.h)
         long b4 = ((long)batch * (N - 1) + 3) / 4;
         if (b4 > cap) b4 = cap;

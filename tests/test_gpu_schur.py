@@ -19,12 +19,16 @@ def dev(a):
 
 @pytest.mark.parametrize("N", [2, 3, 8, 33, 128])
 @pytest.mark.parametrize("precond", ["ss", "jacobi"])
-def test_form_schur_bit_exact_vs_oracle(orc, N, precond):
+@pytest.mark.parametrize("inplace", [0, 1])
+def test_form_schur_bit_exact_vs_oracle(orc, N, precond, inplace):
+    """inplace = 0: the two-kernel register-resident formation (small calls), 1: the three-kernel one with G inverted in place
+    (throughput-sized calls; forced here) — both the oracle's bits."""
     from mpcgpu_amd import PcgSolver
     B = 3
     k = synth.make_kkt(N, B, 555 + N)
     G, C, g, c = synth.pack_kkt_dense(k, np.float32)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("schur_inplace", inplace)
     dG = dev(G)
     poison = float("nan")
     S = torch.full((B, 3 * n * n * N), poison, device="cuda")
@@ -62,6 +66,7 @@ def test_form_schur_fused_variant_within_tolerance(orc, N, precond):
     k = synth.make_kkt(N, B, 555 + N)
     G, C, g, c = synth.pack_kkt_dense(k, np.float32)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("schur_inplace", N % 2)                 # (both formations have a fused build)
     out = {}
     for fma in (0, 1):
         sol.set_option("schur_fma", fma)
@@ -85,6 +90,28 @@ def test_form_schur_fused_variant_within_tolerance(orc, N, precond):
     it0, it1 = out[0][4].astype(np.int64), out[1][4].astype(np.int64)
     assert (np.abs(it1 - it0) <= np.maximum(3, 0.25 * it0)).all(), (it0, it1)
     assert relinf(out[1][5], out[0][5]) < 5e-2                                             # (two fp32 PCG runs on systems of cond 1e5)
+
+
+def test_form_schur_formations_agree_at_a_throughput_sized_batch():
+    """The automatic choice (three kernels from batch * N >= 16 x #CUs) and the forced two-kernel formation write the same bits into
+    S, Pinv, gamma and G^-1 on 96 x 64 knots (a grid-stride loop with ragged last wavefronts on both sides)."""
+    from mpcgpu_amd import PcgSolver
+    N, B = 64, 96
+    k = synth.make_kkt(N, B, 4242)
+    G, C, g, c = synth.pack_kkt_dense(k, np.float32)
+    sol = PcgSolver(N, max_batch=B)
+    outs = []
+    for mode in (-1, 0):
+        sol.set_option("schur_inplace", mode)
+        dG = dev(G)
+        S = torch.full((B, 3 * n * n * N), float("nan"), device="cuda")
+        P = torch.full((B, 3 * n * n * N), float("nan"), device="cuda")
+        gam = torch.full((B, n * N), float("nan"), device="cuda")
+        sol.form_schur(dG, dev(C), dev(g), dev(c), 1e-3, "ss", S=S, Pinv=P, gamma=gam)
+        torch.cuda.synchronize()
+        outs.append([t.cpu().numpy() for t in (S, P, gam, dG)])
+    for a0, a1 in zip(*outs):
+        np.testing.assert_array_equal(a0, a1)
 
 
 @pytest.mark.parametrize("N", [2, 9, 128])
