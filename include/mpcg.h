@@ -198,6 +198,17 @@ int mpcg_pcg_solve_ref_f64(mpcg_handle *h, double *d_S, double *d_Pinv, double *
                            uint32_t *d_pcg_iters, uint8_t *d_pcg_exit, uint32_t pcg_max_iter, double pcg_exit_tol,
                            void *stream);
 
+/* The steps either side of the solve for linsys_t = double: mpcg_form_schur / mpcg_compute_dz with every float replaced by double (same
+ * layouts, same side effects, same preconditioner choices).  Functional twins — one wavefront per knot, operands in LDS — in the float
+ * path's operation order: bit-identical to the oracle's double instantiation (tests/test_gpu_f64.py). */
+int mpcg_form_schur_f64(mpcg_handle *h, uint32_t control_size, double *d_G_dense, const double *d_C_dense,
+                        const double *d_g, const double *d_c, double *d_S, double *d_Pinv, double *d_gamma,
+                        double rho, uint32_t batch, mpcg_precond precond, void *stream);
+int mpcg_compute_dz_f64(mpcg_handle *h, uint32_t control_size, const double *d_Ginv_dense,
+                        const double *d_C_dense, const double *d_g, const double *d_lambda, double *d_dz,
+                        uint32_t batch, void *stream);
+
+
 /* Batched block-tridiagonal DIRECT solve of S lambda = gamma — the GPU-native counterpart of the reference's second
  * linear-system path (LINSYS_SOLVE == 0: qdldl_solve_schur, include/qdldl/sqp.cuh:22-49, called at :261-282 with
  * D2H(values, gamma) + CPU LDL^T + H2D(lambda) inside the timed region).  Reads d_S / d_gamma exactly as

@@ -16,20 +16,25 @@
 template <typename T>
 void form_schur_system(uint32_t state_size, uint32_t control_size, uint32_t knot_points, T* d_G_dense, T* d_C_dense,
                        T* d_g, T* d_c, T* d_S, T* d_Pinv, T* d_gamma, T rho) {
-    static_assert(std::is_same<T, float>::value, "libmpcg_hip is built for linsys_t = float");
+    static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value, "linsys_t is float or double (include/common/settings.cuh:41-49)");
     mpcg_handle* h = mpcg_compat::handle_for(state_size, knot_points);
-    if (mpcg_form_schur(h, control_size, d_G_dense, d_C_dense, d_g, d_c, d_S, d_Pinv, d_gamma, rho, 1, MPCG_PRECOND_SS,
-                        /*stream*/ nullptr) != MPCG_OK)
-        mpcg_compat::die("form_schur_system", h);
+    int rc;
+    if constexpr (std::is_same<T, float>::value)
+        rc = mpcg_form_schur(h, control_size, d_G_dense, d_C_dense, d_g, d_c, d_S, d_Pinv, d_gamma, rho, 1, MPCG_PRECOND_SS, /*stream*/ nullptr);
+    else
+        rc = mpcg_form_schur_f64(h, control_size, d_G_dense, d_C_dense, d_g, d_c, d_S, d_Pinv, d_gamma, rho, 1, MPCG_PRECOND_SS, /*stream*/ nullptr);
+    if (rc != MPCG_OK) mpcg_compat::die("form_schur_system", h);
 }
 
 template <typename T>
 void compute_dz(uint32_t state_size, uint32_t control_size, uint32_t knot_points, T* d_G_dense, T* d_C_dense, T* d_g_val,
                 T* d_lambda, T* d_dz) {
-    static_assert(std::is_same<T, float>::value, "libmpcg_hip is built for linsys_t = float");
+    static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value, "linsys_t is float or double (include/common/settings.cuh:41-49)");
     mpcg_handle* h = mpcg_compat::handle_for(state_size, knot_points);
-    if (mpcg_compute_dz(h, control_size, d_G_dense, d_C_dense, d_g_val, d_lambda, d_dz, 1, /*stream*/ nullptr) != MPCG_OK)
-        mpcg_compat::die("compute_dz", h);
+    int rc;
+    if constexpr (std::is_same<T, float>::value) rc = mpcg_compute_dz(h, control_size, d_G_dense, d_C_dense, d_g_val, d_lambda, d_dz, 1, /*stream*/ nullptr);
+    else rc = mpcg_compute_dz_f64(h, control_size, d_G_dense, d_C_dense, d_g_val, d_lambda, d_dz, 1, /*stream*/ nullptr);
+    if (rc != MPCG_OK) mpcg_compat::die("compute_dz", h);
 }
 
 // The linear solve of the reference's other path (LINSYS_SOLVE == 0) — D2H(values, gamma), qdldl_solve_schur
@@ -37,7 +42,7 @@ void compute_dz(uint32_t state_size, uint32_t control_size, uint32_t knot_points
 // the bd-layout S and gamma that form_schur_system left on the device: block-tridiagonal direct sweep, no host round trip.
 template <typename T>
 void block_solve_schur(uint32_t state_size, uint32_t knot_points, T* d_S, T* d_gamma, T* d_lambda) {
-    static_assert(std::is_same<T, float>::value, "libmpcg_hip is built for linsys_t = float");
+    static_assert(std::is_same<T, float>::value, "mpcg_block_solve is single precision");
     mpcg_handle* h = mpcg_compat::handle_for(state_size, knot_points);
     if (mpcg_block_solve(h, d_S, d_gamma, d_lambda, 1, /*stream*/ nullptr) != MPCG_OK) mpcg_compat::die("block_solve_schur", h);
 }

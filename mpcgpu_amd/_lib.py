@@ -42,6 +42,9 @@ SYMBOLS = {
     "mpcg_form_schur": (C.c_int, [C.c_void_p, C.c_uint32, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float,
                                   C.c_uint32, C.c_int, C.c_void_p]),
     "mpcg_compute_dz": (C.c_int, [C.c_void_p, C.c_uint32, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_void_p]),
+    "mpcg_form_schur_f64": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_double, C.c_uint32, C.c_int, C.c_void_p]),
+    "mpcg_compute_dz_f64": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "mpcg_prep_csr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mpcg_bd_to_csr_lowertri": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_uint32, C.c_void_p]),
     "mpcg_pcg_solve_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,

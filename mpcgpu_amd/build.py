@@ -53,6 +53,23 @@ def build_chain_example(force: bool = False, verbose: bool = False) -> str:
     return CHAIN_BIN
 
 
+CHAIN_BIN64 = os.path.join(_ROOT, "examples", "sqp_linsys_chain_f64")
+
+
+def build_chain_example_f64(force: bool = False, verbose: bool = False) -> str:
+    """The same chain compiled with -DUSE_DOUBLES (linsys_t = double): form_schur_system<double> -> pcg<double, n, N> -> compute_dz<double>."""
+    deps = [CHAIN_SRC, LIB_PATH, os.path.join(_ROOT, "include", "gbd_pcg_compat", "gpu_pcg.cuh"),
+            os.path.join(_ROOT, "include", "mpcgpu_compat", "linsys_steps.cuh")]
+    if force or not os.path.exists(CHAIN_BIN64) or any(os.path.getmtime(d) > os.path.getmtime(CHAIN_BIN64) for d in deps):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-DUSE_DOUBLES", "-I" + os.path.join(_ROOT, "include", "gbd_pcg_compat"),
+               "-I" + os.path.join(_ROOT, "include", "mpcgpu_compat"), CHAIN_SRC, "-L" + _HERE, "-lmpcg_hip",
+               "-Wl,-rpath,$ORIGIN/../mpcgpu_amd", "-o", CHAIN_BIN64]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return CHAIN_BIN64
+
+
 EXAMPLE_BIN64 = os.path.join(_ROOT, "examples", "sqp_pcg_callsite_f64")
 
 

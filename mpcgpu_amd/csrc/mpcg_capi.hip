@@ -72,6 +72,8 @@ struct mpcg_handle {
     float* block_scratch = nullptr;  // W_k, z_k of mpcg_block_solve: max_batch x N x 210 floats (first call)
     float* ginv_scratch = nullptr;   // staging for the in-place G <- G^-1 of mpcg_form_schur
     size_t ginv_scratch_floats = 0;
+    double* ginv_scratch_f64 = nullptr;   // the same for mpcg_form_schur_f64
+    size_t ginv_scratch_f64_elems = 0;
     std::string err;
 };
 
@@ -176,10 +178,11 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
 }
 
 int mpcg_destroy(mpcg_handle* h) {
-    if (h && (h->ginv_scratch || h->cluster_scratch || h->block_scratch)) {
+    if (h && (h->ginv_scratch || h->ginv_scratch_f64 || h->cluster_scratch || h->block_scratch)) {
         (void)hipSetDevice(h->device);
         if (h->block_scratch) (void)hipFree(h->block_scratch);
         if (h->ginv_scratch) (void)hipFree(h->ginv_scratch);
+        if (h->ginv_scratch_f64) (void)hipFree(h->ginv_scratch_f64);
         if (h->cluster_scratch) (void)hipFree(h->cluster_scratch);
     }
     delete h;
@@ -1182,6 +1185,66 @@ int mpcg_compute_dz(mpcg_handle* h, uint32_t control_size, const float* d_Ginv_d
     return MPCG_OK;
 }
 
+
+// ---- linsys_t = double (USE_DOUBLES = 1, include/common/settings.cuh:41-49): the steps either side of the solve in double precision.
+// Functional twins (the one-wavefront-per-knot LDS kernels of schur_kernels.hip.h instantiated for double): same arithmetic order as the
+// float path, bit-identical to the oracle's double instantiation. ----
+int mpcg_form_schur_f64(mpcg_handle* h, uint32_t control_size, double* d_G_dense, const double* d_C_dense, const double* d_g,
+                        const double* d_c, double* d_S, double* d_Pinv, double* d_gamma, double rho, uint32_t batch,
+                        mpcg_precond precond, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur_f64: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
+    if (!d_G_dense || !d_C_dense || !d_g || !d_c || !d_S || (!d_Pinv && precond != MPCG_PRECOND_NONE) || !d_gamma)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur_f64: null device pointer");
+    if (control_size != 7) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur_f64: control_size must be 7 (IIWA-14)");
+    if (precond != MPCG_PRECOND_NONE && precond != MPCG_PRECOND_JACOBI && precond != MPCG_PRECOND_SS)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur_f64: bad preconditioner");
+    if (batch == 0) return MPCG_OK;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur_f64: batch exceeds max_batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int n = (int)h->n, m = (int)control_size, N = (int)h->N;
+    const size_t Gsz = (size_t)(n * n + m * m) * N - m * m;
+    const size_t need = Gsz * h->max_batch;
+    if (h->ginv_scratch_f64_elems < need) {       // first call only (not stream-ordered: hipMalloc)
+        if (h->ginv_scratch_f64) HIP_TRY(h, hipFree(h->ginv_scratch_f64));
+        h->ginv_scratch_f64 = nullptr; h->ginv_scratch_f64_elems = 0;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->ginv_scratch_f64), need * sizeof(double)));
+        h->ginv_scratch_f64_elems = need;
+    }
+    SchurArgsT<double> a;
+    a.G = d_G_dense; a.C = d_C_dense; a.g = d_g; a.c = d_c; a.S = d_S; a.Pinv = d_Pinv; a.gamma = d_gamma;
+    a.Ginv_scratch = h->ginv_scratch_f64; a.Ginv_out = d_G_dense;
+    a.rho = rho; a.n = n; a.m = m; a.N = N; a.batch = (int)batch; a.ss = precond == MPCG_PRECOND_SS; a.pinv = precond != MPCG_PRECOND_NONE;
+    a.k0_only = 0;
+    long blocks = (long)batch * N;
+    const long cap = (long)h->num_cus * 64;
+    if (blocks > cap) blocks = cap;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL((form_schur_kernel<14, 7, double>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL((complete_ss_kernel<14, 7, double>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
+
+int mpcg_compute_dz_f64(mpcg_handle* h, uint32_t control_size, const double* d_Ginv_dense, const double* d_C_dense,
+                        const double* d_g, const double* d_lambda, double* d_dz, uint32_t batch, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_compute_dz_f64: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
+    if (!d_Ginv_dense || !d_C_dense || !d_g || !d_lambda || !d_dz)
+        return fail(h, MPCG_ERR_INVALID, "mpcg_compute_dz_f64: null device pointer");
+    if (control_size != 7) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_compute_dz_f64: control_size must be 7 (IIWA-14)");
+    if (batch == 0) return MPCG_OK;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_compute_dz_f64: batch exceeds max_batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    DzArgsT<double> a{d_Ginv_dense, d_C_dense, d_g, d_lambda, d_dz, (int)h->n, (int)control_size, (int)h->N, (int)batch};
+    long blocks = (long)batch * h->N;
+    const long cap = (long)h->num_cus * 64;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((compute_dz_kernel<14, 7, double>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
 
 int mpcg_prep_csr(mpcg_handle* h, int32_t* d_col_ptr, int32_t* d_row_ind, void* stream) {
     if (!h) return MPCG_ERR_INVALID;

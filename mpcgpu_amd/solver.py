@@ -263,17 +263,23 @@ class PcgSolver:
         its block inverses (the reference's side effect).  Returns (S, Pinv, gamma) device tensors."""
         B = c.shape[0] if c.dim() > 1 else 1
         n, m, N = self.n, control_size, self.N
-        self._chk(G_dense, B * ((n * n + m * m) * N - m * m), torch.float32, "G_dense")
-        self._chk(C_dense, B * (n * n + n * m) * (N - 1), torch.float32, "C_dense")
-        self._chk(g, B * ((n + m) * N - m), torch.float32, "g")
-        self._chk(c, B * n * N, torch.float32, "c")
+        dt = c.dtype                                           # float32, or float64 = linsys_t double (mpcg_form_schur_f64)
+        if dt not in (torch.float32, torch.float64):
+            raise TypeError("form_schur: float32 or float64 tensors")
+        self._chk(G_dense, B * ((n * n + m * m) * N - m * m), dt, "G_dense")
+        self._chk(C_dense, B * (n * n + n * m) * (N - 1), dt, "C_dense")
+        self._chk(g, B * ((n + m) * N - m), dt, "g")
+        self._chk(c, B * n * N, dt, "c")
         dev = c.device
-        S = torch.empty(B, 3 * n * n * N, device=dev) if S is None else S
-        Pinv = torch.empty(B, 3 * n * n * N, device=dev) if Pinv is None else Pinv
-        gamma = torch.empty(B, n * N, device=dev) if gamma is None else gamma
+        S = torch.empty(B, 3 * n * n * N, device=dev, dtype=dt) if S is None else S
+        Pinv = torch.empty(B, 3 * n * n * N, device=dev, dtype=dt) if Pinv is None else Pinv
+        gamma = torch.empty(B, n * N, device=dev, dtype=dt) if gamma is None else gamma
+        for t_, nm_ in ((S, "S"), (Pinv, "Pinv"), (gamma, "gamma")):
+            if t_.dtype != dt:
+                raise TypeError(f"form_schur: {nm_} must have the dtype of the inputs")
         pc = {"ss": _lib.MPCG_PRECOND_SS, "jacobi": _lib.MPCG_PRECOND_JACOBI, "none": _lib.MPCG_PRECOND_NONE}[precond]
-        self._check(self.lib.mpcg_form_schur(self._h, m, _ptr(G_dense), _ptr(C_dense), _ptr(g), _ptr(c), _ptr(S),
-                                             _ptr(Pinv), _ptr(gamma), float(rho), B, pc, _stream()))
+        fn = self.lib.mpcg_form_schur if dt == torch.float32 else self.lib.mpcg_form_schur_f64
+        self._check(fn(self._h, m, _ptr(G_dense), _ptr(C_dense), _ptr(g), _ptr(c), _ptr(S), _ptr(Pinv), _ptr(gamma), float(rho), B, pc, _stream()))
         return S, Pinv, gamma
 
     def generate_kkt(self, plant: "Plant", eePos_traj, xs, xu, timestep: float, qd_cost: float, r_cost: float,
@@ -298,10 +304,16 @@ class PcgSolver:
         """compute_dz (include/common/dz.cuh:124-136), batched."""
         B = lam.shape[0] if lam.dim() > 1 else 1
         n, m, N = self.n, control_size, self.N
+        dt = lam.dtype                                         # float32, or float64 = linsys_t double (mpcg_compute_dz_f64)
+        if dt not in (torch.float32, torch.float64):
+            raise TypeError("compute_dz: float32 or float64 tensors")
+        self._chk(Ginv_dense, B * ((n * n + m * m) * N - m * m), dt, "Ginv_dense")
+        self._chk(C_dense, B * (n * n + n * m) * (N - 1), dt, "C_dense")
+        self._chk(g, B * ((n + m) * N - m), dt, "g")
         if dz is None:
-            dz = torch.empty(B, (n + m) * N - m, device=lam.device)
-        self._check(self.lib.mpcg_compute_dz(self._h, m, _ptr(Ginv_dense), _ptr(C_dense), _ptr(g), _ptr(lam), _ptr(dz),
-                                             B, _stream()))
+            dz = torch.empty(B, (n + m) * N - m, device=lam.device, dtype=dt)
+        fn = self.lib.mpcg_compute_dz if dt == torch.float32 else self.lib.mpcg_compute_dz_f64
+        self._check(fn(self._h, m, _ptr(Ginv_dense), _ptr(C_dense), _ptr(g), _ptr(lam), _ptr(dz), B, _stream()))
         return dz
 
     def csr_nnz(self) -> int:

@@ -62,3 +62,52 @@ def test_f64_tolerance_exit_warm_start_and_flags(orc):
     it3, ex3 = sol.solve_f64(dS, dP, dg, torch.zeros_like(lam), pcg_config(pcg_exit_tol=1e-30, pcg_max_iter=3))
     torch.cuda.synchronize()
     assert (it3.cpu().numpy() == 3).all() and (ex3.cpu().numpy() == 1).all()
+
+
+@pytest.mark.parametrize("N", [2, 3, 8, 33, 128])
+@pytest.mark.parametrize("precond", ["ss", "jacobi"])
+def test_f64_form_schur_and_dz_bit_exact_vs_oracle(orc, N, precond):
+    """linsys_t = double types the whole linear-system step of the reference (include/common/settings.cuh:41-49), not only the PCG:
+    mpcg_form_schur_f64 / mpcg_compute_dz_f64 against the oracle's double instantiation, bit for bit (same operation order, contraction
+    off on both sides), including which bd slots are left unwritten; then the double-precision chain KKT blocks -> Schur -> PCG -> dz
+    solves the KKT system to 1e-9."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    m, B = 7, 3
+    k = synth.make_kkt(N, B, 555 + N)
+    G, C, g, c = synth.pack_kkt_dense(k, np.float64)
+    sol = PcgSolver(N, max_batch=B)
+    dG, dC, dg, dc = dev(G), dev(C), dev(g), dev(c)
+    S = torch.full((B, 3 * n * n * N), float("nan"), device="cuda", dtype=torch.float64)
+    P = torch.full((B, 3 * n * n * N), float("nan"), device="cuda", dtype=torch.float64)
+    gam = torch.full((B, n * N), float("nan"), device="cuda", dtype=torch.float64)
+    sol.form_schur(dG, dC, dg, dc, 1e-3, precond, S=S, Pinv=P, gamma=gam)
+    torch.cuda.synchronize()
+    Sh, Ph, gh, Gih = S.cpu().numpy(), P.cpu().numpy(), gam.cpu().numpy(), dG.cpu().numpy()
+    for b in range(B):
+        So, Po, go, Go = orc.form_schur(G[b], C[b], g[b], c[b], N, np.float64(1e-3), ss=(precond == "ss"))
+        np.testing.assert_array_equal(Sh[b], So)
+        np.testing.assert_array_equal(Ph[b], Po)
+        np.testing.assert_array_equal(gh[b], go)
+        np.testing.assert_array_equal(Gih[b], Go)
+    # solve in double precision and recover dz; compare dz with the oracle's on the same multipliers, bit for bit
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    Sz, Pz = torch.nan_to_num(S), torch.nan_to_num(P)
+    it, ex = sol.solve_f64(Sz, Pz, gam, lam, pcg_config(pcg_exit_tol=1e-22, pcg_max_iter=4000), precond)
+    dz = sol.compute_dz(dG, dC, dg, lam)
+    torch.cuda.synchronize()
+    lamh, dzh = lam.cpu().numpy(), dz.cpu().numpy()
+    for b in range(B):
+        np.testing.assert_array_equal(dzh[b], orc.compute_dz(Gih[b], C[b], g[b], lamh[b], N))
+        # the multipliers solve S lambda = gamma: true residual in float64
+        r = orc.bt_spmv(np.nan_to_num(Sh[b]), lamh[b], N) - gh[b]
+        assert np.abs(r).max() <= 1e-9 * max(1.0, np.abs(gh[b]).max()), (b, np.abs(r).max())
+
+
+def test_f64_wrappers_reject_mixed_precision():
+    from mpcgpu_amd import PcgSolver
+    N, B = 4, 1
+    sol = PcgSolver(N, max_batch=B)
+    k = synth.make_kkt(N, B, 1)
+    G, C, g, c = synth.pack_kkt_dense(k, np.float64)
+    with pytest.raises(ValueError):
+        sol.form_schur(dev(G.astype(np.float32)), dev(C), dev(g), dev(c), 1e-3)

@@ -213,6 +213,12 @@ def test_cpp_sqp_linsys_chain_over_shim_headers():
         assert r.returncode == 0, r.stdout + r.stderr
         out = json.loads(r.stdout.strip().splitlines()[-1])
         assert out["pcg_exit"] == 0 and out["constraint_err"] < 1e-3 and out["stationarity_err"] < 1e-3
+    # the same source with -DUSE_DOUBLES (linsys_t = double): every step in double precision, KKT conditions to 1e-9
+    exe64 = build.build_chain_example_f64()
+    r = subprocess.run([exe64], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["pcg_exit"] == 0 and out["constraint_err"] < 1e-9 and out["stationarity_err"] < 1e-9, out
 
 
 @pytest.mark.parametrize("N", [2, 3, 9, 32, 128, 300])

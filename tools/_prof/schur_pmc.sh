@@ -10,7 +10,7 @@ python - <<'PY'
 import json
 d=json.load(open('gpurun_out/sc_pmc.json'))['kernels']
 for k,v in d.items():
-    if 'schur_dpp' in k or 'complete_ss_dpp' in k:
+    if 'schur' in k or 'complete_ss' in k or 'invert_g' in k:
         print(k)
         for c,x in v.items(): print('   %-22s %14.0f  (%.1f us, %d records)' % (c, x['avg'], x.get('avg_duration_us_profiled',0), x['launches']))
 PY
