@@ -590,6 +590,32 @@ def main():
                            "cold_start": res["cold"], "warm_start_from_previous_sqp_iterate": res["warm"],
                            "note": "cond(-S) of these systems is 1e7-2e7 at N=128 (synthetic generator: ~1e5): from lambda0 = 0 most solves hit the reference's iteration "
                                    "cap, which presupposes the MPC loop's warm starts (tests/make_iiwa_golden.py prints the study)"}
+        # one whole linear-system step of an SQP iteration (include/pcg/sqp.cuh:190-259: KKT blocks, Schur system, PCG from the previous
+        # multipliers, dz) as ONE hipGraph replay: what a caller that keeps the loop on the device pays per iteration and batch
+        try:
+            lam_g = lam_prev.clone()
+            dz_g = torch.empty(B, 21 * N - 7, device=dev)
+
+            def step():
+                lam_g.copy_(lam_prev)
+                G_, C_, g_, c_ = sol.generate_kkt(plant, d_goal, d_xs, d_xu, iiwa.TIMESTEP, iiwa.QD_COST, rc)
+                S_, P_, gam_ = sol.form_schur(G_, C_, g_, c_, synth.RHO_INIT, "ss")
+                sol.solve(S_, P_, gam_, lam_g, cfg, "ss", iters=d_it, exits=d_ex)
+                sol.compute_dz(G_, C_, g_, lam_g, dz=dz_g)
+            step()
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                step()
+            ms_step = timed(gr.replay, 4, warm=1)
+            it_step = d_it.cpu().numpy().astype(np.int64)
+            sqp_step = {"what": "generate_kkt -> form_schur (ss) -> PCG warm-started from the previous iterate's multipliers -> compute_dz, one hipGraph replay",
+                        "ms_per_batch": ms_step, "batch": B, "sqp_linear_steps_per_sec": B / (ms_step * 1e-3), "us_per_trajectory_step": ms_step * 1e3 / B,
+                        "mean_pcg_iters": float(it_step.mean()), "dz_finite": bool(torch.isfinite(dz_g).all().item())}
+            del gr
+        except Exception as e_:                                  # (reported, never fatal for the headline measurement)
+            sqp_step = {"error": repr(e_)}
+        out["iiwa_run"]["sqp_linear_step_graph"] = sqp_step
         w_ = res["warm"]
         out["config"].update({"iiwa_warm_mean_pcg_iters": w_["mean_pcg_iters"], "iiwa_warm_max_iter_exit_rate": w_["max_iter_exit_rate"],
                               "iiwa_warm_linsolves_per_sec": w_["linsolves_per_sec"], "iiwa_warm_pcg_iterations_per_sec": w_["pcg_iterations_per_sec"],
@@ -597,6 +623,7 @@ def main():
                               "iiwa_warm_true_residual_max": w_["true_rel_residual_after_max"],
                               "iiwa_warm_trajectories_whose_residual_grew": w_["trajectories_whose_true_residual_grew"],
                               "iiwa_generate_kkt_ms": ms_kkt, "iiwa_form_schur_ms": ms_schur, "iiwa_warm_pcg_ms": w_["kernel_ms"],
+                              "iiwa_sqp_linear_step_ms": sqp_step.get("ms_per_batch"),
                               "iiwa_regime": "real IIWA-14 systems made on the device (mpcg_generate_kkt -> mpcg_form_schur), lambda warm-started from the previous SQP iterate: "
                                              "the regime the reference's iteration caps presuppose; the headline `value` is the cold-start synthetic batch"})
         del Gk, Ck, Gp, Cp, rS, rP, pS
