@@ -8,12 +8,13 @@ sys.path.insert(0, ROOT)
 import bench
 from mpcgpu_amd import PcgSolver, pcg_config, synth
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-# optional 2nd argument: "lpbc" (default: what the library picks — the clustered lane-per-block kernel for N > 128), "triple" (row-triple
-# cluster kernel), "lpbc_wt" (write-through hand-offs)
+# optional 2nd argument: "lpbc" (default name: what the library picks — since round 3 the clustered lane-PAIR kernel, family 7, for N > 128),
+# "lpbc_old" (round 2's clustered lane-per-block kernel, family 4), "triple" (row-triple cluster kernel), "lpbc_wt" (write-through hand-offs)
 mode = sys.argv[2] if len(sys.argv) > 2 else "lpbc"
 for N, B in ((128, 100), (256, 64), (512, 32), (512, 256), (256, 512), (192, 300), (640, 51)):
     sol = PcgSolver(N, max_batch=B)
     if mode == "triple": sol.set_option("cluster_lpb", 0)
+    if mode == "lpbc_old": sol.set_option("cluster_lpk", 0)
     if mode == "lpbc_wt": sol.set_option("cluster_l2", 0)
     if N <= 128: sol.set_option("cluster", 2)
     dS, dP, dg = bench.build_inputs(sol, N, B, 0, "ss", torch.device("cuda", 0))
@@ -31,4 +32,4 @@ for N, B in ((128, 100), (256, 64), (512, 32), (512, 256), (256, 512), (192, 300
             if ref is None: ref = cur
             elif not np.array_equal(ref, cur): bad += 1000000
     print(f"N={N} batch={B}: {reps} launches, kernel family {sol.get_option('last_kernel_family')} x {sol.get_option('last_kernel_cluster')} members, "
-          f"failures={bad} ({time.time()-t0:.1f} s)", flush=True)
+          f"failures={bad}, fix-up launches that re-solved a trajectory={sol.get_option('cluster_fixups')} ({time.time()-t0:.1f} s)", flush=True)
