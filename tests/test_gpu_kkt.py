@@ -30,7 +30,7 @@ def windows(N, B, seed):
     return iiwa.random_windows(N, B, seed)
 
 
-@pytest.mark.parametrize("N,B", [(8, 3), (32, 5)])
+@pytest.mark.parametrize("N,B", [(2, 1), (3, 2), (8, 3), (32, 5)])
 def test_generate_kkt_vs_host_restatement(env, N, B):
     PcgSolver, plant, _, M = env
     xu, goals, xs = windows(N, B, 11 + N)
@@ -46,6 +46,23 @@ def test_generate_kkt_vs_host_restatement(env, N, B):
         for got, ref, name in zip((G[b], C[b], g[b], c[b]), want, "GCgc"):
             # float output rounding (6e-8 relative) + central-difference noise of the dynamics gradients (~1e-9 x |dID| / h)
             assert np.abs(got - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max()), (b, name, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def test_generate_kkt_is_independent_of_batch_composition(env):
+    """A knot's blocks do not depend on what else is in the call: 300 windows of 128 knots (38,100 knots: more than the 8,192 x 4 a single
+    pass of the grid covers, so the grid-stride loop and its ragged last wavefront run) against the same windows generated in three
+    smaller calls — bit for bit."""
+    PcgSolver, plant, _, _ = env
+    N, B = 128, 300
+    xu, goals, xs = windows(N, B, 5)
+    sol = PcgSolver(N, max_batch=B)
+    args = lambda lo, hi: (plant, dev(goals[lo:hi].reshape(hi - lo, -1)), dev(xs[lo:hi]), dev(xu[lo:hi]), iiwa.TIMESTEP, iiwa.QD_COST, iiwa.r_cost(N))
+    full = [t.cpu().numpy() for t in sol.generate_kkt(*args(0, B))]
+    assert all(np.isfinite(a).all() for a in full)
+    for lo, hi in ((0, 1), (1, 130), (130, 300)):
+        part = [t.cpu().numpy() for t in sol.generate_kkt(*args(lo, hi))]
+        for a, b_, name in zip(full, part, "GCgc"):
+            np.testing.assert_array_equal(a[lo:hi], b_, err_msg=name)
 
 
 def test_generate_kkt_matches_committed_fixture(env):
