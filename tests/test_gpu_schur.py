@@ -92,6 +92,30 @@ def test_form_schur_fused_variant_within_tolerance(orc, N, precond):
     assert relinf(out[1][5], out[0][5]) < 5e-2                                             # (two fp32 PCG runs on systems of cond 1e5)
 
 
+@pytest.mark.parametrize("inplace", [0, 1])
+def test_form_schur_without_preconditioner_leaves_pinv_alone(inplace):
+    """precond = MPCG_PRECOND_NONE (what mpcg_block_solve needs): S, gamma and G^-1 as with a preconditioner, d_Pinv untouched — in both
+    register-resident formations."""
+    from mpcgpu_amd import PcgSolver
+    N, B = 9, 5
+    k = synth.make_kkt(N, B, 31)
+    G, C, g, c = synth.pack_kkt_dense(k, np.float32)
+    sol = PcgSolver(N, max_batch=B)
+    sol.set_option("schur_inplace", inplace)
+    res = {}
+    for pc in ("jacobi", "none"):
+        dG = dev(G)
+        S = torch.full((B, 3 * n * n * N), float("nan"), device="cuda")
+        P = torch.full((B, 3 * n * n * N), float("nan"), device="cuda")
+        gam = torch.full((B, n * N), float("nan"), device="cuda")
+        sol.form_schur(dG, dev(C), dev(g), dev(c), 1e-3, pc, S=S, Pinv=P, gamma=gam)
+        torch.cuda.synchronize()
+        res[pc] = [t.cpu().numpy() for t in (S, gam, dG, P)]
+    for a0, a1 in zip(res["jacobi"][:3], res["none"][:3]):
+        np.testing.assert_array_equal(a0, a1)
+    assert np.isnan(res["none"][3]).all() and not np.isnan(res["jacobi"][3]).all()
+
+
 def test_form_schur_formations_agree_at_a_throughput_sized_batch():
     """The automatic choice (three kernels from batch * N >= 16 x #CUs) and the forced two-kernel formation write the same bits into
     S, Pinv, gamma and G^-1 on 96 x 64 knots (a grid-stride loop with ragged last wavefronts on both sides)."""
