@@ -53,6 +53,9 @@ struct mpcg_handle {
     int lpb = -1;             // lane-per-block kernel (pcg_lpb.hip.h): -1 auto (N <= 128, fp32, automatic configuration), 0 off, 1 forced
     int block_solve_wide = -1; // mpcg_block_solve: one trajectory per wavefront (1), four (0), by batch size (-1)
     int schur_dpp = 1;        // 1: register-resident Schur formation kernels (schur_dpp.hip.h), 0: the LDS versions
+    int sched_hint = 1;       // dispatch the trajectories of a large call longest-expected-first, predicted by the previous call's iteration counts (sched_order_kernel)
+    uint32_t* sched_order = nullptr;   // [max_batch] dispatch order written after every hinted solve
+    uint32_t order_batch = 0;          // batch of the call that wrote it (0: none yet)
     int schur_inplace = -1;   // register-resident Schur formation as three kernels with G inverted in place: -1 auto (throughput-sized calls), 0, 1
     int schur_fma = 0;        // 1: the register-resident kernels compiled with floating-point contraction (fused multiply-adds): faster, not the oracle's bits
     int cluster_waves = -1;   // waves per cluster member: 8 (one member per CU), 4 (two per CU), -1 by batch size
@@ -173,6 +176,11 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
         return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the cluster scratch");
     }
     (void)hipMemset(h->cluster_scratch, 0, cluster_alloc_words(h) * sizeof(unsigned long long));
+    if (hipMalloc(reinterpret_cast<void**>(&h->sched_order), (size_t)max_batch * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipFree(h->cluster_scratch);
+        delete h;
+        return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the dispatch-order buffer");
+    }
     *out = h;
     return MPCG_OK;
 }
@@ -184,6 +192,7 @@ int mpcg_destroy(mpcg_handle* h) {
         if (h->ginv_scratch) (void)hipFree(h->ginv_scratch);
         if (h->ginv_scratch_f64) (void)hipFree(h->ginv_scratch_f64);
         if (h->cluster_scratch) (void)hipFree(h->cluster_scratch);
+        if (h->sched_order) (void)hipFree(h->sched_order);
     }
     delete h;
     return MPCG_OK;
@@ -252,6 +261,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     }
     if (!strcmp(key, "schur_dpp")) { h->schur_dpp = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "schur_fma")) { h->schur_fma = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "sched_hint")) { h->sched_hint = value ? 1 : 0; h->order_batch = 0; return MPCG_OK; }
     if (!strcmp(key, "schur_inplace")) { if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "schur_inplace must be -1 (auto), 0 or 1"); h->schur_inplace = value; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
         if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");
@@ -286,6 +296,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "last_symmetry_violations")) { *value = h->last_sym_violations; return MPCG_OK; }
     if (!strcmp(key, "schur_dpp")) { *value = h->schur_dpp; return MPCG_OK; }
     if (!strcmp(key, "schur_fma")) { *value = h->schur_fma; return MPCG_OK; }
+    if (!strcmp(key, "sched_hint")) { *value = h->sched_hint; return MPCG_OK; }
     if (!strcmp(key, "schur_inplace")) { *value = h->schur_inplace; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "spmv_mfma")) { *value = h->spmv_mfma; return MPCG_OK; }
@@ -953,7 +964,17 @@ int mpcg_pcg_solve(mpcg_handle* h, const float* d_S, const float* d_Pinv, const 
     a.r_out = nullptr; a.p_out = nullptr;
     a.iters = d_iters; a.max_iter_exit = d_max_iter_exit;
     a.N = (int)h->N; a.max_iter = (int)max_iter; a.exit_tol = exit_tol; a.pcols = (int)precond; a.lds_rows = 0;
-    return launch_pcg(h, a, batch, static_cast<hipStream_t>(stream), 4);
+    // Calls with more trajectories than CUs: dispatch longest-expected first, the expectation being the previous call's iteration
+    // counts for the same batch (pcg_kernels.hip.h: sched_order_kernel).  A scheduling hint only: no result depends on it.
+    const bool hinted = h->sched_hint && !h->generic && batch > (uint32_t)h->num_cus;
+    if (hinted && h->order_batch == batch) a.order = h->sched_order;
+    const int rc = launch_pcg(h, a, batch, static_cast<hipStream_t>(stream), 4);
+    if (rc == MPCG_OK && hinted && (h->last.family == FAM_LPK || h->last.family == FAM_LPKC)) {
+        hipLaunchKernelGGL(sched_order_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), d_iters, (int)batch, h->sched_order);
+        HIP_TRY(h, hipGetLastError());
+        h->order_batch = batch;
+    }
+    return rc;
 }
 
 int mpcg_pcg_solve_ref(mpcg_handle* h, float* d_S, float* d_Pinv, float* d_gamma, float* d_lambda,

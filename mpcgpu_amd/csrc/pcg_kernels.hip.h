@@ -190,6 +190,8 @@ struct PcgArgs {
     int redo_stride = 0;
     unsigned redo_skip = 0;
     unsigned long long* redo_count = nullptr;   // fix-up launches: += 1 per trajectory they re-solve (the handle's "cluster_fixups" counter)
+    // dispatch order (pcg_lpk_kernel, pcg_lpkc_kernel): workgroup / draw q solves trajectory order[q] (nullptr: q itself).  See sched_order_kernel.
+    const uint32_t* order = nullptr;
 };
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -1108,6 +1110,40 @@ __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict
         *reinterpret_cast<h8*>(dst + i) = o;
     } else {
         for (size_t e = i; e < count; ++e) dst[e] = (_Float16)src[e];
+    }
+}
+
+// Dispatch order for the NEXT call from the iteration counts of this one: trajectories sorted by descending count (counting sort over
+// min(iters, 1023) / 16; one workgroup).  Why: warm-started solves leave the loop at different iterations, and the hardware hands the
+// workgroups of a launch to the shader engines in index order — a free CU waits behind a busy engine's turn.  1024 N=128 systems with
+// 0..167 iterations (tools/_prof/order_experiment.py): 1.09 ms in random order, 0.73 ms sorted by count (0.79 ms sorted the other way:
+// neighbours of similar length keep the engines in step).  Consecutive SQP iterations of an MPC loop need similar counts per trajectory,
+// so the previous call's counts are the predictor.  Only the order of dispatch changes: every trajectory is solved exactly as before.
+// (64 buckets of 16 iterations: the prefix over the buckets is one wavefront's shuffle scan — the kernel sits between the solve and the
+//  caller's D2H of the results, so it is kept to three barriers: ~3 us.)
+__global__ __launch_bounds__(1024) void sched_order_kernel(const uint32_t* __restrict__ iters, int batch, uint32_t* __restrict__ order) {
+    constexpr int NB = 64, NT = 1024;
+    __shared__ unsigned hist[NB];
+    const int t = threadIdx.x;
+    auto key = [](uint32_t it) -> int { const uint32_t c = it < 1023u ? it : 1023u; return (NB - 1) - (int)(c >> 4); };   // bucket 0 = the longest solves
+    if (t < NB) hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < batch; i += NT) atomicAdd(&hist[key(iters[i])], 1u);
+    __syncthreads();
+    if (t < NB) {                                          // exclusive prefix over the 64 buckets inside wavefront 0
+        const unsigned mine = hist[t];
+        unsigned incl = mine;
+#pragma unroll
+        for (int d = 1; d < NB; d <<= 1) {
+            const unsigned up = __shfl_up(incl, d);
+            if (t >= d) incl += up;
+        }
+        hist[t] = incl - mine;
+    }
+    __syncthreads();
+    for (int i = t; i < batch; i += NT) {
+        const unsigned pos = atomicAdd(&hist[key(iters[i])], 1u);
+        order[pos] = (uint32_t)i;
     }
 }
 

@@ -401,10 +401,12 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpkc_kernel(ClusterArgs ca) 
             reinterpret_cast<int*>(bc)[2] = cl;
         }
         lds_barrier();
-        const int b = reinterpret_cast<const int*>(bc)[2];
-        if (bc[1] != 0.f || b >= ca.batch) break;
+        const int draw = reinterpret_cast<const int*>(bc)[2];
+        if (bc[1] != 0.f || draw >= ca.batch) break;
         kargp_t k_in = kp;
         asm volatile("" : "+s"(k_in));
+        // (dispatch order: the q-th draw of the call solves trajectory order[q] — longest-expected first, sched_order_kernel)
+        const int b = k_in->p.order ? (int)k_in->p.order[draw] : draw;
         const float* gam = k_in->p.gamma + (size_t)b * vstride;
         const float* lam_in = k_in->p.lambda + (size_t)b * vstride;
         int t_st = tid, i_st = i, h_st = h;

@@ -160,3 +160,50 @@ def test_kernel_family_depends_on_batch_and_can_be_pinned(orc, N):
     b_, fb, _ = run(Bbig, pin)
     assert fa == fb
     np.testing.assert_array_equal(a_, b_)                  # pinned: bit-identical whatever the batch
+
+
+@pytest.mark.parametrize("N,B", [(128, 600), (256, 300), (64, 1100)])
+def test_dispatch_order_hint_changes_no_result(N, B):
+    """Option "sched_hint" (default on): calls with more trajectories than CUs dispatch them longest-expected-first, the expectation being
+    the previous call's iteration counts (sched_order_kernel).  A scheduling matter only: with warm starts of very different quality
+    (0 .. cap iterations) the hinted second and third calls return the bits of the un-hinted call, for every trajectory; a call with
+    another batch size in between (no valid prediction) and a capped-at-zero call (all counts equal) do too."""
+    from mpcgpu_amd import PcgSolver, pcg_config, synth
+    import bench
+    dev_ = torch.device("cuda", 0)
+    sol = PcgSolver(N, max_batch=B)
+    dS, dP, dg = bench.build_inputs(sol, N, B, 3, "ss", dev_)
+    cap = synth.pcg_max_iter(N)
+    lam_star = torch.zeros(B, 14 * N, device=dev_)
+    sol.solve(dS, dP, dg, lam_star, pcg_config(pcg_exit_tol=1e-9, pcg_max_iter=3000))
+    gen = torch.Generator(device=dev_); gen.manual_seed(5)
+    amp = 10 ** (-7.0 + 6.0 * torch.rand(B, 1, device=dev_, generator=gen))
+    lam0 = lam_star + amp * lam_star.abs().amax(dim=1, keepdim=True) * torch.randn(B, 14 * N, device=dev_, generator=gen)
+    cfg = pcg_config(pcg_exit_tol=1e-4, pcg_max_iter=cap)
+
+    def run(batch=B, c=cfg):
+        lam = lam0[:batch].clone()
+        it, ex = sol.solve(dS[:batch], dP[:batch], dg[:batch], lam, c)
+        torch.cuda.synchronize()
+        return lam.cpu().numpy(), it.cpu().numpy().copy(), ex.cpu().numpy().copy()
+
+    sol.set_option("sched_hint", 0)
+    ref = run()
+    assert ref[1].min() < 0.3 * cap and ref[1].max() >= 0.9 * cap          # the batch really is mixed
+    sol.set_option("sched_hint", 1)
+    assert sol.get_option("sched_hint") == 1
+    fam = None
+    for _ in range(3):                                                       # 1st: no prediction yet; 2nd, 3rd: ordered by the previous counts
+        got = run()
+        fam = sol.get_option("last_kernel_family")
+        for a0, a1 in zip(ref, got):
+            np.testing.assert_array_equal(a0, a1)
+    assert fam in (6, 7)
+    part = run(batch=B - 37)                                                 # another batch size: the stored order does not apply
+    for a0, a1 in zip(ref, part):
+        np.testing.assert_array_equal(a0[:B - 37], a1)
+    zero = run(c=pcg_config(pcg_exit_tol=1e-4, pcg_max_iter=0))             # all counts equal (0): any order
+    assert (zero[1] == 0).all()
+    got = run()                                                              # ... and the order it left behind is still a permutation
+    for a0, a1 in zip(ref, got):
+        np.testing.assert_array_equal(a0, a1)

@@ -1,0 +1,21 @@
+"""Fixed cost of a register-resident solve (bringing S and Pinv on chip, setup, write-back) against its per-iteration cost:
+kernel time at max_iter = 1, 11, 21, 41 on 1024 trajectories (N = 128) and on one."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench
+from mpcgpu_amd import PcgSolver, pcg_config
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+for B in (1024, 1):
+    sol = PcgSolver(N, max_batch=B)
+    dS, dP, dg = bench.build_inputs(sol, N, B, 0, "ss", torch.device("cuda", 0))
+    lam = torch.zeros(B, 14 * N, device="cuda")
+    ts = {}
+    for K in (1, 11, 21, 41, 81):
+        cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+        def go():
+            lam.zero_(); sol.solve(dS, dP, dg, lam, cfg)
+        ts[K] = bench.timed(go, 5, warm=2) - bench.timed(lambda: lam.zero_(), 5, warm=2)
+    per_it = (ts[81] - ts[41]) / 40
+    print(f"N={N} batch={B}: " + "  ".join(f"K={k}: {v*1e3:.1f} us" for k, v in ts.items()) + f"   per iteration {per_it*1e3:.2f} us, fixed {1e3*(ts[1]-per_it):.1f} us (family {sol.get_option('last_kernel_family')})", flush=True)
