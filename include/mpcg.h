@@ -306,7 +306,7 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * "check_symmetry" (debug, 0/1: see BLOCK SYMMETRY above),
  * read-only: "cluster_fixups" (trajectories re-solved by fix-up launches since mpcg_create because their cluster gave up after the bounded
  * spin — each costs 1.5-4.5 ms of spinning; blocking 8-byte D2H read), "last_symmetry_violations", "num_cus", "pcg_resident" (1 if the current configuration streams nothing inside the PCG loop),
- * "sched_hint" (0 / 1, default 1: an mpcg_pcg_solve call with more trajectories than CUs that runs a register-resident kernel dispatches
+ * "sched_hint" (0 / 1, default 1: an mpcg_pcg_solve call with more trajectories than CUs that runs a register-resident kernel (row-per-lane, lane-per-block, lane-pair, clustered lane-pair) dispatches
  * its trajectories longest-expected-first, the expectation being the iteration counts the handle's previous call with the same batch size
  * wrote to d_iters — warm-started solves leave the loop at very different iterations and the dispatch order decides how well the chip stays
  * filled: -25..35 % on such batches; a scheduling hint only, no result depends on it; one extra ~3 us kernel behind each such solve),

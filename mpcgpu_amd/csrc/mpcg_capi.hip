@@ -969,7 +969,7 @@ int mpcg_pcg_solve(mpcg_handle* h, const float* d_S, const float* d_Pinv, const 
     const bool hinted = h->sched_hint && !h->generic && batch > (uint32_t)h->num_cus;
     if (hinted && h->order_batch == batch) a.order = h->sched_order;
     const int rc = launch_pcg(h, a, batch, static_cast<hipStream_t>(stream), 4);
-    if (rc == MPCG_OK && hinted && (h->last.family == FAM_LPK || h->last.family == FAM_LPKC)) {
+    if (rc == MPCG_OK && hinted && (h->last.family == FAM_LPK || h->last.family == FAM_LPKC || h->last.family == FAM_LPB || h->last.family == FAM_RPL)) {
         hipLaunchKernelGGL(sched_order_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), d_iters, (int)batch, h->sched_order);
         HIP_TRY(h, hipGetLastError());
         h->order_batch = batch;

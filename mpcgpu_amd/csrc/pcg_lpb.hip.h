@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpb_kernel(PcgArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
+    const int b = a.order ? (int)a.order[blockIdx.x] : (int)blockIdx.x;     // (dispatch order: longest-expected first, sched_order_kernel)
     // fix-up launch behind a cluster kernel: only the flagged trajectories run
     if (a.redo_flags && __hip_atomic_load(a.redo_flags + (size_t)b * a.redo_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.redo_skip) return;
     if (a.redo_flags && a.redo_count && tid == 0) __hip_atomic_fetch_add(a.redo_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

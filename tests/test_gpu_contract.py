@@ -162,7 +162,7 @@ def test_kernel_family_depends_on_batch_and_can_be_pinned(orc, N):
     np.testing.assert_array_equal(a_, b_)                  # pinned: bit-identical whatever the batch
 
 
-@pytest.mark.parametrize("N,B", [(128, 600), (256, 300), (64, 1100)])
+@pytest.mark.parametrize("N,B", [(128, 600), (256, 300), (64, 1100), (32, 1300)])
 def test_dispatch_order_hint_changes_no_result(N, B):
     """Option "sched_hint" (default on): calls with more trajectories than CUs dispatch them longest-expected-first, the expectation being
     the previous call's iteration counts (sched_order_kernel).  A scheduling matter only: with warm starts of very different quality
@@ -198,7 +198,7 @@ def test_dispatch_order_hint_changes_no_result(N, B):
         fam = sol.get_option("last_kernel_family")
         for a0, a1 in zip(ref, got):
             np.testing.assert_array_equal(a0, a1)
-    assert fam in (6, 7)
+    assert fam in (5, 6, 7)
     part = run(batch=B - 37)                                                 # another batch size: the stored order does not apply
     for a0, a1 in zip(ref, part):
         np.testing.assert_array_equal(a0[:B - 37], a1)

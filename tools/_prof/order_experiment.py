@@ -10,7 +10,8 @@ import bench
 from mpcgpu_amd import PcgSolver, pcg_config
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 B = 1024
-cap = {128: 167, 256: 118, 512: 67}.get(N, 167)
+B = 4096 if N <= 32 else (2048 if N <= 64 else 1024)
+cap = {32: 173, 128: 167, 256: 118, 512: 67}.get(N, 167)
 dev = torch.device("cuda", 0)
 sol = PcgSolver(N, max_batch=B)
 dS, dP, dg = bench.build_inputs(sol, N, B, 0, "ss", dev)
