@@ -471,6 +471,17 @@ def main():
               "unit_of_work": "one block-tridiagonal SpMV of one trajectory (SURVEY §8d)", "working_set_mb": Bs * 3 * 196 * N * 4 / 1e6,
               "frac_of_measured_copy_ceiling_6.29TBs": b_sp / (ms * 1e-3) / 1e9 / 6290.0,
               "trajectory_spmv_per_sec": Bs / (ms * 1e-3)}
+        # what THIS box's HBM delivers to the plainest stream there is: a device-to-device copy of the same 1.2 GB (read + write bytes);
+        # the SpMV fraction moves with it from box to box (0.65 .. 0.77 of the 8 TB/s peak seen across the pool)
+        try:
+            dst = torch.empty_like(S_big)
+            ms_cp = timed(lambda: dst.copy_(S_big), 5, warm=2)
+            cp_gbs = 2.0 * S_big.numel() * 4 / (ms_cp * 1e-3) / 1e9
+            sp["d2d_copy_gbs_this_run"] = cp_gbs
+            sp["frac_of_d2d_copy_this_run"] = sp["achieved"] / cp_gbs
+            del dst
+        except Exception as e_:
+            sp["d2d_copy_gbs_this_run"] = None
         tr, src = load_traffic(f"bt_spmv_kernel|N{N}_B{Bs}")
         if tr:
             sp["traffic"] = tr["hbm_traffic_bytes_per_launch"]
