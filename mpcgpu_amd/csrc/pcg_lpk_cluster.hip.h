@@ -212,7 +212,12 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpkc_kernel(ClusterArgs ca) 
                 float* zo = lds + ZOUT;
 #pragma unroll
                 for (int s = 0; s < 3; ++s) *reinterpret_cast<f2*>(zo + bA + K2 * s) = z2[s];
-                zo[b0 + 3 * K2 + h] = z6;
+                // (slot 3, entry h: b0 + 3 K2 + h, formed from bA on the spot — as a lane constant of its own it was the one VGPR the kernel
+                //  spilled: a scratch reload + wait in front of this store in every pass)
+                //  (h = lane & 1, re-read from the hardware lane count so that nothing of it lives across the pass.)
+                int ln6;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln6));
+                zo[bA + ((ln6 & 1) ? 1 - K2 : 3 * K2)] = z6;
             }
             // z of the first own knot is the LEFT member's missing part: published now, half a pass before the hand-off
             if (valid && i == 0 && g > 0) publish_pair(std::integral_constant<int, base + LPKC_W_Z>{}, ep, z2[0], z2[1], z2[2], f2{z6, dpp_partner(z6)});
