@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpkc_kernel(ClusterArgs ca) 
     auto half = [&](auto mode_tag, auto slot, const Fetch& f, const Vec& old, float c, int TOUT, int ZOUT) -> Vec {
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr int base = decltype(slot)::value;
-        constexpr int pb = base == LPBC_SLOT_V ? 0 : 8;
+        [[maybe_unused]] constexpr int pb = base == LPBC_SLOT_V ? 0 : 8;     // (stamp numbers of the -DMPCG_PROF build)
         MPCG_STAMP(pb + 0);
         const unsigned ep = epoch + 1;                      // tag of the hand-off that follows this pass
         f2 xk[7];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpkc_kernel(ClusterArgs ca) 
     // Returns the cluster-wide inner product.
     auto exchange = [&](auto slot, bool poller, int TV, int ZV, bool withZ) -> float {
         constexpr int base = decltype(slot)::value;
-        constexpr int pb = base == LPBC_SLOT_V ? 0 : 8;
+        [[maybe_unused]] constexpr int pb = base == LPBC_SLOT_V ? 0 : 8;
         ++epoch;
         MPCG_STAMP(pb + 2);
         if (poller) {
