@@ -144,23 +144,31 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
             bL6[s] = okL ? bs + (uint32_t)(NS * 4) * (uint32_t)(6 + h) : OOB_OFF;
             bD6[s] = okD ? bs + (uint32_t)(NS * 4) * (uint32_t)(6 + h) + BLK4 * 16u : OOB_OFF;
         }
+        // Row pairs (q, q + 1) of one column are 16 contiguous bytes, and in BOTH lanes' slot orders the slot pairs (0, 1) and (4, 5) hold
+        // consecutive row pairs (lane 0: P0 P1 / P4 P5, lane 1: P4 P5 / P0 P1): those four slots come in as two 16-byte loads, slots 2, 3, 6 as
+        // 8-byte loads — five instead of seven load instructions per column.  The load phase is bound by the L1's tag rate (every lane of a
+        // load touches its own cache line: 64 lookups per instruction, ~21 us per 600 KB trajectory at seven loads per column), not by bytes.
+        auto load_col = [&](f2 (&Mx)[7][7], const uint32_t (&bs)[7], int j, uint32_t coff) {
+            const f4 a01 = buf_load4<false>(M, bs[0] + coff), a45 = buf_load4<false>(M, bs[4] + coff);
+            Mx[0][j] = f2{a01.x, a01.y}; Mx[1][j] = f2{a01.z, a01.w};
+            Mx[4][j] = f2{a45.x, a45.y}; Mx[5][j] = f2{a45.z, a45.w};
+            Mx[2][j] = buf_load2(M, bs[2] + coff);
+            Mx[3][j] = buf_load2(M, bs[3] + coff);
+            Mx[6][j] = buf_load2(M, bs[6] + coff);
+        };
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-#pragma unroll
-            for (int s = 0; s < 7; ++s) Ml[s][j] = buf_load2(M, bL[s] + (uint32_t)(NS * 4 * j));
+            load_col(Ml, bL, j, (uint32_t)(NS * 4 * j));
             __builtin_amdgcn_sched_barrier(0);               // (the scheduler would regroup the loads by base register = slot-major)
         }
-#pragma unroll
-        for (int s = 0; s < 7; ++s) Ml[s][6] = buf_load2(M, bL6[s]);
+        load_col(Ml, bL6, 6, 0u);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-#pragma unroll
-            for (int s = 0; s < 7; ++s) Md[s][j] = buf_load2(M, bD[s] + (uint32_t)(NS * 4 * j));
+            load_col(Md, bD, j, (uint32_t)(NS * 4 * j));
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int s = 0; s < 7; ++s) Md[s][6] = buf_load2(M, bD6[s]);
+        load_col(Md, bD6, 6, 0u);
     }
 
     // park the pairs the pass uses last (rows 4..6 of the diagonal block's seventh column) in LDS; they are fetched back inside the pass

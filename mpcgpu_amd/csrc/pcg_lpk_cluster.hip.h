@@ -432,23 +432,28 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpkc_kernel(ClusterArgs ca) 
                 bL6[s] = okL ? bs + (uint32_t)(NS * 4) * (uint32_t)(6 + h_st) : OOB_OFF;
                 bD6[s] = okD ? bs + (uint32_t)(NS * 4) * (uint32_t)(6 + h_st) + BLK4 * 16u : OOB_OFF;
             }
+            // (pcg_lpk_kernel's load: slot pairs (0, 1) and (4, 5) as 16-byte loads, five load instructions per column instead of seven)
+            auto load_col = [&](f2 (&Mx)[7][7], const uint32_t (&bs)[7], int j, uint32_t coff) {
+                const f4 a01 = buf_load4<false>(M, bs[0] + coff), a45 = buf_load4<false>(M, bs[4] + coff);
+                Mx[0][j] = f2{a01.x, a01.y}; Mx[1][j] = f2{a01.z, a01.w};
+                Mx[4][j] = f2{a45.x, a45.y}; Mx[5][j] = f2{a45.z, a45.w};
+                Mx[2][j] = buf_load2(M, bs[2] + coff);
+                Mx[3][j] = buf_load2(M, bs[3] + coff);
+                Mx[6][j] = buf_load2(M, bs[6] + coff);
+            };
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-#pragma unroll
-                for (int s = 0; s < 7; ++s) Ml[s][j] = buf_load2(M, bL[s] + (uint32_t)(NS * 4 * j));
+                load_col(Ml, bL, j, (uint32_t)(NS * 4 * j));
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int s = 0; s < 7; ++s) Ml[s][6] = buf_load2(M, bL6[s]);
+            load_col(Ml, bL6, 6, 0u);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-#pragma unroll
-                for (int s = 0; s < 7; ++s) Md[s][j] = buf_load2(M, bD[s] + (uint32_t)(NS * 4 * j));
+                load_col(Md, bD, j, (uint32_t)(NS * 4 * j));
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int s = 0; s < 7; ++s) Md[s][6] = buf_load2(M, bD6[s]);
+            load_col(Md, bD6, 6, 0u);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
 #pragma unroll
