@@ -16,6 +16,7 @@
 #include "pcg_rpl.hip.h"
 #include "schur_kernels.hip.h"
 #include "schur_dpp.hip.h"
+#include "schur_walk.hip.h"
 #include "block_solve.hip.h"
 #include "pcg_f64.hip.h"
 #include "ldl_host.hpp"
@@ -57,6 +58,12 @@ struct mpcg_handle {
     uint32_t* sched_order = nullptr;   // [max_batch] dispatch order written after every hinted solve
     uint32_t order_batch = 0;          // batch of the call that wrote it (0: none yet)
     int schur_inplace = -1;   // register-resident Schur formation as three kernels with G inverted in place: -1 auto (throughput-sized calls), 0, 1
+    int schur_walk = -1;      // one-pass chunk-walking formation (schur_walk.hip.h): -1 auto (throughput-sized calls), 0 off, 1 forced
+    int schur_chunk = 16;     //   block rows per chunk
+    int schur_walk_waves = 2; //   launch bound of the walking kernel (waves per SIMD): 2, 3 or 4
+    int dz_dpp = 1;           // 1: four-knots-per-wavefront dz recovery (schur_walk.hip.h), 0: the one-workgroup-per-knot LDS kernel
+    float* seam_qinv = nullptr;      // schur_walk: one Q^-1 per chunk seam (max_batch x chunks x 196 floats)
+    size_t seam_qinv_floats = 0;
     int schur_fma = 0;        // 1: the register-resident kernels compiled with floating-point contraction (fused multiply-adds): faster, not the oracle's bits
     int cluster_waves = -1;   // waves per cluster member: 8 (one member per CU), 4 (two per CU), -1 by batch size
     int cluster_adj = 1;      // lane order of the cluster kernel (1: blocks of a row in adjacent lanes)
@@ -190,6 +197,7 @@ int mpcg_destroy(mpcg_handle* h) {
         (void)hipSetDevice(h->device);
         if (h->block_scratch) (void)hipFree(h->block_scratch);
         if (h->ginv_scratch) (void)hipFree(h->ginv_scratch);
+        if (h->seam_qinv) (void)hipFree(h->seam_qinv);
         if (h->ginv_scratch_f64) (void)hipFree(h->ginv_scratch_f64);
         if (h->cluster_scratch) (void)hipFree(h->cluster_scratch);
         if (h->sched_order) (void)hipFree(h->sched_order);
@@ -261,6 +269,10 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     }
     if (!strcmp(key, "schur_dpp")) { h->schur_dpp = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "schur_fma")) { h->schur_fma = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "schur_walk")) { if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "schur_walk must be -1 (auto), 0 or 1"); h->schur_walk = value; return MPCG_OK; }
+    if (!strcmp(key, "schur_chunk")) { if (value < 1 || value > 2048) return fail(h, MPCG_ERR_INVALID, "schur_chunk must be 1..2048 block rows"); h->schur_chunk = value; return MPCG_OK; }
+    if (!strcmp(key, "schur_walk_waves")) { if (value < 2 || value > 4) return fail(h, MPCG_ERR_INVALID, "schur_walk_waves must be 2, 3 or 4"); h->schur_walk_waves = value; return MPCG_OK; }
+    if (!strcmp(key, "dz_dpp")) { h->dz_dpp = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "sched_hint")) { h->sched_hint = value ? 1 : 0; h->order_batch = 0; return MPCG_OK; }
     if (!strcmp(key, "schur_inplace")) { if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "schur_inplace must be -1 (auto), 0 or 1"); h->schur_inplace = value; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
@@ -296,6 +308,10 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "last_symmetry_violations")) { *value = h->last_sym_violations; return MPCG_OK; }
     if (!strcmp(key, "schur_dpp")) { *value = h->schur_dpp; return MPCG_OK; }
     if (!strcmp(key, "schur_fma")) { *value = h->schur_fma; return MPCG_OK; }
+    if (!strcmp(key, "schur_walk")) { *value = h->schur_walk; return MPCG_OK; }
+    if (!strcmp(key, "schur_chunk")) { *value = h->schur_chunk; return MPCG_OK; }
+    if (!strcmp(key, "schur_walk_waves")) { *value = h->schur_walk_waves; return MPCG_OK; }
+    if (!strcmp(key, "dz_dpp")) { *value = h->dz_dpp; return MPCG_OK; }
     if (!strcmp(key, "sched_hint")) { *value = h->sched_hint; return MPCG_OK; }
     if (!strcmp(key, "schur_inplace")) { *value = h->schur_inplace; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
@@ -1130,6 +1146,42 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
     const size_t Gsz = (size_t)(n * n + m * m) * N - m * m;
     // Register-resident formation as three kernels with G inverted in place (schur_dpp.hip.h) once the call is large enough to be
     // throughput-bound; small calls (one trajectory: the MPC loop's own case) keep the two-kernel formation, one launch less.
+    // Round 4: throughput-sized calls run the one-pass chunk-walking formation (schur_walk.hip.h) + its seam kernel.
+    const int wL = h->schur_chunk;
+    const int wchunks = N >= 2 ? (N - 1 + wL - 1) / wL : 0;
+    // (its kernels address every array through a buffer resource with 31-bit byte offsets: 2,352 B of S per knot => below 913 k knots)
+    const bool walk = h->schur_dpp && !h->schur_fma && N >= 2 && (uint64_t)batch * N * 2352u < (1ull << 31) &&
+                      (h->schur_walk == 1 || (h->schur_walk < 0 && h->schur_inplace < 0 && (long)batch * wchunks >= (long)h->num_cus * 16));
+    if (walk) {
+        const size_t need_s = (size_t)h->max_batch * wchunks * 196;
+        if (h->seam_qinv_floats < need_s) {       // first call only (not stream-ordered: hipMalloc)
+            if (h->seam_qinv) HIP_TRY(h, hipFree(h->seam_qinv));
+            h->seam_qinv = nullptr; h->seam_qinv_floats = 0;
+            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->seam_qinv), need_s * sizeof(float)));
+            h->seam_qinv_floats = need_s;
+        }
+        sw::WalkArgs w;
+        w.s.G = d_G_dense; w.s.C = d_C_dense; w.s.g = d_g; w.s.c = d_c; w.s.S = d_S; w.s.Pinv = d_Pinv; w.s.gamma = d_gamma;
+        w.s.Ginv_scratch = nullptr; w.s.Ginv_out = d_G_dense;
+        w.s.rho = rho; w.s.n = n; w.s.m = m; w.s.N = N; w.s.batch = (int)batch; w.s.ss = precond == MPCG_PRECOND_SS; w.s.pinv = precond != MPCG_PRECOND_NONE;
+        w.s.k0_only = 0;
+        w.seam_qinv = h->seam_qinv; w.L = wL; w.chunks = wchunks;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const long capw = (long)h->num_cus * 64;
+        long bw = ((long)batch * wchunks + 3) / 4;
+        if (bw > capw) bw = capw;
+        if (h->schur_walk_waves == 4) hipLaunchKernelGGL(sw::schur_walk_kernel<4>, dim3((unsigned)bw), dim3(64), 0, st, w);
+        else if (h->schur_walk_waves == 3) hipLaunchKernelGGL(sw::schur_walk_kernel<3>, dim3((unsigned)bw), dim3(64), 0, st, w);
+        else hipLaunchKernelGGL(sw::schur_walk_kernel<2>, dim3((unsigned)bw), dim3(64), 0, st, w);
+        HIP_TRY(h, hipGetLastError());
+        if (wchunks > 1) {
+            long bs = ((long)batch * (wchunks - 1) + 3) / 4;
+            if (bs > capw) bs = capw;
+            hipLaunchKernelGGL(sw::schur_seam_kernel, dim3((unsigned)bs), dim3(64), 0, st, w);
+            HIP_TRY(h, hipGetLastError());
+        }
+        return MPCG_OK;
+    }
     const bool inplace = h->schur_dpp && (h->schur_inplace == 1 || (h->schur_inplace < 0 && (long)batch * N >= (long)h->num_cus * 16));
     const size_t need = inplace ? 0 : Gsz * h->max_batch;
     if (h->ginv_scratch_floats < need) {          // first call only (not stream-ordered: hipMalloc)
@@ -1201,7 +1253,13 @@ int mpcg_compute_dz(mpcg_handle* h, uint32_t control_size, const float* d_Ginv_d
     long blocks = (long)batch * h->N;
     const long cap = (long)h->num_cus * 64;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((compute_dz_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    if (h->dz_dpp && h->N >= 2 && (uint64_t)batch * h->N * 1176u < (1ull << 31)) {     // (31-bit byte offsets into C)
+        long b4 = ((long)batch * h->N + 3) / 4;
+        if (b4 > cap * 4) b4 = cap * 4;
+        hipLaunchKernelGGL(sw::compute_dz_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    } else {
+        hipLaunchKernelGGL((compute_dz_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    }
     HIP_TRY(h, hipGetLastError());
     return MPCG_OK;
 }

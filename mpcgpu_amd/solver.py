@@ -274,9 +274,9 @@ class PcgSolver:
         S = torch.empty(B, 3 * n * n * N, device=dev, dtype=dt) if S is None else S
         Pinv = torch.empty(B, 3 * n * n * N, device=dev, dtype=dt) if Pinv is None else Pinv
         gamma = torch.empty(B, n * N, device=dev, dtype=dt) if gamma is None else gamma
-        for t_, nm_ in ((S, "S"), (Pinv, "Pinv"), (gamma, "gamma")):
-            if t_.dtype != dt:
-                raise TypeError(f"form_schur: {nm_} must have the dtype of the inputs")
+        self._chk(S, B * 3 * n * n * N, dt, "S")
+        self._chk(Pinv, B * 3 * n * n * N, dt, "Pinv")
+        self._chk(gamma, B * n * N, dt, "gamma")
         pc = {"ss": _lib.MPCG_PRECOND_SS, "jacobi": _lib.MPCG_PRECOND_JACOBI, "none": _lib.MPCG_PRECOND_NONE}[precond]
         fn = self.lib.mpcg_form_schur if dt == torch.float32 else self.lib.mpcg_form_schur_f64
         self._check(fn(self._h, m, _ptr(G_dense), _ptr(C_dense), _ptr(g), _ptr(c), _ptr(S), _ptr(Pinv), _ptr(gamma), float(rho), B, pc, _stream()))
@@ -310,8 +310,10 @@ class PcgSolver:
         self._chk(Ginv_dense, B * ((n * n + m * m) * N - m * m), dt, "Ginv_dense")
         self._chk(C_dense, B * (n * n + n * m) * (N - 1), dt, "C_dense")
         self._chk(g, B * ((n + m) * N - m), dt, "g")
+        self._chk(lam, B * n * N, dt, "lam")
         if dz is None:
             dz = torch.empty(B, (n + m) * N - m, device=lam.device, dtype=dt)
+        self._chk(dz, B * ((n + m) * N - m), dt, "dz")
         fn = self.lib.mpcg_compute_dz if dt == torch.float32 else self.lib.mpcg_compute_dz_f64
         self._check(fn(self._h, m, _ptr(Ginv_dense), _ptr(C_dense), _ptr(g), _ptr(lam), _ptr(dz), B, _stream()))
         return dz

@@ -6,7 +6,7 @@ reference's trajectory fixtures, and writes
                                       include/dynamics/iiwa/iiwa_eepos_grid.cuh (init_XImats :909-1640, load_update_XImats_helpers
                                       :1770-1845, load_update_XmatsHom_helpers :1857-1904)
   mpcgpu_amd/data/iiwa_traj_0_0.npz   first 400 rows of examples/trajfiles/0_0_traj.csv (x(14), u(7)) and 0_0_eepos.traj (6)
-  tests/golden/iiwa_kkt_N32.npz       KKT blocks (G, C, g, c) of three N=32 windows produced by mpcgpu_amd.iiwa.generate_kkt
+  tests/golden/iiwa_kkt_N32.npz       KKT blocks (G, C, g, c) of three N=32 windows produced by oracle/iiwa_ref.py:generate_kkt
                                       (float64 restatement of include/common/kkt.cuh:22-163), the Schur systems the oracle forms
                                       from them and float64 PCG statistics
 and prints how PCG behaves on real IIWA systems (the numbers quoted in DESIGN.md §3.6)."""
@@ -64,12 +64,14 @@ def extract_model():
 
 def main():
     extract_model()
-    from mpcgpu_amd import iiwa, synth
+    import iiwa_ref as iiwa
+    from mpcgpu_amd import synth
     import oracle as orc
     orc.build()
     M = iiwa.Model()
-    traj = iiwa.read_csv(os.path.join(REF, "examples/trajfiles/0_0_traj.csv"))
-    eep = iiwa.read_csv(os.path.join(REF, "examples/trajfiles/0_0_eepos.traj"))
+    from mpcgpu_amd.iiwa import read_csv
+    traj = read_csv(os.path.join(REF, "examples/trajfiles/0_0_traj.csv"))
+    eep = read_csv(os.path.join(REF, "examples/trajfiles/0_0_eepos.traj"))
     assert traj.shape == (666, 21) and eep.shape == (666, 6)
     # sanity of the restated kinematics against the reference's own fixture: eepos.traj row t = end-effector position of traj row t
     err = max(np.abs(M.ee_pos(traj[t, :7]) - eep[t, :3]).max() for t in (0, 1, 50, 199, 400, 665))

@@ -86,6 +86,7 @@ def test_product_does_not_import_oracle():
     for base in ("mpcgpu_amd", "include"):
         for dp, _, fs in os.walk(os.path.join(ROOT, base)):
             for f in fs:
-                if f.endswith((".py", ".h", ".hip", ".hpp", ".cpp")):
+                if f.endswith((".py", ".h", ".hip", ".hpp", ".cpp", ".cuh", ".inc")):
                     txt = open(os.path.join(dp, f)).read()
                     assert "libmpcg_oracle" not in txt and "import oracle" not in txt and "orc_" not in txt, f
+                    assert "import iiwa_ref" not in txt and "from iiwa_ref" not in txt, f      # (the numpy plant restatement: oracle/iiwa_ref.py)

@@ -1,6 +1,7 @@
 """GPU: mpcg_generate_kkt (mpcgpu_amd/csrc/kkt_plant.hip.h) — the HIP twin of generate_kkt_submatrices
-(include/common/kkt.cuh:22-163) with the IIWA-14 plant as data — against the float64 host restatement mpcgpu_amd/iiwa.py
-(itself pinned on the reference's eepos fixture, tests/test_iiwa_plant.py) and the committed KKT fixtures, and the whole
+(include/common/kkt.cuh:22-163) with the IIWA-14 plant as data — against the float64 restatement oracle/iiwa_ref.py
+(itself pinned on the reference's own trajectory pair, tests/test_iiwa_plant.py), DIRECTLY against that reference-held trajectory
+(the integrator defects of its own rows vanish) and the committed KKT fixtures, and the whole
 device-side chain of one SQP iteration on real IIWA systems (include/pcg/sqp.cuh:190-259): KKT -> Schur -> PCG -> dz."""
 import os
 
@@ -9,6 +10,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN
+import iiwa_ref
 from mpcgpu_amd import iiwa, synth
 from util import relinf
 
@@ -23,7 +25,7 @@ def dev(a):
 @pytest.fixture(scope="module")
 def env():
     from mpcgpu_amd import PcgSolver, Plant, pcg_config
-    return PcgSolver, Plant(), pcg_config, iiwa.Model()
+    return PcgSolver, Plant(), pcg_config, iiwa_ref.Model()
 
 
 def windows(N, B, seed):
@@ -41,11 +43,51 @@ def test_generate_kkt_vs_host_restatement(env, N, B):
     assert all(np.isfinite(a).all() for a in (G, C, g, c))
     for b in range(B):
         # (the device sees the float32-rounded inputs: restate on exactly those)
-        want = iiwa.generate_kkt(M, xu[b].astype(np.float32).astype(np.float64), goals[b].astype(np.float32).astype(np.float64),
+        want = iiwa_ref.generate_kkt(M, xu[b].astype(np.float32).astype(np.float64), goals[b].astype(np.float32).astype(np.float64),
                                  xs[b].astype(np.float32).astype(np.float64), N)
         for got, ref, name in zip((G[b], C[b], g[b], c[b]), want, "GCgc"):
             # float output rounding (6e-8 relative) + central-difference noise of the dynamics gradients (~1e-9 x |dID| / h)
             assert np.abs(got - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max()), (b, name, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def test_generate_kkt_integrator_defects_vanish_on_the_reference_trajectory(env):
+    """THE PIN OF THE DEVICE DYNAMICS ON REFERENCE-HELD DATA: with xu = consecutive rows of the reference's own
+    0_0_traj.csv (tests/golden/iiwa_traj_0_0_full.npz, all 666 rows) and dt = 1/64, the integrator defects c_{k+1} that mpcg_generate_kkt
+    returns (include/common/kkt.cuh:117,160) must vanish on the 656 in-segment transitions — the file was integrated by the reference's own
+    forward dynamics.  Windows of 64 knots tile the file (the last one is anchored at its end); the 9 seam / waypoint transitions are
+    asserted to be what oracle/iiwa_ref.py documents, not masked.  The same call's q_k pins the end-effector kinematics: g_k = J^T (ee - goal)
+    vanishes when the goals are the file's own end-effector rows."""
+    PcgSolver, plant, _, _ = env
+    d = np.load(os.path.join(GOLDEN, "iiwa_traj_0_0_full.npz"))
+    traj, eep = d["xu"], d["eepos"]
+    rows, N = traj.shape[0], 64
+    starts = list(range(0, rows - N, N - 1)) + [rows - N]
+    B = len(starts)
+    xu = np.stack([traj[t0:t0 + N].reshape(-1)[:(n + m) * N - m] for t0 in starts])
+    goals = np.stack([eep[t0:t0 + N] for t0 in starts])
+    xs = xu[:, :n].copy()
+    sol = PcgSolver(N, max_batch=B)
+    G, C, g, c = sol.generate_kkt(plant, dev(goals.reshape(B, -1)), dev(xs), dev(xu), iiwa.TIMESTEP, iiwa.QD_COST, iiwa.r_cost(N))
+    torch.cuda.synchronize()
+    c = c.cpu().numpy().reshape(B, N, n)
+    g = g.cpu().numpy()
+    defect = np.full(rows - 1, np.nan)
+    for b, t0 in enumerate(starts):
+        assert np.abs(c[b, 0]).max() == 0.0                              # c_0 = x_0 - x_s
+        for k in range(N - 1):
+            defect[t0 + k] = np.abs(c[b, k + 1]).max()                   # transition t0+k -> t0+k+1
+    assert not np.isnan(defect).any()
+    good = iiwa_ref.in_segment_transitions(rows)
+    assert len(good) == 656
+    assert defect[good].max() < 5e-6, defect[good].max()                # host restatement: 1.4e-6 max (float32 file), 5.8e-8 median
+    assert np.median(defect[good]) < 2e-7
+    for s0 in iiwa_ref.SEGMENT_STARTS:
+        if s0:
+            assert defect[s0 - 1] > 1e-2                                 # the jump to the next waypoint
+        assert 1e-4 < defect[s0] < 1e-3                                  # the waypoint row's un-integrated start-up velocity: dt * 0.05
+    # kinematics: the position gradient J^T (ee(q) - goal) of every knot vanishes against the file's own end-effector row
+    gq = np.stack([g[b].reshape(-1)[:(n + m) * (N - 1)].reshape(N - 1, n + m)[:, :7] for b in range(B)])
+    assert np.abs(gq).max() < 2e-5, np.abs(gq).max()
 
 
 def test_generate_kkt_is_independent_of_batch_composition(env):

@@ -19,16 +19,29 @@ def dev(a):
 
 @pytest.mark.parametrize("N", [2, 3, 8, 33, 128])
 @pytest.mark.parametrize("precond", ["ss", "jacobi"])
-@pytest.mark.parametrize("inplace", [0, 1])
-def test_form_schur_bit_exact_vs_oracle(orc, N, precond, inplace):
-    """inplace = 0: the two-kernel register-resident formation (small calls), 1: the three-kernel one with G inverted in place
-    (throughput-sized calls; forced here) — both the oracle's bits."""
+@pytest.mark.parametrize("formation", ["two", "three", "walk16", "walk5", "walk1", "walk16w3", "walk16w4"])
+def test_form_schur_bit_exact_vs_oracle(orc, N, precond, formation):
+    """two: the two-kernel register-resident formation (small calls); three: round 3's three kernels with G inverted in place; walk<L>: the
+    one-pass chunk-walking formation + seam kernel (round 4, throughput-sized calls; forced here) with L block rows per chunk — L = 16
+    (one chunk up to N = 17, eight at N = 128), 5 (ragged last chunk, many seams), 1 (every row a seam); w3 / w4: the builds for three / four
+    waves per SIMD.  All the oracle's bits."""
     from mpcgpu_amd import PcgSolver
-    B = 3
+    B = 5 if formation.startswith("walk") else 3      # (5: a wavefront of four chunks straddles trajectories)
     k = synth.make_kkt(N, B, 555 + N)
     G, C, g, c = synth.pack_kkt_dense(k, np.float32)
     sol = PcgSolver(N, max_batch=B)
-    sol.set_option("schur_inplace", inplace)
+    if formation.startswith("walk"):
+        spec = formation[4:]
+        waves = 2
+        if "w" in spec:
+            spec, w = spec.split("w")
+            waves = int(w)
+        sol.set_option("schur_walk", 1)
+        sol.set_option("schur_chunk", int(spec))
+        sol.set_option("schur_walk_waves", waves)
+    else:
+        sol.set_option("schur_walk", 0)
+        sol.set_option("schur_inplace", 1 if formation == "three" else 0)
     dG = dev(G)
     poison = float("nan")
     S = torch.full((B, 3 * n * n * N), poison, device="cuda")
@@ -138,14 +151,17 @@ def test_form_schur_formations_agree_at_a_throughput_sized_batch():
         np.testing.assert_array_equal(a0, a1)
 
 
-@pytest.mark.parametrize("N", [2, 9, 128])
-def test_compute_dz_bit_exact_vs_oracle(orc, N):
+@pytest.mark.parametrize("dz_dpp", [1, 0])
+@pytest.mark.parametrize("N", [2, 3, 9, 128])
+def test_compute_dz_bit_exact_vs_oracle(orc, N, dz_dpp):
+    """dz_dpp = 1: the four-knots-per-wavefront kernel (round 4, default), 0: the one-workgroup-per-knot LDS kernel."""
     from mpcgpu_amd import PcgSolver
-    B = 2
+    B = 3
     k = synth.make_kkt(N, B, 77 + N)
     G, C, g, c = synth.pack_kkt_dense(k, np.float32)
     lam = np.random.default_rng(N).normal(size=(B, n * N)).astype(np.float32)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("dz_dpp", dz_dpp)
     dG = dev(G)
     sol.form_schur(dG, dev(C), dev(g), dev(c), 1e-3)
     dz = sol.compute_dz(dG, dev(C), dev(g), dev(lam))

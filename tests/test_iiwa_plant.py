@@ -1,14 +1,15 @@
-"""CPU: the IIWA-14 producer side (stage A) — mpcgpu_amd/iiwa.py (numpy float64 restatement of
-include/common/kkt.cuh:22-163 + the plant it calls) against the reference's own trajectory fixtures
-(mpcgpu_amd/data/iiwa_traj_0_0.npz = first 400 rows of examples/trajfiles/0_0_traj.csv and 0_0_eepos.traj) and the KKT / Schur
-fixtures tests/make_iiwa_golden.py produced in the build container."""
+"""CPU: the IIWA-14 producer side (stage A) — oracle/iiwa_ref.py (numpy float64 restatement of
+include/common/kkt.cuh:22-163 + the plant it calls) PINNED on the reference's own trajectory pair (tests/golden/iiwa_traj_0_0_full.npz =
+all 666 rows of examples/trajfiles/0_0_traj.csv and 0_0_eepos.traj: outputs of the reference's own kinematics AND forward dynamics), and
+checked against the KKT / Schur fixtures tests/make_iiwa_golden.py produced in the build container."""
 import os
 
 import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT
-from mpcgpu_amd import iiwa, synth
+import iiwa_ref as iiwa
+from mpcgpu_amd import synth
 
 
 @pytest.fixture(scope="module")
@@ -18,21 +19,55 @@ def M():
 
 @pytest.fixture(scope="module")
 def traj():
+    d = np.load(os.path.join(GOLDEN, "iiwa_traj_0_0_full.npz"))
+    return d["xu"], d["eepos"]
+
+
+def test_product_trajectory_fixture_is_the_head_of_the_reference_file(traj):
+    xu, eep = traj
     d = np.load(os.path.join(ROOT, "mpcgpu_amd", "data", "iiwa_traj_0_0.npz"))
-    return d["xu"].astype(np.float64), d["eepos"].astype(np.float64)
+    np.testing.assert_array_equal(d["xu"], xu[:400].astype(np.float32))
+    np.testing.assert_array_equal(d["eepos"], eep[:400].astype(np.float32))
 
 
 def test_end_effector_kinematics_reproduce_the_reference_fixture(M, traj):
     """Row t of 0_0_eepos.traj is the end-effector position of row t of 0_0_traj.csv (the reference generated one from the
-    other with its GRiD kinematics): the restated forward kinematics must reproduce all 400 rows (csv precision ~1e-6)."""
+    other with its GRiD kinematics): the restated forward kinematics must reproduce all 666 rows (csv precision ~1e-6)."""
     xu, eep = traj
-    err = max(np.abs(M.ee_pos(xu[t, :7]) - eep[t, :3]).max() for t in range(400))
+    err = max(np.abs(M.ee_pos(xu[t, :7]) - eep[t, :3]).max() for t in range(xu.shape[0]))
     assert err < 2e-5, err
     # and the Jacobian is the derivative of that map
     q = xu[17, :7]
     J = M.ee_jac(q)
     d = 1e-5 * np.arange(1, 8)
     assert np.abs(M.ee_pos(q + d) - M.ee_pos(q) - J @ d).max() < 1e-8
+
+
+def test_forward_dynamics_reproduce_the_reference_trajectory(M, traj):
+    """THE PIN OF THE DYNAMICS ON REFERENCE-HELD DATA.  0_0_traj.csv was integrated by the reference's own plant:
+    consecutive rows are one Euler step (include/common/integrator.cuh:56-104, dt = 1/64 — examples/track_iiwa_pcg.cu:19) of its forward
+    dynamics (iiwa_eepos_plant.cuh:127-155, GRAVITY = 0) apart, so the integrator defect c_{k+1} = x_{k+1} - f(x_k, u_k) that
+    generate_kkt_submatrices stores (include/common/kkt.cuh:117,160) must vanish on the file's own rows, to its print precision.
+    The file is five point-to-point segments; the step ACROSS a seam is a jump to the next waypoint and the step OUT of a waypoint row
+    leaves q where it was (the row's stored velocity — +-0.01..0.05 rad/s, zero torque — is a start-up perturbation that was not
+    integrated: q defect = -dt qd exactly, qd defect <= 6e-5) — both identified, not masked: they are asserted to be exactly that."""
+    xu, _ = traj
+    dt = iiwa.TIMESTEP
+    rows = xu.shape[0]
+    good = iiwa.in_segment_transitions(rows)
+    assert len(good) == 656
+    d = np.array([np.abs(iiwa.euler_defect(M, xu[t, :14], xu[t, 14:], xu[t + 1, :14])).max() for t in range(rows - 1)])
+    assert d[good].max() < 5e-6, d[good].max()                  # (measured: 1.4e-6 max — the file holds float32 values —, 5.8e-8 median)
+    assert np.median(d[good]) < 1e-7
+    for s0 in iiwa.SEGMENT_STARTS:
+        # the step out of a waypoint row: q stays (defect = -dt * stored qd), the velocity defect is small
+        df = iiwa.euler_defect(M, xu[s0, :14], xu[s0, 14:], xu[s0 + 1, :14])
+        assert np.abs(df[:7] + dt * xu[s0, 7:14]).max() < 1e-6 and np.abs(df[7:]).max() < 1e-4, s0
+        assert np.abs(xu[s0 + 1, :7] - xu[s0, :7]).max() < 1e-6
+        if s0:
+            assert d[s0 - 1] > 1e-2                              # the jump to the next waypoint (not dynamics)
+    # the waypoint rows carry no torque and (nearly) no velocity: nothing about the dynamics is hidden in the 9 excluded transitions
+    assert all(np.abs(xu[s0, 14:]).max() == 0.0 and np.abs(xu[s0, 7:14]).max() <= 0.05 + 1e-9 for s0 in iiwa.SEGMENT_STARTS)
 
 
 def test_rigid_body_dynamics_identities(M, traj):
