@@ -563,9 +563,6 @@ def main():
         Gk, Ck, gk, ck = sol.generate_kkt(plant, d_goal, d_xs, d_xu, iiwa.TIMESTEP, iiwa.QD_COST, rc)
         Gk0 = Gk.clone()
         ms_schur = timed(lambda: (Gk.copy_(Gk0), sol.form_schur(Gk, Ck, gk, ck, synth.RHO_INIT, "ss")), 3, warm=1) - timed(lambda: Gk.copy_(Gk0), 3, warm=1)
-        sol.set_option("schur_fma", 1)      # the opt-in fused-multiply-add build of the same kernels (tolerance-based parity, tests/test_gpu_schur.py)
-        ms_schur_fma = timed(lambda: (Gk.copy_(Gk0), sol.form_schur(Gk, Ck, gk, ck, synth.RHO_INIT, "ss")), 3, warm=1) - timed(lambda: Gk.copy_(Gk0), 3, warm=1)
-        sol.set_option("schur_fma", 0)
         Gk.copy_(Gk0)
         rS, rP, rg = sol.form_schur(Gk, Ck, gk, ck, synth.RHO_INIT, "ss")
         # previous SQP iterate = this one plus a small change of the trajectory -> its multipliers are the warm start
@@ -597,7 +594,7 @@ def main():
                          "trajectories_whose_true_residual_grew": int((r1 > r0 * (1 + 1e-6)).sum().item())}
         out["iiwa_run"] = {"inputs": f"{B} windows of the reference trajectory examples/trajfiles/0_0_traj.csv (first 400 rows), random offset, goals 0..8 steps ahead, "
                                      "state / iterate noise <= 0.05; KKT blocks by mpcg_generate_kkt (IIWA-14 dynamics on the device), Schur by mpcg_form_schur, rho = 1e-3",
-                           "pcg": {"max_iter": max_iter, "exit_tol": args.exit_tol, "precond": "ss"}, "generate_kkt_ms": ms_kkt, "form_schur_ms": ms_schur, "form_schur_fused_option_ms": ms_schur_fma,
+                           "pcg": {"max_iter": max_iter, "exit_tol": args.exit_tol, "precond": "ss"}, "generate_kkt_ms": ms_kkt, "form_schur_ms": ms_schur,
                            "cold_start": res["cold"], "warm_start_from_previous_sqp_iterate": res["warm"],
                            "note": "cond(-S) of these systems is 1e7-2e7 at N=128 (synthetic generator: ~1e5): from lambda0 = 0 most solves hit the reference's iteration "
                                    "cap, which presupposes the MPC loop's warm starts (tests/make_iiwa_golden.py prints the study)"}

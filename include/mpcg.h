@@ -301,7 +301,10 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * hand-off per matrix pass — instead of the row-triple cluster kernel; default on), "cluster_l2" (1, default: its hand-offs stay in
  * the XCD's L2 when all members of a cluster run on one XCD, which the kernel verifies; 0: always write-through), "cluster_fixup" (1: trajectories whose cluster
  * gave up are re-solved by the single-workgroup kernel in a follow-up launch; default on),
- * "cluster_adj" (lane order of the row-triple cluster kernel), "schur_dpp" (1: register/DPP Schur kernels, 0: the LDS versions),
+ * "cluster_adj" (lane order of the row-triple cluster kernel), "schur_dpp" (1: mpcg_form_schur's register-resident formation — a 16-lane DPP row walks a chunk of consecutive block rows,
+ * a second kernel closes the seams between chunks; 0: the LDS kernels; same bits), "schur_chunk" (block rows per chunk: 0 = by call size, from one row per
+ * chunk for a single trajectory to 16 at 1024 x 128 knots; 1..2048 forced; same bits), "dz_dpp" (1: mpcg_compute_dz with four knots per wavefront, 0: one
+ * workgroup per knot; same bits),
  * "block_solve_wide" (mpcg_block_solve: 1 one trajectory per wavefront, 0 four, -1 by batch size; same bits);
  * "check_symmetry" (debug, 0/1: see BLOCK SYMMETRY above),
  * read-only: "cluster_fixups" (trajectories re-solved by fix-up launches since mpcg_create because their cluster gave up after the bounded
@@ -310,10 +313,7 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * its trajectories longest-expected-first, the expectation being the iteration counts the handle's previous call with the same batch size
  * wrote to d_iters — warm-started solves leave the loop at very different iterations and the dispatch order decides how well the chip stays
  * filled: -25..35 % on such batches; a scheduling hint only, no result depends on it; one extra ~3 us kernel behind each such solve),
- * "schur_inplace" (-1 auto / 0 / 1: mpcg_form_schur's register-resident formation as three kernels with G inverted in place — Q and R once per
- * knot, no scratch copy; automatic from batch * knot_points >= 16 x #CUs, smaller calls keep the two-kernel formation: one launch less; same bits),
- * "schur_fma" (0 / 1, default 0: mpcg_form_schur's register-resident kernels built with every rounded multiply + rounded add fused into one
- * multiply-add — ~12 % faster, results within 2e-4 of the default kernels' relative to the block scale instead of bit-identical to the oracle),
+ * "last_schur_chunk" (read-only: block rows per chunk of the last mpcg_form_schur, 0 = the LDS kernels),
  * "last_kernel_family" (kernel of the last solve: 0 single-workgroup row-pair, 1 row-triple cluster, 2 lane-per-block, 3 generic,
  * 4 clustered lane-per-block, 5 row-per-lane, 6 lane-pair-per-knot, 7 clustered lane-pair),
  * "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".

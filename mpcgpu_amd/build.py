@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libmpcg_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "mpcg_capi.hip")]
-DEPS = SOURCES + [os.path.join(_HERE, "csrc", f) for f in ("pcg_kernels.hip.h", "pcg_lpb.hip.h", "pcg_lpk.hip.h", "pcg_lpk_cluster.hip.h", "pcg_lpb_cluster.hip.h", "pcg_rpl.hip.h", "schur_kernels.hip.h", "schur_dpp.hip.h", "schur_walk.hip.h", "schur_dpp_body.inc", "block_solve.hip.h", "pcg_f64.hip.h", "ldl_host.hpp", "kkt_plant.hip.h", "iiwa14_model.inc")] + [
+DEPS = SOURCES + [os.path.join(_HERE, "csrc", f) for f in ("pcg_kernels.hip.h", "pcg_lpb.hip.h", "pcg_lpk.hip.h", "pcg_lpk_cluster.hip.h", "pcg_lpb_cluster.hip.h", "pcg_rpl.hip.h", "schur_kernels.hip.h", "dpp_rows.hip.h", "schur_walk.hip.h", "block_solve.hip.h", "pcg_f64.hip.h", "ldl_host.hpp", "kkt_plant.hip.h", "iiwa14_model.inc")] + [
     os.path.join(_ROOT, "include", "mpcg.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function"]

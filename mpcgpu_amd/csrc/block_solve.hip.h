@@ -3,7 +3,7 @@
 // The reference's second linear-system path (LINSYS_SOLVE == 0) ships the Schur matrix to the host and calls QDLDL
 // (qdldl_solve_schur, include/qdldl/sqp.cuh:22-49: sparse LDL^T factor + solve per SQP iteration, one trajectory,
 // one CPU thread).  The GPU-native counterpart keeps the system where mpcg_form_schur left it (bd layout, stored
-// negated) and runs a block LU sweep per trajectory on the register/DPP primitives of schur_dpp.hip.h:
+// negated) and runs a block LU sweep per trajectory on the register/DPP primitives of dpp_rows.hip.h:
 //   Delta_0 = D_0, y_0 = gamma_0;  k >= 1:  Delta_k = D_k - L_k W_{k-1},  y_k = gamma_k - L_k z_{k-1};
 //   z_k = Delta_k^-1 y_k,  W_k = Delta_k^-1 U_k;   lambda_{N-1} = z_{N-1},  lambda_k = z_k - W_k lambda_{k+1}
 // (D_k = S[k,1], L_k = S[k,0], U_k = S[k,2]; W_k and z_k come out of ONE pivot-free Gauss-Jordan elimination of
@@ -15,7 +15,7 @@
 // (that is what PCG avoids for ONE trajectory), so this is the throughput solver for batches: 1/50 of the flops of
 // 167 PCG iterations.  The test oracle restates the same operation order on the CPU: results are bit-identical in float (tested).
 #pragma once
-#include "schur_dpp.hip.h"
+#include "dpp_rows.hip.h"
 
 namespace mpcg {
 

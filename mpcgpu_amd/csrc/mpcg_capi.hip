@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <new>
+#include <algorithm>
 #include <string>
 
 #include "../../include/mpcg.h"
@@ -15,7 +16,6 @@
 #include "pcg_lpb_cluster.hip.h"
 #include "pcg_rpl.hip.h"
 #include "schur_kernels.hip.h"
-#include "schur_dpp.hip.h"
 #include "schur_walk.hip.h"
 #include "block_solve.hip.h"
 #include "pcg_f64.hip.h"
@@ -53,18 +53,15 @@ struct mpcg_handle {
     int lpk = -1;             // lane-pair-per-knot kernel (pcg_lpk.hip.h, N <= 128): -1 auto (wherever the lane-per-block kernel would run), 0 off, 1 forced
     int lpb = -1;             // lane-per-block kernel (pcg_lpb.hip.h): -1 auto (N <= 128, fp32, automatic configuration), 0 off, 1 forced
     int block_solve_wide = -1; // mpcg_block_solve: one trajectory per wavefront (1), four (0), by batch size (-1)
-    int schur_dpp = 1;        // 1: register-resident Schur formation kernels (schur_dpp.hip.h), 0: the LDS versions
+    int schur_dpp = 1;        // 1: register-resident Schur formation (schur_walk.hip.h: the chunk-walking kernel + its seam kernel), 0: the LDS versions
     int sched_hint = 1;       // dispatch the trajectories of a large call longest-expected-first, predicted by the previous call's iteration counts (sched_order_kernel)
     uint32_t* sched_order = nullptr;   // [max_batch] dispatch order written after every hinted solve
     uint32_t order_batch = 0;          // batch of the call that wrote it (0: none yet)
-    int schur_inplace = -1;   // register-resident Schur formation as three kernels with G inverted in place: -1 auto (throughput-sized calls), 0, 1
-    int schur_walk = -1;      // one-pass chunk-walking formation (schur_walk.hip.h): -1 auto (throughput-sized calls), 0 off, 1 forced
-    int schur_chunk = 16;     //   block rows per chunk
-    int schur_walk_waves = 2; //   launch bound of the walking kernel (waves per SIMD): 2, 3 or 4
+    int schur_chunk = 0;      //   block rows per chunk of the walking kernel: 0 auto (by call size), 1..2048 forced
     int dz_dpp = 1;           // 1: four-knots-per-wavefront dz recovery (schur_walk.hip.h), 0: the one-workgroup-per-knot LDS kernel
+    int last_schur_chunk = 0; //   what the last mpcg_form_schur used (0: the LDS kernels)
     float* seam_qinv = nullptr;      // schur_walk: one Q^-1 per chunk seam (max_batch x chunks x 196 floats)
     size_t seam_qinv_floats = 0;
-    int schur_fma = 0;        // 1: the register-resident kernels compiled with floating-point contraction (fused multiply-adds): faster, not the oracle's bits
     int cluster_waves = -1;   // waves per cluster member: 8 (one member per CU), 4 (two per CU), -1 by batch size
     int cluster_adj = 1;      // lane order of the cluster kernel (1: blocks of a row in adjacent lanes)
     int cluster = -1;         // workgroups per trajectory for the cluster kernel: 0 off, -1 auto, G > 0 forced
@@ -268,13 +265,9 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
         h->cluster_lpb = value; return MPCG_OK;
     }
     if (!strcmp(key, "schur_dpp")) { h->schur_dpp = value ? 1 : 0; return MPCG_OK; }
-    if (!strcmp(key, "schur_fma")) { h->schur_fma = value ? 1 : 0; return MPCG_OK; }
-    if (!strcmp(key, "schur_walk")) { if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "schur_walk must be -1 (auto), 0 or 1"); h->schur_walk = value; return MPCG_OK; }
-    if (!strcmp(key, "schur_chunk")) { if (value < 1 || value > 2048) return fail(h, MPCG_ERR_INVALID, "schur_chunk must be 1..2048 block rows"); h->schur_chunk = value; return MPCG_OK; }
-    if (!strcmp(key, "schur_walk_waves")) { if (value < 2 || value > 4) return fail(h, MPCG_ERR_INVALID, "schur_walk_waves must be 2, 3 or 4"); h->schur_walk_waves = value; return MPCG_OK; }
+    if (!strcmp(key, "schur_chunk")) { if (value < 0 || value > 2048) return fail(h, MPCG_ERR_INVALID, "schur_chunk must be 0 (auto) or 1..2048 block rows"); h->schur_chunk = value; return MPCG_OK; }
     if (!strcmp(key, "dz_dpp")) { h->dz_dpp = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "sched_hint")) { h->sched_hint = value ? 1 : 0; h->order_batch = 0; return MPCG_OK; }
-    if (!strcmp(key, "schur_inplace")) { if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "schur_inplace must be -1 (auto), 0 or 1"); h->schur_inplace = value; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
         if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");
         h->cluster = value; return MPCG_OK;
@@ -307,13 +300,10 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "cluster_lpk")) { *value = h->cluster_lpk; return MPCG_OK; }
     if (!strcmp(key, "last_symmetry_violations")) { *value = h->last_sym_violations; return MPCG_OK; }
     if (!strcmp(key, "schur_dpp")) { *value = h->schur_dpp; return MPCG_OK; }
-    if (!strcmp(key, "schur_fma")) { *value = h->schur_fma; return MPCG_OK; }
-    if (!strcmp(key, "schur_walk")) { *value = h->schur_walk; return MPCG_OK; }
     if (!strcmp(key, "schur_chunk")) { *value = h->schur_chunk; return MPCG_OK; }
-    if (!strcmp(key, "schur_walk_waves")) { *value = h->schur_walk_waves; return MPCG_OK; }
+    if (!strcmp(key, "last_schur_chunk")) { *value = h->last_schur_chunk; return MPCG_OK; }
     if (!strcmp(key, "dz_dpp")) { *value = h->dz_dpp; return MPCG_OK; }
     if (!strcmp(key, "sched_hint")) { *value = h->sched_hint; return MPCG_OK; }
-    if (!strcmp(key, "schur_inplace")) { *value = h->schur_inplace; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "spmv_mfma")) { *value = h->spmv_mfma; return MPCG_OK; }
     if (!strcmp(key, "num_cus")) { *value = h->num_cus; return MPCG_OK; }
@@ -1144,17 +1134,24 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = (int)h->n, m = (int)control_size, N = (int)h->N;
     const size_t Gsz = (size_t)(n * n + m * m) * N - m * m;
-    // Register-resident formation as three kernels with G inverted in place (schur_dpp.hip.h) once the call is large enough to be
-    // throughput-bound; small calls (one trajectory: the MPC loop's own case) keep the two-kernel formation, one launch less.
-    // Round 4: throughput-sized calls run the one-pass chunk-walking formation (schur_walk.hip.h) + its seam kernel.
-    const int wL = h->schur_chunk;
-    const int wchunks = N >= 2 ? (N - 1 + wL - 1) / wL : 0;
-    // (its kernels address every array through a buffer resource with 31-bit byte offsets: 2,352 B of S per knot => below 913 k knots)
-    const bool walk = h->schur_dpp && !h->schur_fma && N >= 2 && (uint64_t)batch * N * 2352u < (1ull << 31) &&
-                      (h->schur_walk == 1 || (h->schur_walk < 0 && h->schur_inplace < 0 && (long)batch * wchunks >= (long)h->num_cus * 16));
-    if (walk) {
-        const size_t need_s = (size_t)h->max_batch * wchunks * 196;
-        if (h->seam_qinv_floats < need_s) {       // first call only (not stream-ordered: hipMalloc)
+    // Register-resident formation (schur_walk.hip.h): a 16-lane row walks a chunk of L consecutive block rows, a second kernel closes the
+    // seams between chunks.  L trades parallelism against seam work: as long as a call has fewer than ~6 wavefronts of four chunks per
+    // CU the chunks are made shorter (L = 1: every row a seam — one trajectory of the MPC loop's own call; 16 at 1024 x 128 knots).
+    // (Its kernels address every array through a buffer resource with 31-bit byte offsets: 2,352 B of S per knot => below 913 k knots.)
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (h->schur_dpp && (uint64_t)batch * N * 2352u < (1ull << 31)) {
+        int wL = h->schur_chunk;
+        if (wL <= 0) {
+            const long rows = (long)batch * (N - 1), want = (long)h->num_cus * 6 * 4;
+            wL = 1;
+            while (wL < 16 && rows / (2 * wL) >= want) wL *= 2;
+        }
+        const int wchunks = (N - 1 + wL - 1) / wL;
+        // seam buffer: one Q^-1 per chunk.  Sized once for whatever the automatic chunk length can ask of this handle (short chunks only while
+        // the call has fewer than 2 x `want` rows; 16-row chunks beyond), so that calls of different batch sizes do not reallocate.
+        const size_t auto_chunks = std::max<size_t>((size_t)h->num_cus * 6 * 4 * 2 + 4, (size_t)h->max_batch * (size_t)((N - 1 + 15) / 16));
+        const size_t need_s = 196 * std::max<size_t>((size_t)batch * wchunks, auto_chunks);
+        if (h->seam_qinv_floats < need_s) {       // first call (or a forced short chunk length) only — not stream-ordered: hipMalloc
             if (h->seam_qinv) HIP_TRY(h, hipFree(h->seam_qinv));
             h->seam_qinv = nullptr; h->seam_qinv_floats = 0;
             HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->seam_qinv), need_s * sizeof(float)));
@@ -1166,13 +1163,11 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
         w.s.rho = rho; w.s.n = n; w.s.m = m; w.s.N = N; w.s.batch = (int)batch; w.s.ss = precond == MPCG_PRECOND_SS; w.s.pinv = precond != MPCG_PRECOND_NONE;
         w.s.k0_only = 0;
         w.seam_qinv = h->seam_qinv; w.L = wL; w.chunks = wchunks;
-        hipStream_t st = static_cast<hipStream_t>(stream);
+        h->last_schur_chunk = wL;
         const long capw = (long)h->num_cus * 64;
         long bw = ((long)batch * wchunks + 3) / 4;
         if (bw > capw) bw = capw;
-        if (h->schur_walk_waves == 4) hipLaunchKernelGGL(sw::schur_walk_kernel<4>, dim3((unsigned)bw), dim3(64), 0, st, w);
-        else if (h->schur_walk_waves == 3) hipLaunchKernelGGL(sw::schur_walk_kernel<3>, dim3((unsigned)bw), dim3(64), 0, st, w);
-        else hipLaunchKernelGGL(sw::schur_walk_kernel<2>, dim3((unsigned)bw), dim3(64), 0, st, w);
+        hipLaunchKernelGGL(sw::schur_walk_kernel, dim3((unsigned)bw), dim3(64), 0, st, w);
         HIP_TRY(h, hipGetLastError());
         if (wchunks > 1) {
             long bs = ((long)batch * (wchunks - 1) + 3) / 4;
@@ -1182,8 +1177,10 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
         }
         return MPCG_OK;
     }
-    const bool inplace = h->schur_dpp && (h->schur_inplace == 1 || (h->schur_inplace < 0 && (long)batch * N >= (long)h->num_cus * 16));
-    const size_t need = inplace ? 0 : Gsz * h->max_batch;
+    h->last_schur_chunk = 0;
+    // the LDS kernels (schur_kernels.hip.h; option "schur_dpp" = 0, and calls beyond the 31-bit offsets above): one wavefront per knot,
+    // G^-1 through a handle-owned staging buffer
+    const size_t need = Gsz * h->max_batch;
     if (h->ginv_scratch_floats < need) {          // first call only (not stream-ordered: hipMalloc)
         if (h->ginv_scratch) HIP_TRY(h, hipFree(h->ginv_scratch));
         h->ginv_scratch = nullptr; h->ginv_scratch_floats = 0;
@@ -1194,48 +1191,14 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
     a.G = d_G_dense; a.C = d_C_dense; a.g = d_g; a.c = d_c; a.S = d_S; a.Pinv = d_Pinv; a.gamma = d_gamma;
     a.Ginv_scratch = h->ginv_scratch; a.Ginv_out = d_G_dense;
     a.rho = rho; a.n = n; a.m = m; a.N = N; a.batch = (int)batch; a.ss = precond == MPCG_PRECOND_SS; a.pinv = precond != MPCG_PRECOND_NONE;
+    a.k0_only = 0;
     long blocks = (long)batch * N;
     const long cap = (long)h->num_cus * 64;
     if (blocks > cap) blocks = cap;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    a.k0_only = 0;
-    if (h->schur_dpp && inplace) {
-        a.Ginv_scratch = nullptr;
-        long b4 = ((long)batch * N + 3) / 4;
-        if (b4 > cap) b4 = cap;
-        if (h->schur_fma) hipLaunchKernelGGL(invert_g_dpp_kernel_fma, dim3((unsigned)b4), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(invert_g_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);
-        HIP_TRY(h, hipGetLastError());
-        if (N > 1) {
-            long b3 = ((long)batch * (N - 1) + 3) / 4;
-            if (b3 > cap) b3 = cap;
-            if (h->schur_fma) hipLaunchKernelGGL(form_schur_inv_dpp_kernel_fma, dim3((unsigned)b3), dim3(64), 0, st, a);
-            else hipLaunchKernelGGL(form_schur_inv_dpp_kernel, dim3((unsigned)b3), dim3(64), 0, st, a);
-            HIP_TRY(h, hipGetLastError());
-        }
-        if (a.ss) {
-            if (h->schur_fma) hipLaunchKernelGGL(complete_ss_dpp_kernel_fma, dim3((unsigned)b4), dim3(64), 0, st, a);
-            else hipLaunchKernelGGL(complete_ss_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);
-            HIP_TRY(h, hipGetLastError());
-        }
-    } else if (h->schur_dpp) {
-        // register-resident kernels, four knots per wave (schur_dpp.hip.h)
-        long b4 = ((long)batch * (N - 1) + 3) / 4;
-        if (b4 > cap) b4 = cap;
-        if (h->schur_fma) hipLaunchKernelGGL(form_schur_dpp_kernel_fma, dim3((unsigned)b4), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(form_schur_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);
-        HIP_TRY(h, hipGetLastError());
-        b4 = ((long)batch * N + 3) / 4;
-        if (b4 > cap) b4 = cap;
-        if (h->schur_fma) hipLaunchKernelGGL(complete_ss_dpp_kernel_fma, dim3((unsigned)b4), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(complete_ss_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, st, a);
-        HIP_TRY(h, hipGetLastError());
-    } else {
-        hipLaunchKernelGGL((form_schur_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
-        HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL((complete_ss_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
-        HIP_TRY(h, hipGetLastError());
-    }
+    hipLaunchKernelGGL((form_schur_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL((complete_ss_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
+    HIP_TRY(h, hipGetLastError());
     return MPCG_OK;
 }
 

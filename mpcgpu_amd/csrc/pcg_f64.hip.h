@@ -15,7 +15,7 @@ namespace mpcg {
 
 // Contraction is OFF in this header (as in the Schur headers): the vector updates are a rounded multiply followed by a rounded add,
 // like the C oracle's; only the products spelled fma_t are fused.  (Until round 2 this was an accident of the include order — the
-// pragma of schur_dpp.hip.h reached this file; the double-precision iteration counts the tests pin depend on it.)
+// pragma of dpp_rows.hip.h reached this file; the double-precision iteration counts the tests pin depend on it.)
 #pragma clang fp contract(off)
 
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }

@@ -36,6 +36,23 @@ namespace sw {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// A/B switches of the round-4 experiments (tools/_prof/ab_walk.sh builds the variants)
+#ifndef SW_PREFETCH
+#define SW_PREFETCH 1      // operands of the next block row requested one row ahead
+#endif
+#ifndef SW_PAIR
+#define SW_PAIR 0          // Q and R inverted together (two dependency chains)
+#endif
+#ifndef SW_ABLATE
+#define SW_ABLATE 0        // timing experiments only: 1 no stores (values kept alive), 2 no loads (operands made up from the offset), 4 no Gauss-Jordan, 8 no products
+#endif
+#ifndef SW_STAGE
+#define SW_STAGE 1         // stores leave through the LDS stage in 16-byte pieces
+#endif
+#ifndef SW_MASKED
+#define SW_MASKED 0        // 1: pivot row scaled under an EXEC mask with the compiler's IEEE division inside the mask
+#endif
+
 // value held by lane L of this lane's 16-lane row
 template <int L>
 __device__ __forceinline__ float rbc(float v) {
@@ -79,16 +96,32 @@ __device__ __forceinline__ void launder(f2 (&D)[NPAIR], const f2 (&Src)[NPAIR]) 
     for (int j = 0; j < NPAIR; ++j) { D[j] = Src[j]; asm volatile("" : "+v"(D[j])); }
 }
 
+// An ordering point for the scheduler: everything that produces `acc` is finished before anything that consumes `a` starts.  Left
+// alone, the scheduler (which sees a 256-register budget) likes to issue ALL 196 multiplies of a product first and the adds afterwards —
+// 196 live products, spilled — whenever the code around the product changes a little; which products it did that to changed from build to
+// build.
+template <int NPAIR>
+__device__ __forceinline__ void pin(float& a, f2 (&acc)[NPAIR]) {
+    if constexpr (NPAIR == 7) asm volatile("" : "+v"(a), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]));
+    else if constexpr (NPAIR == 4) asm volatile("" : "+v"(a), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    else static_assert(NPAIR == 7 || NPAIR == 4, "7 or 4 column pairs");
+}
+
 // C[r][c] = sum_t A[r][t] * B[t][c]      A: NI columns per lane; B: rows in lanes 0..NI-1, NC columns
 template <int NI, int NC>
 __device__ __forceinline__ void gemm_nn(const f2 (&A)[np(NI)], const f2 (&Bsrc)[np(NC)], f2 (&Cm)[np(NC)]) {
     f2 B[np(NC)];
     launder(B, Bsrc);
+#if SW_ABLATE & 8
+    for (int j = 0; j < np(NC); ++j) Cm[j] = B[j] + A[j % np(NI)];
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < np(NC); ++j) Cm[j] = f2{0.f, 0.f};
     SFor<0, NI>::run([&](auto tc) {
         constexpr int T = decltype(tc)::value;
-        const float a = SW_EL(A, T);
+        float a = SW_EL(A, T);
+        pin(a, Cm);                  // the products of term T start after the sums of term T-1: at most NC products in flight
 #pragma unroll
         for (int j = 0; j < np(NC); ++j) {
             const float t0 = a * rbc<T>(B[j].x);
@@ -102,9 +135,18 @@ template <int NI, int NC>
 __device__ __forceinline__ void gemm_nt(const f2 (&A)[np(NI)], const f2 (&Btsrc)[np(NI)], f2 (&Cm)[np(NC)]) {
     f2 Bt[np(NI)];
     launder(Bt, Btsrc);
+#if SW_ABLATE & 8
+    for (int j = 0; j < np(NC); ++j) Cm[j] = Bt[j % np(NI)] + A[j % np(NI)];
+    return;
+#endif
     SFor<0, np(NC)>::run([&](auto jc) {
         constexpr int J = decltype(jc)::value;
         f2 acc{0.f, 0.f};
+        if constexpr (J > 0) {       // column pair J starts after pair J-1 is finished: 2 NI products in flight at most
+            float dummy = Cm[J - 1].x;
+            pin(dummy, Bt);
+            Cm[J - 1].x = dummy;
+        }
 #pragma unroll
         for (int t = 0; t < NI; ++t) {
             const float a = SW_EL(A, t), b = SW_EL(Bt, t);
@@ -137,46 +179,95 @@ __device__ __forceinline__ f2 matvec2(const f2 (&M1)[np(NC)], float v1, const f2
     return acc;
 }
 
-// Gauss-Jordan on [A | I] without pivoting (include/utils/matrix.cuh:120-238), rows in lanes 0..NN-1: A destroyed, I becomes A^-1.
-// lr = lane index inside the 16-lane row.  Half of the 2 NN columns are structurally inert at every pivot step and are skipped (columns of
-// A at or left of the pivot: finished, never read again; columns of I right of the pivot: still unit columns, the reference's update leaves
-// them as they are) — round 3, no bit changed.  Round 4: the shape described in the file header.
+// 1 / x with the bits of the IEEE division (the oracle divides).  v_rcp_f32 + ONE Newton step reproduces the correctly rounded quotient
+// for EVERY float with 2^-100 <= |x| <= 2^100 — checked exhaustively on the chip, all 2^32 bit patterns, tools/_prof/rcp_exhaustive.hip
+// (profiles/r04_rcp_exhaustive.txt: 0 mismatches in that range; outside it — denormal quotients, overflow — the short form differs) — 3
+// dependent instructions instead of the 11 of the compiler's division sequence, at the head of every pivot step's dependency chain.
+// Pivots outside the range (a singular or wildly scaled block) take the division.
+__device__ __forceinline__ float recip_ieee(float x, bool wanted) {
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r0, 1.0f);
+    float r = __builtin_fmaf(e, r0, r0);
+    const float ax = __builtin_fabsf(x);
+    if (__builtin_expect(wanted && !(ax >= 0x1p-100f && ax <= 0x1p100f), 0)) r = 1.0f / x;
+    return r;
+}
+
+// One pivot step P of the Gauss-Jordan elimination of [A | I] (include/utils/matrix.cuh:120-238; rows in lanes 0..NN-1, lr = lane index
+// inside the 16-lane row).  Half of the 2 NN columns are structurally inert at every pivot step and are skipped (columns of A at or left of
+// the pivot: finished, never read again; columns of I right of the pivot: still unit columns, the reference's update leaves them as they
+// are) — round 3, no bit changed.  Round 4: the pivot row is scaled by a per-lane multiplier (1 / pivot in the pivot lane, exactly 1.0 in
+// every other lane: x * 1.0 is x), then every lane adds (-pcol) * (pivot row entry) with +0.0 as the pivot lane's multiplier.
+template <int NN, int P>
+__device__ __forceinline__ void gj_step(f2 (&A)[np(NN)], f2 (&I)[np(NN)], int lr) {
+    constexpr int NP = np(NN);
+    constexpr int JP = P / 2;                    // the pair that holds column P
+    constexpr bool ODD = P & 1;
+    const float app = SW_EL(A, P);               // pivot column entry of this row (the pivot itself in lane P)
+    const bool is_p = lr == P;
+    const float nmul = is_p ? 0.f : -app;        // x + (+0)(x) keeps the bits of x: the pivot lane needs no select
+#if SW_MASKED
+    if (is_p) {
+        const float mrow = 1.0f / app;
+        if (!ODD && 2 * JP + 1 < NN) A[JP].y = A[JP].y * mrow;
+#pragma unroll
+        for (int j = JP + 1; j < NP; ++j) A[j] = A[j] * f2{mrow, mrow};
+#pragma unroll
+        for (int j = 0; j < JP; ++j) I[j] = I[j] * f2{mrow, mrow};
+        if (ODD) I[JP] = I[JP] * f2{mrow, mrow};
+        else I[JP].x = I[JP].x * mrow;
+    }
+#else
+    const float pinv = recip_ieee(app, is_p);    // (matrix.cuh:146)
+    const float mrow = is_p ? pinv : 1.0f;
+    // pair JP of A: column P is finished; its neighbour P+1 (P even) is live.  Pair JP of I: column P is live, its neighbour P+1 (P even) is
+    // still a unit column and must keep its +0 in the pivot lane.
+    if (!ODD && 2 * JP + 1 < NN) A[JP].y = A[JP].y * mrow;
+#pragma unroll
+    for (int j = JP + 1; j < NP; ++j) A[j] = A[j] * f2{mrow, mrow};
+#pragma unroll
+    for (int j = 0; j < JP; ++j) I[j] = I[j] * f2{mrow, mrow};
+    if (ODD) I[JP] = I[JP] * f2{mrow, mrow};
+    else I[JP].x = I[JP].x * mrow;
+#endif
+    // every row: x += (-pcol) * (pivot row entry)
+    if (!ODD && 2 * JP + 1 < NN) A[JP].y = A[JP].y + nmul * rbc<P>(A[JP].y);
+#pragma unroll
+    for (int j = JP + 1; j < NP; ++j) {
+        const float t0 = nmul * rbc<P>(A[j].x);
+        const float t1 = (2 * j + 1 < NN) ? nmul * rbc<P>(A[j].y) : 0.f;
+        acc2(A[j], t0, t1);
+    }
+#pragma unroll
+    for (int j = 0; j < JP; ++j) acc2(I[j], nmul * rbc<P>(I[j].x), nmul * rbc<P>(I[j].y));
+    if (ODD) acc2(I[JP], nmul * rbc<P>(I[JP].x), nmul * rbc<P>(I[JP].y));
+    else I[JP].x = I[JP].x + nmul * rbc<P>(I[JP].x);
+}
+template <int NN>
+__device__ __forceinline__ void unit_rows(f2 (&I)[np(NN)], int lr) {
+#pragma unroll
+    for (int j = 0; j < np(NN); ++j) I[j] = f2{lr == 2 * j ? 1.f : 0.f, lr == 2 * j + 1 ? 1.f : 0.f};
+}
+// A destroyed, I becomes A^-1
 template <int NN>
 __device__ __forceinline__ void invert(f2 (&A)[np(NN)], f2 (&I)[np(NN)], int lr) {
-    constexpr int NP = np(NN);
-#pragma unroll
-    for (int j = 0; j < NP; ++j) I[j] = f2{lr == 2 * j ? 1.f : 0.f, lr == 2 * j + 1 ? 1.f : 0.f};
-    SFor<0, NN>::run([&](auto pc) {
+    unit_rows<NN>(I, lr);
+#if SW_ABLATE & 4
+    for (int j = 0; j < np(NN); ++j) I[j] = I[j] + A[j];
+    return;
+#endif
+    SFor<0, NN>::run([&](auto pc) { gj_step<NN, decltype(pc)::value>(A, I, lr); });
+}
+// two independent inversions advanced together (pivot P of both in the same step): two dependency chains for the scheduler to interleave
+template <int N1, int N2>
+__device__ __forceinline__ void invert_pair(f2 (&A1)[np(N1)], f2 (&I1)[np(N1)], f2 (&A2)[np(N2)], f2 (&I2)[np(N2)], int lr) {
+    static_assert(N2 <= N1, "the shorter one second");
+    unit_rows<N1>(I1, lr);
+    unit_rows<N2>(I2, lr);
+    SFor<0, N1>::run([&](auto pc) {
         constexpr int P = decltype(pc)::value;
-        constexpr int JP = P / 2;                    // the pair that holds column P
-        constexpr bool ODD = P & 1;
-        const float app = SW_EL(A, P);               // pivot column entry of this row (the pivot itself in lane P)
-        const bool is_p = lr == P;
-        const float nmul = is_p ? 0.f : -app;        // x + (+0)(x) keeps the bits of x: the pivot lane needs no select
-        if (is_p) {                                  // EXEC-masked: the pivot row becomes row / pivot   (matrix.cuh:146)
-            const float pinv = 1.0f / app;
-            // pair JP of A: column P is finished; its neighbour P+1 (P even) is live.  Pair JP of I: column P is live, its neighbour P+1 (P
-            // even) is still a unit column and must keep its +0.
-            if (!ODD) { if (2 * JP + 1 < NN) A[JP].y = A[JP].y * pinv; }
-#pragma unroll
-            for (int j = JP + 1; j < NP; ++j) A[j] = A[j] * f2{pinv, pinv};
-#pragma unroll
-            for (int j = 0; j < JP; ++j) I[j] = I[j] * f2{pinv, pinv};
-            if (ODD) I[JP] = I[JP] * f2{pinv, pinv};
-            else I[JP].x = I[JP].x * pinv;
-        }
-        // every row: x += (-pcol) * (pivot row entry)
-        if (!ODD && 2 * JP + 1 < NN) A[JP].y = A[JP].y + nmul * rbc<P>(A[JP].y);
-#pragma unroll
-        for (int j = JP + 1; j < NP; ++j) {
-            const float t0 = nmul * rbc<P>(A[j].x);
-            const float t1 = (2 * j + 1 < NN) ? nmul * rbc<P>(A[j].y) : 0.f;
-            acc2(A[j], t0, t1);
-        }
-#pragma unroll
-        for (int j = 0; j < JP; ++j) acc2(I[j], nmul * rbc<P>(I[j].x), nmul * rbc<P>(I[j].y));
-        if (ODD) acc2(I[JP], nmul * rbc<P>(I[JP].x), nmul * rbc<P>(I[JP].y));
-        else I[JP].x = I[JP].x + nmul * rbc<P>(I[JP].x);
+        gj_step<N1, P>(A1, I1, lr);
+        if constexpr (P < N2) gj_step<N2, P>(A2, I2, lr);
     });
 }
 
@@ -189,10 +280,18 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), /*stride*/ 0, (int)(uint32_t)bytes, 0x00020000);
 }
 __device__ __forceinline__ float bld(rsrc_t r, uint32_t off) {
+#if SW_ABLATE & 2
+    return 1.0f + (float)(off & 1023u) * 0x1p-12f;
+#else
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+#endif
 }
 __device__ __forceinline__ void bst(rsrc_t r, uint32_t off, float v) {
+#if SW_ABLATE & 1
+    asm volatile("" :: "v"(v), "v"(off));
+#else
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+#endif
 }
 // row lr of a column-major rows x COLS matrix that starts at byte `off`, as column pairs.  Rows beyond the matrix repeat its last row:
 // what those lanes compute stays in those lanes (every broadcast reads a lane below `rows`) and is never stored.
@@ -235,6 +334,82 @@ __device__ __forceinline__ void store_rows_t(const f2 (&M)[np(COLS)], rsrc_t r, 
         if (2 * j + 1 < COLS) bst(r, v + 8u * j + 4u, M[j].y * mult);
     }
 }
+// ---- stores through an LDS stage (round 4b).  A block held rows-in-lanes leaves the wavefront as 14 dword stores whose 64 lanes touch four
+// 56-byte segments each — 150 store instructions per block row, and the walking kernel turned out to be bound by exactly that: the memory
+// pipeline takes them one instruction at a time, later wavefronts queue behind earlier ones, and the next row's loads wait behind them all
+// (tools/_prof/ab_walk.sh: with the stores compiled out 354 -> 269 us, with all I/O out 265).  So a group writes its block into its slot of
+// the wavefront's LDS stage in memory order (14 ds_write_b32, conflict-free), and the WHOLE wavefront then copies each group's slot out in
+// 16-byte pieces: 49 lanes x dwordx4 per 14x14 block — 4 store instructions per block (one per group) instead of 14, every one a run of
+// 784 contiguous bytes.  The group's destination offset travels to the other lanes as an SGPR (v_readlane -> the store's soffset).
+// No barrier: one wavefront per workgroup, LDS operations of a wavefront execute in
+// order; the wavefront-scope fences only keep the COMPILER from reordering a lane's reads against the other lanes' writes. ----
+typedef __attribute__((address_space(3))) float lds_f;
+constexpr int SW_SLOT = 392;                 // floats per group in the stage: two 14x14 blocks
+__device__ __forceinline__ void stage_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// rows-in-lanes block -> column-major ROWS x COLS at float offset o of this group's slot
+template <int ROWS, int COLS>
+__device__ __forceinline__ void stage_put(lds_f* slot, int o, const f2 (&M)[np(COLS)], int lr, float mult) {
+    if (lr < ROWS) {
+#pragma unroll
+        for (int j = 0; j < np(COLS); ++j) {
+            slot[o + 2 * j * ROWS + lr] = M[j].x * mult;
+            if (2 * j + 1 < COLS) slot[o + (2 * j + 1) * ROWS + lr] = M[j].y * mult;
+        }
+    }
+}
+// the same block TRANSPOSED: row lr becomes column lr of the staged COLS x COLS block
+template <int COLS>
+__device__ __forceinline__ void stage_put_t(lds_f* slot, int o, const f2 (&M)[np(COLS)], int lr, float mult) {
+    if (lr < COLS) {
+#pragma unroll
+        for (int j = 0; j < np(COLS); ++j) {
+            slot[o + lr * COLS + 2 * j] = M[j].x * mult;
+            if (2 * j + 1 < COLS) slot[o + lr * COLS + 2 * j + 1] = M[j].y * mult;
+        }
+    }
+}
+// copy the first NFL floats of every group's slot to that group's destination: dst = byte offset in r (uniform inside a 16-lane group),
+// SW_OOB = this group stores nothing.  GB = bytes per lane and store: 16 (destination 16-byte aligned... or not: the hardware takes
+// dword-aligned 16-byte stores), or 4.
+template <int NFL, int GB>
+__device__ __forceinline__ void stage_flush(lds_f* stage, rsrc_t r, uint32_t dst, int lane) {
+    constexpr int NG = NFL * 4 / GB;                     // pieces per group
+    constexpr int NR = (NG + 63) / 64;                   // store instructions per group
+    static_assert(NFL * 4 % GB == 0, "whole pieces");
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u4 lds_u4;
+    stage_fence();
+    // all LDS reads first (one round trip), then the stores.  The soffset operand is not bounds-checked (only voffset is): a disabled
+    // group's lanes get the out-of-range voffset, like the lanes beyond the last piece.
+    u4 v16[4][NR];
+    float v4[4][NR];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            lds_f* src = stage + g * SW_SLOT + (q * 64 * GB) / 4;
+            if constexpr (GB == 16) v16[g][q] = *(lds_u4*)(src + lane * 4);
+            else v4[g][q] = src[lane];
+        }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t sd = (uint32_t)__builtin_amdgcn_readlane((int)dst, 16 * g);
+        const bool en = sd != SW_OOB;                    // (uniform)
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int idx = q * 64 + lane;
+            const uint32_t vo = (en && (q * 64 + 64 <= NG || idx < NG)) ? (uint32_t)(idx * GB) : SW_OOB;
+            if constexpr (GB == 16) __builtin_amdgcn_raw_buffer_store_b128(v16[g][q], r, (int)vo, (int)(en ? sd : 0u), 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v4[g][q]), r, (int)vo, (int)(en ? sd : 0u), 0);
+        }
+    }
+    stage_fence();
+}
+
 template <int NN>
 __device__ __forceinline__ void add_rho(f2 (&M)[np(NN)], int lr, float rho) {
 #pragma unroll
@@ -251,8 +426,7 @@ struct WalkArgs {
 
 // One 16-lane row = one chunk: block rows k0 = 1 + j L ... k1 - 1 of trajectory b; chunk 0 also emits block row 0 (linsys_setup.cuh:152-277),
 // which needs nothing but Q_0.  Four chunks per wavefront, in lock-step.  (Host: every array below 2^31 bytes.)
-template <int MINW>
-__global__ __launch_bounds__(64, MINW) void schur_walk_kernel(WalkArgs w) {
+__global__ __launch_bounds__(64, 2) void schur_walk_kernel(WalkArgs w) {
     constexpr int n = 14, m = 7;
     constexpr uint32_t nn = n * n, mm = m * m, nm = n * m;
     constexpr uint32_t Gset = nn + mm, Cset = nn + nm, gset = n + m;
@@ -268,6 +442,8 @@ __global__ __launch_bounds__(64, MINW) void schur_walk_kernel(WalkArgs w) {
     const int lr = lane & 15;
     const bool r14 = lr < n, r7 = lr < m;
     const uint32_t l14 = 4u * (r14 ? lr : n - 1), l7 = 4u * (r7 ? lr : m - 1);
+    __shared__ float sStage[4 * SW_SLOT];                   // the store stage (6,272 B per wavefront)
+    lds_f* stage = (lds_f*)sStage;
     const unsigned items = B * (unsigned)chunks;
     for (unsigned base = blockIdx.x * 4u; base < items; base += gridDim.x * 4u) {
         const unsigned item = base + (unsigned)(lane >> 4);
@@ -302,31 +478,70 @@ __global__ __launch_bounds__(64, MINW) void schur_walk_kernel(WalkArgs w) {
             store_rows<n>(Qi, rQ, (b * (uint32_t)chunks + j) * nn * 4u, n, lr, st14 && !first, 1.f);
         }
         bool have_tm = j == 0;
+        // The operands of a block row are requested one row AHEAD, each set as soon as the registers of the previous set are dead (the raw
+        // Q / R right after their inversion, A / B after the last product that reads them): half a row of arithmetic hides the HBM latency
+        // without a register of its own.  (Past the chunk's end the requests repeat its last row.)
+        f2 Ak[np(n)], Bk[np(m)], Rk[np(m)], Qp[np(n)];                                            // linsys_setup.cuh:318-325
+        float qk, rk, qp, ck;
+        auto row_of = [&](int s_) -> uint32_t { const int kk_ = k0 + s_; return (uint32_t)(kk_ < k1 ? kk_ : k1 - 1); };
+        auto load_QR = [&](uint32_t k_) {
+            const uint32_t oGk_ = oG + (k_ - 1) * Gset * 4u;
+            load_rows<m>(Rk, rG, oGk_ + nn * 4u, m, lr);
+            load_rows<n>(Qp, rG, oGk_ + Gset * 4u, n, lr);
+        };
+        auto load_AB = [&](uint32_t k_) {
+            const uint32_t oCk_ = oC + (k_ - 1) * Cset * 4u;
+            load_rows<n>(Ak, rC, oCk_, n, lr);
+            load_rows<m>(Bk, rC, oCk_ + nn * 4u, n, lr);
+        };
+        auto load_vec = [&](uint32_t k_) {
+            qk = bld(rg, og + (k_ - 1) * gset * 4u + l14); rk = bld(rg, og + (k_ - 1) * gset * 4u + n * 4u + l7);
+            qp = bld(rg, og + k_ * gset * 4u + l14); ck = bld(rc, oc + k_ * n * 4u + l14);
+        };
+        load_QR(row_of(0)); load_AB(row_of(0)); load_vec(row_of(0));
         for (int s = 0; s < L; ++s) {
             const int kk = k0 + s;
             const bool rowl = kk < k1;
-            const uint32_t k = (uint32_t)(rowl ? kk : k1 - 1);   // rows past the chunk's end redo its last row and store nothing
+            const uint32_t k = row_of(s), kn = row_of(s + 1);    // rows past the chunk's end redo its last row and store nothing
             const bool on14 = st14 && rowl, on7 = live && r7 && rowl;
-            const uint32_t oCk = oC + (k - 1) * Cset * 4u, oGk = oG + (k - 1) * Gset * 4u, oSk = oS + k * 3u * nn * 4u;
-            f2 Ak[np(n)], Bk[np(m)], Rk[np(m)], Qp[np(n)];                                        // linsys_setup.cuh:318-325
-            load_rows<n>(Ak, rC, oCk, n, lr);
-            load_rows<m>(Bk, rC, oCk + nn * 4u, n, lr);
-            load_rows<m>(Rk, rG, oGk + nn * 4u, m, lr);
-            load_rows<n>(Qp, rG, oGk + Gset * 4u, n, lr);
-            const float qk = bld(rg, og + (k - 1) * gset * 4u + l14), rk = bld(rg, og + (k - 1) * gset * 4u + n * 4u + l7);
-            const float qp = bld(rg, og + k * gset * 4u + l14), ck = bld(rc, oc + k * n * 4u + l14);
+            const uint32_t oGk = oG + (k - 1) * Gset * 4u, oSk = oS + k * 3u * nn * 4u;
+#if SW_STAGE
+            // the stage's lane constants (piece offsets, slot addresses) are re-derived from an opaque copy of the lane number in every
+            // trip: as loop invariants the compiler keeps two dozen of them in registers across the loop and spills
+            int lane_s = lane;
+            asm volatile("" : "+v"(lane_s));
+            const int lr_s = lane_s & 15;
+            lds_f* slot = stage + (lane_s >> 4) * SW_SLOT;
+#endif
             add_rho<n>(Qp, lr, a.rho);
             add_rho<m>(Rk, lr, a.rho);
             f2 Qpi[np(n)], Rki[np(m)];
             SW_FENCE();
-            invert<n>(Qp, Qpi, lr);                                                               // :356-368
+#if SW_PAIR
+            invert_pair<n, m>(Qp, Qpi, Rk, Rki, lr);                                              // :356-368
+#else
+            invert<n>(Qp, Qpi, lr);
             SW_FENCE();
             invert<m>(Rk, Rki, lr);
+#endif
             SW_FENCE();
             // G <- G^-1 (:371-380): R_{k-1} and Q_k are this chunk's own — except the chunk's LAST Q when a right neighbour exists (that one
             // reads it raw in its prologue and hands its inverse to the seam kernel)
+#if SW_STAGE
+            {
+                const bool gl = live && rowl;                                                     // (uniform inside the group)
+                stage_put<m, m>(slot, 0, Rki, lr_s, 1.f);
+                stage_flush<mm, 4>(stage, rG, gl ? oGk + nn * 4u : SW_OOB, lane_s);
+                stage_put<n, n>(slot, 0, Qpi, lr_s, 1.f);
+                stage_flush<nn, 16>(stage, rG, (gl && (kk < k1 - 1 || k1 == N)) ? oGk + Gset * 4u : SW_OOB, lane_s);
+            }
+#else
             store_rows<m>(Rki, rG, oGk + nn * 4u, m, lr, on7, 1.f);
             store_rows<n>(Qpi, rG, oGk + Gset * 4u, n, lr, on14 && (kk < k1 - 1 || k1 == N), 1.f);
+#endif
+#if SW_PREFETCH
+            load_QR(kn);                                                                          // (next row; after this row's in-place stores)
+#endif
             f2 phi[np(n)], BR[np(m)];
             gemm_nn<n, n>(Ak, Qi, phi);                                                           // phi = Abar Qi      :397-398
             SW_FENCE();
@@ -337,6 +552,9 @@ __global__ __launch_bounds__(64, MINW) void schur_walk_kernel(WalkArgs w) {
             const float v2 = matvec<m>(BR, rk);                                                   // :431-436
             gam += v2 + gv.y;                                                                     // :441-443
             bst(rgam, on14 ? oc + k * n * 4u + 4u * lr : SW_OOB, -gam);                           // :528-532
+#if SW_PREFETCH
+            load_vec(kn);
+#endif
             f2 theta[np(n)];
             {
                 f2 t1[np(n)];
@@ -347,9 +565,23 @@ __global__ __launch_bounds__(64, MINW) void schur_walk_kernel(WalkArgs w) {
                 for (int q = 0; q < np(n); ++q) { theta[q] = theta[q] + Qpi[q]; theta[q] = theta[q] + t1[q]; }   // :466-468, 485-487
             }
             SW_FENCE();
+#if SW_PREFETCH
+            load_AB(kn);
+#endif
+#if SW_STAGE
+            {
+                const bool gl = live && rowl;
+                stage_put<n, n>(slot, 0, phi, lr_s, -1.f);                                          // S[k,0]             :490-497
+                stage_put<n, n>(slot, nn, theta, lr_s, -1.f);                                       // S[k,1]             :500-507
+                stage_flush<2 * nn, 16>(stage, rS, gl ? oSk : SW_OOB, lane_s);
+                stage_put_t<n>(slot, 0, phi, lr_s, -1.f);                                           // S[k-1,2] = -phi^T  :536-557
+                stage_flush<nn, 16>(stage, rS, gl ? oSk - nn * 4u : SW_OOB, lane_s);
+            }
+#else
             store_rows<n>(phi, rS, oSk, n, lr, on14, -1.f);                                       // S[k,0]             :490-497
             store_rows<n>(theta, rS, oSk + nn * 4u, n, lr, on14, -1.f);                           // S[k,1]             :500-507
             store_rows_t<n>(phi, rS, oSk - nn * 4u, lr, on14, -1.f);                              // S[k-1,2] = -phi^T  :536-557
+#endif
 #pragma unroll
             for (int q = 0; q < np(n); ++q) Qi[q] = Qpi[q];
             if (a.pinv) {                                                                         // (uniform)
@@ -357,7 +589,12 @@ __global__ __launch_bounds__(64, MINW) void schur_walk_kernel(WalkArgs w) {
                 SW_FENCE();
                 invert<n>(theta, Ti, lr);                                                         // :510-514
                 SW_FENCE();
+#if SW_STAGE
+                stage_put<n, n>(slot, 0, Ti, lr_s, -1.f);                                           // Pinv[k,1] = -theta^-1   :517-524
+                stage_flush<nn, 16>(stage, rP, (live && rowl) ? oSk + nn * 4u : SW_OOB, lane_s);
+#else
                 store_rows<n>(Ti, rP, oSk + nn * 4u, n, lr, on14, -1.f);                          // Pinv[k,1] = -theta^-1   :517-524
+#endif
                 if (a.ss) {                                                                       // (uniform)  :9-137
                     // stored blocks are D = -theta^-1, L = -phi; the reference forms -(D_k L_k) D_{k-1} and -(D_{k-1} L_k^T) D_k from the stored
                     // (negated) blocks: the three sign flips cancel exactly, so the un-negated operands give the stored values directly
@@ -366,17 +603,30 @@ __global__ __launch_bounds__(64, MINW) void schur_walk_kernel(WalkArgs w) {
                     SW_FENCE();
                     gemm_nn<n, n>(t1, Tm, t2);                                                    // (Dk L) Dm       :102
                     SW_FENCE();
+#if SW_STAGE
+                    stage_put<n, n>(slot, 0, t2, lr_s, 1.f);                                        // Pinv[k,0]       :106-113
+                    stage_flush<nn, 16>(stage, rP, (live && rowl && have_tm) ? oSk : SW_OOB, lane_s);
+#else
                     store_rows<n>(t2, rP, oSk, n, lr, on14 && have_tm, 1.f);                      // Pinv[k,0]       :106-113
+#endif
                     gemm_nt<n, n>(Tm, phi, t1);                                                   // Dm phi^T        :121
                     SW_FENCE();
                     gemm_nn<n, n>(t1, Ti, t2);                                                    // (Dm phi^T) Dk   :123
                     SW_FENCE();
+#if SW_STAGE
+                    stage_put<n, n>(slot, 0, t2, lr_s, 1.f);                                        // Pinv[k-1,2]     :127-134
+                    stage_flush<nn, 16>(stage, rP, (live && rowl && have_tm) ? oSk - nn * 4u : SW_OOB, lane_s);
+#else
                     store_rows<n>(t2, rP, oSk - nn * 4u, n, lr, on14 && have_tm, 1.f);            // Pinv[k-1,2]     :127-134
+#endif
                 }
 #pragma unroll
                 for (int q = 0; q < np(n); ++q) Tm[q] = Ti[q];
             }
             have_tm = true;
+#if !SW_PREFETCH
+            load_QR(kn); load_AB(kn); load_vec(kn);
+#endif
         }
     }
 }
