@@ -456,7 +456,6 @@ def main():
     ap.add_argument("--precond", default="ss", choices=["ss", "jacobi"])
     ap.add_argument("--exit-tol", type=float, default=1e-4)
     ap.add_argument("--max-iter", type=int, default=0, help="0 = reference table (settings.cuh:123-139)")
-    ap.add_argument("--lpb", type=int, default=-1, help="lane-per-block kernel: -1 auto, 0 off (single-workgroup kernels), 1 forced")
     ap.add_argument("--pcg-waves", type=int, default=0)
     ap.add_argument("--reg-rows", type=int, default=-1)
     ap.add_argument("--lds-rows", type=int, default=-2)
@@ -520,8 +519,6 @@ def main():
     d_lam = torch.zeros(B, 14 * N, device=dev)
     d_it = torch.zeros(B, dtype=torch.int32, device=dev)
     d_ex = torch.zeros(B, dtype=torch.uint8, device=dev)
-    if args.lpb != -1:
-        sol.set_option("pcg_lpb", args.lpb)
     if args.pcg_waves:
         sol.set_option("pcg_waves", args.pcg_waves)
     if args.reg_rows >= 0:
@@ -564,7 +561,7 @@ def main():
     t_local = time.perf_counter() - t0
     t_all = D.max_over_ranks(t_local, dev)
 
-    fam = {0: "pcg_traj_kernel", 1: "pcg_cluster_kernel", 2: "pcg_lpb_kernel", 3: "pcg_generic_kernel", 4: "pcg_lpbc_kernel", 5: "pcg_rpl_kernel", 6: "pcg_lpk_kernel", 7: "pcg_lpkc_kernel"}[sol.get_option("last_kernel_family")]
+    fam = {0: "pcg_traj_kernel", 3: "pcg_generic_kernel", 5: "pcg_rpl_kernel", 6: "pcg_lpk_kernel", 7: "pcg_lpkc_kernel"}[sol.get_option("last_kernel_family")]
     kdesc = {"family": fam, **{k: sol.get_option("last_kernel_" + k) for k in ("waves", "reg_rows", "lds_rows", "stream_bufs", "cluster", "lds_bytes")}}
     it_host = h_it.numpy().astype(np.int64)          # what the timed region's last step copied back
     ex_host = h_ex.numpy().copy()

@@ -6,6 +6,8 @@
 //   hipcc --offload-arch=gfx950 -O2 -Iinclude/gbd_pcg_compat examples/sqp_pcg_callsite.cpp -Lmpcgpu_amd -lmpcg_hip
 #include <cmath>
 #include <cstdio>
+#include <cstring>
+#include <thread>
 #include <vector>
 
 #include "gpu_pcg.cuh"
@@ -109,8 +111,41 @@ int main() {
             rmax = fmax(rmax, fabs(h_gamma[k * n + i] - acc));
             gmax = fmax(gmax, fabs(h_gamma[k * n + i]));
         }
-    printf("{\"pcg_iters\": %u, \"pcg_exit\": %d, \"smem\": %zu, \"rel_residual\": %.3e}\n", pcg_iters, (int)pcg_exit,
-           ppcg_kernel_smem_size, rmax / gmax);
+    // ---- the same launch line from TWO host threads, each on its own stream (mpcgLaunchPcg's optional last argument) and its own iterate
+    // buffers: the shim gives every host thread its own library handle, so the launches may overlap; both must reproduce the bits above ----
+    int mt_ok = 1;
+    {
+        auto worker = [&](int id, int* ok) {
+            hipStream_t st;
+            gpuErrchk(hipStreamCreate(&st));
+            T *l, *r, *p_, *v, *e;
+            uint32_t* it;
+            bool* ex;
+            gpuErrchk(hipMalloc(&l, n * N * sizeof(T))); gpuErrchk(hipMalloc(&r, n * N * sizeof(T))); gpuErrchk(hipMalloc(&p_, n * N * sizeof(T)));
+            gpuErrchk(hipMalloc(&v, N * sizeof(T))); gpuErrchk(hipMalloc(&e, N * sizeof(T)));
+            gpuErrchk(hipMalloc(&it, sizeof(uint32_t))); gpuErrchk(hipMalloc(&ex, sizeof(bool)));
+            uint32_t mi = config.pcg_max_iter;
+            T tol = config.pcg_exit_tol;
+            void* a[] = {(void*)&d_S, (void*)&d_Pinv, (void*)&d_gamma, (void*)&l, (void*)&r, (void*)&p_, (void*)&v, (void*)&e, (void*)&it, (void*)&ex, (void*)&mi, (void*)&tol};
+            std::vector<T> out(n * N);
+            for (int rep = 0; rep < 10 && *ok; ++rep) {
+                gpuErrchk(hipMemsetAsync(l, 0, n * N * sizeof(T), st));
+                gpuErrchk(mpcgLaunchPcg<T>(pcg_kernel, knot_points, PCG_NUM_THREADS, a, ppcg_kernel_smem_size, st));
+                gpuErrchk(hipMemcpyAsync(out.data(), l, n * N * sizeof(T), hipMemcpyDeviceToHost, st));
+                gpuErrchk(hipStreamSynchronize(st));
+                if (memcmp(out.data(), h_lambda.data(), n * N * sizeof(T)) != 0) *ok = 0;
+            }
+            (void)id;
+            gpuErrchk(hipFree(l)); gpuErrchk(hipFree(r)); gpuErrchk(hipFree(p_)); gpuErrchk(hipFree(v)); gpuErrchk(hipFree(e)); gpuErrchk(hipFree(it)); gpuErrchk(hipFree(ex));
+            gpuErrchk(hipStreamDestroy(st));
+        };
+        int ok0 = 1, ok1 = 1;
+        std::thread t0(worker, 0, &ok0), t1(worker, 1, &ok1);
+        t0.join(); t1.join();
+        mt_ok = ok0 && ok1;
+    }
+    printf("{\"pcg_iters\": %u, \"pcg_exit\": %d, \"smem\": %zu, \"rel_residual\": %.3e, \"two_threads_two_streams_same_bits\": %d}\n", pcg_iters, (int)pcg_exit,
+           ppcg_kernel_smem_size, rmax / gmax, mt_ok);
 
     // ---- include/pcg/sqp.cuh:380-386 ----
     gpuErrchk(hipFree(d_pcg_iters));
@@ -123,5 +158,5 @@ int main() {
     gpuErrchk(hipFree(d_S));
     gpuErrchk(hipFree(d_gamma));
     gpuErrchk(hipFree(d_lambda));
-    return (pcg_exit == false && pcg_iters > 0 && rmax / gmax < 1e-4) ? 0 : 1;
+    return (pcg_exit == false && pcg_iters > 0 && rmax / gmax < 1e-4 && mt_ok) ? 0 : 1;
 }

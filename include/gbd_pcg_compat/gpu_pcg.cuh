@@ -18,6 +18,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
+#include <thread>
+#include <tuple>
 #include <type_traits>
 #include <utility>
 
@@ -41,18 +44,29 @@ inline void die(const char* what, const mpcg_handle* h) {
     exit(EXIT_FAILURE);                 // the reference's error convention: gpuErrchk aborts
 }
 
-// one cached handle per (device, knot_points); the solver keeps no per-call global scratch
+// One cached handle per (host thread, device, knot_points): a handle is re-entrant per handle, not across threads, so two host threads
+// (the native multi-device driver pattern: a thread + stream + handle per device, examples/multi_gpu_pcg.cpp) never share one; the cache
+// itself is guarded by a mutex.  The solver keeps no per-call global scratch.
 inline mpcg_handle* handle_for(uint32_t state_size, uint32_t knot_points) {
-    static std::map<std::pair<int, uint32_t>, mpcg_handle*> cache;
+    static std::mutex mu;
+    static std::map<std::tuple<std::thread::id, int, uint32_t>, mpcg_handle*> cache;
     int dev = 0;
     gpuErrchk(hipGetDevice(&dev));
-    auto key = std::make_pair(dev, knot_points);
+    const auto key = std::make_tuple(std::this_thread::get_id(), dev, knot_points);
+    std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     mpcg_handle* h = nullptr;
     if (mpcg_create(&h, dev, state_size, knot_points, 1) != MPCG_OK) die("mpcg_create", nullptr);
     cache[key] = h;
     return h;
+}
+
+// the stream the next pcg<> launch of THIS host thread goes to (mpcgLaunchPcg's optional last argument sets it around the call; the
+// reference's own call site runs on the default stream, include/pcg/sqp.cuh:225-236)
+inline hipStream_t& launch_stream() {
+    static thread_local hipStream_t s = nullptr;
+    return s;
 }
 
 }  // namespace mpcg_compat
@@ -85,21 +99,27 @@ void pcg(T* d_S, T* d_Pinv, T* d_gamma, T* d_lambda, T* d_r, T* d_p, T* d_v_temp
     int rc;
     if constexpr (std::is_same<T, float>::value)
         rc = mpcg_pcg_solve_ref(h, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp, d_iters,
-                                reinterpret_cast<uint8_t*>(d_max_iter_exit), max_iter, exit_tol, /*stream*/ nullptr);
+                                reinterpret_cast<uint8_t*>(d_max_iter_exit), max_iter, exit_tol, mpcg_compat::launch_stream());
     else
         rc = mpcg_pcg_solve_ref_f64(h, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp, d_iters,
-                                    reinterpret_cast<uint8_t*>(d_max_iter_exit), max_iter, exit_tol, /*stream*/ nullptr);
+                                    reinterpret_cast<uint8_t*>(d_max_iter_exit), max_iter, exit_tol, mpcg_compat::launch_stream());
     if (rc != MPCG_OK) mpcg_compat::die("pcg", h);
 }
 
 // Replaces cudaLaunchCooperativeKernel at include/pcg/sqp.cuh:230.  `kernel` is the void* the call
 // site made from pcg<T,n,N>; `args` is its pcgKernelArgs array (addresses of the 12 arguments).
 // Grid/block/smem are accepted and ignored: the launch shape is the library's business.  T defaults to float; inside
-// sqpSolvePcg<T> write mpcgLaunchPcg<T>(...) if the build may use linsys_t = double.
+// sqpSolvePcg<T> write mpcgLaunchPcg<T>(...) if the build may use linsys_t = double.  `stream` (optional, as cudaLaunchCooperativeKernel's
+// last argument): the stream of this launch; default = the null stream, as at the reference's call site.
 template <typename T = float>
-inline hipError_t mpcgLaunchPcg(void* kernel, unsigned /*grid*/, unsigned /*block*/, void** args, size_t /*smem*/) {
+inline hipError_t mpcgLaunchPcg(void* kernel, unsigned /*grid*/, unsigned /*block*/, void** args, size_t /*smem*/, hipStream_t stream = nullptr) {
     using F = void (*)(T*, T*, T*, T*, T*, T*, T*, T*, uint32_t*, bool*, uint32_t, T);
     F f = reinterpret_cast<F>(kernel);
+    struct StreamScope {
+        hipStream_t prev;
+        explicit StreamScope(hipStream_t s) : prev(mpcg_compat::launch_stream()) { mpcg_compat::launch_stream() = s; }
+        ~StreamScope() { mpcg_compat::launch_stream() = prev; }
+    } scope(stream);
     f(*static_cast<T**>(args[0]), *static_cast<T**>(args[1]), *static_cast<T**>(args[2]),
       *static_cast<T**>(args[3]), *static_cast<T**>(args[4]), *static_cast<T**>(args[5]),
       *static_cast<T**>(args[6]), *static_cast<T**>(args[7]), *static_cast<uint32_t**>(args[8]),

@@ -275,56 +275,43 @@ int mpcg_ldl_pattern(const mpcg_ldl *l, const int32_t **h_col_ptr, const int32_t
 int mpcg_ldl_solve(mpcg_ldl *l, const float *h_val, const float *h_gamma, float *h_lambda);
 int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, const float *d_gamma, float *d_lambda, void *stream);
 
-/* Launch-configuration knobs (tuning / experiments; defaults are chosen by mpcg_create from
- * knot_points): "pcg_waves" (4, 8 or 16 wavefronts per trajectory workgroup), "pcg_reg_rows" (block
- * rows per matrix per wave kept in registers for the whole solve; only compiled (waves, rows) pairs
- * are accepted at launch), "pcg_lds_rows" (rows per matrix per wave cached in LDS, -1 = what fits),
- * "pcg_stream_bufs", "nt_loads" (SpMV kernel), "pcg_max_wg_per_cu", "spmv_blocks_per_cu"; "pcg16_*" = the
- * same for fp16 storage.  reg/lds rows count TRIPLES of block rows per matrix per wave.  "cluster": workgroups
- * (= CUs) per trajectory for the cluster kernels that long horizons use (-1 auto, 0 off, G forced).  Members exchange
- * inner-product partials and boundary knots through global memory, so all members of a cluster must be resident:
- * the clustered lane-per-block kernel (default) launches as many clusters as fit the chip and lets each draw trajectories
- * from a queue (any batch = one launch); the row-triple cluster kernel ("cluster_lpb" = 0) runs floor(#CUs / G)
- * trajectories per launch, larger batches in consecutive launches (automatic mode, N >= 256) or on the single-workgroup
- * kernel (forced G).  A cluster that cannot make progress (a peer not resident: another stream holds its CU) gives up after
- * a bounded spin and the follow-up launch of the single-workgroup kernel re-solves its trajectory ("cluster_fixup" = 0:
- * no follow-up launch, d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for such a trajectory).
- * "lds_extra" (single-triple LDS slots beyond the uniform cache of the <.,.,1> kernels: -1 what fits, 0 none),
- * "cluster_waves" (waves per cluster member: 8 = one member per CU, 4 = two per CU, -1 by horizon and batch),
- * "pcg_rpl" (-1 auto / 0 / 1: the row-per-lane kernel for knot_points <= 64 — a DPP row per knot, vectors in registers; automatic for
- * knot_points <= 32 and for calls of at most one trajectory per CU up to 64), "rpl_waves" (its wavefronts per trajectory: 0 auto, 4, 8, 16),
- * "pcg_lpk" (-1 auto / 0 / 1: the lane-pair-per-knot kernel, knot_points <= 128 — round 3's default for 36 < knot_points <= 128),
- * "pcg_lpb" (-1 auto / 0 / 1: the lane-per-block kernel, knot_points <= 128 — round 2's default; 1 selects it instead of the lane-pair kernel),
- * "cluster_lpk" (-1 auto (on) / 0 / 1: the clustered lane-pair kernel where a clustered register-resident kernel runs; 0: the clustered
- * lane-per-block kernel),
- * "cluster_lpb" (-1 auto / 0 / 1: the clustered lane-per-block kernel — members of up to 128 knots, everything in registers, one
- * hand-off per matrix pass — instead of the row-triple cluster kernel; default on), "cluster_l2" (1, default: its hand-offs stay in
- * the XCD's L2 when all members of a cluster run on one XCD, which the kernel verifies; 0: always write-through), "cluster_fixup" (1: trajectories whose cluster
- * gave up are re-solved by the single-workgroup kernel in a follow-up launch; default on),
- * "cluster_adj" (lane order of the row-triple cluster kernel), "schur_dpp" (1: mpcg_form_schur's register-resident formation — a 16-lane DPP row walks a chunk of consecutive block rows,
- * a second kernel closes the seams between chunks; 0: the LDS kernels; same bits), "schur_chunk" (block rows per chunk: 0 = by call size, from one row per
- * chunk for a single trajectory to 16 at 1024 x 128 knots; 1..2048 forced; same bits), "dz_dpp" (1: mpcg_compute_dz with four knots per wavefront, 0: one
- * workgroup per knot; same bits),
- * "block_solve_wide" (mpcg_block_solve: 1 one trajectory per wavefront, 0 four, -1 by batch size; same bits);
- * "check_symmetry" (debug, 0/1: see BLOCK SYMMETRY above),
- * read-only: "cluster_fixups" (trajectories re-solved by fix-up launches since mpcg_create because their cluster gave up after the bounded
- * spin — each costs 1.5-4.5 ms of spinning; blocking 8-byte D2H read), "last_symmetry_violations", "num_cus", "pcg_resident" (1 if the current configuration streams nothing inside the PCG loop),
- * "sched_hint" (0 / 1, default 1: an mpcg_pcg_solve call with more trajectories than CUs that runs a register-resident kernel (row-per-lane, lane-per-block, lane-pair, clustered lane-pair) dispatches
- * its trajectories longest-expected-first, the expectation being the iteration counts the handle's previous call with the same batch size
- * wrote to d_iters — warm-started solves leave the loop at very different iterations and the dispatch order decides how well the chip stays
- * filled: -25..35 % on such batches; a scheduling hint only, no result depends on it; one extra ~3 us kernel behind each such solve),
- * "last_schur_chunk" (read-only: block rows per chunk of the last mpcg_form_schur, 0 = the LDS kernels),
- * "last_kernel_family" (kernel of the last solve: 0 single-workgroup row-pair, 1 row-triple cluster, 2 lane-per-block, 3 generic,
- * 4 clustered lane-per-block, 5 row-per-lane, 6 lane-pair-per-knot, 7 clustered lane-pair),
- * "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
+/* Options (tuning / experiments; defaults are chosen by mpcg_create from knot_points and per call from the batch).
+ * Kernel selection of a float solve (state_size 14):
+ *   "pcg_rpl" (-1 auto / 0 / 1): the row-per-lane kernel for knot_points <= 64 — a DPP row per knot, vectors in registers; automatic for
+ *       knot_points <= 32 and for calls of at most one trajectory per CU up to 64; "rpl_waves" (its wavefronts per trajectory: 0 auto, 4, 8, 16);
+ *   "pcg_lpk" (-1 auto / 0 / 1): the lane-pair-per-knot kernel, knot_points <= 128 — everything in registers; automatic for 36 < knot_points <= 128;
+ *   "cluster" (-1 auto / 0 off / G = 2..8 forced): workgroups (= CUs of one XCD) per trajectory of the clustered lane-pair kernel, automatic
+ *       for knot_points > 128 (G = ceil(N / 128)).  Members exchange inner-product partials and boundary knots through the XCD's L2
+ *       ("cluster_l2" = 0: always write-through), so all members of a cluster must be resident: the launch holds as many clusters as fit the
+ *       chip and each draws trajectories from a queue (any batch = one launch).  A cluster that cannot make progress (a peer not resident:
+ *       another stream holds its CU) gives up after a bounded spin and the follow-up launch of a single-workgroup kernel re-solves its
+ *       trajectory ("cluster_fixup" = 0: no follow-up launch, d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for such a trajectory);
+ *   otherwise (and for fp16 storage, explicit pcg_* knobs, the fix-up launches) the single-workgroup row-pair kernel: "pcg_waves" (4, 8 or 16
+ *       wavefronts per trajectory workgroup), "pcg_reg_rows" (TRIPLES of block rows per matrix and wave kept in registers for the whole
+ *       solve; only compiled (waves, rows) pairs are accepted at launch), "pcg_lds_rows" (triples per matrix and wave cached in LDS, -1 =
+ *       what fits), "pcg_stream_bufs", "pcg_max_wg_per_cu", "lds_extra" (single-triple LDS slots beyond the uniform cache of the <.,.,1>
+ *       kernels: -1 what fits, 0 none); "pcg16_*" = the same for fp16 storage.  Setting any pcg_* knob switches the automatic selection off.
+ * "sched_hint" (0 / 1, default 1): an mpcg_pcg_solve call with more trajectories than CUs that runs a register-resident kernel dispatches its
+ *       trajectories longest-expected-first, the expectation being the iteration counts the handle's previous call with the same batch size
+ *       wrote to d_iters — warm-started solves leave the loop at very different iterations and the dispatch order decides how well the chip stays
+ *       filled: -25..35 % on such batches; a scheduling hint only, no result depends on it; one extra ~3 us kernel behind each such solve.
+ * "check_symmetry" (debug, 0/1: see BLOCK SYMMETRY above).
+ * Around the solve: "schur_dpp" (1: mpcg_form_schur's register-resident formation — a 16-lane DPP row walks a chunk of consecutive block rows, a second
+ *       kernel closes the seams between chunks; 0: the LDS kernels; same bits), "schur_chunk" (block rows per chunk: 0 = by call size, from one
+ *       row per chunk for a single trajectory to 16 at 1024 x 128 knots; 1..2048 forced; same bits), "dz_dpp" (1: mpcg_compute_dz with four knots
+ *       per wavefront, 0: one workgroup per knot; same bits), "block_solve_wide" (mpcg_block_solve: 1 one trajectory per wavefront, 0 four, -1 by
+ *       batch size; same bits), "nt_loads" / "spmv_blocks_per_cu" (mpcg_bt_spmv), "spmv_mfma" (the MFMA experiment kernel).
+ * Read-only: "cluster_fixups" (trajectories re-solved by fix-up launches since mpcg_create — each costs 1.5-4.5 ms of spinning; blocking 8-byte
+ *       D2H read), "last_symmetry_violations", "num_cus", "pcg_resident" (1 if the single-workgroup configuration streams nothing inside the PCG
+ *       loop), "last_schur_chunk" (block rows per chunk of the last mpcg_form_schur, 0 = the LDS kernels), "last_kernel_family" (kernel of the
+ *       last solve: 0 single-workgroup row-pair, 3 generic, 5 row-per-lane, 6 lane-pair-per-knot, 7 clustered lane-pair; 1, 2, 4 were kernels
+ *       retired in round 4), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
  * WHICH kernel family serves a call depends on knot_points AND on the call's batch (e.g. 32 < N <= 64: row-per-lane kernel up to one
- * trajectory per CU, lane-pair / lane-per-block kernel beyond; N <= 32: 8 waves x 1 slot or 4 x 2 by batch).  Families sum the inner
- * products in different orders, so the SAME trajectory solved alone and inside a large batch may differ in the last fp32 bits (and, near
- * the tolerance, by an iteration); within one family results are bitwise reproducible run to run and independent of batch composition.
- * Pin a family with "pcg_rpl" / "pcg_lpb" / "pcg_lpk" / "rpl_waves" when bit-stability across batch sizes matters.
- * None of the residency knobs changes results within a lane-order family (bitwise identical, tested); kernels that
- * keep everything resident use the adjacent-lane order and agree with the streaming ones to fp32 round-off of the
- * inner products, as does the cluster kernel, which sums the inner products per workgroup first. */
+ * trajectory per CU, lane-pair kernel beyond; N <= 32: 8 waves x 1 slot or 4 x 2 by batch).  Families sum the inner products in different
+ * orders, so the SAME trajectory solved alone and inside a large batch may differ in the last fp32 bits (and, near the tolerance, by an
+ * iteration); within one family results are bitwise reproducible run to run and independent of batch composition.  Pin a family with
+ * "pcg_rpl" / "pcg_lpk" / "rpl_waves" when bit-stability across batch sizes matters.  None of the residency knobs changes results within a
+ * lane-order family (bitwise identical, tested). */
 int mpcg_set_option(mpcg_handle *h, const char *key, int value);
 int mpcg_get_option(const mpcg_handle *h, const char *key, int *value);
 

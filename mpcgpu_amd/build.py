@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libmpcg_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "mpcg_capi.hip")]
-DEPS = SOURCES + [os.path.join(_HERE, "csrc", f) for f in ("pcg_kernels.hip.h", "pcg_lpb.hip.h", "pcg_lpk.hip.h", "pcg_lpk_cluster.hip.h", "pcg_lpb_cluster.hip.h", "pcg_rpl.hip.h", "schur_kernels.hip.h", "dpp_rows.hip.h", "schur_walk.hip.h", "block_solve.hip.h", "pcg_f64.hip.h", "ldl_host.hpp", "kkt_plant.hip.h", "iiwa14_model.inc")] + [
+DEPS = SOURCES + [os.path.join(_HERE, "csrc", f) for f in ("pcg_kernels.hip.h", "pcg_lpk.hip.h", "pcg_lpk_cluster.hip.h", "pcg_rpl.hip.h", "schur_kernels.hip.h", "dpp_rows.hip.h", "schur_walk.hip.h", "block_solve.hip.h", "pcg_f64.hip.h", "ldl_host.hpp", "kkt_plant.hip.h", "iiwa14_model.inc")] + [
     os.path.join(_ROOT, "include", "mpcg.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -78,7 +78,7 @@ def build_example_f64(force: bool = False, verbose: bool = False) -> str:
     deps = [EXAMPLE_SRC, LIB_PATH, os.path.join(_ROOT, "include", "gbd_pcg_compat", "gpu_pcg.cuh")]
     if force or not os.path.exists(EXAMPLE_BIN64) or any(os.path.getmtime(d) > os.path.getmtime(EXAMPLE_BIN64) for d in deps):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-DUSE_DOUBLES", "-I" + os.path.join(_ROOT, "include", "gbd_pcg_compat"),
-               EXAMPLE_SRC, "-L" + _HERE, "-lmpcg_hip", "-Wl,-rpath,$ORIGIN/../mpcgpu_amd", "-o", EXAMPLE_BIN64]
+               EXAMPLE_SRC, "-L" + _HERE, "-lmpcg_hip", "-lpthread", "-Wl,-rpath,$ORIGIN/../mpcgpu_amd", "-o", EXAMPLE_BIN64]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -90,7 +90,7 @@ def build_example(force: bool = False, verbose: bool = False) -> str:
     deps = [EXAMPLE_SRC, LIB_PATH, os.path.join(_ROOT, "include", "gbd_pcg_compat", "gpu_pcg.cuh")]
     if force or not os.path.exists(EXAMPLE_BIN) or any(os.path.getmtime(d) > os.path.getmtime(EXAMPLE_BIN) for d in deps):
         cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(_ROOT, "include", "gbd_pcg_compat"),
-               EXAMPLE_SRC, "-L" + _HERE, "-lmpcg_hip", "-Wl,-rpath,$ORIGIN/../mpcgpu_amd", "-o", EXAMPLE_BIN]
+               EXAMPLE_SRC, "-L" + _HERE, "-lmpcg_hip", "-lpthread", "-Wl,-rpath,$ORIGIN/../mpcgpu_amd", "-o", EXAMPLE_BIN]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -10,10 +10,8 @@
 
 #include "../../include/mpcg.h"
 #include "pcg_kernels.hip.h"
-#include "pcg_lpb.hip.h"
 #include "pcg_lpk.hip.h"
 #include "pcg_lpk_cluster.hip.h"
-#include "pcg_lpb_cluster.hip.h"
 #include "pcg_rpl.hip.h"
 #include "schur_kernels.hip.h"
 #include "schur_walk.hip.h"
@@ -38,7 +36,7 @@ struct PcgKnobs {
 };
 
 // What the last solve on this handle actually launched (read-only "last_kernel_*" options; tests assert on it).
-enum { FAM_NONE = -1, FAM_TRAJ = 0, FAM_CLUSTER = 1, FAM_LPB = 2, FAM_GENERIC = 3, FAM_LPBC = 4, FAM_RPL = 5, FAM_LPK = 6, FAM_LPKC = 7 };
+enum { FAM_NONE = -1, FAM_TRAJ = 0, /* 1, 2, 4: kernels retired in round 4 (HISTORY.md) */ FAM_GENERIC = 3, FAM_RPL = 5, FAM_LPK = 6, FAM_LPKC = 7 };
 struct LastKernel { int family = FAM_NONE, waves = 0, reg_rows = 0, lds_rows = 0, stream_bufs = 0, cluster = 0, lds_bytes = 0, lds_extra = 0; };
 
 struct mpcg_handle {
@@ -50,23 +48,17 @@ struct mpcg_handle {
     int nt_loads = 1;         // non-temporal hint on the matrix stream
     int rpl = -1;             // row-per-lane kernel (pcg_rpl.hip.h, N <= 64): -1 auto, 0 off, 1 forced
     int rpl_waves = 0;        //   its wavefronts per trajectory: 0 auto, 4 / 8 / 16
-    int lpk = -1;             // lane-pair-per-knot kernel (pcg_lpk.hip.h, N <= 128): -1 auto (wherever the lane-per-block kernel would run), 0 off, 1 forced
-    int lpb = -1;             // lane-per-block kernel (pcg_lpb.hip.h): -1 auto (N <= 128, fp32, automatic configuration), 0 off, 1 forced
+    int lpk = -1;             // lane-pair-per-knot kernel (pcg_lpk.hip.h, N <= 128): -1 auto (36 < N <= 128 beyond the row-per-lane kernel's calls), 0 off, 1 forced
     int block_solve_wide = -1; // mpcg_block_solve: one trajectory per wavefront (1), four (0), by batch size (-1)
     int schur_dpp = 1;        // 1: register-resident Schur formation (schur_walk.hip.h: the chunk-walking kernel + its seam kernel), 0: the LDS versions
     int sched_hint = 1;       // dispatch the trajectories of a large call longest-expected-first, predicted by the previous call's iteration counts (sched_order_kernel)
-    uint32_t* sched_order = nullptr;   // [max_batch] dispatch order written after every hinted solve
-    uint32_t order_batch = 0;          // batch of the call that wrote it (0: none yet)
+    uint32_t* sched_order = nullptr;   // [1 + max_batch] {batch it was made for, dispatch order}: written after every hinted solve, checked on the device
     int schur_chunk = 0;      //   block rows per chunk of the walking kernel: 0 auto (by call size), 1..2048 forced
     int dz_dpp = 1;           // 1: four-knots-per-wavefront dz recovery (schur_walk.hip.h), 0: the one-workgroup-per-knot LDS kernel
     int last_schur_chunk = 0; //   what the last mpcg_form_schur used (0: the LDS kernels)
     float* seam_qinv = nullptr;      // schur_walk: one Q^-1 per chunk seam (max_batch x chunks x 196 floats)
     size_t seam_qinv_floats = 0;
-    int cluster_waves = -1;   // waves per cluster member: 8 (one member per CU), 4 (two per CU), -1 by batch size
-    int cluster_adj = 1;      // lane order of the cluster kernel (1: blocks of a row in adjacent lanes)
-    int cluster = -1;         // workgroups per trajectory for the cluster kernel: 0 off, -1 auto, G > 0 forced
-    int cluster_lpb = -1;     // clustered lane-per-block kernel (pcg_lpb_cluster.hip.h) instead of the row-triple cluster kernel: -1 auto (on), 0 off, 1 on
-    int cluster_lpk = -1;     // clustered lane-PAIR kernel (pcg_lpk_cluster.hip.h) where the clustered lane-per-block kernel would run: -1 auto (on), 0 off, 1 on
+    int cluster = -1;         // workgroups per trajectory of the clustered lane-pair kernel (pcg_lpk_cluster.hip.h): 0 off, -1 auto (N > 128), G > 0 forced
     int cluster_l2 = 1;       // clustered lane-per-block kernel: 1 = L2-resident hand-offs when a cluster's members share an XCD, 0 = always write-through
     int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
     int check_symmetry = 0;   // debug: 1 = every solve that would run a lower-triangle kernel first verifies block symmetry of S and Pinv (synchronises)
@@ -121,14 +113,11 @@ const char* mpcg_build_info(void) {
     return "libmpcg_hip gfx950 fp32 n=14 (row-per-lane DPP PCG for short horizons, lane-per-block register-resident PCG, clustered PCG for long horizons, wave64 row-triple streaming PCG)";
 }
 
-// device scratch of the cluster kernels, shared by both (they never run concurrently on one handle):
-//   row-triple cluster kernel   [flags: one 128-byte line per trajectory of a launch, at most one per CU][cells: 512 B per member]
-//   clustered lane-per-block    [queue line][flags: one line per trajectory of the CALL, up to max_batch][cells]
+// device scratch of the clustered kernel: [queue line][flags: one 128-byte line per trajectory of the CALL, up to max_batch][cells: 1 KB
+// per member of the launch, up to two members per CU]
 static size_t cluster_alloc_words(const mpcg_handle* h) {
-    const size_t cells = (size_t)2 * h->num_cus * CL_WG_WORDS;
-    const size_t a = (size_t)h->num_cus * CL_FLAG_STRIDE + cells;
-    const size_t b = (size_t)2 * h->num_cus * LPBC_WG_WORDS + CL_FLAG_STRIDE + (size_t)h->max_batch * CL_FLAG_STRIDE;
-    return (a > b ? a : b) + 16;         // + one line for the "cluster_fixups" counter (never re-zeroed by a launch)
+    return (size_t)2 * h->num_cus * LPBC_WG_WORDS + CL_FLAG_STRIDE + (size_t)h->max_batch * CL_FLAG_STRIDE
+           + 16;                         // + one line for the "cluster_fixups" counter (never re-zeroed by a launch)
 }
 static unsigned long long* fixup_counter(const mpcg_handle* h) { return h->cluster_scratch + cluster_alloc_words(h) - 16; }
 
@@ -180,7 +169,8 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
         return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the cluster scratch");
     }
     (void)hipMemset(h->cluster_scratch, 0, cluster_alloc_words(h) * sizeof(unsigned long long));
-    if (hipMalloc(reinterpret_cast<void**>(&h->sched_order), (size_t)max_batch * sizeof(uint32_t)) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&h->sched_order), ((size_t)max_batch + 1) * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(h->sched_order, 0, ((size_t)max_batch + 1) * sizeof(uint32_t)) != hipSuccess) {      // tag 0 = no permutation yet (sched_pick)
         (void)hipFree(h->cluster_scratch);
         delete h;
         return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the dispatch-order buffer");
@@ -211,7 +201,6 @@ static int* knob_ptr(mpcg_handle* h, const char* key) {
     if (!strcmp(key, "pcg_lds_rows")) return &h->k.lds_rows;
     if (!strcmp(key, "pcg_stream_bufs")) return &h->k.stream_bufs;
     if (!strcmp(key, "lds_extra")) return &h->k.lds_extra;
-    if (!strcmp(key, "cluster_waves")) return &h->cluster_waves;
     if (!strcmp(key, "block_solve_wide")) return &h->block_solve_wide;
     if (!strcmp(key, "pcg16_waves")) return &h->k.waves16;
     if (!strcmp(key, "pcg16_reg_rows")) return &h->k.reg_rows16;
@@ -245,29 +234,15 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
         if (value == 1 && h->N > kLpbMaxN) return fail(h, MPCG_ERR_UNSUPPORTED, "pcg_lpk: the lane-pair kernel holds knot_points <= 128");
         h->lpk = value; return MPCG_OK;
     }
-    if (!strcmp(key, "pcg_lpb")) {
-        if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "pcg_lpb must be -1 (auto), 0 (off) or 1 (forced)");
-        if (value == 1 && h->N > kLpbMaxN) return fail(h, MPCG_ERR_UNSUPPORTED, "pcg_lpb: the lane-per-block kernel holds knot_points <= 128");
-        h->lpb = value; return MPCG_OK;                 // (does not touch the knobs of the other kernels)
-    }
     if (int* p = knob_ptr(h, key)) { *p = value; if (is_pcg) h->auto_cfg = false; return MPCG_OK; }
     if (!strcmp(key, "nt_loads")) { h->nt_loads = value ? 1 : 0; return MPCG_OK; }
-    if (!strcmp(key, "cluster_adj")) { h->cluster_adj = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_fixup")) { h->cluster_fixup = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_l2")) { h->cluster_l2 = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "check_symmetry")) { h->check_symmetry = value ? 1 : 0; return MPCG_OK; }
-    if (!strcmp(key, "cluster_lpk")) {
-        if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "cluster_lpk must be -1 (auto), 0 or 1");
-        h->cluster_lpk = value; return MPCG_OK;
-    }
-    if (!strcmp(key, "cluster_lpb")) {
-        if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "cluster_lpb must be -1 (auto), 0 or 1");
-        h->cluster_lpb = value; return MPCG_OK;
-    }
     if (!strcmp(key, "schur_dpp")) { h->schur_dpp = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "schur_chunk")) { if (value < 0 || value > 2048) return fail(h, MPCG_ERR_INVALID, "schur_chunk must be 0 (auto) or 1..2048 block rows"); h->schur_chunk = value; return MPCG_OK; }
     if (!strcmp(key, "dz_dpp")) { h->dz_dpp = value ? 1 : 0; return MPCG_OK; }
-    if (!strcmp(key, "sched_hint")) { h->sched_hint = value ? 1 : 0; h->order_batch = 0; return MPCG_OK; }
+    if (!strcmp(key, "sched_hint")) { h->sched_hint = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
         if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");
         h->cluster = value; return MPCG_OK;
@@ -284,7 +259,6 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!h || !key || !value) return MPCG_ERR_INVALID;
     if (!strcmp(key, "pcg_waves")) { *value = h->k.waves; return MPCG_OK; }
     if (!strcmp(key, "pcg_max_wg_per_cu")) { *value = h->k.max_wg_per_cu; return MPCG_OK; }
-    if (!strcmp(key, "pcg_lpb")) { *value = h->lpb; return MPCG_OK; }
     if (!strcmp(key, "pcg_lpk")) { *value = h->lpk; return MPCG_OK; }
     if (!strcmp(key, "pcg_rpl")) { *value = h->rpl; return MPCG_OK; }
     if (!strcmp(key, "rpl_waves")) { *value = h->rpl_waves; return MPCG_OK; }
@@ -292,12 +266,9 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "nt_loads")) { *value = h->nt_loads; return MPCG_OK; }
     if (!strcmp(key, "pcg_resident")) { *value = stream_bufs_for(h, h->k, h->k.waves, 4) == 0; return MPCG_OK; }   // 1: the single-workgroup configuration streams nothing
     if (!strcmp(key, "cluster")) { *value = h->cluster; return MPCG_OK; }
-    if (!strcmp(key, "cluster_adj")) { *value = h->cluster_adj; return MPCG_OK; }
     if (!strcmp(key, "cluster_fixup")) { *value = h->cluster_fixup; return MPCG_OK; }
-    if (!strcmp(key, "cluster_lpb")) { *value = h->cluster_lpb; return MPCG_OK; }
     if (!strcmp(key, "cluster_l2")) { *value = h->cluster_l2; return MPCG_OK; }
     if (!strcmp(key, "check_symmetry")) { *value = h->check_symmetry; return MPCG_OK; }
-    if (!strcmp(key, "cluster_lpk")) { *value = h->cluster_lpk; return MPCG_OK; }
     if (!strcmp(key, "last_symmetry_violations")) { *value = h->last_sym_violations; return MPCG_OK; }
     if (!strcmp(key, "schur_dpp")) { *value = h->schur_dpp; return MPCG_OK; }
     if (!strcmp(key, "schur_chunk")) { *value = h->schur_chunk; return MPCG_OK; }
@@ -477,19 +448,7 @@ static void choose_auto(const mpcg_handle* h, PcgKnobs& k, uint32_t batch, int e
     }
 }
 
-// ---- lane-per-block kernel (pcg_lpb.hip.h): everything register-resident, N <= 128 ----
-template <int NWR>
-static int launch_lpb_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
-    const size_t lds = pcg_lpb_lds_floats((int)h->N, 4 * NWR) * sizeof(float);
-    auto kern = pcg_lpb_kernel<NWR>;
-    if (lds > 48 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(batch), dim3(NWR * 256), lds, st, a);
-    HIP_TRY(h, hipGetLastError());
-    h->last = LastKernel{FAM_LPB, 4 * NWR, 0, 0, 0, 0, (int)lds, 0};
-    return MPCG_OK;
-}
-// ---- lane-pair-per-knot kernel (pcg_lpk.hip.h): the round-3 successor of the lane-per-block kernel, same residency ----
+// ---- lane-pair-per-knot kernel (pcg_lpk.hip.h): everything register-resident, N <= 128 ----
 template <int NWR>
 static int launch_lpk_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
     const size_t lds = pcg_lpk_lds_floats(4 * NWR) * sizeof(float);
@@ -501,19 +460,15 @@ static int launch_lpk_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStr
     h->last = LastKernel{FAM_LPK, 4 * NWR, 0, 0, 0, 0, (int)lds, 0};
     return MPCG_OK;
 }
-// which of the two one-CU register-resident kernels serves a call that use_lpb() accepted
-static bool prefer_lpk(const mpcg_handle* h) { return h->lpk == 1 || (h->lpk == -1 && h->lpb != 1); }
-static int launch_lpb(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
-    if (prefer_lpk(h)) return h->N <= 64 ? launch_lpk_t<1>(h, a, batch, st) : launch_lpk_t<2>(h, a, batch, st);
-    return h->N <= 64 ? launch_lpb_t<1>(h, a, batch, st) : launch_lpb_t<2>(h, a, batch, st);
+static int launch_lpk(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    return h->N <= 64 ? launch_lpk_t<1>(h, a, batch, st) : launch_lpk_t<2>(h, a, batch, st);
 }
 // Automatic use: 36 < N <= 128 (where the row-per-lane kernel has not taken the call).  Its per-lane work does not shrink with the horizon
-// (one block per lane whatever N), so up to N = 36 — where the row-pair kernel <4,3,0> fits two trajectories per CU — that one stays
-// ahead in throughput (N=36: 292 vs 222 M it/s at batch 2048); beyond it the order flips (N=40: 240 vs 209 M, N=48: 229 vs 205 M,
-// N=64: 220 vs 139 M — tools/_prof/n48.py).
-static bool use_lpb(const mpcg_handle* h, int esz) {
-    if (esz != 4 || h->N > kLpbMaxN || (h->lpb == 0 && h->lpk != 1)) return false;
-    return h->lpb == 1 || h->lpk == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 36);
+// (a lane pair per knot whatever N), so up to N = 36 — where the row-pair kernel <4,3,0> fits two trajectories per CU — that one stays
+// ahead in throughput (N=36: 292 vs 222 M it/s at batch 2048); beyond it the order flips (tools/_prof/n48.py).
+static bool use_lpk(const mpcg_handle* h, int esz) {
+    if (esz != 4 || h->N > kLpbMaxN || h->lpk == 0) return false;
+    return h->lpk == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 36);
 }
 
 // ---- row-per-lane kernel (pcg_rpl.hip.h): short horizons, NW wavefronts x RHO slots of four knots ----
@@ -552,128 +507,44 @@ static int launch_rpl(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
 static bool use_rpl(const mpcg_handle* h, int esz, uint32_t batch) {
     if (esz != 4 || h->N > kRplMaxN || h->rpl == 0) return false;
     if (h->rpl == 1) return true;
-    if (h->lpb == 1 || h->lpk == 1) return false;
+    if (h->lpk == 1) return false;
     return h->auto_cfg && h->cluster <= 0 && (h->N <= 32 || batch <= (uint32_t)h->num_cus);
-}
-
-// ---- cluster kernel: G workgroups per trajectory, everything resident, batch*G <= #CUs ----
-#define MPCG_CLUSTER_VARIANTS(X) X(8, 3) X(8, 2) X(16, 1)
-
-// scratch = [flags: one 128-byte line per trajectory of a launch (at most one per CU)][cells: 512 B per member, up to two members per CU]
-static size_t cluster_flag_words(const mpcg_handle* h) { return (size_t)h->num_cus * CL_FLAG_STRIDE; }
-static size_t cluster_scratch_words(const mpcg_handle* h) { return cluster_flag_words(h) + (size_t)2 * h->num_cus * CL_WG_WORDS; }
-
-template <int NW, int RT>
-static int launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, int G, int lt, hipStream_t st) {
-    const int kl_max = 3 * ((((int)h->N + 2) / 3 + G - 1) / G);
-    const size_t lds = pcg_cluster_lds_floats(kl_max, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
-    ClusterArgs ca;
-    ca.kl_max = kl_max;
-    ca.p = a; ca.p.lds_rows = lt; ca.fail_flags = h->cluster_scratch; ca.scratch = h->cluster_scratch + cluster_flag_words(h); ca.G = G;
-    auto kern = h->cluster_adj ? pcg_cluster_kernel<NW, RT, true> : pcg_cluster_kernel<NW, RT, false>;
-    if (lds > 48 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // one fill: the flags of a full launch + the cells this launch uses (they are contiguous)
-    const size_t zw = cluster_flag_words(h) + (size_t)batch * G * CL_WG_WORDS;
-    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster_scratch, zw);
-    HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL(kern, dim3(batch * (unsigned)G), dim3(NW * 64), lds, st, ca);
-    HIP_TRY(h, hipGetLastError());
-    h->last = LastKernel{FAM_CLUSTER, NW, RT, lt, 0, G, (int)lds, 0};
-    return MPCG_OK;
 }
 
 static int launch_traj(mpcg_handle* h, const PcgKnobs& k, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz, bool record);
 
-// returns 1 when the cluster kernel does not apply.
-// Auto policy (profiles/r01_latency_cluster.txt): G = ceil(#triples / 24) workgroups of 8 waves x 3 register
-// triples hold a whole trajectory; used for the horizons the lane-per-block kernel cannot hold (N > 128).
-//   N >= 256: always — even at full batch it beats the single-workgroup kernel (N=512: 5.1 M vs 3.0 M it/s,
-//             N=256: 11.0 M vs 9.7 M) — in chunks of floor(#CUs / G) trajectories per launch, because every
-//             member of a cluster must be resident;
-//   128 < N < 256: when the whole batch fits one launch, batch * G <= #CUs; larger batches run the single-workgroup kernel.
-// NW_ = 8: one member per CU (8 waves x 3 register triples).  NW_ = 4: members of 4 waves x (3 register + 1 LDS)
-// triples need < 256 registers and < 80 KiB of LDS, so TWO members — of different clusters, usually — share a CU and
-// compute through each other's cluster-wide waits: the throughput configuration for long horizons.
-// Fail-safe: members must be co-resident, which a plain launch cannot guarantee when another stream holds CUs.  A member
-// that waits longer than CL_SPIN_TICKS gives up (the cluster's trajectory is flagged in the scratch block); every chunk
-// is followed by a launch of the single-workgroup kernel in which only the flagged trajectories run (the others exit
-// at once), so the caller always gets a solved system — PCG converges from whatever lambda the abandoned attempt left.
-template <int NW, int RT>
-static int try_launch_cluster_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int per_cu) {
-    const int ntr = ((int)h->N + 2) / 3;
-    const int lt_cap = NW == 4 ? 1 : 0;                  // LDS triples per wave and matrix a member may use by default
-    int G = h->cluster;
-    const bool forced = G > 0;
-    if (!forced) {
-        if (h->N <= kLpbMaxN) return 1;
-        G = (ntr + NW * (RT + lt_cap) - 1) / (NW * (RT + lt_cap));
-    }
-    if (G < 2 || G > ntr || G > h->num_cus) return 1;
-    const uint32_t chunk = (uint32_t)(per_cu * h->num_cus / G);
-    if (batch > chunk && (forced || h->N < 256)) return 1;
-    const int per_wg = (ntr + G - 1) / G;                // triples of the largest member
-    const int TT = (per_wg + NW - 1) / NW;
-    const int lt = TT > RT ? TT - RT : 0;
-    const size_t lds = pcg_cluster_lds_floats(3 * per_wg, NW) * sizeof(float) + pcg_lds_cache_floats(NW, lt, 4) * sizeof(float);
-    if (lds > kLdsMax / (size_t)per_cu) return 1;
-    // single-workgroup configuration of the fix-up launch (only where that kernel can hold the horizon's vectors)
-    PcgKnobs kf = h->k;
-    choose_auto(h, kf, 1, 4);
-    const bool fixup = h->cluster_fixup && lds_bytes_for(h->N, kf.waves) <= kLdsMax;
-    const size_t mstride = (size_t)h->N * ROWF, vstride = (size_t)h->N * NS;
-    for (uint32_t lo = 0; lo < batch; lo += chunk) {
-        const uint32_t nb = batch - lo < chunk ? batch - lo : chunk;
-        PcgArgs c = a;
-        c.S = static_cast<const float*>(a.S) + lo * mstride;
-        c.Pinv = static_cast<const float*>(a.Pinv) + lo * mstride;
-        c.gamma = a.gamma + lo * vstride;
-        c.lambda = a.lambda + lo * vstride;
-        if (a.r_out) c.r_out = a.r_out + lo * vstride;
-        if (a.p_out) c.p_out = a.p_out + lo * vstride;
-        c.iters = a.iters + lo;
-        c.max_iter_exit = a.max_iter_exit + lo;
-        int rc = launch_cluster_t<NW, RT>(h, c, nb, G, lt, st);
-        if (rc != MPCG_OK) return rc;
-        if (fixup) {
-            c.redo_flags = h->cluster_scratch;                     // flag of trajectory b of this chunk
-            c.redo_stride = CL_FLAG_STRIDE;
-            c.redo_count = fixup_counter(h);
-            rc = launch_traj(h, kf, c, nb, st, 4, /*record=*/false);
-            if (rc != MPCG_OK) return rc;
-        }
-    }
-    return MPCG_OK;
-}
-
-// ---- clustered lane-per-block kernel (pcg_lpb_cluster.hip.h): G members x up to 64 NWR knots, all blocks in registers ----
-// returns 1 when it does not apply.  NWR = 2: one 8-wave member per CU; NWR = 1: 4-wave members, two per CU.
-// Every launch holds at most floor(per_cu #CUs / G) trajectories (all members of a cluster must be resident); larger batches
-// run as consecutive launches on the stream, each followed by the fix-up launch of the single-workgroup kernel.
-static int lpbc_members(const mpcg_handle* h, int nmax) {
+// ---- clustered lane-pair kernel (pcg_lpk_cluster.hip.h): G members x up to 128 knots, all blocks in registers ----
+// Members must be co-resident, which a plain launch cannot guarantee when another stream holds CUs: a member that waits longer than the
+// bounded spin gives up; every member that FINISHES a trajectory counts itself in that trajectory's flag, and the launch is followed by a
+// launch of a single-workgroup kernel in which only the trajectories whose count is not G run — the caller always gets a solved system.
+static int lpkc_members(const mpcg_handle* h) {
+    const int nmax = 128;
     const int G = h->cluster > 0 ? h->cluster : ((int)h->N + nmax - 1) / nmax;
     if (G < 2 || G > LPBC_MAX_G || G > h->num_cus || G > (int)h->N) return 0;
     if (((int)h->N + G - 1) / G > nmax) return 0;        // the largest member: ceil(N / G) knots
     return G;
 }
-// scratch of the clustered lane-per-block kernel: [queue: one 128-byte line][flags: one line per trajectory of the call = members that
-// finished it][cells: 1 KB per member of the launch] — what a call uses is contiguous, so one small fill precedes every launch
-template <int NWR, bool LPK>
-static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
-    constexpr int per_cu = NWR == 2 ? 1 : 2;
-    const int G = lpbc_members(h, 64 * NWR);
+// clusters the chip holds: the kernel pins cluster cl to XCD cl % 8 (all its members on one XCD, 32 CUs each), so residency is a
+// per-XCD count — 8 x floor(CUs of one XCD / G).  (Sized chip-wide, G = 3, 5, 6, 7 over-subscribed some XCDs by a member that could
+// not start while the persistent clusters held the CUs: its peers spun to the limit and the trajectories fell to the fix-up launch.)
+static uint32_t lpkc_resident_clusters(const mpcg_handle* h, int G) {
+    const int xcd_slots = h->num_cus / 8;
+    return h->num_cus >= 8 && xcd_slots >= G ? (uint32_t)(8 * (xcd_slots / G)) : (uint32_t)(h->num_cus / G);
+}
+// returns 1 when it does not apply.  One persistent launch for any batch: clusters draw trajectories from a queue.
+// scratch: [queue: one 128-byte line][flags: one line per trajectory of the call][cells: 1 KB per member of the launch] — what a call uses
+// is contiguous, so one small fill precedes every launch
+static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
+    if (h->cluster == 0 || esz != 4) return 1;
+    if (h->cluster < 0 && (!h->auto_cfg || h->N <= kLpbMaxN)) return 1;     // explicit pcg_* knobs, or a horizon one CU holds
+    constexpr int NWR = 2;
+    const int G = lpkc_members(h);
     if (G == 0) return 1;
     if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "batch exceeds max_batch");
-    // clusters the chip holds: the kernel pins cluster cl to XCD cl % 8 (all its members on one XCD, 32 CUs each), so residency is a
-    // per-XCD count — 8 x floor(slots of one XCD / G).  (Sized chip-wide, G = 3, 5, 6, 7 over-subscribed some XCDs by a member that could
-    // not start while the persistent clusters held the CUs: its peers spun to the limit and the trajectories fell to the fix-up launch.)
-    const int xcd_slots = per_cu * (h->num_cus / 8);
-    const uint32_t resident = h->num_cus >= 8 && xcd_slots >= G ? (uint32_t)(8 * (xcd_slots / G)) : (uint32_t)(per_cu * h->num_cus / G);
+    const uint32_t resident = lpkc_resident_clusters(h, G);
     const uint32_t clusters = batch < resident ? batch : resident;
-    const size_t lds = (LPK ? pcg_lpkc_lds_floats(4 * NWR) : pcg_lpbc_lds_floats(4 * NWR)) * sizeof(float);
-    void (*kern)(ClusterArgs);
-    if constexpr (LPK) kern = pcg_lpkc_kernel<NWR>; else kern = pcg_lpbc_kernel<NWR>;
+    const size_t lds = pcg_lpkc_lds_floats(4 * NWR) * sizeof(float);
+    void (*kern)(ClusterArgs) = pcg_lpkc_kernel<NWR>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PcgKnobs kf = h->k;
@@ -701,44 +572,11 @@ static int try_launch_lpbc_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, h
         c.redo_stride = CL_FLAG_STRIDE;
         c.redo_skip = (unsigned)G;
         c.redo_count = fixup_counter(h);
-        const int rc = h->N <= kLpbMaxN ? launch_lpb(h, c, batch, st) : launch_traj(h, kf, c, batch, st, 4, /*record=*/false);
+        const int rc = h->N <= kLpbMaxN ? launch_lpk(h, c, batch, st) : launch_traj(h, kf, c, batch, st, 4, /*record=*/false);
         if (rc != MPCG_OK) return rc;
     }
-    h->last = LastKernel{LPK ? FAM_LPKC : FAM_LPBC, 4 * NWR, 0, 0, 0, G, (int)lds, 0};
+    h->last = LastKernel{FAM_LPKC, 4 * NWR, 0, 0, 0, G, (int)lds, 0};
     return MPCG_OK;
-}
-static int try_launch_lpbc(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
-    if (h->cluster_lpb == 0) return 1;
-    if (h->cluster <= 0 && h->N <= kLpbMaxN) return 1;   // one CU holds it: pcg_lpk_kernel / pcg_lpb_kernel
-    const bool lpk = h->cluster_lpk != 0;                // round 3: the lane-pair arithmetic inside the same hand-off machinery
-    if (h->cluster_waves == 4) {
-        const int rc = lpk ? try_launch_lpbc_t<1, true>(h, a, batch, st) : try_launch_lpbc_t<1, false>(h, a, batch, st);
-        if (rc != 1) return rc;
-    }
-    return lpk ? try_launch_lpbc_t<2, true>(h, a, batch, st) : try_launch_lpbc_t<2, false>(h, a, batch, st);
-}
-
-static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
-    if (h->cluster == 0 || esz != 4) return 1;
-    if (h->cluster < 0 && !h->auto_cfg) return 1;       // explicit pcg_* knobs: the caller asked for a single-workgroup variant
-    {
-        const int rc = try_launch_lpbc(h, a, batch, st);
-        if (rc != 1) return rc;
-    }
-    // "cluster_waves": 8, 4, or -1 = 4-wave members (two per CU) when the batch needs more than one launch of 8-wave
-    // members anyway, i.e. when the call is about throughput
-    int waves = h->cluster_waves;
-    if (waves < 0) {
-        const int ntr = ((int)h->N + 2) / 3;
-        const int g8 = (ntr + 23) / 24;
-        // (N=512: 6.3 vs 5.3 M it/s at batch 1024; N=256: no gain, the members' passes get too long)
-        waves = (h->N >= 384 && g8 >= 2 && batch > (uint32_t)(h->num_cus / g8)) ? 4 : 8;
-    }
-    if (waves == 4) {
-        const int rc = try_launch_cluster_t<4, 3>(h, a, batch, st, 2);
-        if (rc != 1) return rc;
-    }
-    return try_launch_cluster_t<8, 3>(h, a, batch, st, 1);
 }
 
 static int launch_traj(mpcg_handle* h, const PcgKnobs& k, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz, bool record) {
@@ -765,9 +603,10 @@ static int launch_traj(mpcg_handle* h, const PcgKnobs& k, const PcgArgs& a, uint
 }
 
 // Kernel selection of one solve:
-//   1. lane-per-block kernel: fp32, N <= 128, automatic configuration (or "pcg_lpb" = 1);
-//   2. cluster kernel: forced ("cluster" = G), or automatic configuration and a horizon one CU cannot hold;
-//   3. single-workgroup kernel <waves, reg_rows, stream_bufs> — the handle's knobs, adjusted per call by the
+//   1. row-per-lane kernel: fp32, N <= 32 (N <= 64 for latency-sized calls), automatic configuration (or "pcg_rpl" = 1);
+//   2. lane-pair kernel: fp32, 36 < N <= 128, automatic configuration (or "pcg_lpk" = 1);
+//   3. clustered lane-pair kernel: forced ("cluster" = G), or automatic configuration and a horizon one CU cannot hold;
+//   4. single-workgroup kernel <waves, reg_rows, stream_bufs> — the handle's knobs, adjusted per call by the
 //      automatic policy unless the caller set any pcg_* knob.
 static int launch_generic_f32(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st);
 
@@ -795,12 +634,12 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
         if (esz != 4) return fail(h, MPCG_ERR_UNSUPPORTED, "fp16 matrix storage exists for state_size = 14 only");
         return launch_generic_f32(h, a, batch, st);
     }
-    if (use_rpl(h, esz, batch)) return launch_rpl(h, a, batch, st);      // (an explicit "pcg_lpb" = 1 wins over the automatic choice of this one)
+    if (use_rpl(h, esz, batch)) return launch_rpl(h, a, batch, st);      // (an explicit "pcg_lpk" = 1 wins over the automatic choice of this one)
     // "check_symmetry" (debug, off by default): the kernels below read only the left + diagonal block columns (mpcg.h "Block symmetry").
     // Verify the precondition on this call's matrices; a call that violates it is solved by a kernel that reads all three columns.
     bool lower_ok = true;
     h->last_sym_violations = 0;
-    if (h->check_symmetry && esz == 4 && (use_lpb(h, esz) || (h->cluster != 0 && h->cluster_lpb != 0 && (h->cluster > 0 || h->N > kLpbMaxN)))) {
+    if (h->check_symmetry && esz == 4 && (use_lpk(h, esz) || (h->cluster != 0 && (h->cluster > 0 || h->N > kLpbMaxN)))) {
         int v = 0;
         const int rc = symmetry_violations(h, a, batch, st, &v);
         if (rc != MPCG_OK) return rc;
@@ -808,7 +647,7 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
         lower_ok = v == 0;
     }
     if (lower_ok) {
-        if (use_lpb(h, esz)) return launch_lpb(h, a, batch, st);
+        if (use_lpk(h, esz)) return launch_lpk(h, a, batch, st);
         const int rc = try_launch_cluster(h, a, batch, st, esz);
         if (rc != 1) return rc;
     } else if (h->N <= kRplMaxN && h->rpl != 0) {
@@ -835,26 +674,11 @@ static int occupancy(mpcg_handle* h, const PcgKnobs& k, int* per_cu) {
 // LDS bytes of the launch a default-configured batch-1 solve makes (what pcgSharedMemSize stands for)
 static size_t default_launch_lds_bytes(uint32_t N, int num_cus) {
     if (N <= kRplMaxN) return pcg_rpl_lds_floats((int)N, N <= 16 ? 4 : 8) * sizeof(float);      // row-per-lane kernel (a batch-1 call)
-    if (N > 64 && N <= kLpbMaxN) return pcg_lpk_lds_floats(8) * sizeof(float);          // lane-pair kernel (N <= 64: a batch-1 call runs the row-per-lane kernel)
-    if (N <= 48) {                                       // <8,2,0>: everything in registers, vectors in LDS
-        mpcg_handle t0;
-        t0.N = N; t0.n = NS; t0.num_cus = num_cus;
-        choose_auto(&t0, t0.k, 1, 4);
-        return traj_lds(&t0, t0.k, t0.k.waves, 0, 4).bytes;
-    }
+    if (N <= kLpbMaxN) return pcg_lpk_lds_floats(8) * sizeof(float);                    // lane-pair kernel
     mpcg_handle tmp;
     tmp.N = N; tmp.n = NS; tmp.num_cus = num_cus;
-    if (lpbc_members(&tmp, 128) > 0) return pcg_lpkc_lds_floats(8) * sizeof(float);      // clustered lane-pair kernel
-    const int ntr = ((int)N + 2) / 3;
-    const int G = (ntr + 23) / 24;                       // 8-wave cluster members, 3 register triples per wave and matrix
-    if (G >= 2 && G <= num_cus) {
-        const int per_wg = (ntr + G - 1) / G;
-        const int TT = (per_wg + 7) / 8;
-        const int lt = TT > 3 ? TT - 3 : 0;
-        const size_t lds = pcg_cluster_lds_floats(3 * per_wg, 8) * sizeof(float) + pcg_lds_cache_floats(8, lt, 4) * sizeof(float);
-        if (lds <= kLdsMax) return lds;
-    }
-    choose_auto(&tmp, tmp.k, 1, 4);
+    if (lpkc_members(&tmp) > 0) return pcg_lpkc_lds_floats(8) * sizeof(float);          // clustered lane-pair kernel
+    choose_auto(&tmp, tmp.k, 1, 4);                                                     // (beyond 8 x 128 knots: the single-workgroup streaming kernel)
     const int sb = stream_bufs_for(&tmp, tmp.k, tmp.k.waves, 4);
     return traj_lds(&tmp, tmp.k, tmp.k.waves, sb == 0 ? 0 : 1, 4).bytes;
 }
@@ -922,24 +746,16 @@ int mpcg_check_pcg_occupancy(mpcg_handle* h, uint32_t* resident_trajectories) {
 #define X(NW_, RHO_) if (nw == NW_ && rho == RHO_) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_rpl_kernel<NW_, RHO_, true>, NW_ * 64, lds));
         MPCG_RPL_VARIANTS(X)
 #undef X
-    } else if (use_lpb(h, 4)) {
-        if (prefer_lpk(h)) {
-            const size_t lds = pcg_lpk_lds_floats(h->N <= 64 ? 4 : 8) * sizeof(float);
-            if (h->N <= 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpk_kernel<1>, 256, lds));
-            else {
-                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_lpk_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpk_kernel<2>, 512, lds));
-            }
-        } else {
-            const size_t lds = pcg_lpb_lds_floats((int)h->N, h->N <= 64 ? 4 : 8) * sizeof(float);
-            if (h->N <= 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpb_kernel<1>, 256, lds));
-            else HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpb_kernel<2>, 512, lds));
+    } else if (use_lpk(h, 4)) {
+        const size_t lds = pcg_lpk_lds_floats(h->N <= 64 ? 4 : 8) * sizeof(float);
+        if (h->N <= 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpk_kernel<1>, 256, lds));
+        else {
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_lpk_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpk_kernel<2>, 512, lds));
         }
-    } else if (h->auto_cfg && h->cluster != 0 && h->cluster_lpb != 0 && h->N > kLpbMaxN && lpbc_members(h, 128) > 0) {
-        // clustered kernels: resident CLUSTERS (= trajectories in flight), sized per XCD as try_launch_lpbc_t does
-        const int G = lpbc_members(h, 128);
-        const int xcd_slots = h->num_cus / 8;
-        *resident_trajectories = h->num_cus >= 8 && xcd_slots >= G ? (uint32_t)(8 * (xcd_slots / G)) : (uint32_t)(h->num_cus / G);
+    } else if (h->cluster != 0 && (h->cluster > 0 || (h->auto_cfg && h->N > kLpbMaxN)) && lpkc_members(h) > 0) {
+        // clustered kernel (the condition of try_launch_cluster): resident CLUSTERS = trajectories in flight, the count the launch itself uses
+        *resident_trajectories = lpkc_resident_clusters(h, lpkc_members(h));
         return MPCG_OK;
     } else {
         PcgKnobs k = h->k;
@@ -973,12 +789,11 @@ int mpcg_pcg_solve(mpcg_handle* h, const float* d_S, const float* d_Pinv, const 
     // Calls with more trajectories than CUs: dispatch longest-expected first, the expectation being the previous call's iteration
     // counts for the same batch (pcg_kernels.hip.h: sched_order_kernel).  A scheduling hint only: no result depends on it.
     const bool hinted = h->sched_hint && !h->generic && batch > (uint32_t)h->num_cus;
-    if (hinted && h->order_batch == batch) a.order = h->sched_order;
+    if (hinted) { a.order = h->sched_order; a.order_tag = batch; }       // (used only if the stored permutation was made for this batch: sched_pick)
     const int rc = launch_pcg(h, a, batch, static_cast<hipStream_t>(stream), 4);
-    if (rc == MPCG_OK && hinted && (h->last.family == FAM_LPK || h->last.family == FAM_LPKC || h->last.family == FAM_LPB || h->last.family == FAM_RPL)) {
+    if (rc == MPCG_OK && hinted && (h->last.family == FAM_LPK || h->last.family == FAM_LPKC || h->last.family == FAM_RPL)) {
         hipLaunchKernelGGL(sched_order_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), d_iters, (int)batch, h->sched_order);
         HIP_TRY(h, hipGetLastError());
-        h->order_batch = batch;
     }
     return rc;
 }
@@ -1563,7 +1378,7 @@ int mpcg_qdldl_solve_schur(mpcg_handle* h, mpcg_ldl* l, const float* d_val, cons
 
 // diagnostic: copy the first `count` u64 words of the cluster scratch (fail flags first) to the host; synchronises the device
 int mpcg_debug_read_cluster_scratch(mpcg_handle* h, unsigned long long* out, int count) {
-    if (!h || !out || count < 0 || (size_t)count > cluster_scratch_words(h)) return MPCG_ERR_INVALID;
+    if (!h || !out || count < 0 || (size_t)count > cluster_alloc_words(h)) return MPCG_ERR_INVALID;
     if (hipDeviceSynchronize() != hipSuccess) return MPCG_ERR_HIP;
     return hipMemcpy(out, h->cluster_scratch, sizeof(unsigned long long) * (size_t)count, hipMemcpyDeviceToHost) == hipSuccess ? MPCG_OK : MPCG_ERR_HIP;
 }

@@ -185,14 +185,24 @@ struct PcgArgs {
     int lds_rows;                          // LT: triples per matrix per wave cached in LDS
     int lds_extra_s, lds_extra_p;          // <.,.,1> kernels: waves 0..x-1 cache one more triple of S / of Pinv in LDS
     // fix-up launches behind a cluster kernel: trajectory b runs only if redo_flags[b * redo_stride] != redo_skip
-    // (row-triple cluster kernel: flag = "a member gave up", skip 0;  clustered lane-per-block kernel: flag = members that finished, skip G)
+    // (flag = members of the cluster that finished the trajectory, skip = G)
     const unsigned long long* redo_flags = nullptr;
     int redo_stride = 0;
     unsigned redo_skip = 0;
     unsigned long long* redo_count = nullptr;   // fix-up launches: += 1 per trajectory they re-solve (the handle's "cluster_fixups" counter)
-    // dispatch order (pcg_lpk_kernel, pcg_lpkc_kernel): workgroup / draw q solves trajectory order[q] (nullptr: q itself).  See sched_order_kernel.
+    // dispatch order (pcg_lpk_kernel, pcg_lpkc_kernel, ...): workgroup / draw q solves trajectory sched_pick(order, q, order_tag) (nullptr: q
+    // itself).  See sched_order_kernel.
     const uint32_t* order = nullptr;
+    uint32_t order_tag = 0;       // batch of THIS call: the stored permutation is used only if it was made for the same batch
 };
+
+// order[0] = the batch the permutation order[1 ..] was computed for (0: none yet).  The tag is checked on the DEVICE, in stream order with
+// the kernel that wrote it: whatever the host believed when the call was enqueued (or captured into a graph that has not run yet), a
+// workgroup never follows a permutation of another batch size, or an uninitialised one.
+__device__ __forceinline__ int sched_pick(const uint32_t* order, int q, uint32_t tag) {
+    if (!order) return q;
+    return order[0] == tag ? (int)order[1 + q] : q;
+}
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
@@ -677,25 +687,13 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : N
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cluster variant: G workgroups (on G CUs) solve ONE trajectory together — for long horizons whose S
-// and Pinv do not fit one CU, at batches small enough for all batch*G workgroups to be co-resident
-// (the launcher enforces batch*G <= #CUs: every spin below waits for a RESIDENT peer).
-// Workgroup g owns a contiguous range of triples (all of it register/LDS resident, no stream) and
-// keeps full-length iterate vectors in LDS of which it maintains its own knots plus one halo knot
-// either side.  Per PCG iteration the workgroups exchange, through global memory:
-//   2 inner-product partials (all-to-all among the G workgroups; the only two cluster-wide waits) and 2 x 2
-//   halo knots (neighbours; published right after the vector update, fetched inside the next pass by the one
-//   wave that needs them, so their latency hides behind the interior block rows).
-// Hand-off = the R2 recipe of cdna_hip_programming.md §6 G16: 8-byte {epoch, value} granules written with
-// ONE relaxed agent-scope atomic store each (sc1, write-through) and polled with relaxed agent-scope
-// loads — the tag is the flag, no fences; epochs increase by one per exchange and never repeat, the
-// scratch words are zeroed by a memset node before every launch.  Every spin is bounded: on timeout
-// the trajectory is abandoned with iters = 0xFFFFFFFF, exit flag 2.
-// The partials are summed in workgroup order by every workgroup, so all of them take the same
-// decisions, and the result is deterministic.
+// Shared by the clustered kernel (pcg_lpk_cluster.hip.h: G workgroups on G CUs solve ONE trajectory) and its host side: the scratch
+// of epoch-tagged hand-off cells and completion flags.  Hand-off = the R2 recipe of cdna_hip_programming.md §6 G16: {epoch, value}
+// granules written with one relaxed agent-scope store and polled with relaxed agent-scope loads — the tag is the flag, no fences;
+// every spin is bounded.  (Rounds 1-2 had two more clustered kernels on this machinery — a row-triple one here and a lane-per-block one;
+// both retired in round 4, HISTORY.md.)
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) unsigned long long gu64;
-constexpr int CL_WG_WORDS = 64;          // u64 words of scratch per workgroup: 2x2x14 halo + 2 partials (+pad)
 // "This cluster gave up" flags: one per trajectory of the launch, each in a 128-byte line of its own at the FRONT of the
 // scratch buffer, read by the fix-up launch with agent-scope loads.  They must not share a line with the polled cells: a
 // plainly cached copy of such a line (left in some XCD's L2 by the fix-up kernel) made the next graph replay's pollers
@@ -706,359 +704,17 @@ constexpr int CL_FLAG_STRIDE = 16;       // u64 words between flags
 // CU): the member gives up and the host-side fix-up launch re-solves the trajectory with the single-workgroup kernel.
 constexpr unsigned CL_SPIN_LIMIT = 1u << 16;
 
-// LDS of one cluster member: its own KL knots (+ one halo knot either side for p and r), not the whole horizon
-__host__ __device__ constexpr size_t pcg_cluster_lds_floats(int KL, int NW) {
-    return 2 * r4((size_t)(KL + 2) * NS) + 2 * r4((size_t)KL * NS) + r4(2 * (size_t)NW + 4);
-}
-
 struct ClusterArgs {
-    int kl_max;                              // knots of the largest member: 3 * ceil(#triples / G)
+    int kl_max;                              // knots of the largest member
     PcgArgs p;
-    unsigned long long* scratch;         // [batch*G][CL_WG_WORDS], zeroed before the launch
-    unsigned long long* fail_flags;      // [batch][CL_FLAG_STRIDE], zeroed before the launch (lane-per-block clusters: count of members that finished)
+    unsigned long long* scratch;         // [clusters * G][LPBC_WG_WORDS] hand-off cells, zeroed before the launch
+    unsigned long long* fail_flags;      // [batch][CL_FLAG_STRIDE], zeroed before the launch: count of members that finished the trajectory
     int G;
-    unsigned long long* queue = nullptr; // lane-per-block clusters: next trajectory to hand out (zeroed before the launch)
-    int batch = 0;                       //   "  : trajectories of the call
-    int clusters = 0;                    //   "  : clusters of the launch (the grid holds 8 ceil(clusters / 8) of them)
-    int l2_handoff = 1;                  //   "  : 1 = hand-offs through the XCD's L2 when all members of a cluster share an XCD (verified in the kernel)
+    unsigned long long* queue = nullptr; // next trajectory to hand out (zeroed before the launch)
+    int batch = 0;                       // trajectories of the call
+    int clusters = 0;                    // clusters of the launch (the grid holds 8 ceil(clusters / 8) of them)
+    int l2_handoff = 1;                  // 1 = hand-offs through the XCD's L2 when all members of a cluster share an XCD (verified in the kernel)
 };
-
-template <int NW, int RT, bool ADJ>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && RT <= 3 ? 2 : NW / 4)) void pcg_cluster_kernel(ClusterArgs ca) {
-    typedef float MT;
-    typedef typename MatT<MT>::pair mpair;
-    typedef typename MatT<MT>::chunk mchunk;
-    struct Trip { mpair m[NS]; };
-    constexpr uint32_t ESZ = sizeof(MT);
-    const PcgArgs& a = ca.p;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int N = a.N;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = ca.G;
-    const int b = blockIdx.x / G;                       // trajectory
-    const int g = blockIdx.x - b * G;                   // member of its cluster
-    constexpr int NTHR = NW * 64;
-
-    // this workgroup's triples [t0, t1) and knots [k0, k1)
-    const int NTR = (N + 2) / 3;
-    const int t0 = (int)(((long)g * NTR) / G), t1 = (int)(((long)(g + 1) * NTR) / G);
-    const int k0 = 3 * t0, k1 = min(3 * t1, N);
-    // The member keeps only ITS knots of the iterate vectors (+ one halo knot either side of p and r): KL = ca.kl_max
-    // knots of LDS per vector.  The pointers are biased by -k0 knots so that the code below keeps indexing with
-    // global knot numbers: knot k of a padded vector is at v + (k + 1) * NS for k in [k0 - 1, k1], of an unpadded
-    // one at v + k * NS for k in [k0, k1).
-    const int KL = ca.kl_max;
-    float* xp_l = lds;
-    float* xr_l = xp_l + r4((size_t)(KL + 2) * NS);
-    float* lam_l = xr_l + r4((size_t)(KL + 2) * NS);
-    float* tmp_l = lam_l + r4((size_t)KL * NS);
-    float* xp = xp_l - (ptrdiff_t)k0 * NS;
-    float* xr = xr_l - (ptrdiff_t)k0 * NS;
-    float* lam = lam_l - (ptrdiff_t)k0 * NS;
-    float* tmp = tmp_l - (ptrdiff_t)k0 * NS;
-    float* red_v = tmp_l + r4((size_t)KL * NS);         // [NW] wave partials of v
-    float* red_e = red_v + NW;                          // [NW] wave partials of eta
-    float* bc = red_v + 2 * NW;                         // [4] broadcast cell: total, timeout flag
-    mchunk* mc_base = reinterpret_cast<mchunk*>(red_v + r4(2 * (size_t)NW + 4));
-
-    const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;
-    const rsrc_t rS = make_rsrc(static_cast<const MT*>(a.S) + (size_t)b * mstride, (uint32_t)(mstride * ESZ));
-    const rsrc_t rP = make_rsrc(static_cast<const MT*>(a.Pinv) + (size_t)b * mstride, (uint32_t)(mstride * ESZ));
-    const float* gam = a.gamma + (size_t)b * vstride;
-    float* lam_g = a.lambda + (size_t)b * vstride;
-    gu64* my_words = (gu64*)ca.scratch + (size_t)blockIdx.x * CL_WG_WORDS;
-    gu64* cl_words = (gu64*)ca.scratch + (size_t)b * G * CL_WG_WORDS;      // the cluster's block
-
-    const bool active = lane < 63;
-    // (the all-resident lane order of pcg_traj_kernel: lane = 3 (7 rho + q) + s, blocks of a row merged by DPP wave shifts)
-    const int lg = active ? (ADJ ? lane / 3 : lane % 21) : 0;
-    const int ls = active ? (ADJ ? lane - 3 * lg : lane / 21) : 0;
-    const int lrho = lg / 7;
-    const int lq = lg - 7 * lrho;
-    const bool head = active && ls == 0;
-    const uint32_t lane_byte = (uint32_t)(ls * 196 + lq * 2) * ESZ;
-
-    const int TT = max(0, (t1 - t0 - w + NW - 1) / NW);   // this wave's triples: tr = t0 + w + NW*j  (launcher: TT <= RT + LT)
-    const int LT = a.lds_rows;
-
-    auto trip_off = [&](int j, int cols) -> uint32_t {
-        const int k = 3 * (t0 + w + NW * j) + lrho;
-        const bool ok = active && j < TT && k < N && !(ls == 0 && k == 0) && !(ls == 2 && k == N - 1) && (cols == 3 || ls == 1);
-        return ok ? (uint32_t)k * (ROWF * ESZ) + lane_byte : OOB_OFF;
-    };
-    auto load_trip = [&](rsrc_t M, int j, int cols) -> Trip {
-        const uint32_t off = trip_off(j, cols);
-        Trip t;
-#pragma unroll
-        for (int u = 0; u < NS; ++u) t.m[u] = MatT<MT>::load(M, off + (NS * ESZ) * u);
-        return t;
-    };
-    Trip regS[RT > 0 ? RT : 1], regP[RT > 0 ? RT : 1];
-#pragma unroll
-    for (int j = 0; j < RT; ++j) {
-        regS[j] = load_trip(rS, j, 3);
-        regP[j] = load_trip(rP, j, a.pcols);
-    }
-    const int slane = active ? lane : SLOT_LANES - 1;
-    mchunk* mc = mc_base + (size_t)w * 2 * LT * SLOT_LANES * 7;
-    for (int j = 0; j < LT; ++j) {
-        const Trip ta = load_trip(rS, RT + j, 3);
-        const Trip tb = load_trip(rP, RT + j, a.pcols);
-        mchunk* d0 = mc + ((size_t)j * SLOT_LANES + slane) * 7;
-        mchunk* d1 = mc + ((size_t)(LT + j) * SLOT_LANES + slane) * 7;
-        if (active) {
-#pragma unroll
-            for (int u = 0; u < 7; ++u) {
-                d0[u] = mchunk{ta.m[2 * u].x, ta.m[2 * u].y, ta.m[2 * u + 1].x, ta.m[2 * u + 1].y};
-                d1[u] = mchunk{tb.m[2 * u].x, tb.m[2 * u].y, tb.m[2 * u + 1].x, tb.m[2 * u + 1].y};
-            }
-        }
-    }
-    auto lds_trip = [&](int mat, int j) -> Trip {
-        const mchunk* src = mc + ((size_t)(mat * LT + j) * SLOT_LANES + slane) * 7;
-        Trip t;
-#pragma unroll
-        for (int u = 0; u < 7; ++u) {
-            const mchunk v = src[u];
-            t.m[2 * u] = mpair{v.x, v.y};
-            t.m[2 * u + 1] = mpair{v.z, v.w};
-        }
-        return t;
-    };
-
-    // ---- stage the member's knots; lambda0 also for the halo knots k0-1 and k1 (it is complete in global memory: the
-    //      setup SpMV needs no exchange); knots outside [0, N) are the zero padding ----
-    for (int e = tid; e < (KL + 2) * NS; e += NTHR) { xp_l[e] = 0.f; xr_l[e] = 0.f; }
-    lds_barrier();
-    for (int e = NS * (k0 - 1) + tid; e < NS * (k1 + 1); e += NTHR) {
-        const int k = e / NS;                           // (e >= -NS: k0 >= 0; e in [-NS, 0) only for k0 = 0, skipped below)
-        if (e < 0 || k >= N) continue;
-        const float l0 = lam_g[e];
-        xp[NS + e] = l0;
-        if (k >= k0 && k < k1) {
-            lam[e] = l0;
-            xr[NS + e] = gam[e];
-        }
-    }
-    lds_barrier();
-
-    struct Pend { f2 a0, a1, a2, d; int k; bool valid; };
-    auto begin = [&](const Trip& t, int j, const float* xv, const float* dv) -> Pend {
-        Pend q;
-        const int k = 3 * (t0 + w + NW * j) + lrho;
-        q.valid = j < TT && k < N;
-        q.k = q.valid ? k : k0;                          // (any knot of this member will do for the zero rows)
-        const f2* x2 = reinterpret_cast<const f2*>(xv + (q.k + ls) * NS);
-        f2 acc = {0.f, 0.f}, acc1 = {0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 7; ++u) {
-            const f2 x = x2[u];
-            MatT<MT>::fma(acc, t.m[2 * u], x.x);
-            MatT<MT>::fma(acc1, t.m[2 * u + 1], x.y);
-        }
-        acc += acc1;
-        q.d = *reinterpret_cast<const f2*>(dv + (q.k + 1) * NS + 2 * lq);
-        q.a0 = acc;
-        if constexpr (ADJ) {
-            q.a1 = wave_shl1(acc);
-            q.a2 = wave_shl1(q.a1);
-        } else {
-            q.a1.x = __shfl_down(acc.x, 21);
-            q.a1.y = __shfl_down(acc.y, 21);
-            q.a2.x = __shfl_down(acc.x, 42);
-            q.a2.y = __shfl_down(acc.y, 42);
-        }
-        return q;
-    };
-    auto finish = [&](const Pend& q, float& part) {
-        if (head && q.valid) {
-            const f2 y = (q.a0 + q.a1) + q.a2;
-            *reinterpret_cast<f2*>(tmp + q.k * NS + 2 * lq) = y;
-            part += fmaf(y.y, q.d.y, y.x * q.d.x);
-        }
-    };
-    // The halo knots of the operand arrive DURING the pass: the wave that owns the first (last) triple of this
-    // member polls the left (right) neighbour's granules just before that triple and drops them into the halo
-    // knot of its LDS vector — only that wave reads them, and LDS operations of one wave execute in order, so no
-    // workgroup barrier is involved.  Triple j = 0 is processed last so that the left halo has had time to land.
-    auto fetch_halo = [&](float* v, int which, int side, unsigned ep) {
-        const int i = lane;                             // lanes 0..13: the 14 entries of the neighbour's boundary knot
-        const gu64* src = cl_words + (size_t)(side ? g + 1 : g - 1) * CL_WG_WORDS + which * 28 + (side ? 0 : NS) + (i < NS ? i : 0);
-        unsigned long long x = 0;
-        unsigned spins = 0;
-        bool ok;
-        do {
-            ok = true;
-            if (i < NS) {
-                x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = (unsigned)(x >> 32) == ep;
-            }
-            if (__all(ok)) break;
-            __builtin_amdgcn_s_sleep(1);
-        } while (++spins < CL_SPIN_LIMIT);
-        if (i < NS) v[((side ? k1 : k0 - 1) + 1) * NS + i] = __builtin_bit_cast(float, (unsigned)x);
-        if (spins >= CL_SPIN_LIMIT && lane == 0) bc[1] = 1.f;          // sticky timeout flag
-    };
-    auto pass = [&](auto which, float* xv, const float* dv, unsigned ep) -> float {
-        constexpr int MAT = decltype(which)::value;
-        float part = 0.f;
-        auto halos_for = [&](int j) {                   // wave-uniform
-            const int tr = t0 + w + NW * j;
-            if (j < TT && tr == t1 - 1 && g < G - 1) fetch_halo(xv, MAT, 1, ep);
-            if (j < TT && tr == t0 && g > 0) fetch_halo(xv, MAT, 0, ep);
-        };
-#pragma unroll
-        for (int j = 1; j < RT; ++j) { halos_for(j); const Pend q = begin(MAT ? regP[j] : regS[j], j, xv, dv); finish(q, part); }
-        for (int j = 0; j < LT; ++j) { halos_for(RT + j); const Trip tt = lds_trip(MAT, j); const Pend q = begin(tt, RT + j, xv, dv); finish(q, part); }
-        if constexpr (RT > 0) { halos_for(0); const Pend q = begin(MAT ? regP[0] : regS[0], 0, xv, dv); finish(q, part); }
-        asm volatile(
-            "s_nop 1\n\t"
-            "v_add_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "s_nop 1\n\t"
-            "v_add_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "s_nop 1\n\t"
-            "v_add_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "s_nop 1\n\t"
-            "v_add_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "s_nop 1"
-            : "+v"(part));
-        const int pb = __builtin_bit_cast(int, part);
-        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 16));
-        if constexpr (!ADJ) return part + r1;
-        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 32));
-        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 48));
-        return ((part + r1) + r2) + r3;
-    };
-    using MatS = std::integral_constant<int, 0>;
-    using MatP = std::integral_constant<int, 1>;
-
-    unsigned epoch = 0;
-    bool failed = false;                               // uniform across the workgroup (published through LDS)
-    // all-to-all sum of one float per member, in member order; called by all threads, result uniform.
-    // slot: 0 / 1 (two words so that consecutive reductions never share a word)
-    auto cluster_sum = [&](float* red, int slot) -> float {
-        lds_barrier();                                  // wave partials red[0..NW) are in LDS
-        ++epoch;
-        if (w == 0) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < NW; ++i) s += red[i];
-            if (lane == 0)
-                __hip_atomic_store(my_words + 56 + slot, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, s),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long x = 0;
-            unsigned spins = 0;
-            bool ok;
-            do {
-                ok = true;
-                if (lane < G) {
-                    x = __hip_atomic_load(cl_words + (size_t)lane * CL_WG_WORDS + 56 + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = (unsigned)(x >> 32) == epoch;
-                }
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(1);
-            } while (++spins < CL_SPIN_LIMIT);
-            float tot = 0.f;
-            const int bits = (int)(unsigned)x;
-            for (int i = 0; i < G; ++i) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, i));
-            if (lane == 0) { bc[0] = tot; if (spins >= CL_SPIN_LIMIT) bc[1] = 1.f; }
-        }
-        lds_barrier();
-        if (bc[1] != 0.f) failed = true;
-        return bc[0];
-    };
-    // publish this member's first / last knot of `v` (padded vector) for the neighbours; returns the epoch the
-    // consumers must wait for.  Called by all threads right after the element-wise update of the own knots.
-    auto publish_halo = [&](const float* v, int which) -> unsigned {
-        lds_barrier();                                  // own knots of v are written
-        ++epoch;
-        if (w == 0 && lane < 28) {                      // lanes 0..13: first knot (side 0), 14..27: last knot (side 1)
-            const int side = lane / NS, i = lane - side * NS;
-            const int k = side ? k1 - 1 : k0;
-            const float val = v[(k + 1) * NS + i];
-            __hip_atomic_store(my_words + which * 28 + lane, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, val),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return epoch;
-    };
-
-    // own vector items: float2 #e, e in [7*k0, 7*k1)
-    const int e_lo = (NS / 2) * k0, e_hi = (NS / 2) * k1;
-    f2* xp2 = reinterpret_cast<f2*>(xp + NS);
-    f2* xr2 = reinterpret_cast<f2*>(xr + NS);
-    f2* lam2 = reinterpret_cast<f2*>(lam);
-    const f2* tmp2 = reinterpret_cast<const f2*>(tmp);
-
-    // ---- setup: r = gamma - S lambda0 (own knots) ; r~ = Pinv r ; eta ; p = r~ ----
-    if (tid == 0) bc[1] = 0.f;
-    {   // the setup SpMV has its operand (lambda0) complete in every member: no halo to wait for (epoch 0 never matches,
-        // so make the fetch a no-op by pretending to be a single-member cluster for this pass)
-        float part = 0.f;
-#pragma unroll
-        for (int j = 0; j < RT; ++j) { const Pend q = begin(regS[j], j, xp, xp); finish(q, part); }
-        for (int j = 0; j < LT; ++j) { const Trip tt = lds_trip(0, j); const Pend q = begin(tt, RT + j, xp, xp); finish(q, part); }
-    }
-    lds_barrier();
-    for (int e = e_lo + tid; e < e_hi; e += NTHR) xr2[e] = xr2[e] - tmp2[e];
-    unsigned ep_r = publish_halo(xr, 1);
-    {
-        const float part = pass(MatP{}, xr, xr, ep_r);
-        if (lane == 0) red_e[w] = part;
-    }
-    float eta = cluster_sum(red_e, 1);
-    for (int e = e_lo + tid; e < e_hi; e += NTHR) xp2[e] = tmp2[e];
-    unsigned ep_p = publish_halo(xp, 0);
-
-    uint32_t iters = 0;
-    uint32_t max_iter_exit = 1;
-    if (failed) {
-        iters = 0xFFFFFFFFu; max_iter_exit = 2;
-    } else if (fabsf(eta) < a.exit_tol) {
-        max_iter_exit = 0;
-    } else {
-        for (int it = 0; it < a.max_iter; ++it) {
-            {
-                const float part = pass(MatS{}, xp, xp, ep_p);
-                if (lane == 0) red_v[w] = part;
-            }
-            const float alpha = eta / cluster_sum(red_v, 0);
-            for (int e = e_lo + tid; e < e_hi; e += NTHR) {
-                lam2[e] = lam2[e] + alpha * xp2[e];
-                xr2[e] = xr2[e] - alpha * tmp2[e];
-            }
-            ep_r = publish_halo(xr, 1);
-            {
-                const float part = pass(MatP{}, xr, xr, ep_r);
-                if (lane == 0) red_e[w] = part;
-            }
-            const float eta_new = cluster_sum(red_e, 1);
-            if (failed) { iters = 0xFFFFFFFFu; max_iter_exit = 2; break; }
-            iters = (uint32_t)(it + 1);
-            if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; break; }
-            const float beta = eta_new / eta;
-            for (int e = e_lo + tid; e < e_hi; e += NTHR) xp2[e] = tmp2[e] + beta * xp2[e];
-            eta = eta_new;
-            ep_p = publish_halo(xp, 0);
-        }
-    }
-
-    // ---- write back own knots (a member that gave up leaves lambda alone and flags the trajectory for the fix-up launch) ----
-    if (failed) {
-        if (tid == 0) __hip_atomic_store(ca.fail_flags + (size_t)b * CL_FLAG_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        for (int e = NS * k0 + tid; e < NS * k1; e += NTHR) {
-            lam_g[e] = lam[e];
-            if (a.r_out) a.r_out[(size_t)b * vstride + e] = xr[NS + e];
-            if (a.p_out) a.p_out[(size_t)b * vstride + e] = xp[NS + e];
-        }
-    }
-    if (tid == 0 && g == 0) {
-        a.iters[b] = iters;
-        a.max_iter_exit[b] = (uint8_t)max_iter_exit;
-    }
-}
 
 // Zero-fill of the cluster scratch (flags + hand-off cells) in front of every cluster launch.  A kernel of our own
 // rather than hipMemsetAsync: captured into a hipGraph next to other fills, the memset NODE replayed with another
@@ -1143,8 +799,9 @@ __global__ __launch_bounds__(1024) void sched_order_kernel(const uint32_t* __res
     __syncthreads();
     for (int i = t; i < batch; i += NT) {
         const unsigned pos = atomicAdd(&hist[key(iters[i])], 1u);
-        order[pos] = (uint32_t)i;
+        order[1 + pos] = (uint32_t)i;
     }
+    if (t == 0) order[0] = (uint32_t)batch;                // (visible, together with the permutation, to the next kernel of the stream)
 }
 
 // ------------------------------------------------------------------------------------------------

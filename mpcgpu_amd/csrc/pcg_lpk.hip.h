@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = a.order ? (int)a.order[blockIdx.x] : (int)blockIdx.x;     // (dispatch order: longest-expected first, sched_order_kernel)
+    const int b = sched_pick(a.order, (int)blockIdx.x, a.order_tag);     // (dispatch order: longest-expected first, sched_order_kernel)
     if (a.redo_flags && __hip_atomic_load(a.redo_flags + (size_t)b * a.redo_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.redo_skip) return;
     if (a.redo_flags && a.redo_count && tid == 0) __hip_atomic_fetch_add(a.redo_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float* red_v = lds + L::RED;

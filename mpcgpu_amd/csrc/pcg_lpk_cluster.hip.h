@@ -17,10 +17,59 @@
 // slots of the local T / Z vectors (slot 0 and slot KL + 1), folds the partials, and ONE barrier ends the exchange.  Two hand-offs and two
 // barriers per PCG iteration, nothing else: no part vectors, no element-wise phases (pcg_lpbc_kernel: two hand-offs and four barriers).
 #pragma once
-#include "pcg_lpb_cluster.hip.h"
 #include "pcg_lpk.hip.h"
 
 namespace mpcg {
+
+// ---- hand-off cells in the cluster scratch (round 2's machinery, kept from the retired clustered lane-per-block kernel) ----
+constexpr int LPBC_MAX_G = 8;              // members: G x NW wave partials are polled by the 64 lanes of one wave
+constexpr int LPBC_WG_WORDS = 128;         // u64 words of hand-off cells per member (1 KB)
+// Cells of one member: two alternating exchange slots, each = NW 8-byte granules {tag, wave partial} (words 0..7) and three groups of
+// five 16-byte granules {tag, v0, v1, v2} — 14 values each: yD and yL of the last own knot (for the right neighbour), t (for the left one).
+constexpr int LPBC_SLOT_V = 0, LPBC_SLOT_E = 40;
+constexpr int LPBC_W_YD = 8, LPBC_W_YL = 18, LPBC_W_T = 28;
+constexpr int LPBC_SLOT_T = 120;                     // leader only: {sequence number, trajectory index} of the cluster's current trajectory
+constexpr int LPBC_SLOT_X = 121;                     // every member, once per launch: {1, XCC id} (the same-XCD check)
+
+// Granule accesses in the "uniform 64-bit base (SGPR pair) + 32-bit lane byte offset" addressing form, spelled out: left to
+// the compiler, the per-lane addresses of the two exchange slots become 64-bit VGPR pointers that are hoisted out of the PCG
+// loop — four registers this kernel does not have; they spill, and the publishing wave reloads its store address from scratch
+// right in front of every hand-off.  (s_nop 4: the base may just have been written by a v_readlane — an SGPR spill reload — and a
+// VMEM instruction reading a VALU-written SGPR needs 5 wait states; the compiler's hazard recogniser does not look into asm.)
+// sc1 = agent scope (write-through store / L2-coherent load), as __hip_atomic_*(relaxed, agent).
+// WORD = compile-time word index inside the member's block of cells: the instruction's immediate offset, so that the two exchange
+// slots and the hand-out word share ONE base register pair.
+template <int WORD>
+__device__ __forceinline__ void granule_store(gu64* sbase, unsigned byte_off, unsigned long long v) {
+    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 offset:%3 sc1" : : "v"(byte_off), "v"(v), "s"(sbase), "n"(8 * WORD) : "memory");
+}
+// The same store WITHOUT sc1: the granule stays in this XCD's L2, where a poller on the same XCD finds it (its sc1 load bypasses
+// only L1) without the round trip to the memory side that a write-through store forces on both.  Only valid when the whole
+// cluster sits on one XCD, which the members verify at start-up (pcg_lpbc_kernel: `same_xcd`).
+template <int WORD>
+__device__ __forceinline__ void granule_store_l2(gu64* sbase, unsigned byte_off, unsigned long long v) {
+    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 offset:%3" : : "v"(byte_off), "v"(v), "s"(sbase), "n"(8 * WORD) : "memory");
+}
+template <int WORD>
+__device__ __forceinline__ unsigned long long granule_load(const gu64* sbase, unsigned byte_off) {
+    unsigned long long x;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:%3 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(byte_off), "s"(sbase), "n"(8 * WORD) : "memory");
+    return x;
+}
+
+// 16-byte granules {tag, v0, v1, v2}: one dwordx4 store / load (observed untorn on gfx950, MI355X_MICROARCH.md "R2's granule"), three
+// values per fabric / L2 transaction instead of one.  L2 = without sc1 (see granule_store_l2).
+template <int WORD, bool L2>
+__device__ __forceinline__ void granule_store16(gu64* sbase, unsigned byte_off, f4 v) {
+    if constexpr (L2) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(byte_off), "v"(v), "s"(sbase), "n"(8 * WORD) : "memory");
+    else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3 sc1\n\ts_nop 1" : : "v"(byte_off), "v"(v), "s"(sbase), "n"(8 * WORD) : "memory");
+}
+__device__ __forceinline__ f4 granule_load16(const gu64* sbase, unsigned byte_off) {
+    f4 x;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(byte_off), "s"(sbase) : "memory");
+    return x;
+}
+
 
 // LDS: the lane-pair kernel's seven pair-major vectors (knot slot 0 = the left halo knot k0 - 1, slots 1..KL = own knots, slot KL + 1 = the
 // right halo knot k1) | broadcast cell | hand-off tables (5 x 64 ints) | parked matrix pairs.
@@ -411,7 +460,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpkc_kernel(ClusterArgs ca) 
         kargp_t k_in = kp;
         asm volatile("" : "+s"(k_in));
         // (dispatch order: the q-th draw of the call solves trajectory order[q] — longest-expected first, sched_order_kernel)
-        const int b = k_in->p.order ? (int)k_in->p.order[draw] : draw;
+        const int b = sched_pick(k_in->p.order, draw, k_in->p.order_tag);
         const float* gam = k_in->p.gamma + (size_t)b * vstride;
         const float* lam_in = k_in->p.lambda + (size_t)b * vstride;
         int t_st = tid, i_st = i, h_st = h;

@@ -312,7 +312,7 @@ constexpr int rpl_min_waves() { return (int)(sizeof(T) / 4) * RHO * (PC3 ? 84 : 
 
 template <int NW, int RHO, bool PC3>
 __global__ __launch_bounds__(NW * 64, (rpl_min_waves<float, RHO, PC3>())) void pcg_rpl_kernel(PcgArgs a) {
-    const int b = a.order ? (int)a.order[blockIdx.x] : (int)blockIdx.x;     // (dispatch order: longest-expected first, sched_order_kernel)
+    const int b = sched_pick(a.order, (int)blockIdx.x, a.order_tag);     // (dispatch order: longest-expected first, sched_order_kernel)
     if (a.redo_flags && __hip_atomic_load(a.redo_flags + (size_t)b * a.redo_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.redo_skip) return;
     const size_t mstride = (size_t)a.N * ROWF, vstride = (size_t)a.N * NS;
     RplTraj<float> t;

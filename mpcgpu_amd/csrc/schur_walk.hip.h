@@ -503,7 +503,8 @@ __global__ __launch_bounds__(64, 2) void schur_walk_kernel(WalkArgs w) {
             const int kk = k0 + s;
             const bool rowl = kk < k1;
             const uint32_t k = row_of(s), kn = row_of(s + 1);    // rows past the chunk's end redo its last row and store nothing
-            const bool on14 = st14 && rowl, on7 = live && r7 && rowl;
+            const bool on14 = st14 && rowl;
+            [[maybe_unused]] const bool on7 = live && r7 && rowl;
             const uint32_t oGk = oG + (k - 1) * Gset * 4u, oSk = oS + k * 3u * nn * 4u;
 #if SW_STAGE
             // the stage's lane constants (piece offsets, slot addresses) are re-derived from an opaque copy of the lane number in every

@@ -1,13 +1,13 @@
-"""GPU: the cluster kernel — G workgroups on G CUs solve one trajectory together (long horizons, small
-batches).  Same PCG, inner products summed per workgroup then across workgroups, so iterates match the
-single-workgroup kernel / the float64 oracle within the fp32 band; flags, counts and lambda conventions
-are identical; results are deterministic."""
+"""GPU: the clustered lane-pair kernel (pcg_lpk_cluster.hip.h, family 7) — fp32 horizons beyond 128 knots, G = ceil(N / 128) workgroups
+on G CUs of one XCD per trajectory, one hand-off per matrix pass: forced member counts against the single-workgroup kernel and the oracle,
+the automatic policy on ragged horizons, batches larger than the chip holds clusters, determinism and batch-composition independence,
+warm starts, and the fix-up path when a member cannot become resident."""
 import numpy as np
 import pytest
 import torch
 
 from mpcgpu_amd import synth
-from util import fp32_band, relinf
+from util import fp32_band, relinf, rel_residual
 
 pytestmark = pytest.mark.gpu
 n = 14
@@ -17,15 +17,127 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("N,G,B", [(128, 2, 3), (200, 3, 2), (256, 4, 2), (512, 8, 2), (512, 16, 1), (64, 2, 1),
-                                   (512, -411, 40), (256, -406, 70)])      # G < 0: 4-wave members, -(400 + G), two per CU
+@pytest.mark.parametrize("N", [129, 131, 255, 257, 300, 512, 640])
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
-@pytest.mark.parametrize("lpbc", [1, 0])       # 1: clustered register-resident kernel (round 3: lane-pair, family 7), 0: row-triple cluster kernel (family 1)
-def test_cluster_matches_oracle_and_single_workgroup(orc, N, G, B, pc, lpbc):
+@pytest.mark.parametrize("l2", [1, 0])
+def test_auto_policy_ragged_horizons_vs_oracle(orc, N, pc, l2):
+    """Default handle, no knobs: N > 128 runs family 7 with G = ceil(N / 128) members of floor/ceil(N / G) knots."""
     from mpcgpu_amd import PcgSolver, pcg_config
-    waves4 = G < 0
-    if waves4:
-        G = -G - 400
+    B = 2
+    k = synth.make_kkt(N, B, 9100 + N)
+    S, Pinv, g = synth.form_schur(k, poison_unused=True)
+    lam0 = np.random.default_rng(N).normal(0, 0.2, (B, n * N)).astype(np.float32)
+    sol = PcgSolver(N, max_batch=B)
+    sol.set_option("cluster_l2", l2)               # 1 (default): L2-resident hand-offs inside an XCD; 0: write-through hand-offs
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    for K in (2, 25):
+        lam = dev(lam0)
+        it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), pc)
+        torch.cuda.synchronize()
+        assert sol.get_option("last_kernel_family") == 7 and sol.get_option("last_kernel_cluster") == (N + 127) // 128
+        assert sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes(14, N)
+        assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all()
+        for t in range(B):
+            Sz, Pz = np.nan_to_num(S[t]), np.nan_to_num(Pinv[t])
+            r64 = orc.pcg(Sz.astype(np.float64), Pz.astype(np.float64), g[t].astype(np.float64), lam0[t].astype(np.float64), N, K, 0.0, pc)
+            band = fp32_band(orc, Sz, Pz, g[t], lam0[t], N, K, pc, r64["lam"], trials=2)
+            assert relinf(lam.cpu().numpy()[t], r64["lam"]) <= max(2e-5 if K == 2 else 1e-3, 4 * band)
+
+
+def test_full_batch_in_several_launches_is_deterministic_and_composition_independent(orc):
+    """N = 256, 300 trajectories: 128 clusters fit the chip, so the call is three launches (128 + 128 + 44), each followed by its
+    fix-up launch.  Same answer twice, the same answer for a sub-batch, tolerance exits and counts like the CPU restatement."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, B = 256, 300
+    k = synth.make_kkt(N, B, 77)
+    S, Pinv, g = synth.form_schur(k, poison_unused=True)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    sol = PcgSolver(N, max_batch=B)
+    cfg = pcg_config(pcg_exit_tol=1e-4, pcg_max_iter=60)
+    runs = []
+    for _ in range(2):
+        lam = torch.zeros(B, n * N, device="cuda")
+        it, ex = sol.solve(dS, dP, dg, lam, cfg, "ss")
+        torch.cuda.synchronize()
+        runs.append((lam.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy()))
+    assert sol.get_option("last_kernel_family") == 7 and sol.get_option("last_kernel_cluster") == 2
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    assert (runs[0][2] <= 1).all() and (runs[0][1] <= 60).all()          # no cluster gave up (flag 2 / 0xFFFFFFFF)
+    sub = [0, 127, 128, 255, 256, 299]
+    lam_s = torch.zeros(len(sub), n * N, device="cuda")
+    it_s, _ = sol.solve(dev(S[sub]), dev(Pinv[sub]), dev(g[sub]), lam_s, cfg, "ss")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(lam_s.cpu().numpy(), runs[0][0][sub])
+    np.testing.assert_array_equal(it_s.cpu().numpy(), runs[0][1][sub])
+    for t in (0, 128, 299):
+        Sz, Pz = np.nan_to_num(S[t]), np.nan_to_num(Pinv[t])
+        r32 = orc.pcg(Sz, Pz, g[t], np.zeros(n * N, np.float32), N, 60, 1e-4, "ss")
+        assert abs(int(runs[0][1][t]) - int(r32["iters"])) <= max(3, 0.12 * r32["iters"]), (t, runs[0][1][t], r32["iters"])
+        assert rel_residual(S[t], g[t], runs[0][0][t], N) <= 2 * rel_residual(S[t], g[t], r32["lam"], N) + 1e-6
+
+
+def test_warm_start_and_zero_iterations():
+    """lambda in/out: a second call starting from the converged lambda exits at once with 0 iterations and leaves lambda alone."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, B = 384, 3
+    k = synth.make_kkt(N, B, 5)
+    S, Pinv, g = synth.form_schur(k)
+    sol = PcgSolver(N, max_batch=B)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    lam = torch.zeros(B, n * N, device="cuda")
+    it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=1e-2, pcg_max_iter=2000), "ss")
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 7 and (ex.cpu().numpy() == 0).all() and (it.cpu().numpy() > 0).all()
+    before = lam.clone()
+    it2, ex2 = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=1e-2, pcg_max_iter=2000), "ss")
+    torch.cuda.synchronize()
+    assert (it2.cpu().numpy() == 0).all() and (ex2.cpu().numpy() == 0).all()
+    assert torch.equal(lam, before)
+
+
+def test_options_round_trip_and_selection():
+    """"cluster": -1 auto / 0 off / G forced; the retired kernels' options are gone (MPCG_ERR_INVALID, handle still usable); L2-resident and
+    write-through hand-offs give the same bits."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    from mpcgpu_amd._lib import MpcgError
+    N = 256
+    k = synth.make_kkt(N, 1, 2)
+    S, Pinv, g = synth.form_schur(k)
+    sol = PcgSolver(N, max_batch=1)
+    assert sol.get_option("cluster") == -1 and sol.get_option("cluster_fixup") == 1
+    for gone in ("cluster_lpb", "cluster_lpk", "cluster_waves", "cluster_adj", "pcg_lpb"):
+        with pytest.raises(MpcgError):
+            sol.set_option(gone, 1)
+    with pytest.raises(MpcgError):
+        sol.set_option("cluster", 33)
+    fam = {}
+    for v in (-1, 0, 2):
+        sol.set_option("cluster", v)
+        lam = torch.zeros(1, n * N, device="cuda")
+        it, ex = sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=7), "ss")
+        torch.cuda.synchronize()
+        fam[v] = (sol.get_option("last_kernel_family"), int(it.item()), lam.cpu().numpy())
+    assert fam[-1][0] == 7 and fam[2][0] == 7 and fam[0][0] == 0 and all(f[1] == 7 for f in fam.values())
+    np.testing.assert_array_equal(fam[-1][2], fam[2][2])
+    # hand-offs through the XCD's L2 (default, when the members of a cluster share an XCD) or write-through: same arithmetic, same bits
+    assert sol.get_option("cluster_l2") == 1
+    sol.set_option("cluster_l2", 0)
+    lam = torch.zeros(1, n * N, device="cuda")
+    sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=7), "ss")
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 7
+    np.testing.assert_array_equal(lam.cpu().numpy(), fam[2][2])
+    assert relinf(fam[0][2][0], fam[2][2][0]) <= 2e-3          # two kernels, same PCG, 7 iterations: fp32 round-off of the products and inner products
+
+
+@pytest.mark.parametrize("N,G,B", [(128, 2, 3), (200, 3, 2), (256, 4, 2), (512, 8, 2), (64, 2, 1), (512, 4, 40), (256, 2, 70)])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+def test_forced_member_counts_match_oracle_and_single_workgroup(orc, N, G, B, pc):
+    """"cluster" = G on horizons one CU could hold as well: same PCG, inner products summed per member then across members, so iterates match
+    the single-workgroup kernel / the float64 oracle within the fp32 band; flags, counts and lambda conventions are identical; results are
+    deterministic."""
+    from mpcgpu_amd import PcgSolver, pcg_config
     k = synth.make_kkt(N, B, 7700 + N + G)
     S, Pinv, g = synth.form_schur(k, poison_unused=True)
     lam0 = np.random.default_rng(N).normal(0, 0.2, (B, n * N)).astype(np.float32)
@@ -34,17 +146,13 @@ def test_cluster_matches_oracle_and_single_workgroup(orc, N, G, B, pc, lpbc):
     for mode in ("cluster", "single"):
         sol = PcgSolver(N, max_batch=B)
         sol.set_option("cluster", G if mode == "cluster" else 0)
-        sol.set_option("cluster_waves", 4 if waves4 else 8)
-        sol.set_option("cluster_lpb", lpbc)
         for K, tol in ((3, 0.0), (30, 0.0), (400, 1e-3)):
             lam = dev(lam0)
             it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=tol, pcg_max_iter=K), pc)
             torch.cuda.synchronize()
             out[(mode, K)] = (lam.cpu().numpy(), it.cpu().numpy().astype(np.int64), ex.cpu().numpy())
             if mode == "cluster":                      # the kernel under test really ran
-                # (the clustered lane-per-block kernel takes up to 8 members; beyond, the row-triple cluster kernel runs)
-                assert sol.get_option("last_kernel_family") == (7 if lpbc and G <= 8 else 1) and sol.get_option("last_kernel_cluster") == G
-                assert sol.get_option("last_kernel_waves") == (4 if waves4 else 8)
+                assert sol.get_option("last_kernel_family") == 7 and sol.get_option("last_kernel_cluster") == G and sol.get_option("last_kernel_waves") == 8
         if mode == "cluster":      # deterministic: bitwise identical on a second run
             lam = dev(lam0)
             sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=1e-3, pcg_max_iter=400), pc)
@@ -64,15 +172,57 @@ def test_cluster_matches_oracle_and_single_workgroup(orc, N, G, B, pc, lpbc):
     assert (np.abs(c[1] - s1[1]) <= np.maximum(3, 0.12 * s1[1])).all(), (c[1], s1[1])
 
 
-def test_cluster_falls_back_when_it_does_not_apply():
-    """batch * G > #CUs (peers could not all be resident) or G > #triples: the single-workgroup kernel runs."""
+def test_cluster_does_not_apply_beyond_eight_members():
+    """G > 8 members (or more members than knots allow): the single-workgroup kernel runs."""
     from mpcgpu_amd import PcgSolver, pcg_config
-    N, B = 32, 200
+    N, B = 32, 20
     k = synth.make_kkt(N, B, 3)
     S, Pinv, g = synth.form_schur(k)
     sol = PcgSolver(N, max_batch=B)
-    sol.set_option("cluster", 4)                       # 200 * 4 > 256 CUs
+    sol.set_option("cluster", 16)
     lam = torch.zeros(B, n * N, device="cuda")
     it, ex = sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=5))
     torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") != 7
     assert (it.cpu().numpy() == 5).all() and np.isfinite(lam.cpu().numpy()).all()
+
+
+def test_cluster_falls_back_when_peers_are_not_resident(orc):
+    """The cluster kernel (N > 128) needs all members of a trajectory resident.  Keep 255 of the 256 CUs busy with a
+    long solve on another stream, then run a batch-1 N=256 solve (2 members of the clustered lane-pair kernel): the members that do get a CU give up
+    after the bounded spin, and the fix-up launch re-solves the trajectory with the single-workgroup kernel —
+    the caller gets a normal result (no flag 2, no 0xFFFFFFFF)."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    # the blocker: N=128 lane-pair kernel, one workgroup per CU, 255 trajectories, ~20 ms
+    Nb, Bb = 128, 255
+    kb = synth.make_kkt(Nb, 8, 5)
+    Sb, Pb, gb = synth.form_schur(kb)
+    rep = (Bb + 7) // 8
+    dSb, dPb, dgb = (dev(np.tile(a, (rep, 1))[:Bb]) for a in (Sb, Pb, gb))
+    blocker = PcgSolver(Nb, max_batch=Bb)
+    lam_b = torch.zeros(Bb, n * Nb, device="cuda")
+    N, K = 256, 25
+    k = synth.make_kkt(N, 1, 6)
+    S, Pinv, g = synth.form_schur(k, poison_unused=True)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    sol = PcgSolver(N, max_batch=1)
+    assert sol.get_option("num_cus") == 256
+    lam = torch.zeros(1, n * N, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        blocker.solve(dSb, dPb, dgb, lam_b, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=12000))
+    with torch.cuda.stream(s2):
+        it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 7 and sol.get_option("last_kernel_cluster") == 2
+    assert int(it.item()) == K and int(ex.item()) == 1, (it, ex)
+    Sz, Pz = np.nan_to_num(S[0]), np.nan_to_num(Pinv[0])
+    r64 = orc.pcg(Sz.astype(np.float64), Pz.astype(np.float64), g[0].astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")
+    band = fp32_band(orc, Sz, Pz, g[0], np.zeros(n * N), N, K, "ss", r64["lam"])
+    assert relinf(lam.cpu().numpy()[0], r64["lam"]) <= max(1e-3, 4 * band)
+    # and undisturbed, the same call runs the cluster kernel to the same answer (fp32 round-off of the inner products)
+    lam2 = torch.zeros(1, n * N, device="cuda")
+    it2, ex2 = sol.solve(dS, dP, dg, lam2, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
+    torch.cuda.synchronize()
+    assert int(it2.item()) == K and relinf(lam2.cpu().numpy()[0], r64["lam"]) <= max(1e-3, 4 * band)

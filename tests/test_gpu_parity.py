@@ -314,6 +314,7 @@ def test_cpp_callsite_over_shim_headers():
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["pcg_exit"] == 0 and 0 < out["pcg_iters"] < 200 and out["rel_residual"] < 1e-4
+    assert out["two_threads_two_streams_same_bits"] == 1     # mpcgLaunchPcg(..., stream) from two host threads: a handle per thread, the same bits
     assert out["smem"] == 4 * (6 * (32 + 2) * 14 + 16)   # pcgSharedMemSize = the dynamic LDS of the launch a default solve makes (N = 32: the row-per-lane kernel, 8 waves)
     # the same source with -DUSE_DOUBLES: pcg<double, n, N>, mpcgLaunchPcg<double>
     exe64 = build.EXAMPLE_BIN64 if os.path.exists(build.EXAMPLE_BIN64) else build.build_example_f64()

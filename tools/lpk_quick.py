@@ -37,7 +37,7 @@ for N, B in shapes:
     for pc in ("ss", "jacobi"):
         cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=synth.pcg_max_iter(N))
         res, lams = {}, {}
-        for name, opt in (("lpk", "pcg_lpk"), ("lpb", "pcg_lpb")):
+        for name, opt in (("lpk", "pcg_lpk"),):
             sol = PcgSolver(N, max_batch=B)
             sol.set_option(opt, 1)
             ms, its, lam = timeit(sol, S, P, g, B, N, cfg, pc)
@@ -45,7 +45,7 @@ for N, B in shapes:
             res[name] = {"ms": round(ms, 4), "Mit_s": round(its / ms / 1e3, 1), "family": sol.get_option("last_kernel_family")}
         cfg2 = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=10)
         d = []
-        for name, opt in (("lpk", "pcg_lpk"), ("lpb", "pcg_lpb")):
+        for name, opt in (("lpk", "pcg_lpk"),):
             sol = PcgSolver(N, max_batch=B)
             sol.set_option(opt, 1)
             lam = torch.zeros(B, 14 * N, device=dev)

@@ -1,6 +1,5 @@
-"""Timing of the clustered lane-pair kernel (pcg_lpk_cluster.hip.h, family 7) against the clustered lane-per-block kernel it succeeds
-(family 4, "cluster_lpk" = 0): fixed iteration counts = the reference's caps, batch 1024 / 64 / 1, and the mixed-iteration (warm-start) batch.
-(Correctness: tests/test_gpu_lpbc.py runs every test on both.)"""
+"""Timing of the clustered lane-pair kernel (pcg_lpk_cluster.hip.h, family 7): fixed iteration counts = the reference's caps, batch 1024 / 64 / 1,
+and the mixed-iteration (warm-start) batch.  (Correctness: tests/test_gpu_cluster.py.)"""
 import os, sys, json
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,9 +28,8 @@ for N in (256, 512, 192, 384):
         S, P, g = (torch.from_numpy(np.tile(a, (rep, 1))[:B]).to(dev) for a in (S0, P0, g0))
         cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=synth.pcg_max_iter(N))
         res, lams = {}, {}
-        for name, v in (("lpkc", -1), ("lpbc", 0)):
+        for name, v in (("lpkc", -1),):
             sol = PcgSolver(N, max_batch=B)
-            sol.set_option("cluster_lpk", v)
             ms, it, lam = timeit(sol, S, P, g, None, B, N, cfg)
             its = int(it.sum().item())
             lams[name] = lam
@@ -51,9 +49,8 @@ for N in (256, 512, 192, 384):
         lam0 = star + amp * star.abs().amax(dim=1, keepdim=True) * torch.randn(B, 14 * N, device=dev, generator=gen)
         cfg = pcg_config(pcg_exit_tol=1e-4, pcg_max_iter=synth.pcg_max_iter(N))
         res = {}
-        for name, v in (("lpkc", -1), ("lpbc", 0)):
+        for name, v in (("lpkc", -1),):
             sol = PcgSolver(N, max_batch=B)
-            sol.set_option("cluster_lpk", v)
             ms, it, _ = timeit(sol, S, P, g, lam0, B, N, cfg)
             ms -= 0.0
             res[name] = {"ms": round(ms, 4), "mean_it": float(it.float().mean().item()), "Mit_s": round(int(it.sum().item()) / ms / 1e3, 2), "linsolves_per_s": int(B / ms * 1e3)}

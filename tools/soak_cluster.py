@@ -8,14 +8,11 @@ sys.path.insert(0, ROOT)
 import bench
 from mpcgpu_amd import PcgSolver, pcg_config, synth
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-# optional 2nd argument: "lpbc" (default name: what the library picks — since round 3 the clustered lane-PAIR kernel, family 7, for N > 128),
-# "lpbc_old" (round 2's clustered lane-per-block kernel, family 4), "triple" (row-triple cluster kernel), "lpbc_wt" (write-through hand-offs)
-mode = sys.argv[2] if len(sys.argv) > 2 else "lpbc"
+# optional 2nd argument: "wt" = write-through hand-offs instead of L2-resident ones
+mode = sys.argv[2] if len(sys.argv) > 2 else "l2"
 for N, B in ((128, 100), (256, 64), (512, 32), (512, 256), (256, 512), (192, 300), (640, 51)):
     sol = PcgSolver(N, max_batch=B)
-    if mode == "triple": sol.set_option("cluster_lpb", 0)
-    if mode == "lpbc_old": sol.set_option("cluster_lpk", 0)
-    if mode == "lpbc_wt": sol.set_option("cluster_l2", 0)
+    if mode == "wt": sol.set_option("cluster_l2", 0)
     if N <= 128: sol.set_option("cluster", 2)
     dS, dP, dg = bench.build_inputs(sol, N, B, 0, "ss", torch.device("cuda", 0))
     cfg = pcg_config(pcg_exit_tol=1e-4, pcg_max_iter=synth.pcg_max_iter(N))
