@@ -12,19 +12,25 @@
  *     k*3n^2 + col*n^2; col 0/1/2 = left / diagonal / right block of block row k
  *     (include/pcg/linsys_setup.cuh:36-57, 490-507).  Stored NEGATED (:15-19).  Blocks (0,col 0) and
  *     (N-1,col 2) are never written by the reference (:97,118) and are never read here.
- *   - BLOCK SYMMETRY (precondition of the PCG entry points).  PCG needs symmetric S and Pinv, and the reference's are: it writes
- *     S[k,right] as the transposed copy of S[k+1,left] (include/pcg/linsys_setup.cuh:536-557, bit for bit) and forms the symmetric-stair
- *     Pinv[k,right] / Pinv[k+1,left] as the same product twice (:97-136, equal to ~1e-7 relative).  The register-resident kernels that
- *     serve fp32 horizons above 32 knots by default ("last_kernel_family" 2, 4, 6 and 7) READ ONLY THE LEFT AND DIAGONAL block columns and
- *     apply L_{k+1}^T where the reference's kernel reads block (k,right); the right blocks of d_S / d_Pinv may hold anything (tests
- *     poison them with NaN).  On the reference's matrices the results agree to fp32 round-off of the products (~1e-7 of |Pinv| per
- *     apply; bit-identical for S).  A caller whose Pinv is NOT block-symmetric gets the solve of its symmetrised lower triangle from
- *     these kernels, and of the full three columns from the others (families 0, 1, 3, 5 read all three) — which one depends on
- *     knot_points and batch through kernel selection.  To detect that situation: option "check_symmetry" = 1 (debug, off by default)
- *     makes every solve that would run a lower-triangle kernel first verify
- *         max | M[k,right] - M[k+1,left]^T |  <=  1e-5 max | M[k,right], M[k+1,left] |     for M = S and (SS) Pinv, every k,
- *     (one extra kernel + a blocking 8-byte D2H copy per solve) and run a three-column kernel instead when it fails;
- *     "last_symmetry_violations" reports the number of offending block pairs of the last solve.
+ *   - BLOCK SYMMETRY.  PCG needs symmetric S and Pinv, and the reference's are: it writes S[k,right] as the transposed copy of
+ *     S[k+1,left] (include/pcg/linsys_setup.cuh:536-557, bit for bit) and forms the symmetric-stair Pinv[k,right] / Pinv[k+1,left] as the
+ *     same triple product associated two ways (:97-136; in float they differ by ~3e-5 of the largest entry on the bench's systems).  The register-resident kernels that serve fp32 horizons above 36 knots by
+ *     default ("last_kernel_family" 6 and 7) READ ONLY THE LEFT AND DIAGONAL block columns and apply L_{k+1}^T where the reference's kernel
+ *     reads block (k,right); the right blocks of d_S / d_Pinv may then hold anything (tests poison them with NaN).  On the reference's
+ *     matrices the results agree to that round-off of Pinv (iterates after K iterations: 1e-6 .. 3e-5, inside the fp32 band; bit-identical for S).
+ *     THE HANDLE CHECKS THIS ONCE, BY ITSELF (round 4): until it knows, every solve that would run a lower-triangle kernel is launched
+ *     guarded — a check kernel tests
+ *         max | M[k,right] - M[k+1,left]^T |  <=  1e-2 max | M[k,right], M[k+1,left] |     for M = S and (SS) Pinv, every k
+ *     (a test for STRUCTURAL asymmetry — a caller-made Pinv — not for the rounding differences above)
+ *     into a flag on the device, the lower-triangle kernel runs only if the flag is clear and a kernel that reads all three block columns
+ *     only if it is set — so even the FIRST solve of a caller with a non-symmetric Pinv is the solve of its three columns.  The flag reaches
+ *     the host by an asynchronous copy that later calls poll (no call synchronises, nothing is copied per solve once the answer is in):
+ *     from then on the handle launches plain lower-triangle kernels ("symmetry_state" 1) or, after a violation, three-column kernels for
+ *     good ("symmetry_state" 2; mpcg_last_error() carries a warning).  The latch is per handle: a caller that changes the structure of its
+ *     matrices later must use a fresh handle — or "check_symmetry" = 1 (debug), which verifies every solve with a blocking 8-byte copy
+ *     and reports the number of offending block pairs as "last_symmetry_violations".  A caller that fills ONLY the left and diagonal block
+ *     columns (the right one unwritten) says so with "assume_symmetric" = 1 before its first solve: no check, lower-triangle kernels at
+ *     once.  Families 0, 3 and 5 read all three columns anyway.
  *   - gamma, lambda: [N][n] floats per trajectory; lambda is in/out (warm start,
  *     include/mpcsim.cuh:186,267,337).
  *   - every pointer named d_* is a DEVICE pointer on the handle's device; `stream` is a hipStream_t

@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void zero_words_kernel(unsigned long long* p, 
 // k < N-1): counts the pairs whose blocks differ by more than rel_tol x the largest entry of the pair,
 //   max_ij | M[k, right](i, j) - M[k+1, left](j, i) |  >  rel_tol * max | M[k, right], M[k+1, left] |        (NaN counts as a violation).
 __global__ __launch_bounds__(256) void bd_symmetry_check_kernel(const float* __restrict__ M, int N, int batch, float rel_tol,
-                                                                unsigned long long* __restrict__ violations) {
+                                                                unsigned long long* __restrict__ violations, unsigned long long* __restrict__ flag) {
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= (long)batch * (N - 1)) return;
@@ -753,7 +753,10 @@ __global__ __launch_bounds__(256) void bd_symmetry_check_kernel(const float* __r
         amax = fmaxf(amax, __shfl_xor(amax, o));
         bad |= __shfl_xor((int)bad, o) != 0;
     }
-    if (lane == 0 && (bad || dmax > rel_tol * amax)) atomicAdd(violations, 1ull);
+    if (lane == 0 && (bad || dmax > rel_tol * amax)) {
+        if (violations) atomicAdd(violations, 1ull);        // the debug option's count
+        if (flag) atomicOr(flag, 1ull);                     // the handle's latch (0 / 1: what the gated launches compare with)
+    }
 }
 
 // fp32 -> fp16 copy of a bd-layout matrix (round to nearest even), 8 elements per thread.

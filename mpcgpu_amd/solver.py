@@ -148,6 +148,10 @@ class PcgSolver:
     def set_option(self, key: str, value: int):
         self._check(self.lib.mpcg_set_option(self._h, key.encode(), int(value)))
 
+    def last_error(self) -> str:
+        """mpcg_last_error: the text of the handle's last error — or warning (the symmetry latch leaves one)."""
+        return self.lib.mpcg_last_error(self._h).decode()
+
     def get_option(self, key: str) -> int:
         v = C.c_int()
         self._check(self.lib.mpcg_get_option(self._h, key.encode(), C.byref(v)))

@@ -32,7 +32,9 @@ def test_check_symmetry_passes_on_reference_matrices_and_catches_asymmetric_pinv
     lam = torch.zeros(B, n * N, device="cuda")
     sol.solve(dev(S), dev(Pinv), dev(g), lam, cfg, "ss")
     fam_default = sol.get_option("last_kernel_family")
-    assert fam_default in (2, 4, 6, 7)                       # a lower-triangle kernel serves this call
+    assert fam_default in (6, 7)                             # a lower-triangle kernel serves this call
+    torch.cuda.synchronize()
+    assert sol.get_option("symmetry_state") == 1             # ... and the handle has latched "block-symmetric" (the asynchronous copy has landed)
     sol.set_option("check_symmetry", 1)
     lam1 = torch.zeros(B, n * N, device="cuda")
     sol.solve(dev(S), dev(Pinv), dev(g), lam1, cfg, "ss")
@@ -51,12 +53,85 @@ def test_check_symmetry_passes_on_reference_matrices_and_catches_asymmetric_pinv
         ref = orc.pcg(S[b].astype(np.float64), Pa[b].astype(np.float64), g[b].astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")["lam"]
         band = fp32_band(orc, S[b], Pa[b], g[b], np.zeros(n * N), N, K, "ss", ref)
         assert relinf(lam2[b].cpu().numpy(), ref) <= max(1e-3, 4 * band)
-    # with the check off the same call silently gets the lower-triangle solve: a different answer (that is the documented hazard)
+    # with the debug check off, a handle that has LATCHED "symmetric" keeps its lower-triangle kernels: the same call silently gets the
+    # lower-triangle solve — the documented limit of a per-handle latch (a caller that changes structure uses a fresh handle)
     sol.set_option("check_symmetry", 0)
     lam3 = torch.zeros(B, n * N, device="cuda")
     sol.solve(dev(S), dev(Pa), dev(g), lam3, cfg, "ss")
     assert sol.get_option("last_kernel_family") == fam_default
     assert relinf(lam3.cpu().numpy(), lam.cpu().numpy()) < 1e-6 < relinf(lam3.cpu().numpy(), lam2.cpu().numpy())
+
+
+@pytest.mark.parametrize("N,B", [(128, 3), (256, 2), (48, 300)])
+def test_symmetry_latch_gives_an_asymmetric_pinv_the_three_column_solve_from_the_first_call(orc, N, B):
+    """the symmetry contract by default.  A fresh handle, NO option touched, the reference-shaped 12-argument entry for the
+    first trajectory (and the batched one for all): a caller-made Pinv whose right blocks are not the transposes of the left ones must get
+    the PCG of its three block columns (oracle, precond_cols = 3) — from the very first solve, which runs guarded; after the asynchronous
+    copy of the flag has landed the handle is on three-column kernels for good and mpcg_last_error() says why."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    K = 12
+    k = synth.make_kkt(N, min(B, 4), 4500 + N)
+    S, Pinv, g = (np.tile(a, ((B + 3) // 4, 1))[:B] for a in synth.form_schur(k, precond="ss"))
+    Pa = np.array(Pinv, np.float32).reshape(B, N, 3, 196).copy()
+    Pa[:, :, 2] *= 0.9
+    Pa = Pa.reshape(B, -1)
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    dS, dPa, dg = dev(S), dev(Pa), dev(g)
+    refs = {}
+    for b in (0, B - 1):
+        refs[b] = orc.pcg(S[b].astype(np.float64), Pa[b].astype(np.float64), g[b].astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")["lam"]
+
+    def ok(lam_row, b):
+        band = fp32_band(orc, S[b], Pa[b], g[b], np.zeros(n * N), N, K, "ss", refs[b])
+        return relinf(lam_row, refs[b]) <= max(1e-3, 4 * band)
+    # 1. batched entry, first call of a fresh handle
+    sol = PcgSolver(N, max_batch=B)
+    lam = torch.zeros(B, n * N, device="cuda")
+    it, ex = sol.solve(dS, dPa, dg, lam, cfg, "ss")
+    assert sol.get_option("last_kernel_family") in (6, 7)            # the guarded launch of the lower-triangle family ...
+    torch.cuda.synchronize()
+    assert (it.cpu().numpy() == K).all()
+    assert ok(lam[0].cpu().numpy(), 0) and ok(lam[B - 1].cpu().numpy(), B - 1)      # ... whose result is the three-column solve
+    assert sol.get_option("symmetry_state") == 2 and "block-symmetric" in sol.last_error()
+    lam2 = torch.zeros(B, n * N, device="cuda")
+    sol.solve(dS, dPa, dg, lam2, cfg, "ss")
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") in (0, 5)            # latched: three-column kernels, no check kernel any more
+    assert ok(lam2[0].cpu().numpy(), 0) and ok(lam2[B - 1].cpu().numpy(), B - 1)
+    # 2. the reference's 12-argument entry on a fresh handle (one trajectory)
+    if N > 64:
+        sol1 = PcgSolver(N, max_batch=1)
+        l1 = torch.zeros(n * N, device="cuda")
+        r1, p1 = torch.empty(n * N, device="cuda"), torch.empty(n * N, device="cuda")
+        v1, e1 = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+        i1, x1 = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.uint8, device="cuda")
+        sol1.solve_ref(dS[0], dPa[0], dg[0], l1, r1, p1, v1, e1, i1, x1, K, 0.0)
+        torch.cuda.synchronize()
+        assert int(i1.item()) == K and ok(l1.cpu().numpy(), 0)
+
+
+@pytest.mark.parametrize("N,B", [(128, 3), (256, 2)])
+def test_symmetry_latch_on_reference_matrices_costs_nothing_after_the_first_calls(N, B):
+    """The reference's own (block-symmetric) matrices: the guarded first solve and the plain solves after the latch give the same bits,
+    and NaN-poisoned right blocks — which a three-column kernel would choke on — are still fine once the handle knows."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    K = 15
+    k = synth.make_kkt(N, B, 4600 + N)
+    S, Pinv, g = synth.form_schur(k, precond="ss")
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    sol = PcgSolver(N, max_batch=B)
+    assert sol.get_option("symmetry_state") == 0
+    lam = torch.zeros(B, n * N, device="cuda")
+    sol.solve(dev(S), dev(Pinv), dev(g), lam, cfg, "ss")             # guarded
+    torch.cuda.synchronize()
+    assert sol.get_option("symmetry_state") == 1 and sol.get_option("cluster_fixups") == 0
+    Sp, Pp, _ = synth.form_schur(k, precond="ss", poison_unused=True)
+    Sp = Sp.reshape(B, N, 3, 196).copy(); Pp = Pp.reshape(B, N, 3, 196).copy()
+    Sp[:, :, 2] = np.nan; Pp[:, :, 2] = np.nan                       # the right block column is never read by the latched handle
+    lam2 = torch.zeros(B, n * N, device="cuda")
+    sol.solve(dev(Sp.reshape(B, -1)), dev(Pp.reshape(B, -1)), dev(g), lam2, cfg, "ss")
+    torch.cuda.synchronize()
+    assert torch.equal(lam, lam2) and sol.get_option("last_kernel_family") in (6, 7)
 
 
 @pytest.mark.parametrize("N,G", [(384, 3), (640, 5), (256, 2)])

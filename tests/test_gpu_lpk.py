@@ -46,6 +46,9 @@ def lpk_solve(P, N, S, Pinv, g, lam0, max_iter, tol, pc="ss"):
     sol = PcgSolver(N, max_batch=B)
     if N <= 64:
         sol.set_option("pcg_lpk", 1)          # (the automatic policy uses this kernel for 64 < N <= 128, and for 36 < N <= 64 beyond one trajectory per CU)
+    # these tests hand over matrices whose right block column is NaN (it must never be read): a lower-triangle-only caller says so,
+    # otherwise the handle's first solves would CHECK the right blocks against the left ones (tests/test_gpu_contract.py: the symmetry latch)
+    sol.set_option("assume_symmetric", 1)
     lam = dev(np.asarray(lam0, np.float32))
     it, ex = sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=tol, pcg_max_iter=max_iter), pc)
     torch.cuda.synchronize()
@@ -134,6 +137,7 @@ def test_lpk_flags_warm_start_and_r_p_outputs(P, orc):
     N = 32
     sol = P[0](N)
     sol.set_option("pcg_lpk", 1)
+    sol.set_option("assume_symmetric", 1)      # (right blocks are NaN here: a lower-triangle-only caller)
     d_lambda = torch.zeros(n * N, device="cuda")
     d_r = torch.full((n * N,), 7.0, device="cuda")
     d_p = torch.full((n * N,), 7.0, device="cuda")
