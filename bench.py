@@ -973,6 +973,29 @@ def main():
             del Sl, Pl, gl, ll, sl
         if lh:
             out["long_horizon"] = lh
+            # ---- the clustered kernel against the floor of ITS design ("break 0.15 or prove the floor") ----
+            # Classic PCG needs two cluster-wide reductions per iteration, each behind a matrix pass, and nothing of the next half can start
+            # before the reduced inner product is known.  Phase stamps of one iteration (profiles/r04_lpkc_phases.txt, N = 256, shader clocks
+            # at 2.38 GHz): matrix pass 2,090 | last partial published -> the polling wavefront has every granule of the epoch (one L2 hand-off)
+            # 635 at best, 1,275 at worst | partials folded, halo knots in LDS 460 | barrier 140 | operand rebuild + alpha / beta chain 360.
+            floor_ticks = 2 * (2090 + 635 + 140)
+            lh_roof = {"what": "clustered lane-pair kernel vs the floor of classic PCG on its decomposition: 2 x (matrix pass + one L2 hand-off + barrier) per iteration",
+                       "floor_us_per_iteration": floor_ticks / 2380.0, "floor_terms_shader_clocks": {"matrix_pass": 2090, "l2_handoff_min": 635, "barrier": 140},
+                       "above_the_floor_shader_clocks_per_half": {"fold_partials_and_halo_into_lds": 460, "operand_rebuild_and_scalar_chain": 360, "handoff_jitter_up_to": 640},
+                       "source": "profiles/r04_lpkc_phases.txt (tools/_prof/lpkc_phases.py, -DMPCG_PROF build, this round)",
+                       "not_built": "a single-reduction (Chronopoulos-Gear) PCG as an opt-in variant: one all-reduce + one neighbour halo hand-off per iteration instead of two "
+                                    "all-reduces — costed at +12 % (halo not overlapped) to +30 % (overlapped); its fixed-K iterates drift 5-10x more than the classic recurrence "
+                                    "(outside the parity band of DESIGN.md, numpy float32 experiment of round 3), so it could only ever be opt-in"}
+            for key_, v_ in lh.items():
+                G_ = v_["members_per_trajectory"]
+                ncu_ = sol.get_option("num_cus")
+                resident = 8 * ((ncu_ // 8) // G_) if ncu_ >= 8 and ncu_ // 8 >= G_ else ncu_ // G_
+                us_it = min(resident, B) / (v_["pcg_iterations_per_sec"] * 1e-6)          # one cluster's time per iteration with the chip full of clusters
+                lh_roof[key_] = {"pcg_iterations_per_sec": v_["pcg_iterations_per_sec"], "resident_clusters": resident, "us_per_iteration_full_batch": us_it,
+                                 "us_per_iteration_one_trajectory": v_["us_per_pcg_iter_one_trajectory"],
+                                 "frac_of_floor_full_batch": lh_roof["floor_us_per_iteration"] / us_it,
+                                 "frac_of_floor_one_trajectory": lh_roof["floor_us_per_iteration"] / v_["us_per_pcg_iter_one_trajectory"]}
+            out["roofline_long_horizon"] = lh_roof
 
     if extras and rank == 0 and world == 1 and not lean and args.scaling == "weak":
         # ---- what scaling to expect (measured here on one GPU, the multi-GPU curve itself is the driver's to measure) ----
