@@ -64,6 +64,7 @@ struct KktArgs {
     float* G; float* C; float* g; float* c;
     int N; int batch;
     double dt, qd_cost, r_cost;
+    int analytic;                        // 1: round 1 = the analytic gradient recursion of the inverse dynamics (default); 0: one-sided differences
 };
 
 // The model tables are read through the CONSTANT address space (same 64-bit address as the global pointer): loads from it are
@@ -208,11 +209,138 @@ __device__ __forceinline__ void rnea(const PlantC& P, kkt_lds_vd* fl, kkt_lds_it
     }
 }
 
+
+// ---- round 1, analytic (round 4): d ID / d(q, qd) at (q, qd, qdd) by the derivative recursion of the inverse dynamics — what the reference
+// computes with GRiD's generated forwardDynamicsAndGradient (iiwa_eepos_plant.cuh:127-155); written here from the recursion itself:
+//     v_i = X_i v_{i-1} + S qd_i,   a_i = X_i a_{i-1} + S qdd_i + v_i x S qd_i,   f_i = I_i a_i + v_i x* I_i v_i,   F_{i-1} += X_i^T F_i,   tau_i = S^T F_i
+// with d(X_i u)/dq_i = -S x (X_i u) and d(X_i^T F)/dq_i = X_i^T (S x* F)  (S = unit rotation about the joint's z axis).  For column j:
+//     links i < j: dv = da = 0.   i = j, d/dq_j:  dv = -S x v_j,  da = -S x (X_j a_{j-1}) + dv x S qd_j;    d/dqd_j:  dv = S,  da = v_j x S
+//     links i > j: dv_i = X_i dv_{i-1},  da_i = X_i da_{i-1} + dv_i x S qd_i          (the nominal recursion without its S qd / S qdd sources)
+//     every i >= j: df_i = I_i da_i + dv_i x* (I_i v_i) + v_i x* (I_i dv_i);   backward as above, plus X_j^T (S x* F_j) into link j-1 for d/dq_j.
+// One lane per column (0..6: q, 7..13: qd) exactly like the difference round it replaces — and a 15th lane runs the NOMINAL recursion
+// (q, qd, qdd) in lock-step in the same instruction stream: what the column lanes need from it at link i (v_i, I_i v_i, X_i a_{i-1} going up,
+// F_i coming down) exists in lane 14's registers at that very point and travels by DPP row broadcast — no nominal sweep of its own, nothing
+// of it in LDS.  The link forces wait for the backward sweep in the same LDS region as before, as FLOATS (15 records fit where 14 double
+// records were; a derivative needs no cancellation headroom: rounding its forces to 6e-8 relative moves dtau by that much).
+typedef __attribute__((address_space(3))) volatile float kkt_lds_vf;
+template <int L>
+__device__ __forceinline__ double bc64(double x) {            // x of lane L of this lane's 16-lane group
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x150 + L, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x150 + L, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+constexpr int KKT_NOM = 2 * PJ;          // the lane of the nominal recursion
+// l: lane in the group (0..14 run).  On return this lane's record holds dtau_i (rows RN_TAU(i), float) for its column.
+__device__ __forceinline__ void rnea_grad(const PlantC& P, kkt_lds_vf* fl, kkt_lds_item* I, const int l) {
+    const bool nom = l == KKT_NOM;
+    const bool isq = l < PJ;
+    const int col = l < PJ ? l : l - PJ;                      // (lane 14: 7 — never equal to a link index)
+    const double nmask = nom ? 0.0 : 1.0;
+    double vw[3] = {0, 0, 0}, vu[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, au[3] = {0, 0, 0};
+    double f[6] = {0, 0, 0, 0, 0, 0};
+#pragma nounroll
+    for (int kv = 0; kv < PJ; ++kv) {
+        const int k = __builtin_amdgcn_readfirstlane(kv);
+        const double qdk = I->Xq[PJ + k], qddk = I->Qdd[k];
+        const double sn = I->Sc[0][k], cs = I->Sc[1][k];
+        cdouble* E = P.ET(k);
+        cdouble* B = P.BT(k);
+        double tw[3], tu[3], sw[3], su[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            tw[r] = E[3 * r] * vw[0] + E[3 * r + 1] * vw[1] + E[3 * r + 2] * vw[2];
+            tu[r] = B[3 * r] * vw[0] + B[3 * r + 1] * vw[1] + B[3 * r + 2] * vw[2] + E[3 * r] * vu[0] + E[3 * r + 1] * vu[1] + E[3 * r + 2] * vu[2];
+            sw[r] = E[3 * r] * aw[0] + E[3 * r + 1] * aw[1] + E[3 * r + 2] * aw[2];
+            su[r] = B[3 * r] * aw[0] + B[3 * r + 1] * aw[1] + B[3 * r + 2] * aw[2] + E[3 * r] * au[0] + E[3 * r + 1] * au[1] + E[3 * r + 2] * au[2];
+        }
+        double w[3], u[3], bw[3], bu[3];
+        w[0] = cs * tw[0] + sn * tw[1]; w[1] = cs * tw[1] - sn * tw[0]; w[2] = tw[2] + (nom ? qdk : 0.0);
+        u[0] = cs * tu[0] + sn * tu[1]; u[1] = cs * tu[1] - sn * tu[0]; u[2] = tu[2];
+        bw[0] = cs * sw[0] + sn * sw[1]; bw[1] = cs * sw[1] - sn * sw[0]; bw[2] = sw[2];
+        bu[0] = cs * su[0] + sn * su[1]; bu[1] = cs * su[1] - sn * su[0]; bu[2] = su[2];
+        // what the column lanes need of the nominal recursion at this link: v_k (after its S qd), X_k a_{k-1} (before S qdd and the cross term)
+        double nvw[3], nvu[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { nvw[r] = bc64<KKT_NOM>(w[r]); nvu[r] = bc64<KKT_NOM>(u[r]); }
+        const double naw0 = bc64<KKT_NOM>(bw[0]), naw1 = bc64<KKT_NOM>(bw[1]), nau0 = bc64<KKT_NOM>(bu[0]), nau1 = bc64<KKT_NOM>(bu[1]);
+        if (k == col) {                                       // this lane's own joint: the sources of its column (everything above was zero)
+            if (isq) {
+                w[0] = nvw[1]; w[1] = -nvw[0]; w[2] = 0.0; u[0] = nvu[1]; u[1] = -nvu[0]; u[2] = 0.0;            // dv = -S x v
+                bw[0] = naw1; bw[1] = -naw0; bw[2] = 0.0; bu[0] = nau1; bu[1] = -nau0; bu[2] = 0.0;               // da = -S x (X a_parent) [+ dv x S qd below]
+            } else {
+                w[0] = 0.0; w[1] = 0.0; w[2] = 1.0; u[0] = 0.0; u[1] = 0.0; u[2] = 0.0;                            // dv = S
+                bw[0] = nvw[1]; bw[1] = -nvw[0]; bw[2] = 0.0; bu[0] = nvu[1]; bu[1] = -nvu[0]; bu[2] = 0.0;       // da = v x S
+            }
+        }
+        if (nom) bw[2] += qddk;                               // + S qdd (nominal lane only)
+        // + (v or dv) x (S qd_k): column 2 of crm(.) times qd_k — the same expression in the nominal and in the column lanes
+        bw[0] += w[1] * qdk; bw[1] -= w[0] * qdk;
+        bu[0] += u[1] * qdk; bu[1] -= u[0] * qdk;
+        double Ia[6], Iv[6];
+        cdouble* Ik = P.Ib(k);
+        auto imul = [&](const double (&W)[3], const double (&U)[3], double (&o)[6]) {
+            o[0] = Ik[0] * W[0] + Ik[1] * W[1] + Ik[2] * W[2] + (Ik[7] * U[2] - Ik[8] * U[1]);
+            o[1] = Ik[1] * W[0] + Ik[3] * W[1] + Ik[4] * W[2] + (Ik[8] * U[0] - Ik[6] * U[2]);
+            o[2] = Ik[2] * W[0] + Ik[4] * W[1] + Ik[5] * W[2] + (Ik[6] * U[1] - Ik[7] * U[0]);
+            o[3] = Ik[9] * U[0] - (Ik[7] * W[2] - Ik[8] * W[1]);
+            o[4] = Ik[9] * U[1] - (Ik[8] * W[0] - Ik[6] * W[2]);
+            o[5] = Ik[9] * U[2] - (Ik[6] * W[1] - Ik[7] * W[0]);
+        };
+        imul(bw, bu, Ia);
+        imul(w, u, Iv);
+        // f = I a + x x* (I v_nom) + v_nom x* (I x)        x = this lane's v-like vector; the nominal lane: x = v_nom, second cross term off
+        double nIv[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) nIv[r] = bc64<KKT_NOM>(Iv[r]);
+        const double zw0 = nmask * nvw[0], zw1 = nmask * nvw[1], zw2 = nmask * nvw[2], zu0 = nmask * nvu[0], zu1 = nmask * nvu[1], zu2 = nmask * nvu[2];
+        f[0] = Ia[0] + (w[1] * nIv[2] - w[2] * nIv[1]) + (u[1] * nIv[5] - u[2] * nIv[4]) + (zw1 * Iv[2] - zw2 * Iv[1]) + (zu1 * Iv[5] - zu2 * Iv[4]);
+        f[1] = Ia[1] + (w[2] * nIv[0] - w[0] * nIv[2]) + (u[2] * nIv[3] - u[0] * nIv[5]) + (zw2 * Iv[0] - zw0 * Iv[2]) + (zu2 * Iv[3] - zu0 * Iv[5]);
+        f[2] = Ia[2] + (w[0] * nIv[1] - w[1] * nIv[0]) + (u[0] * nIv[4] - u[1] * nIv[3]) + (zw0 * Iv[1] - zw1 * Iv[0]) + (zu0 * Iv[4] - zu1 * Iv[3]);
+        f[3] = Ia[3] + (w[1] * nIv[5] - w[2] * nIv[4]) + (zw1 * Iv[5] - zw2 * Iv[4]);
+        f[4] = Ia[4] + (w[2] * nIv[3] - w[0] * nIv[5]) + (zw2 * Iv[3] - zw0 * Iv[5]);
+        f[5] = Ia[5] + (w[0] * nIv[4] - w[1] * nIv[3]) + (zw0 * Iv[4] - zw1 * Iv[3]);
+        if (k < PJ - 1) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) fl[6 * k + r] = (float)f[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { vw[r] = w[r]; vu[r] = u[r]; aw[r] = bw[r]; au[r] = bu[r]; }
+    }
+    fl[RN_TAU(PJ - 1)] = (float)f[2];
+#pragma nounroll
+    for (int kv = PJ - 1; kv >= 1; --kv) {                   // F_parent += X_k^T (F_k [+ S x* F_k(nominal) in the d/dq_k lane])
+        const int k = __builtin_amdgcn_readfirstlane(kv);
+        const double sn = I->Sc[0][k], cs = I->Sc[1][k];
+        cdouble* E = P.ET(k);
+        cdouble* B = P.BT(k);
+        // S x* [n; l] = [e_z x n ; e_z x l] = (-n1, n0, 0 ; -l1, l0, 0) of the nominal lane's accumulated force of link k
+        const double nf0 = bc64<KKT_NOM>(f[0]), nf1 = bc64<KKT_NOM>(f[1]), nf3 = bc64<KKT_NOM>(f[3]), nf4 = bc64<KKT_NOM>(f[4]);
+        const bool mine = isq && k == col;
+        const double g0 = f[0] - (mine ? nf1 : 0.0), g1 = f[1] + (mine ? nf0 : 0.0), g3 = f[3] - (mine ? nf4 : 0.0), g4 = f[4] + (mine ? nf3 : 0.0);
+        const double n0 = cs * g0 - sn * g1, n1 = sn * g0 + cs * g1, n2 = f[2];
+        const double l0 = cs * g3 - sn * g4, l1 = sn * g3 + cs * g4, l2 = f[5];
+        double fp[6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            fp[r] = (double)fl[6 * (k - 1) + r] + E[r] * n0 + E[3 + r] * n1 + E[6 + r] * n2 + B[r] * l0 + B[3 + r] * l1 + B[6 + r] * l2;
+            fp[3 + r] = (double)fl[6 * (k - 1) + 3 + r] + E[r] * l0 + E[3 + r] * l1 + E[6 + r] * l2;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) f[r] = fp[r];
+        fl[RN_TAU(k - 1)] = (float)f[2];
+    }
+}
+
 // Output staging (floats, in the group's records once the last sweep is over): [Q R | Q_last] [-A -B] [q r | q_last] [c_0] [c_{k+1}]
 typedef __attribute__((address_space(3))) float kkt_lds_f;
 constexpr int ST_G = 0, ST_Q1 = ST_G + 14 * 14 + 7 * 7, ST_C = ST_Q1 + 14 * 14, ST_g = ST_C + 14 * 14 + 14 * 7, ST_g1 = ST_g + 21, ST_c0 = ST_g1 + 14,
               ST_c1 = ST_c0 + 14, ST_END = ST_c1 + 14;
-static_assert(ST_END * sizeof(float) <= KKT_RL * RN_ROWS * sizeof(double), "staging fits the group's records");
+// records of a group: round 0 runs PJ + 4 double records; round 1 either 2 PJ double records (differences) or 2 PJ + 1 FLOAT records (analytic)
+constexpr int KKT_R0 = PJ + 4;
+__host__ __device__ constexpr int kkt_rec_lanes(bool analytic) { return analytic ? KKT_R0 : KKT_RL; }
+static_assert(ST_END * sizeof(float) <= KKT_R0 * RN_ROWS * sizeof(double), "staging fits the group's records");
+static_assert((2 * PJ + 1) * RN_ROWS * sizeof(float) <= KKT_R0 * RN_ROWS * sizeof(double), "the analytic round's float records fit the round-0 records");
 template <int LEN>
 __device__ __forceinline__ void kkt_copy_out(float* dst, kkt_lds_f* src, int l) {
 #pragma unroll
@@ -220,19 +348,24 @@ __device__ __forceinline__ void kkt_copy_out(float* dst, kkt_lds_f* src, int l) 
     if (LEN % KKT_GL != 0 && l < LEN % KKT_GL) dst[LEN - LEN % KKT_GL + l] = src[LEN - LEN % KKT_GL + l];
 }
 
-__global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a) {
+#ifndef KKT_WAVES_ANALYTIC
+#define KKT_WAVES_ANALYTIC 2
+#endif
+template <bool ANALYTIC>
+__global__ __launch_bounds__(KKT_THREADS, ANALYTIC ? KKT_WAVES_ANALYTIC : 2) void generate_kkt_kernel(KktArgs a) {
     constexpr int n = 2 * PJ, m = PJ, nn = n * n, mm = m * m, nm = n * m;
     __shared__ KktItemLds sI[KKT_ITEMS];
-    __shared__ double sF[KKT_ITEMS * KKT_RL][RN_ROWS];      // the recursion records (16.6 KB)
-    static_assert(sizeof(KktItemLds) * KKT_ITEMS + sizeof(double) * KKT_ITEMS * KKT_RL * RN_ROWS <= 20480, "eight wavefronts per CU");
+    constexpr int RL = kkt_rec_lanes(ANALYTIC);             // double records per group: 11 (analytic: 13.0 KB per wavefront) or 14 (16.6 KB)
+    __shared__ double sF[KKT_ITEMS * RL][RN_ROWS];          // the recursion records
+    static_assert(sizeof(KktItemLds) * KKT_ITEMS + sizeof(double) * KKT_ITEMS * RL * RN_ROWS <= (ANALYTIC ? 16384 : 20480), "ten / eight wavefronts per CU");
     // The model tables are read with RUNTIME joint indices.  With compile-time indices (unrolled sweeps) all table entries are
     // loop-invariant loads that the compiler hoists into registers: 512 VGPR + AGPR and scratch.
     const int lane = threadIdx.x, gi = lane / KKT_GL, l = lane - gi * KKT_GL;
     kkt_lds_item* I = (kkt_lds_item*)&sI[gi];
-    kkt_lds_vd* recs = (kkt_lds_vd*)&sF[gi * KKT_RL][0];
+    kkt_lds_vd* recs = (kkt_lds_vd*)&sF[gi * RL][0];
     auto rec = [&](int j) -> kkt_lds_vd* { return recs + j * RN_ROWS; };                // record of lane j of this group
-    kkt_lds_vd* fl = rec(l < KKT_RL ? l : 0);                // (lanes 14, 15 never touch theirs)
-    kkt_lds_f* st = (kkt_lds_f*)&sF[gi * KKT_RL][0];
+    kkt_lds_vd* fl = rec(l < RL ? l : 0);                    // (lanes beyond the records never touch theirs)
+    kkt_lds_f* st = (kkt_lds_f*)&sF[gi * RL][0];
     const PlantC P{reinterpret_cast<cdouble*>(reinterpret_cast<unsigned long long>(a.plant))};
     const int N = a.N;
     const long total = (long)a.batch * (N - 1);
@@ -335,13 +468,21 @@ __global__ __launch_bounds__(KKT_THREADS, 2) void generate_kkt_kernel(KktArgs a)
         __syncthreads();
         // ---- round 1: lanes 0..6 ID(q + h e_l, qd, qdd), 7..13 ID(q, qd + h e_(l-7), qdd); each lane then owns column l of
         //      [dqdd/dq, dqdd/dqd] = -Minv (ID(. + h e) - u) / h  and writes column l of A and Q (lanes 0..6: of B and R too) ----
+        // analytic gradient (default): 15 lanes — 14 columns + the nominal recursion in lane 14; records re-used as 15 x RN_ROWS floats
+        kkt_lds_vf* flf = (kkt_lds_vf*)recs + (l <= KKT_NOM ? l : 0) * RN_ROWS;
+        if (ANALYTIC && l <= KKT_NOM && !(KKT_ABLATE & 1)) rnea_grad(P, flf, I, l);
         if (l < n) {
-            RneaTask t;
-            t.sj = l < PJ ? l : -1; t.pj = l < PJ ? -1 : l - PJ; t.qdscale = 1.0; t.knot_qdd = true; t.unit = -1; t.base = -1;
-            if (!(KKT_ABLATE & 1)) rnea(P, fl, I, t, a6w, a6u);
             double d[PJ], colv[PJ];
+            if constexpr (ANALYTIC) {
 #pragma unroll
-            for (int i = 0; i < PJ; ++i) d[i] = (fl[RN_TAU(i)] - I->U[i]) * (-1.0 / KKT_FD_H);
+                for (int i = 0; i < PJ; ++i) d[i] = -(double)flf[RN_TAU(i)];
+            } else {
+                RneaTask t;
+                t.sj = l < PJ ? l : -1; t.pj = l < PJ ? -1 : l - PJ; t.qdscale = 1.0; t.knot_qdd = true; t.unit = -1; t.base = -1;
+                if (!(KKT_ABLATE & 1)) rnea(P, fl, I, t, a6w, a6u);
+#pragma unroll
+                for (int i = 0; i < PJ; ++i) d[i] = (fl[RN_TAU(i)] - I->U[i]) * (-1.0 / KKT_FD_H);
+            }
             asm volatile("" ::: "memory");                // (the float staging stores below reuse the records: keep them behind these loads)
 #pragma unroll
             for (int i = 0; i < PJ; ++i) {

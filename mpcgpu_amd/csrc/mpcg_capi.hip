@@ -54,6 +54,7 @@ struct mpcg_handle {
     int sched_hint = 1;       // dispatch the trajectories of a large call longest-expected-first, predicted by the previous call's iteration counts (sched_order_kernel)
     uint32_t* sched_order = nullptr;   // [1 + max_batch] {batch it was made for, dispatch order}: written after every hinted solve, checked on the device
     int schur_chunk = 0;      //   block rows per chunk of the walking kernel: 0 auto (by call size), 1..2048 forced
+    int kkt_analytic = 1;     // mpcg_generate_kkt: 1 = analytic gradient recursion of the inverse dynamics (as the reference's GRiD code), 0 = one-sided float64 differences (the checker)
     int dz_dpp = 1;           // 1: four-knots-per-wavefront dz recovery (schur_walk.hip.h), 0: the one-workgroup-per-knot LDS kernel
     int last_schur_chunk = 0; //   what the last mpcg_form_schur used (0: the LDS kernels)
     float* seam_qinv = nullptr;      // schur_walk: one Q^-1 per chunk seam (max_batch x chunks x 196 floats)
@@ -274,6 +275,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "schur_dpp")) { h->schur_dpp = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "schur_chunk")) { if (value < 0 || value > 2048) return fail(h, MPCG_ERR_INVALID, "schur_chunk must be 0 (auto) or 1..2048 block rows"); h->schur_chunk = value; return MPCG_OK; }
     if (!strcmp(key, "dz_dpp")) { h->dz_dpp = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "kkt_analytic")) { h->kkt_analytic = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "sched_hint")) { h->sched_hint = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
         if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");
@@ -307,6 +309,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "schur_chunk")) { *value = h->schur_chunk; return MPCG_OK; }
     if (!strcmp(key, "last_schur_chunk")) { *value = h->last_schur_chunk; return MPCG_OK; }
     if (!strcmp(key, "dz_dpp")) { *value = h->dz_dpp; return MPCG_OK; }
+    if (!strcmp(key, "kkt_analytic")) { *value = h->kkt_analytic; return MPCG_OK; }
     if (!strcmp(key, "sched_hint")) { *value = h->sched_hint; return MPCG_OK; }
     if (!strcmp(key, "spmv_blocks_per_cu")) { *value = h->spmv_blocks_per_cu; return MPCG_OK; }
     if (!strcmp(key, "spmv_mfma")) { *value = h->spmv_mfma; return MPCG_OK; }
@@ -1411,10 +1414,12 @@ int mpcg_generate_kkt(mpcg_handle* h, const mpcg_plant* plant, uint32_t control_
     a.plant = plant->d; a.eePos_traj = d_eePos_traj; a.xs = d_xs; a.xu = d_xu;
     a.G = d_G_dense; a.C = d_C_dense; a.g = d_g; a.c = d_c;
     a.N = (int)h->N; a.batch = (int)batch; a.dt = timestep; a.qd_cost = qd_cost; a.r_cost = r_cost;
+    a.analytic = h->kkt_analytic;
     long blocks = ((long)batch * (h->N - 1) + KKT_ITEMS - 1) / KKT_ITEMS;      // one wavefront per KKT_ITEMS (trajectory, knot) pairs
     const long cap = (long)h->num_cus * 32;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(generate_kkt_kernel, dim3((unsigned)blocks), dim3(KKT_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    if (h->kkt_analytic) hipLaunchKernelGGL(generate_kkt_kernel<true>, dim3((unsigned)blocks), dim3(KKT_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(generate_kkt_kernel<false>, dim3((unsigned)blocks), dim3(KKT_THREADS), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRY(h, hipGetLastError());
     return MPCG_OK;
 }

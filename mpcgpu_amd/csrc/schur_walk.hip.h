@@ -426,7 +426,10 @@ struct WalkArgs {
 
 // One 16-lane row = one chunk: block rows k0 = 1 + j L ... k1 - 1 of trajectory b; chunk 0 also emits block row 0 (linsys_setup.cuh:152-277),
 // which needs nothing but Q_0.  Four chunks per wavefront, in lock-step.  (Host: every array below 2^31 bytes.)
-__global__ __launch_bounds__(64, 2) void schur_walk_kernel(WalkArgs w) {
+#ifndef SW_WAVES
+#define SW_WAVES 2         // launch bound: wavefronts per SIMD the register allocation aims at
+#endif
+__global__ __launch_bounds__(64, SW_WAVES) void schur_walk_kernel(WalkArgs w) {
     constexpr int n = 14, m = 7;
     constexpr uint32_t nn = n * n, mm = m * m, nm = n * m;
     constexpr uint32_t Gset = nn + mm, Cset = nn + nm, gset = n + m;

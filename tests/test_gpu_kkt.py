@@ -32,11 +32,15 @@ def windows(N, B, seed):
     return iiwa.random_windows(N, B, seed)
 
 
+@pytest.mark.parametrize("analytic", [1, 0])
 @pytest.mark.parametrize("N,B", [(2, 1), (3, 2), (8, 3), (32, 5)])
-def test_generate_kkt_vs_host_restatement(env, N, B):
+def test_generate_kkt_vs_host_restatement(env, N, B, analytic):
+    """analytic = 1 (default): the gradient recursion of the inverse dynamics (what the reference's GRiD code computes); 0: one-sided float64
+    differences, the round-2/3 kernel kept as the checker.  Both against the float64 host restatement with central differences."""
     PcgSolver, plant, _, M = env
     xu, goals, xs = windows(N, B, 11 + N)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("kkt_analytic", analytic)
     G, C, g, c = sol.generate_kkt(plant, dev(goals.reshape(B, -1)), dev(xs), dev(xu), iiwa.TIMESTEP, iiwa.QD_COST, iiwa.r_cost(N))
     torch.cuda.synchronize()
     G, C, g, c = (t.cpu().numpy() for t in (G, C, g, c))
@@ -46,8 +50,10 @@ def test_generate_kkt_vs_host_restatement(env, N, B):
         want = iiwa_ref.generate_kkt(M, xu[b].astype(np.float32).astype(np.float64), goals[b].astype(np.float32).astype(np.float64),
                                  xs[b].astype(np.float32).astype(np.float64), N)
         for got, ref, name in zip((G[b], C[b], g[b], c[b]), want, "GCgc"):
-            # float output rounding (6e-8 relative) + central-difference noise of the dynamics gradients (~1e-9 x |dID| / h)
-            assert np.abs(got - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max()), (b, name, np.abs(got - ref).max(), np.abs(ref).max())
+            # float output rounding (6e-8 relative) + the host's central-difference noise (~1e-9 x |dID| / h); the difference kernel adds its own
+            # one-sided truncation (1e-7 .. 1e-6), the analytic one only the float rounding of the link forces it parks in LDS
+            tol = (1e-6 if analytic else 3e-6) * max(1.0, np.abs(ref).max())
+            assert np.abs(got - ref).max() <= tol, (b, name, np.abs(got - ref).max(), np.abs(ref).max())
 
 
 def test_generate_kkt_integrator_defects_vanish_on_the_reference_trajectory(env):
@@ -88,6 +94,36 @@ def test_generate_kkt_integrator_defects_vanish_on_the_reference_trajectory(env)
     # kinematics: the position gradient J^T (ee(q) - goal) of every knot vanishes against the file's own end-effector row
     gq = np.stack([g[b].reshape(-1)[:(n + m) * (N - 1)].reshape(N - 1, n + m)[:, :7] for b in range(B)])
     assert np.abs(gq).max() < 2e-5, np.abs(gq).max()
+
+
+def test_analytic_gradient_does_not_depend_on_the_size_of_the_torques(env):
+    """the one-sided difference divides (ID(x + h e_j) - u) by h = 3e-8 and so amplifies whatever ID(q, qd, FD(u)) - u is left by
+    the explicitly inverted mass matrix — an error that grows with |u| and cond(M).  The analytic recursion has no such term: with torques
+    a thousand times larger (|u| ~ 300 N m, accelerations of 1e3 rad/s^2) the dynamics Jacobians still match the float64 host restatement to
+    float rounding, and dqdd/dq, dqdd/dqd scale exactly as they must."""
+    PcgSolver, plant, _, M = env
+    N, B = 4, 3
+    xu, goals, xs = windows(N, B, 99)
+    xu = xu.copy()
+    for b in range(B):
+        w = xu[b]
+        for k in range(N - 1):
+            w[k * 21 + 14:k * 21 + 21] = 300.0 * np.cos(np.arange(7) + k + b)          # u_k
+    sol = PcgSolver(N, max_batch=B)
+    res = {}
+    for analytic in (1, 0):
+        sol.set_option("kkt_analytic", analytic)
+        G, C, g, c = sol.generate_kkt(plant, dev(goals.reshape(B, -1)), dev(xs), dev(xu), iiwa.TIMESTEP, iiwa.QD_COST, iiwa.r_cost(N))
+        torch.cuda.synchronize()
+        res[analytic] = C.cpu().numpy()
+    worst = {1: 0.0, 0: 0.0}
+    for b in range(B):
+        ref = iiwa_ref.generate_kkt(M, xu[b].astype(np.float32).astype(np.float64), goals[b].astype(np.float32).astype(np.float64),
+                                    xs[b].astype(np.float32).astype(np.float64), N)[1]
+        for analytic in (1, 0):
+            worst[analytic] = max(worst[analytic], np.abs(res[analytic][b] - ref).max() / max(1.0, np.abs(ref).max()))
+    assert worst[1] <= 1e-6, worst
+    assert worst[1] <= worst[0] + 1e-9, worst              # never worse than the difference quotient
 
 
 def test_generate_kkt_is_independent_of_batch_composition(env):
