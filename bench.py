@@ -1050,6 +1050,7 @@ def main():
                 if obj is not None and e:
                     obj["traffic"] = e["hbm_traffic_bytes_per_launch"]
                     obj["traffic_is"] = pmc_note
+                    obj.pop("traffic_source", None)           # (the committed profile's figure has just been replaced by this run's)
                     obj["traffic_over_algorithmic"] = e["hbm_traffic_bytes_per_launch"] / (obj.get("algorithmic_bytes_per_launch") or obj.get("hbm_algorithmic_bytes_per_launch")
                                                                                          or obj["bytes_per_unit"] * obj["units_per_launch"])
             if "form_schur" in prod:

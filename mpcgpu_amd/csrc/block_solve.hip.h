@@ -233,3 +233,5 @@ __global__ __launch_bounds__(64, 2) void bt_block_solve_wide_kernel(BlockSolveAr
 }
 
 }  // namespace mpcg
+
+#pragma clang fp contract(fast)     // (hipcc's default for device code: what the headers included after this one are written for)

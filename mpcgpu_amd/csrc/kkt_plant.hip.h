@@ -26,6 +26,8 @@
 // on the way out.  LDS is what bounds the resident wavefronts: 19.9 KB per wavefront = EIGHT per CU (two per SIMD, round 3; 30 KB =
 // five before), which is what hides the dependent-issue latency of the recursion.
 #pragma once
+// Float64 work checked by tolerance, not by bits: multiply-adds are FUSED here (the bit-exact headers switch contraction off and back on).
+#pragma clang fp contract(fast)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

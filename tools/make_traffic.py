@@ -15,8 +15,6 @@ for name, k in pmc.items():
         continue
     if "pcg_lpk_kernel" in name:
         key = f"pcg_lpk_kernel|N{N}_B{B}_{pc}_it{mi}_tol{float(tol):g}"
-    elif "pcg_lpb_kernel" in name:
-        key = f"pcg_lpb_kernel|N{N}_B{B}_{pc}_it{mi}_tol{float(tol):g}"
     elif "bt_spmv_kernel" in name:
         key = f"bt_spmv_kernel|N{N}_B{spB}"
     elif "pcg_traj_kernel<16, 0, 2" in name:
