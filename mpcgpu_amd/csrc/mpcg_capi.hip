@@ -98,8 +98,15 @@ static int fail(mpcg_handle* h, int code, const std::string& msg) {
     } while (0)
 
 // the symmetry latch: has the asynchronous copy of the device flag landed?
-static void sym_poll(mpcg_handle* h) {
-    if (!h->sym_pending || hipEventQuery(h->sym_event) != hipSuccess) return;
+// (never while `st` is being captured into a graph: an event query is not a capturable operation and would invalidate the capture —
+//  a capturing caller stays on the guarded launches, which are plain kernel launches)
+static void sym_poll(mpcg_handle* h, hipStream_t st = nullptr, bool have_stream = false) {
+    if (!h->sym_pending) return;
+    if (have_stream) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+    }
+    if (hipEventQuery(h->sym_event) != hipSuccess) return;
     h->sym_pending = false;
     if (*h->sym_host) {
         h->sym_state = 2;
@@ -735,7 +742,7 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
         lower_ok = v == 0;
     } else if (esz == 4 && a.redo_flags == nullptr && (use_lpk(h, esz) || (h->cluster != 0 && (h->cluster > 0 || (h->auto_cfg && h->N > kLpbMaxN))))) {
         // the symmetry latch (see launch_guarded): no synchronisation, no per-solve D2H
-        sym_poll(h);
+        sym_poll(h, st, true);
         if (h->sym_state == 2) lower_ok = false;
         else if (h->sym_state == 0) {
             const int rc = launch_guarded(h, a, batch, st);
