@@ -144,9 +144,10 @@ int mpcg_bt_spmv(mpcg_handle *h, const float *d_M, const float *d_x, float *d_y,
                  uint32_t batch, int cols, void *stream);
 
 /* ---- reduced-precision matrix storage (BASELINE config 5's fp16 sweep) ----
- * S and Pinv may be kept in IEEE half precision (same bd layout, 2-byte elements): half the bytes,
- * so twice as much of a trajectory stays resident in registers/LDS.  All arithmetic, gamma and lambda
- * stay fp32 (v_fma_mix_f32).  The solve is then exactly the fp32 PCG of the ROUNDED matrices: its
+ * S and Pinv may be kept in IEEE half precision (same bd layout, 2-byte elements): half the HBM
+ * footprint and half the bytes of the one load per solve.  Beyond N = 36 the register-resident
+ * kernels convert the blocks to fp32 once, while loading them; all arithmetic, gamma and lambda
+ * stay fp32.  The solve is then exactly the fp32 PCG of the ROUNDED matrices: its
  * answer differs from the fp32-storage answer by the storage rounding (relative 2^-11 per entry), not
  * by anything iteration-dependent; entries must be within the half range (|x| < 65504).
  * mpcg_convert_f32_to_f16: round-to-nearest-even copy of `count` elements (any bd-layout buffer).
@@ -292,7 +293,7 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  *       chip and each draws trajectories from a queue (any batch = one launch).  A cluster that cannot make progress (a peer not resident:
  *       another stream holds its CU) gives up after a bounded spin and the follow-up launch of a single-workgroup kernel re-solves its
  *       trajectory ("cluster_fixup" = 0: no follow-up launch, d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for such a trajectory);
- *   otherwise (and for fp16 storage, explicit pcg_* knobs, the fix-up launches) the single-workgroup row-pair kernel: "pcg_waves" (4, 8 or 16
+ *   otherwise (explicit pcg_* knobs, the fix-up launches, fp16 storage at N <= 36) the single-workgroup row-pair kernel: "pcg_waves" (4, 8 or 16
  *       wavefronts per trajectory workgroup), "pcg_reg_rows" (TRIPLES of block rows per matrix and wave kept in registers for the whole
  *       solve; only compiled (waves, rows) pairs are accepted at launch), "pcg_lds_rows" (triples per matrix and wave cached in LDS, -1 =
  *       what fits), "pcg_stream_bufs", "pcg_max_wg_per_cu", "lds_extra" (single-triple LDS slots beyond the uniform cache of the <.,.,1>

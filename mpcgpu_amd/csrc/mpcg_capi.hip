@@ -510,7 +510,7 @@ static int launch_lpk(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
 // (a lane pair per knot whatever N), so up to N = 36 — where the row-pair kernel <4,3,0> fits two trajectories per CU — that one stays
 // ahead in throughput (N=36: 292 vs 222 M it/s at batch 2048); beyond it the order flips (tools/_prof/n48.py).
 static bool use_lpk(const mpcg_handle* h, int esz) {
-    if (esz != 4 || h->N > kLpbMaxN || h->lpk == 0) return false;
+    if ((esz != 4 && esz != 2) || h->N > kLpbMaxN || h->lpk == 0) return false;     // (fp16 storage: converted once at the load)
     return h->lpk == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 36);
 }
 
@@ -578,7 +578,7 @@ static uint32_t lpkc_resident_clusters(const mpcg_handle* h, int G) {
 // scratch: [queue: one 128-byte line][flags: one line per trajectory of the call][cells: 1 KB per member of the launch] — what a call uses
 // is contiguous, so one small fill precedes every launch
 static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
-    if (h->cluster == 0 || esz != 4) return 1;
+    if (h->cluster == 0 || (esz != 4 && esz != 2)) return 1;
     if (h->cluster < 0 && (!h->auto_cfg || h->N <= kLpbMaxN)) return 1;     // explicit pcg_* knobs, or a horizon one CU holds
     constexpr int NWR = 2;
     const int G = lpkc_members(h);
@@ -591,7 +591,7 @@ static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PcgKnobs kf = h->k;
-    choose_auto(h, kf, 1, 4);
+    choose_auto(h, kf, 1, esz);
     const bool fixup = h->cluster_fixup && (h->N <= kLpbMaxN || lds_bytes_for(h->N, kf.waves) <= kLdsMax);
     ClusterArgs ca;
     ca.kl_max = 64 * NWR;
@@ -615,7 +615,7 @@ static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
         c.redo_stride = CL_FLAG_STRIDE;
         c.redo_skip = (unsigned)G;
         c.redo_count = fixup_counter(h);
-        const int rc = h->N <= kLpbMaxN ? launch_lpk(h, c, batch, st) : launch_traj(h, kf, c, batch, st, 4, /*record=*/false);
+        const int rc = h->N <= kLpbMaxN ? launch_lpk(h, c, batch, st) : launch_traj(h, kf, c, batch, st, esz, /*record=*/false);
         if (rc != MPCG_OK) return rc;
     }
     h->last = LastKernel{FAM_LPKC, 4 * NWR, 0, 0, 0, G, (int)lds, 0};
@@ -660,14 +660,22 @@ static int launch_generic_f32(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
 static constexpr float kSymRelTol = 1e-2f;
 
 // block pairs of S and (SS only) Pinv that fail the check.  Blocking: waits for `st`.
+// S (and Pinv when it has off-diagonal blocks) of one call through bd_symmetry_check_kernel, in the call's storage type
+static void launch_symmetry_check(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, unsigned blocks, unsigned long long* cnt, unsigned long long* flag) {
+    for (const void* m : {a.S, a.pcols == 3 ? a.Pinv : nullptr}) {
+        if (!m) continue;
+        if (a.esz == 2)
+            hipLaunchKernelGGL(bd_symmetry_check_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, static_cast<const _Float16*>(m), (int)h->N, (int)batch, kSymRelTol, cnt, flag);
+        else
+            hipLaunchKernelGGL(bd_symmetry_check_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(m), (int)h->N, (int)batch, kSymRelTol, cnt, flag);
+    }
+}
 static int symmetry_violations(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int* out) {
     unsigned long long* cnt = fixup_counter(h) + 8;
     HIP_TRY(h, hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st));
     const long items = (long)batch * ((long)h->N - 1);
     const unsigned blocks = (unsigned)((items + 3) / 4);
-    hipLaunchKernelGGL(bd_symmetry_check_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.S), (int)h->N, (int)batch, kSymRelTol, cnt, (unsigned long long*)nullptr);
-    if (a.pcols == 3)
-        hipLaunchKernelGGL(bd_symmetry_check_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.Pinv), (int)h->N, (int)batch, kSymRelTol, cnt, (unsigned long long*)nullptr);
+    launch_symmetry_check(h, a, batch, st, blocks, cnt, nullptr);
     HIP_TRY(h, hipGetLastError());
     unsigned long long v = 0;
     HIP_TRY(h, hipMemcpyAsync(&v, cnt, sizeof v, hipMemcpyDeviceToHost, st));
@@ -686,17 +694,16 @@ static int launch_guarded(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipS
     unsigned long long* flag = fixup_counter(h) + 9;
     const long items = (long)batch * ((long)h->N - 1);
     const unsigned blocks = (unsigned)((items + 3) / 4);
-    hipLaunchKernelGGL(bd_symmetry_check_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.S), (int)h->N, (int)batch, kSymRelTol, (unsigned long long*)nullptr, flag);
-    if (a.pcols == 3)
-        hipLaunchKernelGGL(bd_symmetry_check_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a.Pinv), (int)h->N, (int)batch, kSymRelTol, (unsigned long long*)nullptr, flag);
+    launch_symmetry_check(h, a, batch, st, blocks, nullptr, flag);
     HIP_TRY(h, hipGetLastError());
     PcgArgs p = a;
     p.redo_flags = flag; p.redo_stride = 0; p.redo_skip = 1; p.redo_count = nullptr;         // skip if the flag is 1
     bool need_fallback = true;
     int rc;
-    if (use_lpk(h, 4)) rc = launch_lpk(h, p, batch, st);
+    const int esz = a.esz;
+    if (use_lpk(h, esz)) rc = launch_lpk(h, p, batch, st);
     else {
-        rc = try_launch_cluster(h, p, batch, st, 4);
+        rc = try_launch_cluster(h, p, batch, st, esz);
         if (rc == 1) return 1;                                                                // (does not apply: the caller falls through)
         need_fallback = !h->cluster_fixup;
     }
@@ -705,11 +712,11 @@ static int launch_guarded(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipS
     if (need_fallback) {
         PcgArgs f = a;
         f.redo_flags = flag; f.redo_stride = 0; f.redo_skip = 0; f.redo_count = nullptr;     // skip if the flag is 0
-        if (h->N <= kRplMaxN && h->rpl != 0) rc = launch_rpl(h, f, batch, st);               // full block rows in registers
+        if (esz == 4 && h->N <= kRplMaxN && h->rpl != 0) rc = launch_rpl(h, f, batch, st);   // full block rows in registers
         else {
             PcgKnobs k = h->k;
-            choose_auto(h, k, batch, 4);
-            rc = launch_traj(h, k, f, batch, st, 4, /*record=*/false);
+            choose_auto(h, k, batch, esz);
+            rc = launch_traj(h, k, f, batch, st, esz, /*record=*/false);
         }
         if (rc != MPCG_OK) return rc;
         h->last = primary;
@@ -723,8 +730,10 @@ static int launch_guarded(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipS
     return MPCG_OK;
 }
 
-static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
+static int launch_pcg(mpcg_handle* h, const PcgArgs& a_in, uint32_t batch, hipStream_t st, int esz) {
     HIP_TRY(h, hipSetDevice(h->device));
+    PcgArgs a = a_in;
+    a.esz = esz;
     if (h->generic) {
         if (esz != 4) return fail(h, MPCG_ERR_UNSUPPORTED, "fp16 matrix storage exists for state_size = 14 only");
         return launch_generic_f32(h, a, batch, st);
@@ -734,13 +743,13 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
     // Verify the precondition on this call's matrices; a call that violates it is solved by a kernel that reads all three columns.
     bool lower_ok = true;
     h->last_sym_violations = 0;
-    if (h->check_symmetry && esz == 4 && (use_lpk(h, esz) || (h->cluster != 0 && (h->cluster > 0 || h->N > kLpbMaxN)))) {
+    if (h->check_symmetry && (use_lpk(h, esz) || (h->cluster != 0 && (h->cluster > 0 || h->N > kLpbMaxN)))) {
         int v = 0;
         const int rc = symmetry_violations(h, a, batch, st, &v);
         if (rc != MPCG_OK) return rc;
         h->last_sym_violations = v;
         lower_ok = v == 0;
-    } else if (esz == 4 && a.redo_flags == nullptr && (use_lpk(h, esz) || (h->cluster != 0 && (h->cluster > 0 || (h->auto_cfg && h->N > kLpbMaxN))))) {
+    } else if (a.redo_flags == nullptr && (use_lpk(h, esz) || (h->cluster != 0 && (h->cluster > 0 || (h->auto_cfg && h->N > kLpbMaxN))))) {
         // the symmetry latch (see launch_guarded): no synchronisation, no per-solve D2H
         sym_poll(h, st, true);
         if (h->sym_state == 2) lower_ok = false;
@@ -753,7 +762,7 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
         if (use_lpk(h, esz)) return launch_lpk(h, a, batch, st);
         const int rc = try_launch_cluster(h, a, batch, st, esz);
         if (rc != 1) return rc;
-    } else if (h->N <= kRplMaxN && h->rpl != 0) {
+    } else if (esz == 4 && h->N <= kRplMaxN && h->rpl != 0) {
         return launch_rpl(h, a, batch, st);              // full block rows in registers
     }
     PcgKnobs k = h->k;

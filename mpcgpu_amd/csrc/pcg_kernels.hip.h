@@ -194,6 +194,7 @@ struct PcgArgs {
     // itself).  See sched_order_kernel.
     const uint32_t* order = nullptr;
     uint32_t order_tag = 0;       // batch of THIS call: the stored permutation is used only if it was made for the same batch
+    int esz = 4;                  // bytes per element of S / Pinv: 4 float, 2 _Float16 storage (the register-resident kernels convert at load)
 };
 
 // order[0] = the batch the permutation order[1 ..] was computed for (0: none yet).  The tag is checked on the DEVICE, in stream order with
@@ -729,20 +730,21 @@ __global__ __launch_bounds__(256) void zero_words_kernel(unsigned long long* p, 
 // columns of S and Pinv and use L_{k+1}^T where the reference's kernel reads block (k, right).  One wavefront per (trajectory,
 // k < N-1): counts the pairs whose blocks differ by more than rel_tol x the largest entry of the pair,
 //   max_ij | M[k, right](i, j) - M[k+1, left](j, i) |  >  rel_tol * max | M[k, right], M[k+1, left] |        (NaN counts as a violation).
-__global__ __launch_bounds__(256) void bd_symmetry_check_kernel(const float* __restrict__ M, int N, int batch, float rel_tol,
+template <typename MT>
+__global__ __launch_bounds__(256) void bd_symmetry_check_kernel(const MT* __restrict__ M, int N, int batch, float rel_tol,
                                                                 unsigned long long* __restrict__ violations, unsigned long long* __restrict__ flag) {
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= (long)batch * (N - 1)) return;
     const long b = item / (N - 1);
     const int k = (int)(item - b * (N - 1));
-    const float* R = M + ((size_t)b * N + k) * ROWF + 2 * NS * NS;          // block (k, right), column-major
-    const float* Lt = M + ((size_t)b * N + k + 1) * ROWF;                   // block (k+1, left)
+    const MT* R = M + ((size_t)b * N + k) * ROWF + 2 * NS * NS;             // block (k, right), column-major
+    const MT* Lt = M + ((size_t)b * N + k + 1) * ROWF;                      // block (k+1, left)
     float dmax = 0.f, amax = 0.f;
     bool bad = false;
     for (int e = lane; e < NS * NS; e += 64) {
         const int i = e % NS, j = e / NS;
-        const float x = R[j * NS + i], y = Lt[i * NS + j];
+        const float x = (float)R[j * NS + i], y = (float)Lt[i * NS + j];
         const float d = fabsf(x - y);
         bad |= !(d == d);
         dmax = fmaxf(dmax, d);

@@ -88,6 +88,85 @@ __device__ __forceinline__ float dpp_partner(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
+// ---- the matrix registers of a lane: seven columns of D_k and L_k (lane 0 of the pair: columns 0..6; lane 1: 8..13, 7), row pairs in the
+// lane's slot order (slot s holds row pair P_q: lane 0: q = s; lane 1: q = (4, 5, 6, 3, 0, 1, 2)[s]).  Shared by pcg_lpk_kernel and
+// pcg_lpkc_kernel.  `M` = the trajectory's matrix (bd layout), element size ES bytes: 4 = float, 2 = _Float16 storage (mpcg_pcg_solve_f16:
+// converted to fp32 ONCE here — the blocks stay in registers for the whole solve, so fp16 storage costs the resident kernels nothing per
+// iteration and every product is the fp32 product of the rounded entry).
+//   * Column-major issue order: the seven row pairs of one column of a block are contiguous (56 / 28 bytes), so the loads of a column stay inside
+//     one or two 128-byte lines (slot-major order touched 64 lines per load and came back to each 13 loads later: the 16 KB L1 had long
+//     evicted it, every line crossed L2 -> L1 seven times).
+//   * Byte of (pair q, column c) inside a block = (14 c + 2 q) ES: one lane-variable base per slot, the column as the instruction's immediate
+//     offset (columns 8h + j for j < 6, 6 + h for j = 6).
+//   * Row pairs (q, q + 1) of one column are contiguous, and in BOTH lanes' slot orders the slot pairs (0, 1) and (4, 5) hold consecutive row
+//     pairs (lane 0: P0 P1 / P4 P5, lane 1: P4 P5 / P0 P1): those four slots come in as two double-width loads, slots 2, 3, 6 as single ones —
+//     five instead of seven load instructions per column.  The load phase is bound by the L1's tag rate (every lane of a load touches its
+//     own cache line: 64 lookups per instruction, ~21 us per 600 KB trajectory at seven loads per column), not by bytes.
+__device__ __forceinline__ f2 lpk_h2f(uint32_t w) {
+    const h2 v = __builtin_bit_cast(h2, w);
+    return f2{(float)v.x, (float)v.y};
+}
+template <int ES>
+__device__ __forceinline__ void lpk_load_blocks(rsrc_t M, int k, int h, bool okD, bool okL, f2 (&Md)[7][7], f2 (&Ml)[7][7]) {
+    static_assert(ES == 4 || ES == 2, "float or _Float16 storage");
+    constexpr uint32_t PB = 2u * ES, CB = (uint32_t)NS * ES, BLKB = (uint32_t)(NS * NS) * ES;     // bytes of a row pair, a column, a block
+    const uint32_t rowb = (uint32_t)k * ((uint32_t)ROWF * ES);
+    uint32_t bL[7], bD[7], bL6[7], bD6[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int q1 = s < 3 ? s + 4 : (s == 3 ? 3 : s - 4);
+        const uint32_t bs = rowb + PB * (uint32_t)(h ? q1 : s);
+        bL[s] = okL ? bs + CB * 8u * (uint32_t)h : OOB_OFF;
+        bD[s] = okD ? bs + CB * 8u * (uint32_t)h + BLKB : OOB_OFF;
+        bL6[s] = okL ? bs + CB * (uint32_t)(6 + h) : OOB_OFF;
+        bD6[s] = okD ? bs + CB * (uint32_t)(6 + h) + BLKB : OOB_OFF;
+    }
+    auto raw = [](uint32_t w) -> float { return __builtin_bit_cast(float, w); };
+    auto load_col = [&](f2 (&Mx)[7][7], const uint32_t (&bs)[7], int j, uint32_t coff) {
+        if constexpr (ES == 4) {
+            const f4 a01 = buf_load4<false>(M, bs[0] + coff), a45 = buf_load4<false>(M, bs[4] + coff);
+            Mx[0][j] = f2{a01.x, a01.y}; Mx[1][j] = f2{a01.z, a01.w};
+            Mx[4][j] = f2{a45.x, a45.y}; Mx[5][j] = f2{a45.z, a45.w};
+            Mx[2][j] = buf_load2(M, bs[2] + coff);
+            Mx[3][j] = buf_load2(M, bs[3] + coff);
+            Mx[6][j] = buf_load2(M, bs[6] + coff);
+        } else {
+            // the two halves of a row pair arrive as ONE dword, parked in .x until every load is under way (lpk_load_blocks' tail converts in
+            // place: a conversion here would wait for its load and serialise the latencies of the 28 columns)
+            const f2 a01 = buf_load2(M, bs[0] + coff), a45 = buf_load2(M, bs[4] + coff);
+            Mx[0][j].x = a01.x; Mx[1][j].x = a01.y;
+            Mx[4][j].x = a45.x; Mx[5][j].x = a45.y;
+            Mx[2][j].x = raw((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(M, (int)(bs[2] + coff), 0, 0));
+            Mx[3][j].x = raw((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(M, (int)(bs[3] + coff), 0, 0));
+            Mx[6][j].x = raw((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(M, (int)(bs[6] + coff), 0, 0));
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        load_col(Ml, bL, j, CB * (uint32_t)j);
+        __builtin_amdgcn_sched_barrier(0);               // (the scheduler would regroup the loads by base register = slot-major)
+    }
+    load_col(Ml, bL6, 6, 0u);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        load_col(Md, bD, j, CB * (uint32_t)j);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    load_col(Md, bD6, 6, 0u);
+    if constexpr (ES == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int s = 0; s < 7; ++s) Ml[s][j] = lpk_h2f(__builtin_bit_cast(uint32_t, Ml[s][j].x));
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int s = 0; s < 7; ++s) Md[s][j] = lpk_h2f(__builtin_bit_cast(uint32_t, Md[s][j].x));
+    }
+}
+
 template <int NWR>
 __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
     typedef LpkLds<NWR> L;
@@ -125,50 +204,11 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
     // ---- matrix registers: seven columns of D_k and L_k (lane 0: columns 0..6; lane 1: 8..13, 7), row pairs in this lane's slot order ----
     f2 Md[7][7], Ml[7][7];                                 // [slot][j]
     {
-        const rsrc_t M = make_rsrc((isP ? static_cast<const float*>(a.Pinv) : static_cast<const float*>(a.S)) + (size_t)b * mstride,
-                                   (uint32_t)(mstride * sizeof(float)));
-        const uint32_t rowb = (uint32_t)k * (ROWF * 4u);
+        const size_t es = a.esz == 2 ? 2 : 4;
+        const rsrc_t M = make_rsrc(static_cast<const char*>(isP ? a.Pinv : a.S) + (size_t)b * mstride * es, (uint32_t)(mstride * es));
         const bool okD = valid, okL = valid && k > 0 && hasL;
-        // Column-major issue order: the seven row pairs of one column of a block are 56 contiguous bytes, so seven consecutive loads of a lane
-        // stay inside one or two 128-byte lines (slot-major order touched 64 lines per load and came back to each 13 loads later: the 16 KB
-        // L1 had long evicted it, every line crossed L2 -> L1 seven times).
-        // slot s holds row pair P_q: lane 0: q = s; lane 1: q = (4, 5, 6, 3, 0, 1, 2)[s].  Byte of (pair q, column c) inside a block = 56 c + 8 q:
-        // one lane-variable base per slot, the column as the instruction's immediate offset (columns 8h + j for j < 6, 6 + h for j = 6)
-        uint32_t bL[7], bD[7], bL6[7], bD6[7];
-#pragma unroll
-        for (int s = 0; s < 7; ++s) {
-            const int q1 = s < 3 ? s + 4 : (s == 3 ? 3 : s - 4);
-            const uint32_t bs = rowb + 8u * (uint32_t)(h ? q1 : s);
-            bL[s] = okL ? bs + (uint32_t)(NS * 4 * 8) * (uint32_t)h : OOB_OFF;
-            bD[s] = okD ? bs + (uint32_t)(NS * 4 * 8) * (uint32_t)h + BLK4 * 16u : OOB_OFF;
-            bL6[s] = okL ? bs + (uint32_t)(NS * 4) * (uint32_t)(6 + h) : OOB_OFF;
-            bD6[s] = okD ? bs + (uint32_t)(NS * 4) * (uint32_t)(6 + h) + BLK4 * 16u : OOB_OFF;
-        }
-        // Row pairs (q, q + 1) of one column are 16 contiguous bytes, and in BOTH lanes' slot orders the slot pairs (0, 1) and (4, 5) hold
-        // consecutive row pairs (lane 0: P0 P1 / P4 P5, lane 1: P4 P5 / P0 P1): those four slots come in as two 16-byte loads, slots 2, 3, 6 as
-        // 8-byte loads — five instead of seven load instructions per column.  The load phase is bound by the L1's tag rate (every lane of a
-        // load touches its own cache line: 64 lookups per instruction, ~21 us per 600 KB trajectory at seven loads per column), not by bytes.
-        auto load_col = [&](f2 (&Mx)[7][7], const uint32_t (&bs)[7], int j, uint32_t coff) {
-            const f4 a01 = buf_load4<false>(M, bs[0] + coff), a45 = buf_load4<false>(M, bs[4] + coff);
-            Mx[0][j] = f2{a01.x, a01.y}; Mx[1][j] = f2{a01.z, a01.w};
-            Mx[4][j] = f2{a45.x, a45.y}; Mx[5][j] = f2{a45.z, a45.w};
-            Mx[2][j] = buf_load2(M, bs[2] + coff);
-            Mx[3][j] = buf_load2(M, bs[3] + coff);
-            Mx[6][j] = buf_load2(M, bs[6] + coff);
-        };
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            load_col(Ml, bL, j, (uint32_t)(NS * 4 * j));
-            __builtin_amdgcn_sched_barrier(0);               // (the scheduler would regroup the loads by base register = slot-major)
-        }
-        load_col(Ml, bL6, 6, 0u);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            load_col(Md, bD, j, (uint32_t)(NS * 4 * j));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        load_col(Md, bD6, 6, 0u);
+        if (a.esz == 2) lpk_load_blocks<2>(M, k, h, okD, okL, Md, Ml);
+        else lpk_load_blocks<4>(M, k, h, okD, okL, Md, Ml);
     }
 
     // park the pairs the pass uses last (rows 4..6 of the diagonal block's seventh column) in LDS; they are fetched back inside the pass

@@ -469,43 +469,13 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpkc_kernel(ClusterArgs ca) 
         int t_st = tid, i_st = i, h_st = h;
         asm volatile("" : "+v"(t_st), "+v"(i_st), "+v"(h_st));
         {
-            // matrix registers: seven columns of D_k and L_k, k = k0 + i (pcg_lpk_kernel's load, column-major issue order)
-            const rsrc_t M = make_rsrc((isP ? static_cast<const float*>(k_in->p.Pinv) : static_cast<const float*>(k_in->p.S)) + (size_t)b * mstride,
-                                       (uint32_t)(mstride * sizeof(float)));
-            const uint32_t rowb = (uint32_t)(k0 + i_st) * (ROWF * 4u);
+            // matrix registers: seven columns of D_k and L_k, k = k0 + i (lpk_load_blocks, pcg_lpk.hip.h; fp16 storage converted once, here)
+            const int esz = k_in->p.esz;
+            const size_t es = esz == 2 ? 2 : 4;
+            const rsrc_t M = make_rsrc(static_cast<const char*>(isP ? k_in->p.Pinv : k_in->p.S) + (size_t)b * mstride * es, (uint32_t)(mstride * es));
             const bool okD = valid, okL = valid && k0 + i_st > 0 && hasL;
-            uint32_t bL[7], bD[7], bL6[7], bD6[7];
-#pragma unroll
-            for (int s = 0; s < 7; ++s) {
-                const int q1 = s < 3 ? s + 4 : (s == 3 ? 3 : s - 4);
-                const uint32_t bs = rowb + 8u * (uint32_t)(h_st ? q1 : s);
-                bL[s] = okL ? bs + (uint32_t)(NS * 4 * 8) * (uint32_t)h_st : OOB_OFF;
-                bD[s] = okD ? bs + (uint32_t)(NS * 4 * 8) * (uint32_t)h_st + BLK4 * 16u : OOB_OFF;
-                bL6[s] = okL ? bs + (uint32_t)(NS * 4) * (uint32_t)(6 + h_st) : OOB_OFF;
-                bD6[s] = okD ? bs + (uint32_t)(NS * 4) * (uint32_t)(6 + h_st) + BLK4 * 16u : OOB_OFF;
-            }
-            // (pcg_lpk_kernel's load: slot pairs (0, 1) and (4, 5) as 16-byte loads, five load instructions per column instead of seven)
-            auto load_col = [&](f2 (&Mx)[7][7], const uint32_t (&bs)[7], int j, uint32_t coff) {
-                const f4 a01 = buf_load4<false>(M, bs[0] + coff), a45 = buf_load4<false>(M, bs[4] + coff);
-                Mx[0][j] = f2{a01.x, a01.y}; Mx[1][j] = f2{a01.z, a01.w};
-                Mx[4][j] = f2{a45.x, a45.y}; Mx[5][j] = f2{a45.z, a45.w};
-                Mx[2][j] = buf_load2(M, bs[2] + coff);
-                Mx[3][j] = buf_load2(M, bs[3] + coff);
-                Mx[6][j] = buf_load2(M, bs[6] + coff);
-            };
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                load_col(Ml, bL, j, (uint32_t)(NS * 4 * j));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            load_col(Ml, bL6, 6, 0u);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                load_col(Md, bD, j, (uint32_t)(NS * 4 * j));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            load_col(Md, bD6, 6, 0u);
+            if (esz == 2) lpk_load_blocks<2>(M, k0 + i_st, h_st, okD, okL, Md, Ml);
+            else lpk_load_blocks<4>(M, k0 + i_st, h_st, okD, okL, Md, Ml);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
 #pragma unroll

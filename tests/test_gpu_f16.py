@@ -41,10 +41,17 @@ def test_f16_storage_equals_fp32_solve_of_rounded_matrices(orc, N, pc):
     lam16 = torch.zeros(B, n * N, device="cuda")
     it, ex = sol.solve_f16(S16, P16, dev(g), lam16, cfg, pc)
     lam32 = torch.zeros(B, n * N, device="cuda")
+    fam16 = sol.get_option("last_kernel_family")
     sol.solve(Sr.contiguous(), Pr.contiguous(), dev(g), lam32, cfg, pc)
     torch.cuda.synchronize()
     assert (it.cpu().numpy() == K).all()
+    assert N <= 36 or fam16 == sol.get_option("last_kernel_family")
     lam16, lam32 = lam16.cpu().numpy(), lam32.cpu().numpy()
+    if N > 36:
+        # the register-resident kernels (lane-pair N <= 128, clustered above) convert the blocks once, at the load: from there on the solve IS the
+        # fp32 solve of the rounded matrices — same kernel, same registers, same bits
+        assert sol.get_option("last_kernel_family") == (6 if N <= 128 else 7)
+        np.testing.assert_array_equal(lam16, lam32)
     Srh, Prh = Sr.cpu().numpy(), Pr.cpu().numpy()
     for b in range(B):
         r64 = orc.pcg(np.nan_to_num(Srh[b]).astype(np.float64), np.nan_to_num(Prh[b]).astype(np.float64),
@@ -73,3 +80,30 @@ def test_f16_storage_true_residual_floor(orc):
         r32 = rel_residual(S[b], g[b], lam32[b].cpu().numpy(), N)
         r16 = rel_residual(S[b], g[b], lam16[b].cpu().numpy(), N)
         assert r32 < 1e-4 and 1e-5 < r16 < 5e-2 and r16 > 3 * r32
+
+
+def test_f16_storage_asymmetric_matrices_take_the_three_column_kernel(orc):
+    """The lower-triangle kernels' symmetry latch also guards fp16 storage: a Pinv whose right blocks are not the transposes of the left ones is
+    solved as given (three block columns), like the fp32 path (tests/test_gpu_contract.py)."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, B, K = 64, 3, 12
+    k = synth.make_kkt(N, B, 4242)
+    S, Pinv, g = synth.form_schur(k, rho=1e-2)
+    Pa = Pinv.copy().reshape(B, N, 3, 196)
+    Pa[:, :-1, 2, :] *= 1.25                                # right blocks scaled: no longer L_{k+1}^T
+    Pa = Pa.reshape(B, -1)
+    sol = PcgSolver(N, max_batch=B)
+    S16, P16 = sol.to_f16(dev(S)), sol.to_f16(dev(Pa))
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    lam = torch.zeros(B, n * N, device="cuda")
+    sol.solve_f16(S16, P16, dev(g), lam, cfg, "ss")
+    torch.cuda.synchronize()
+    Sr, Pr = S16.float().cpu().numpy(), P16.float().cpu().numpy()
+    for b in range(B):
+        r64 = orc.pcg(Sr[b].astype(np.float64), Pr[b].astype(np.float64), g[b].astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")
+        band = fp32_band(orc, Sr[b], Pr[b], g[b], np.zeros(n * N), N, K, "ss", r64["lam"])
+        assert relinf(lam[b].cpu().numpy(), r64["lam"]) <= max(1e-3, 4 * band)
+    for _ in range(3):                                      # the latch lands on a later call
+        sol.solve_f16(S16, P16, dev(g), lam.zero_(), cfg, "ss")
+        torch.cuda.synchronize()
+    assert sol.get_option("symmetry_state") == 2
