@@ -44,10 +44,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define SW_PAIR 0          // Q and R inverted together (two dependency chains)
 #endif
 #ifndef SW_ABLATE
-#define SW_ABLATE 0        // timing experiments only: 1 no stores (values kept alive), 2 no loads (operands made up from the offset), 4 no Gauss-Jordan, 8 no products
+#define SW_ABLATE 0        // timing experiments only: 1 no stores (values kept alive), 2 no loads (operands made up from the offset), 4 no Gauss-Jordan, 8 no products, 16 stores confined to 64 KB per array
 #endif
 #ifndef SW_STAGE
 #define SW_STAGE 1         // stores leave through the LDS stage in 16-byte pieces
+#endif
+#ifndef SW_NT_STORE
+#define SW_NT_STORE 0      // cache policy of the output stores (buffer aux bits: 2 = nt)
 #endif
 #ifndef SW_MASKED
 #define SW_MASKED 0        // 1: pivot row scaled under an EXEC mask with the compiler's IEEE division inside the mask
@@ -290,7 +293,7 @@ __device__ __forceinline__ void bst(rsrc_t r, uint32_t off, float v) {
 #if SW_ABLATE & 1
     asm volatile("" :: "v"(v), "v"(off));
 #else
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, SW_NT_STORE);
 #endif
 }
 // row lr of a column-major rows x COLS matrix that starts at byte `off`, as column pairs.  Rows beyond the matrix repeat its last row:
@@ -403,8 +406,17 @@ __device__ __forceinline__ void stage_flush(lds_f* stage, rsrc_t r, uint32_t dst
         for (int q = 0; q < NR; ++q) {
             const int idx = q * 64 + lane;
             const uint32_t vo = (en && (q * 64 + 64 <= NG || idx < NG)) ? (uint32_t)(idx * GB) : SW_OOB;
-            if constexpr (GB == 16) __builtin_amdgcn_raw_buffer_store_b128(v16[g][q], r, (int)vo, (int)(en ? sd : 0u), 0);
-            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v4[g][q]), r, (int)vo, (int)(en ? sd : 0u), 0);
+#if SW_ABLATE & 1
+            if constexpr (GB == 16) asm volatile("" :: "v"(v16[g][q]), "v"(vo)); else asm volatile("" :: "v"(v4[g][q]), "v"(vo));
+#else
+#if SW_ABLATE & 16      // every store lands in the first 64 KB of its array (L2-resident): the issue side of the stores without their HBM side
+            const uint32_t sd_ = sd & 0xFFF0u;
+#else
+            const uint32_t sd_ = sd;
+#endif
+            if constexpr (GB == 16) __builtin_amdgcn_raw_buffer_store_b128(v16[g][q], r, (int)vo, (int)(en ? sd_ : 0u), SW_NT_STORE);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v4[g][q]), r, (int)vo, (int)(en ? sd_ : 0u), SW_NT_STORE);
+#endif
         }
     }
     stage_fence();
@@ -502,6 +514,12 @@ __global__ __launch_bounds__(64, SW_WAVES) void schur_walk_kernel(WalkArgs w) {
             qp = bld(rg, og + k_ * gset * 4u + l14); ck = bld(rc, oc + k_ * n * 4u + l14);
         };
         load_QR(row_of(0)); load_AB(row_of(0)); load_vec(row_of(0));
+        // The first row's operands are waited for HERE, all of them.  Without this the compiler's wait-count bookkeeping merges two loop
+        // entries — this one, where the requests above are the youngest memory operations, and the back edge, where the same registers were
+        // requested BEFORE the previous row's 24 output stores — into the stricter of the two: vmcnt(5) ... vmcnt(0) at the top of every
+        // row, i.e. every row also waited for the previous row's stores.  (With it: vmcnt(61) ... — loads only.  No measurable difference
+        // in time, profiles/r04_walk_store_side.txt: the stores' cost is on the memory side.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
         for (int s = 0; s < L; ++s) {
             const int kk = k0 + s;
             const bool rowl = kk < k1;

@@ -67,3 +67,37 @@ def test_linsys_chain_replays_from_a_hipgraph(N, B):
         np.testing.assert_array_equal(ex.cpu().numpy(), we)
         np.testing.assert_array_equal(lam.cpu().numpy(), wl)
         np.testing.assert_array_equal(dz.cpu().numpy(), wz)
+
+
+@pytest.mark.parametrize("N", [128, 256])
+def test_capture_while_the_symmetry_latch_is_still_pending(N):
+    """A handle whose first lower-triangle solves are still waiting for the latch's asynchronous flag copy may be captured: the library must
+    not query the latch's event during capture (not a capturable operation — it invalidated the capture, round 4), it stays on the guarded
+    launches, and the replay reproduces the eager result."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    B = 3
+    k = synth.make_kkt(N, B, 31337 + N)
+    S, Pinv, g = (dev(a) for a in synth.form_schur(k, rho=1e-2))
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=20)
+    ref = PcgSolver(N, max_batch=B)
+    want = torch.zeros(B, n * N, device="cuda")
+    for _ in range(3):
+        ref.solve(S, Pinv, g, want.zero_(), cfg, "ss")
+        torch.cuda.synchronize()
+    sol = PcgSolver(N, max_batch=B)                         # fresh handle: latch undecided
+    lam = torch.zeros(B, n * N, device="cuda")
+    it = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        sol.solve(S, Pinv, g, lam, cfg, "ss", iters=it, exits=ex)      # eager: starts the flag copy; NOT synchronised before the capture below
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            lam.zero_()
+            sol.solve(S, Pinv, g, lam, cfg, "ss", iters=it, exits=ex)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(lam.cpu().numpy(), want.cpu().numpy())
+    assert sol.get_option("symmetry_state") in (0, 1)
