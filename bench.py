@@ -791,9 +791,11 @@ def main():
             prod[nm_] = {"frac": gbs / HBM_PEAK_GBS, "bound": "hbm", "kernel_ms": ms__, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "bytes_per_unit": mdl["bytes_per_unit"], "flops_per_unit": mdl["flops_per_unit"], "units_per_launch": knots, "unit_of_work": "one knot point of one trajectory",
                          "useful_tflops": tfl, "frac_of_valu_peak": tfl / pk, "valu_peak_tflops": pk, "arithmetic": mdl["dtype"], "traffic": None}
-        prod["generate_kkt"]["bound"] = "fp64 VALU issue / latency (its HBM floor is 0.04 ms)"
+        prod["generate_kkt"]["bound"] = "fp64 VALU issue: ~6,000 instructions per wavefront of four knots at 4 clocks each = 0.32 ms (its HBM floor is 0.04 ms)"
         prod["form_schur"]["kernels"] = "schur_walk_kernel + schur_seam_kernel (chunk length %d)" % sol.get_option("last_schur_chunk")
-        prod["form_schur"]["bound"] = "hbm by the model; in fact VALU issue (DPP multiplies, 2 wavefronts per SIMD) with the store path second"
+        prod["form_schur"]["bound"] = ("hbm: its output pattern alone (8,192 row streams of the bd layout, no arithmetic) takes 0.20 ms = 3.7 TB/s on this chip, "
+                                       "~0.28 ms with the input reads (profiles/r04_walk_store_side.txt); VALU floor 0.27 ms (unfused DPP multiplies, bit-exact with the oracle)")
+        prod["form_schur"]["frac_of_its_store_pattern_ceiling_3.7TBs"] = prod["form_schur"]["achieved"] / 3700.0
         # previous SQP iterate = this one plus a small change of the trajectory -> its multipliers are the warm start
         d_xu_prev = d_xu + 2e-3 * torch.randn_like(d_xu)
         d_xu_prev[:, :14] = d_xu[:, :14]

@@ -74,7 +74,7 @@ struct mpcg_handle {
     unsigned long long* cluster_scratch = nullptr;
     bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any valid pcg_* set_option clears this)
     bool generic = false;     // state_size != 14: only the PCG entry points work, through pcg_generic_kernel
-    int spmv_blocks_per_cu = 4;    // (sweep at 4096 trajectories = 1.2 GB of S, a true HBM stream: profiles/r02_tune_spmv.txt)
+    int spmv_blocks_per_cu = 2;    // (sweep at 4096 trajectories = 1.2 GB of S, a true HBM stream: profiles/r04_spmv.txt; until round 4: 4)
     int spmv_mfma = 0;        // 1 = the MFMA experiment kernel for mpcg_bt_spmv
     float* block_scratch = nullptr;  // W_k, z_k of mpcg_block_solve: max_batch x N x 210 floats (first call)
     float* ginv_scratch = nullptr;   // staging for the in-place G <- G^-1 of mpcg_form_schur
@@ -138,7 +138,7 @@ extern "C" {
 int mpcg_abi_version(void) { return MPCG_ABI_VERSION; }
 
 const char* mpcg_build_info(void) {
-    return "libmpcg_hip gfx950 fp32 n=14 (row-per-lane DPP PCG for short horizons, lane-per-block register-resident PCG, clustered PCG for long horizons, wave64 row-triple streaming PCG)";
+    return "libmpcg_hip gfx950 fp32 n=14 (row-per-lane DPP PCG for short horizons, lane-pair register-resident PCG to N = 128, clustered lane-pair PCG beyond, wave64 row-triple streaming PCG; chunk-walking Schur formation; IIWA-14 KKT blocks with the analytic inverse-dynamics gradient)";
 }
 
 // device scratch of the clustered kernel: [queue line][flags: one 128-byte line per trajectory of the CALL, up to max_batch][cells: 1 KB
@@ -943,7 +943,8 @@ int mpcg_bt_spmv(mpcg_handle* h, const float* d_M, const float* d_x, float* d_y,
     SpmvArgs a{d_M, d_x, d_y, (int)h->N, (int)batch, cols};
     constexpr int NW = 4;
     const long total = (long)batch * h->N;
-    long blocks = (total + NW - 1) / NW;
+    const long tasks = h->spmv_mfma ? total : (total + SPMV_SPAN - 1) / SPMV_SPAN;     // a wavefront's unit: a block row (MFMA experiment) or a span of rows
+    long blocks = (tasks + NW - 1) / NW;
     const long cap = (long)h->num_cus * h->spmv_blocks_per_cu;
     if (blocks > cap) blocks = cap;
     hipStream_t st = static_cast<hipStream_t>(stream);

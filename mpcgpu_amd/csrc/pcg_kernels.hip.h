@@ -811,58 +811,117 @@ __global__ __launch_bounds__(1024) void sched_order_kernel(const uint32_t* __res
 
 // ------------------------------------------------------------------------------------------------
 // Stand-alone batched block-tridiagonal SpMV  y = M x  (roofline kernel).
-// One wave per block row, waves stride over the (trajectory, knot) list so that the chip reads
-// one contiguous region at a time; x is read from global (L1/L2-resident, 56 B per knot).
+// One wavefront per block row at a time; a wavefront walks SPANS of SPMV_SPAN = 16 consecutive block rows (37,632 contiguous bytes of
+// the matrix), spans strided over the grid.  x is read from global (L2-resident, 56 B per knot).  Round 4, three findings
+// (tools/_prof/read_pattern.hip, tools/_prof/spmv_sweep.py, profiles/r04_spmv.txt):
+//   * the load shape (49 lanes x 16 B, three loads per row) reads 1.2 GB at 6.8-7.1 TB/s when nothing else is in the kernel: not the limit;
+//   * the x pairs used to be loaded inside compute(): vector-memory results return in issue order, so waiting for them also waited for the
+//     NEXT task's matrix loads issued just before — the double buffer overlapped nothing (one wavefront per SIMD: 2.4 -> 3.9 TB/s);
+//   * the y stores — 2 % of the bytes — cost 25 % of the time: 56 bytes per row from four lanes, 2.3 rows of DIFFERENT wavefronts (on different
+//     XCDs: different L2s) per 128-byte line, i.e. every line went to memory as several partial writes.  Now the 16 rows of a span are staged
+//     in LDS (896 B = exactly seven lines, the span starts on a line boundary) and leave as ONE store of 56 lanes x 16 B.
 // ------------------------------------------------------------------------------------------------
 struct SpmvArgs { const float* M; const float* x; float* y; int N; int batch; int cols; };
+#ifndef SPMV_SPAN_ROWS
+#define SPMV_SPAN_ROWS 16
+#endif
+#ifndef SPMV_DEPTH
+#define SPMV_DEPTH 2
+#endif
+constexpr int SPMV_SPAN = SPMV_SPAN_ROWS;                  // rows per span: a multiple of 16 (16 x 56 B of y = seven whole 128-byte lines)
+constexpr int SPMV_D = SPMV_DEPTH;                         // block rows in flight per wavefront
+static_assert(SPMV_SPAN % 16 == 0 && SPMV_SPAN % SPMV_D == 0, "whole lines of y, whole rounds of the buffers");
 
 template <int NW, bool NT>
 __global__ __launch_bounds__(NW * 64) void bt_spmv_kernel(SpmvArgs a) {
+    __shared__ __attribute__((aligned(16))) float ystage[NW][SPMV_SPAN * NS];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = a.N;
     const long total = (long)a.batch * N;
+    const long spans = (total + SPMV_SPAN - 1) / SPMV_SPAN;
     const long gw = (long)blockIdx.x * NW + w, GW = (long)gridDim.x * NW;
     const LaneMap L(lane);
     // One SRD per launch would need > 4 GiB of range at large batch, so the descriptor is rebuilt
     // per task from the (wave-uniform) trajectory index.
     const uint32_t lane_off = lane < BLK4 ? (uint32_t)lane * 16u : OOB_OFF;
     const size_t mstride = (size_t)N * ROWF;
-    auto load_task = [&](long q) -> Rows {
+    // A task's operands — the three float4 of the block row AND this lane's pairs of x — are requested together.
+    struct Task { Rows m; f2 xl, xk, xr; };
+    auto load_task = [&](long q) -> Task {
         const bool valid = q < total;
         const long qq = valid ? q : 0;
         const int bt = (int)(qq / N);
-        const int k = valid ? (int)(qq - (long)bt * N) : N;        // k = N -> all three loads OOB
+        const int kq = (int)(qq - (long)bt * N);
+        const int k = valid ? kq : N;                              // k = N -> all three loads OOB
         const rsrc_t r = make_rsrc(a.M + (size_t)bt * mstride, (uint32_t)(mstride * sizeof(float)));
-        return load_rows<NT>(r, k, N, a.cols, lane_off);
+        Task t;
+        t.m = load_rows<NT>(r, k, N, a.cols, lane_off);
+        // x of knots k-1, k, k+1 of this trajectory; a neighbour that does not exist has an all-zero block: point at knot k to stay in range
+        const float* xk = a.x + (size_t)qq * NS + L.g2;            // 8-byte aligned: 56 q and 8 g bytes
+        t.xk = *reinterpret_cast<const f2*>(xk);
+        t.xl = *reinterpret_cast<const f2*>(kq > 0 ? xk - NS : xk);
+        t.xr = *reinterpret_cast<const f2*>(kq < N - 1 ? xk + NS : xk);
+        return t;
     };
-
-    auto compute = [&](const Rows& use, long q) {
-        if (q >= total) return;
-        const int k = (int)(q % N);
-        const float* xk = a.x + (size_t)q * NS;            // x of knot k of this trajectory
+    auto fma4 = [&](f4& acc, const f4 m, const f2 x) {
+        const float x01 = L.a01 ? x.x : x.y;
+        const float x23 = L.a23 ? x.x : x.y;
+        acc.x = fmaf(m.x, x01, acc.x);
+        acc.y = fmaf(m.y, x01, acc.y);
+        acc.z = fmaf(m.z, x23, acc.z);
+        acc.w = fmaf(m.w, x23, acc.w);
+    };
+    float* ys = ystage[w];
+    // row r of the current span: its 14 results (lanes 0..3 of reduce_rows: 4 + 4 + 4 + 2) into the stage
+    auto compute = [&](const Task& use, int r) {
         f4 acc = {0.f, 0.f, 0.f, 0.f};
-        // a neighbour that does not exist has an all-zero block; point at xk to stay in range
-        const float* xl = (k > 0) ? xk - NS : xk;
-        const float* xrr = (k < N - 1) ? xk + NS : xk;
-        fma_block(acc, use.m0, xl, L);
-        fma_block(acc, use.m1, xk, L);
-        fma_block(acc, use.m2, xrr, L);
+        fma4(acc, use.m.m0, use.xl);
+        fma4(acc, use.m.m1, use.xk);
+        fma4(acc, use.m.m2, use.xr);
         const f4 y = reduce_rows(acc, lane);
-        float* yk = a.y + (size_t)q * NS + 4 * lane;       // 56q + 16*lane bytes: 8-byte aligned
+        float* yr = ys + r * NS + 4 * lane;                // (8-byte aligned)
         if (lane < 3) {
-            *reinterpret_cast<f2*>(yk) = f2{y.x, y.y};
-            *reinterpret_cast<f2*>(yk + 2) = f2{y.z, y.w};
+            *reinterpret_cast<f2*>(yr) = f2{y.x, y.y};
+            *reinterpret_cast<f2*>(yr + 2) = f2{y.z, y.w};
         } else if (lane == 3) {
-            *reinterpret_cast<f2*>(yk) = f2{y.x, y.y};
+            *reinterpret_cast<f2*>(yr) = f2{y.x, y.y};
         }
     };
-    Rows rowA = load_task(gw), rowB;
-    for (long q = gw; q < total; q += 2 * GW) {
-        rowB = load_task(q + GW);
-        compute(rowA, q);
-        rowA = load_task(q + 2 * GW);
-        compute(rowB, q + GW);
+    // (rows past the end of the batch compute on out-of-bounds = zero blocks and are not stored)
+    constexpr int D = SPMV_D;
+    Task buf[D];
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) buf[d] = load_task(gw * SPMV_SPAN + d);
+    for (long sp = gw; sp < spans; sp += GW) {
+        const long q0 = sp * SPMV_SPAN;
+        const long qn = (sp + GW) * SPMV_SPAN;             // first row of this wavefront's next span
+#pragma unroll 1
+        for (int r = 0; r < SPMV_SPAN; r += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int ahead = r + d + D - 1;           // the row requested now: D - 1 rows ahead, into the buffer freed last
+                buf[(d + D - 1) % D] = load_task(ahead < SPMV_SPAN ? q0 + ahead : qn + (ahead - SPMV_SPAN));
+                compute(buf[d], r + d);
+            }
+        }
+        // the span's y: 16 x 14 floats = 56 float4, one coalesced store (fewer at the ragged end of the batch)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const long rows_here = total - q0 < SPMV_SPAN ? total - q0 : SPMV_SPAN;
+#pragma unroll
+        for (int e = 4 * lane; e < SPMV_SPAN * NS; e += 256) {
+            if (e < rows_here * NS) {
+                const f4 v = *reinterpret_cast<const f4*>(ys + e);
+                float* yo = a.y + (size_t)q0 * NS + e;
+                if (e + 4 <= rows_here * NS) *reinterpret_cast<f4*>(yo) = v;
+                else { yo[0] = v.x; yo[1] = v.y; }        // (rows x 14 floats is even: a ragged tail is two floats)
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 

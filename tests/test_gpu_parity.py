@@ -79,6 +79,29 @@ def test_spmv_matches_golden_and_oracle(P, orc, N, cols):
         assert relinf(y, G["spmv_y"]) < 2e-6
 
 
+@pytest.mark.parametrize("N,B", [(3, 1), (9, 3), (33, 5), (50, 7), (128, 3)])
+def test_spmv_ragged_row_counts_and_output_bounds(P, orc, N, B):
+    """The kernel walks spans of 16 block rows and stores a span's y as whole 128-byte lines: row counts that are no multiple of 16 (the last
+    span is ragged, spans straddle trajectories), every trajectory against the oracle, and nothing written outside y (guard words on both sides,
+    and an x whose neighbours in memory are NaN)."""
+    k = synth.make_kkt(N, B, 77 + N)
+    S, _, _ = synth.form_schur(k, poison_unused=True)
+    rng = np.random.default_rng(N)
+    x = rng.normal(size=(B, n * N)).astype(np.float32)
+    sol = P[0](N, max_batch=B)
+    xg = torch.full((B * n * N + 64,), float("nan"), device="cuda")
+    xg[32:32 + B * n * N] = dev(x).reshape(-1)
+    yg = torch.full((B * n * N + 64,), 12345.0, device="cuda")
+    sol.bt_spmv(dev(S), xg[32:32 + B * n * N].view(B, -1), yg[32:32 + B * n * N].view(B, -1))
+    torch.cuda.synchronize()
+    out = yg.cpu().numpy()
+    assert (out[:32] == 12345.0).all() and (out[-32:] == 12345.0).all()
+    y = out[32:-32].reshape(B, -1)
+    assert np.isfinite(y).all()
+    for b in range(B):
+        assert relinf(y[b], orc.bt_spmv(np.nan_to_num(S[b]).astype(np.float64), x[b], N)) < 5e-6
+
+
 def test_spmv_batched_full_size_properties(P, orc):
     """N=128, batch 64: oracle parity on sampled trajectories + linearity + symmetry x^T S y = y^T S x."""
     N, B = 128, 64
