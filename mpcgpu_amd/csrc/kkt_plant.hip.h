@@ -371,7 +371,12 @@ __global__ __launch_bounds__(KKT_THREADS, ANALYTIC ? KKT_WAVES_ANALYTIC : 2) voi
     const PlantC P{reinterpret_cast<cdouble*>(reinterpret_cast<unsigned long long>(a.plant))};
     const int N = a.N;
     const long total = (long)a.batch * (N - 1);
-    for (long base = (long)blockIdx.x * KKT_ITEMS; base < total; base += (long)gridDim.x * KKT_ITEMS) {
+    // A wavefront's trips cover CONSECUTIVE groups of four knots (not a grid stride): the knots' pieces of g (84 B), c (56 B), G (980 B) and
+    // C (1176 B) are then neighbours in memory and most 128-byte lines are completed inside one L2 instead of leaving two XCDs as partial writes.
+    const long groups = (total + KKT_ITEMS - 1) / KKT_ITEMS, per = (groups + gridDim.x - 1) / gridDim.x;
+    const long g_begin = (long)blockIdx.x * per, g_end = g_begin + per < groups ? g_begin + per : groups;
+    for (long grp = g_begin; grp < g_end; ++grp) {
+        const long base = grp * KKT_ITEMS;
         const bool live = base + gi < total;                // (a group without a knot recomputes the last one and writes nothing)
         const long item = live ? base + gi : total - 1;
         const int b = (int)(item / (N - 1)), k = (int)(item - (long)b * (N - 1));

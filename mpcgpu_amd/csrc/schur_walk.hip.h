@@ -728,6 +728,9 @@ __global__ __launch_bounds__(64, 4) void compute_dz_dpp_kernel(DzArgs a) {
     const bool r14 = lr < n, r7 = lr < m;
     const uint32_t l14 = 4u * (r14 ? lr : n - 1), l7 = 4u * (r7 ? lr : m - 1);
     const unsigned items = B * (unsigned)N;
+    // (one group of four knots per workgroup and trip.  Tried in round 4: spans of 4 / 8 / 16 consecutive groups per wavefront, so that its
+    //  84-byte pieces of dz meet in one L2 as whole lines — what gained 25 % in bt_spmv_kernel: 60-63 us against 56.6 here, the serial
+    //  trips cost more memory-level parallelism than the partial lines cost.)
     for (unsigned base = blockIdx.x * 4u; base < items; base += gridDim.x * 4u) {
         const unsigned item = base + (unsigned)(lane >> 4);
         const bool live = item < items;
