@@ -682,6 +682,17 @@ def main():
             del dst
         except Exception as e_:
             sp["d2d_copy_gbs_this_run"] = None
+        # ... and to a pure read of the same array (the library's probe kernel: 16-byte nontemporal loads, nothing else)
+        try:
+            sink = torch.zeros(1, device=dev)
+            def rd20():
+                for _ in range(20):
+                    sol.probe_hbm_read(S_big, sink)
+            ms_rd = timed(rd20, 3, warm=1) / 20
+            sp["read_ceiling_gbs_this_run"] = S_big.numel() * 4 / (ms_rd * 1e-3) / 1e9
+            sp["frac_of_read_ceiling_this_run"] = sp["achieved"] / sp["read_ceiling_gbs_this_run"]
+        except Exception as e_:
+            sp["read_ceiling_gbs_this_run"] = None
         tr, src = load_traffic(f"bt_spmv_kernel|N{N}_B{Bs}")
         if tr:
             sp["traffic"] = tr["hbm_traffic_bytes_per_launch"]
@@ -1066,13 +1077,15 @@ def main():
         if sp is not None and rr is not None and "roofline" in out and out["roofline"] is sp:
             g_ = lambda d_, k_: d_.get(k_) if d_ else None
             ordered = {"bound": sp["bound"], "kernel": sp["kernel"], "achieved": sp["achieved"], "peak": sp["peak"], "unit": sp["unit"], "frac": sp["frac"],
-                       "traffic": sp.get("traffic"), "traffic_is": sp.get("traffic_is") or pmc_note, "kernel_ms": sp["kernel_ms"],
+                       "traffic": sp.get("traffic"), "kernel_ms": sp["kernel_ms"],
+                       "read_ceiling_gbs_this_run": sp.get("read_ceiling_gbs_this_run"), "frac_of_read_ceiling_this_run": sp.get("frac_of_read_ceiling_this_run"),
                        "headline_kernel": rr["kernel"], "headline_bound": rr["bound"], "headline_frac": rr["frac"], "headline_achieved": rr["achieved"],
                        "headline_peak": rr["peak"], "headline_unit": rr["unit"], "headline_kernel_ms": rr["kernel_ms"],
                        "headline_valu_active_frac": rr.get("valu_active_frac"), "headline_traffic": rr.get("traffic"),
-                       "form_schur_frac": g_(prod.get("form_schur"), "frac"), "form_schur_traffic_over_algorithmic": g_(prod.get("form_schur"), "traffic_over_algorithmic"),
-                       "compute_dz_frac": g_(prod.get("compute_dz"), "frac"), "generate_kkt_frac_of_fp64_valu_peak": g_(prod.get("generate_kkt"), "frac_of_valu_peak"),
-                       "d2d_copy_gbs_this_run": sp.get("d2d_copy_gbs_this_run")}
+                       "form_schur_frac": g_(prod.get("form_schur"), "frac"), "compute_dz_frac": g_(prod.get("compute_dz"), "frac"),
+                       "generate_kkt_frac_of_fp64_valu_peak": g_(prod.get("generate_kkt"), "frac_of_valu_peak"),
+                       "traffic_is": sp.get("traffic_is") or pmc_note, "d2d_copy_gbs_this_run": sp.get("d2d_copy_gbs_this_run"),
+                       "form_schur_traffic_over_algorithmic": g_(prod.get("form_schur"), "traffic_over_algorithmic")}
             ordered["note"] = ("top level = the HBM-bound kernel of the path (stand-alone block-tridiagonal SpMV, north_star's >= 60 % target; NOT in the timed region); "
                                "headline_* = the register-resident PCG kernel `value` is measured on (fp32 VALU bound; HBM sees one read of the lower block triangle per solve); "
                                "the producers' full objects: roofline_producers")

@@ -143,6 +143,13 @@ int mpcg_pcg_solve_ref(mpcg_handle *h,
 int mpcg_bt_spmv(mpcg_handle *h, const float *d_M, const float *d_x, float *d_y,
                  uint32_t batch, int cols, void *stream);
 
+/* Measurement aid, not part of the path: read `bytes` bytes at d_src once (16-byte nontemporal loads,
+ * two workgroups per CU, nothing else in the kernel) — the HBM read ceiling of THIS device for
+ * mpcg_bt_spmv's roofline fraction to be read against (bench.py times it next to the SpMV).
+ * d_src 16-byte aligned, bytes a multiple of 16; d_sink: 4 bytes of device memory (written only
+ * if the data sum to one particular value). */
+int mpcg_probe_hbm_read(mpcg_handle *h, const void *d_src, size_t bytes, float *d_sink, void *stream);
+
 /* ---- reduced-precision matrix storage (BASELINE config 5's fp16 sweep) ----
  * S and Pinv may be kept in IEEE half precision (same bd layout, 2-byte elements): half the HBM
  * footprint and half the bytes of the one load per solve.  Beyond N = 36 the register-resident

@@ -36,6 +36,7 @@ SYMBOLS = {
     "mpcg_pcg_solve_ref": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
                                      C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]),
     "mpcg_bt_spmv": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_uint32, C.c_int, C.c_void_p]),
+    "mpcg_probe_hbm_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _f32p, C.c_void_p]),
     "mpcg_convert_f32_to_f16": (C.c_int, [C.c_void_p, _f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mpcg_pcg_solve_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.c_float,
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -956,6 +956,17 @@ int mpcg_bt_spmv(mpcg_handle* h, const float* d_M, const float* d_x, float* d_y,
 }
 
 
+int mpcg_probe_hbm_read(mpcg_handle* h, const void* d_src, size_t bytes, float* d_sink, void* stream) {
+    if (!h) return MPCG_ERR_INVALID;
+    if (!d_src || !d_sink) return fail(h, MPCG_ERR_INVALID, "mpcg_probe_hbm_read: null device pointer");
+    if ((reinterpret_cast<uintptr_t>(d_src) & 15u) || (bytes & 15u)) return fail(h, MPCG_ERR_INVALID, "mpcg_probe_hbm_read: d_src and bytes must be multiples of 16");
+    if (bytes == 0) return MPCG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(hbm_read_probe_kernel, dim3((unsigned)(2 * h->num_cus)), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const f4*>(d_src), d_sink, bytes / 16);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
+
 int mpcg_convert_f32_to_f16(mpcg_handle* h, const float* d_src, uint16_t* d_dst, size_t count, void* stream) {
     if (!h) return MPCG_ERR_INVALID;
     if (!d_src || !d_dst) return fail(h, MPCG_ERR_INVALID, "mpcg_convert_f32_to_f16: null device pointer");

@@ -761,6 +761,22 @@ __global__ __launch_bounds__(256) void bd_symmetry_check_kernel(const MT* __rest
     }
 }
 
+// mpcg_probe_hbm_read: a pure read of n4 float4 (tools/_prof/read_rate.hip: 7.07 TB/s with two workgroups per CU, profiles/r04_spmv.txt)
+__global__ __launch_bounds__(256) void hbm_read_probe_kernel(const f4* __restrict__ in, float* out, size_t n4) {
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(in + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += v[u];
+    }
+    for (; i < n4; i += stride) acc += __builtin_nontemporal_load(in + i);
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = 1.f;
+}
+
 // fp32 -> fp16 copy of a bd-layout matrix (round to nearest even), 8 elements per thread.
 __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t count) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;

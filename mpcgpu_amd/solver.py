@@ -343,6 +343,14 @@ class PcgSolver:
         self._check(self.lib.mpcg_bd_to_csr_lowertri(self._h, _ptr(S), _ptr(val), float(mult), B, _stream()))
         return val
 
+    def probe_hbm_read(self, src, sink=None):
+        """Pure read of `src` (measurement aid: the device's HBM read ceiling, mpcg_probe_hbm_read)."""
+        if sink is None:
+            sink = torch.zeros(1, dtype=torch.float32, device=src.device)
+        nbytes = src.numel() * src.element_size()
+        self._check(self.lib.mpcg_probe_hbm_read(self._h, _ptr(src), nbytes - nbytes % 16, _ptr(sink), _stream()))
+        return sink
+
     def bt_spmv(self, M, x, y=None, cols: int = 3):
         B = x.shape[0] if x.dim() > 1 else 1
         n, N = self.n, self.N

@@ -282,3 +282,16 @@ def test_dispatch_order_hint_changes_no_result(N, B):
     got = run()                                                              # ... and the order it left behind is still a permutation
     for a0, a1 in zip(ref, got):
         np.testing.assert_array_equal(a0, a1)
+
+
+def test_hbm_read_probe_contract():
+    """mpcg_probe_hbm_read (measurement aid next to mpcg_bt_spmv): reads, writes nothing for ordinary data, rejects misaligned arguments."""
+    from mpcgpu_amd import PcgSolver
+    sol = PcgSolver(8, max_batch=1)
+    src = torch.randn(1 << 20, device="cuda")
+    sink = torch.full((1,), 7.0, device="cuda")
+    sol.probe_hbm_read(src, sink)
+    torch.cuda.synchronize()
+    assert sink.item() == 7.0
+    with pytest.raises(RuntimeError):
+        sol.probe_hbm_read(src[1:], sink)                   # 4-byte aligned only

@@ -22,3 +22,12 @@ for nt in (1, 0):
         sol.set_option("spmv_blocks_per_cu", bpc)
         ms = t(lambda: sol.bt_spmv(S, x, y))
         print("nt_loads=%d spmv_blocks_per_cu=%2d: %.3f ms  %.0f GB/s" % (nt, bpc, ms, B * 313824 / ms / 1e6))
+# back-to-back launches (the bench's way: 20 per timing) against one launch per timing
+sol.set_option("nt_loads", 1)
+for bpc in (2, 3, 4):
+    sol.set_option("spmv_blocks_per_cu", bpc)
+    def many():
+        for _ in range(20):
+            sol.bt_spmv(S, x, y)
+    ms1, ms20 = t(lambda: sol.bt_spmv(S, x, y)), t(many, 5) / 20
+    print("spmv_blocks_per_cu=%d: single launch %.3f ms (%.0f GB/s) | 20 back to back %.3f ms each (%.0f GB/s)" % (bpc, ms1, B * 313824 / ms1 / 1e6, ms20, B * 313824 / ms20 / 1e6))
