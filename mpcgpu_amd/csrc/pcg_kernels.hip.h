@@ -836,6 +836,8 @@ __global__ __launch_bounds__(1024) void sched_order_kernel(const uint32_t* __res
 //   * the y stores — 2 % of the bytes — cost 25 % of the time: 56 bytes per row from four lanes, 2.3 rows of DIFFERENT wavefronts (on different
 //     XCDs: different L2s) per 128-byte line, i.e. every line went to memory as several partial writes.  Now the 16 rows of a span are staged
 //     in LDS (896 B = exactly seven lines, the span starts on a line boundary) and leave as ONE store of 56 lanes x 16 B.
+//   * x: one 16-byte load per lane and SPAN (18 knots = 1008 B), a span ahead, parked in LDS — instead of three 8-byte global loads per lane and
+//     ROW in the same in-order queue as the matrix stream (+11 % on top of the y stage).
 // ------------------------------------------------------------------------------------------------
 struct SpmvArgs { const float* M; const float* x; float* y; int N; int batch; int cols; };
 #ifndef SPMV_SPAN_ROWS
@@ -850,11 +852,14 @@ static_assert(SPMV_SPAN % 16 == 0 && SPMV_SPAN % SPMV_D == 0, "whole lines of y,
 
 template <int NW, bool NT>
 __global__ __launch_bounds__(NW * 64) void bt_spmv_kernel(SpmvArgs a) {
+    constexpr int XF = (SPMV_SPAN + 2) * NS;               // floats of x a span multiplies: its rows' knots and one knot either side
+    constexpr int XP = (XF / 4 + 63) / 64;                 // ... as 64-lane pieces of float4 (18 x 14 = 252 floats = 63 float4: one piece)
     __shared__ __attribute__((aligned(16))) float ystage[NW][SPMV_SPAN * NS];
+    __shared__ __attribute__((aligned(16))) float xstage[NW][XP * 256];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = a.N;
-    const long total = (long)a.batch * N;
+    const long total = (long)a.batch * N, totalF = total * NS;
     const long spans = (total + SPMV_SPAN - 1) / SPMV_SPAN;
     const long gw = (long)blockIdx.x * NW + w, GW = (long)gridDim.x * NW;
     const LaneMap L(lane);
@@ -862,8 +867,7 @@ __global__ __launch_bounds__(NW * 64) void bt_spmv_kernel(SpmvArgs a) {
     // per task from the (wave-uniform) trajectory index.
     const uint32_t lane_off = lane < BLK4 ? (uint32_t)lane * 16u : OOB_OFF;
     const size_t mstride = (size_t)N * ROWF;
-    // A task's operands — the three float4 of the block row AND this lane's pairs of x — are requested together.
-    struct Task { Rows m; f2 xl, xk, xr; };
+    struct Task { Rows m; int kq; };
     auto load_task = [&](long q) -> Task {
         const bool valid = q < total;
         const long qq = valid ? q : 0;
@@ -873,12 +877,26 @@ __global__ __launch_bounds__(NW * 64) void bt_spmv_kernel(SpmvArgs a) {
         const rsrc_t r = make_rsrc(a.M + (size_t)bt * mstride, (uint32_t)(mstride * sizeof(float)));
         Task t;
         t.m = load_rows<NT>(r, k, N, a.cols, lane_off);
-        // x of knots k-1, k, k+1 of this trajectory; a neighbour that does not exist has an all-zero block: point at knot k to stay in range
-        const float* xk = a.x + (size_t)qq * NS + L.g2;            // 8-byte aligned: 56 q and 8 g bytes
-        t.xk = *reinterpret_cast<const f2*>(xk);
-        t.xl = *reinterpret_cast<const f2*>(kq > 0 ? xk - NS : xk);
-        t.xr = *reinterpret_cast<const f2*>(kq < N - 1 ? xk + NS : xk);
+        t.kq = kq;
         return t;
+    };
+    // x of the span that starts at row q0: knots q0 - 1 .. q0 + SPAN of the flat [batch N][14] array, ONE 16-byte load per lane, requested a
+    // whole span ahead and parked in LDS for the span's rows (three 8-byte LDS reads per row and lane instead of three global loads: those were
+    // 48 vector-memory instructions per span in the same in-order queue as the matrix stream).  Entries outside the array read as zero.
+    auto load_x = [&](long q0, f4 (&xp)[XP]) {
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+            const long gi = (q0 - 1) * NS + 4 * (lane + 64 * p);
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gi >= 0 && gi + 4 <= totalF) v = *reinterpret_cast<const f4*>(a.x + gi);          // (8-byte aligned: the hardware takes dword-aligned 16-byte loads)
+            else {
+                if (gi >= 0 && gi < totalF) v.x = a.x[gi];
+                if (gi + 1 >= 0 && gi + 1 < totalF) v.y = a.x[gi + 1];
+                if (gi + 2 >= 0 && gi + 2 < totalF) v.z = a.x[gi + 2];
+                if (gi + 3 >= 0 && gi + 3 < totalF) v.w = a.x[gi + 3];
+            }
+            xp[p] = v;
+        }
     };
     auto fma4 = [&](f4& acc, const f4 m, const f2 x) {
         const float x01 = L.a01 ? x.x : x.y;
@@ -889,12 +907,17 @@ __global__ __launch_bounds__(NW * 64) void bt_spmv_kernel(SpmvArgs a) {
         acc.w = fmaf(m.w, x23, acc.w);
     };
     float* ys = ystage[w];
-    // row r of the current span: its 14 results (lanes 0..3 of reduce_rows: 4 + 4 + 4 + 2) into the stage
+    const float* xs = xstage[w] + L.g2;                    // slot s = knot q0 - 1 + s; this lane's column pair
+    // row r of the current span: its 14 results (lanes 0..3 of reduce_rows: 4 + 4 + 4 + 2) into the stage.  A neighbour that does not exist
+    // has an all-zero block: its operand is the row's own knot, to stay finite.
     auto compute = [&](const Task& use, int r) {
+        const f2 xk = *reinterpret_cast<const f2*>(xs + (r + 1) * NS);
+        const f2 xl = *reinterpret_cast<const f2*>(xs + (use.kq > 0 ? r : r + 1) * NS);
+        const f2 xr = *reinterpret_cast<const f2*>(xs + (use.kq < N - 1 ? r + 2 : r + 1) * NS);
         f4 acc = {0.f, 0.f, 0.f, 0.f};
-        fma4(acc, use.m.m0, use.xl);
-        fma4(acc, use.m.m1, use.xk);
-        fma4(acc, use.m.m2, use.xr);
+        fma4(acc, use.m.m0, xl);
+        fma4(acc, use.m.m1, xk);
+        fma4(acc, use.m.m2, xr);
         const f4 y = reduce_rows(acc, lane);
         float* yr = ys + r * NS + 4 * lane;                // (8-byte aligned)
         if (lane < 3) {
@@ -904,14 +927,25 @@ __global__ __launch_bounds__(NW * 64) void bt_spmv_kernel(SpmvArgs a) {
             *reinterpret_cast<f2*>(yr) = f2{y.x, y.y};
         }
     };
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     // (rows past the end of the batch compute on out-of-bounds = zero blocks and are not stored)
     constexpr int D = SPMV_D;
     Task buf[D];
+    f4 xp[XP];
+    load_x(gw * SPMV_SPAN, xp);
 #pragma unroll
     for (int d = 0; d < D - 1; ++d) buf[d] = load_task(gw * SPMV_SPAN + d);
     for (long sp = gw; sp < spans; sp += GW) {
         const long q0 = sp * SPMV_SPAN;
         const long qn = (sp + GW) * SPMV_SPAN;             // first row of this wavefront's next span
+#pragma unroll
+        for (int p = 0; p < XP; ++p) *reinterpret_cast<f4*>(xstage[w] + 4 * (lane + 64 * p)) = xp[p];
+        wave_sync();
+        load_x(qn, xp);                                    // the next span's x: a span ahead
 #pragma unroll 1
         for (int r = 0; r < SPMV_SPAN; r += D) {
 #pragma unroll
@@ -922,9 +956,7 @@ __global__ __launch_bounds__(NW * 64) void bt_spmv_kernel(SpmvArgs a) {
             }
         }
         // the span's y: 16 x 14 floats = 56 float4, one coalesced store (fewer at the ragged end of the batch)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_sync();
         const long rows_here = total - q0 < SPMV_SPAN ? total - q0 : SPMV_SPAN;
 #pragma unroll
         for (int e = 4 * lane; e < SPMV_SPAN * NS; e += 256) {
@@ -935,9 +967,7 @@ __global__ __launch_bounds__(NW * 64) void bt_spmv_kernel(SpmvArgs a) {
                 else { yo[0] = v.x; yo[1] = v.y; }        // (rows x 14 floats is even: a ragged tail is two floats)
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_sync();
     }
 }
 
