@@ -1,8 +1,8 @@
-# Round profile recipe (run on the GPU box through gpurun):  bash tools/profile_round.sh r03x
+# Round profile recipe (run on the GPU box through gpurun):  bash tools/profile_round.sh r04x
 #   1. GPU tests   2. un-profiled bench line   3. rocprofv3 --kernel-trace --stats of the same bench command
 #   4. separate --pmc passes (FETCH_SIZE | WRITE_SIZE | two SQ sets) of `bench.py --profile-lean`   5. summaries -> gpurun_out/<tag>_*
 # Copy gpurun_out/<tag>_* into profiles/ and run tools/make_traffic.py afterwards (here, not on the box).
-TAG=${1:-r03}
+TAG=${1:-r04}
 set -x
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -5 > gpurun_out/${TAG}_pytest_gpu.log
