@@ -14,6 +14,8 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 fam_count, worst, bad, breakdown, marginal = collections.Counter(), 0.0, 0, 0, 0
+f16_count = collections.Counter()
+worst16 = 0.0
 t0 = time.time()
 for ci in range(cases):
     N = int(rng.choice([rng.integers(2, 33), rng.integers(33, 129), rng.integers(129, 400)], p=[0.4, 0.4, 0.2]))
@@ -46,8 +48,35 @@ for ci in range(cases):
         worst = max(worst, e / tol)
         marginal += int(tol < e <= 2 * tol)               # (the test-suite tolerance is a heuristic: report, fail from 2x)
         ok = ok and e <= 2 * tol
+    # fp16 matrix storage on the same case: on the register-resident families the blocks are converted once at the load, so the solve must be
+    # BIT-identical to the fp32 solve of the rounded matrices; elsewhere (round-1 kernel with mixed-precision FMAs) inside the band
+    S16, P16 = sol.to_f16(dev(np.nan_to_num(S))), sol.to_f16(dev(np.nan_to_num(P)))
+    l16, l32 = dev(lam0.copy()), dev(lam0.copy())
+    cfgk = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    sol.solve_f16(S16, P16, dev(g), l16, cfgk, pc)
+    fam16 = sol.get_option("last_kernel_family")
+    sol.solve(S16.float().contiguous(), P16.float().contiguous(), dev(g), l32, cfgk, pc)
+    torch.cuda.synchronize()
+    f16_count[fam16] += 1
+    fam32 = sol.get_option("last_kernel_family")
+    a16, a32 = l16.cpu().numpy(), l32.cpu().numpy()
+    Sr, Pr = S16.float().cpu().numpy(), P16.float().cpu().numpy()
+    if fam16 in (6, 7) and fam32 == fam16 and np.isfinite(a32).all() and not np.array_equal(a16, a32):
+        ok = False
+        print(f"  fp16 storage differs from the fp32 solve of the rounded matrices (family {fam16})")
+    for b in range(B):
+        if not np.isfinite(orc.pcg(Sr[b], Pr[b], g[b], lam0[b], N, K, 0.0, pc)["lam"]).all():
+            continue
+        ref = orc.pcg(Sr[b].astype(np.float64), Pr[b].astype(np.float64), g[b].astype(np.float64), lam0[b].astype(np.float64), N, K, 0.0, pc)["lam"]
+        band = fp32_band(orc, Sr[b], Pr[b], g[b], lam0[b], N, K, pc, ref)
+        e = relinf(a16[b], ref)
+        tol = max(2e-5 if K <= 3 else 1e-3, 4 * band)
+        worst16 = max(worst16, e / tol)
+        if not (np.isfinite(a16[b]).all() and e <= 2 * tol):
+            ok = False
+            print(f"  fp16 storage: trajectory {b} off the float64 iterate of the rounded system by {e:.2e} (tolerance {tol:.2e}, family {fam16})")
     if not ok:
         bad += 1
         print(f"MISMATCH case {ci}: N={N} B={B} {pc} K={K} family {fam}: iters {it_h.tolist()} exit {ex_h.tolist()} finite {bool(np.isfinite(lam_h).all())}", flush=True)
-print(f"{cases} random cases in {time.time()-t0:.0f} s: kernel families {dict(sorted(fam_count.items()))}, worst error / tolerance {worst:.3f} ({marginal} trajectories between 1x and 2x), trajectories skipped because float32 CG itself breaks down (over-iterated, exit_tol 0) {breakdown}, mismatches {bad}")
+print(f"{cases} random cases in {time.time()-t0:.0f} s: kernel families {dict(sorted(fam_count.items()))}, worst error / tolerance {worst:.3f} ({marginal} trajectories between 1x and 2x), trajectories skipped because float32 CG itself breaks down (over-iterated, exit_tol 0) {breakdown}; fp16 storage of the same cases: families {dict(sorted(f16_count.items()))}, worst error / tolerance {worst16:.3f}; mismatches {bad}")
 sys.exit(1 if bad else 0)
