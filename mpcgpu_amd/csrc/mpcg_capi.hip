@@ -186,7 +186,7 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     h->device = device; h->n = state_size; h->N = knot_points; h->max_batch = max_batch;
     h->generic = generic;
     h->num_cus = prop.multiProcessorCount;
-    h->nt_loads = 1;                    // SpMV kernel only: the matrix is read once — non-temporal loads, +4..9 % (profiles/r02_tune_spmv.txt)
+    h->nt_loads = 1;                    // SpMV kernel only: the matrix is read once — non-temporal loads, +4..9 % (profiles/r02_tune_spmv.txt, r04_spmv.txt)
     choose_auto(h, h->k, 1, 4);         // knobs of the single-workgroup kernels as a batch-1 call would pick them
     choose_auto(h, h->k, 1, 2);
     // hand-off cells of the cluster kernel (512 B per member, up to two members per CU), allocated here so that every solve is pure stream work
@@ -508,7 +508,7 @@ static int launch_lpk(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
 }
 // Automatic use: 36 < N <= 128 (where the row-per-lane kernel has not taken the call).  Its per-lane work does not shrink with the horizon
 // (a lane pair per knot whatever N), so up to N = 36 — where the row-pair kernel <4,3,0> fits two trajectories per CU — that one stays
-// ahead in throughput (N=36: 292 vs 222 M it/s at batch 2048); beyond it the order flips (tools/_prof/n48.py).
+// ahead in throughput (N=36: 292 vs 222 M it/s at batch 2048); beyond it the order flips (HISTORY.md §3.1c).
 static bool use_lpk(const mpcg_handle* h, int esz) {
     if ((esz != 4 && esz != 2) || h->N > kLpbMaxN || h->lpk == 0) return false;     // (fp16 storage: converted once at the load)
     return h->lpk == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 36);

@@ -34,17 +34,13 @@ rd.restype = C.c_int
 NAMES = ["S regs", "S lds", "S stream", "S fold", "S barrier", "vec update", "barrier", "(P start)",
          "P regs", "P lds", "P stream", "P fold", "P barrier", "p update", "barrier"]
 IDX = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]
-LPB_NAMES = ["S direct", "S transp", "S fold", "(to red)", "S barrier", "alpha+r upd", "barrier", "(P start)",
-             "P direct", "P transp", "P fold", "(to red)", "P barrier", "eta+p upd", "barrier"]
 LPK_NAMES = ["S transp", "S direct", "S merge+dot", "(to barrier)", "barrier A", "alpha+r/lam", "barrier B", "(P start)",
              "P transp", "P direct", "P merge+dot", "(to barrier)", "barrier C", "eta+p upd", "barrier D"]
 for spec in args.cfg or ["4:7:-1"]:
-    f = [int(x) for x in spec.split(":")] if spec not in ("lpb", "lpk") else [4 if N <= 64 else 8]
+    f = [int(x) for x in spec.split(":")] if spec != "lpk" else [4 if N <= 64 else 8]
     if spec == "lpk":      # lane-pair-per-knot kernel (round 3 default for 36 < N <= 128): waves 0-3 S, 4-7 Pinv (stamps of the other role's pass stay 0)
         NAMES = LPK_NAMES
         sol.set_option("pcg_lpk", 1)
-    elif spec == "lpb":      # the lane-per-block kernel (default for N <= 128): waves 0-1 S off-diagonal, 2-3 S diagonal, 4-5 / 6-7 Pinv
-        NAMES = LPB_NAMES
     else:
         sol.set_option("cluster", 0)
         sol.set_option("pcg_waves", f[0]); sol.set_option("pcg_reg_rows", f[1]); sol.set_option("pcg_lds_rows", f[2] if len(f) > 2 else -1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The clustered lane-per-block kernel next to a memory-streaming kernel on another stream (uneven load: some CUs busy, L2 under
+"""The clustered kernel next to a memory-streaming kernel on another stream (uneven load: some CUs busy, L2 under
 pressure, members possibly not co-resident).  Every call must return valid results — identical to the undisturbed run where the
 cluster kernel itself produced them, within the fp32 band where the fix-up launch (another kernel) had to step in."""
 import os, sys, time
