@@ -37,6 +37,10 @@
 #pragma once
 #include "pcg_kernels.hip.h"
 
+#ifndef LPK_STAGED_LOAD
+#define LPK_STAGED_LOAD 1      // matrix registers filled through the LDS stage (lpk_load_blocks_lds); 0: lane-private loads (lpk_load_blocks)
+#endif
+
 namespace mpcg {
 
 // LDS layout of one vector: PAIR-MAJOR, V[q][slot] = entries (2q, 2q+1) of knot slot - 1 as one float2, q = 0..6,
@@ -53,7 +57,8 @@ template <int NWR> struct LpkLds {
     static constexpr int VS = 7 * KN * 2;                      // floats per vector
     // P0, R0: staging of lambda0 / gamma, at the end p and r for d_p / d_r (inside the loop p and r live in registers only) |
     // US, ZS: what the S pass publishes | RT, ZP: the Pinv pass | lambda | wave partials
-    static constexpr int P0 = 0, R0 = VS, US = 2 * VS, ZS = 3 * VS, RT = 4 * VS, ZP = 5 * VS, LAM = 6 * VS, RED = 7 * VS, MX = RED + NW, NPARK = 3, TOTAL = MX + NPARK * 2 * NW * 64;
+    static constexpr int P0 = 0, R0 = VS, US = 2 * VS, ZS = 3 * VS, RT = 4 * VS, ZP = 5 * VS, LAM = 6 * VS, RED = 7 * VS, MX = RED + NW, NPARK = 3, TILE2 = MX + NPARK * 2 * NW * 64,
+                         TOTAL = TILE2 + (LPK_STAGED_LOAD ? NW * 8 * 14 * 14 : 0);      // (TILE2: the second load tile of every wavefront, lpk_load_blocks_lds)
     // MX: NPARK matrix register pairs per lane parked in LDS (lane-private float2 slots, [pair][thread]: conflict-free): the register file
     // holds 196 matrix registers + the working set of a half-iteration only just; left to the compiler the overflow goes to SCRATCH, whose
     // reloads (global-memory latency, three per pass) cost more than the whole FMA stream
@@ -167,6 +172,99 @@ __device__ __forceinline__ void lpk_load_blocks(rsrc_t M, int k, int h, bool okD
     }
 }
 
+// ---- the same registers filled through an LDS stage (round 4; default).  lpk_load_blocks above gives every lane its own 16-byte pieces: 70
+// load instructions per lane, each touching 64 different cache lines — the load of a 600 KB trajectory was bound by the L1's tag rate at
+// ~15 us, a fifth of a warm-started single-trajectory SQP step.  But a lane's share of a block is CONTIGUOUS in memory — lane 0 of a knot's
+// pair owns columns 0..6 = the first 392 bytes (196 for fp16) of each block, lane 1 the second half — so the wavefront reads whole blocks
+// with full-width loads STRAIGHT INTO LDS (`buffer_load_dwordx4 ... lds`: no staging registers) and the lanes pick their halves out of it:
+//   * ROUND r = 0..7 (block column L: r < 4, D: r >= 4): the blocks of the eight knots of lanes 16 (r & 3) .. + 15, 8 x 784 contiguous bytes
+//     per knot, as 392 pieces of 16 bytes (8 for fp16) = 6.1 load instructions of 64 lanes, ~10 cache lines each instead of 64;
+//   * the pieces land in memory order in one of the wavefront's two 6,272-byte tiles (one aliases the iterate vectors' region, not yet in
+//     use; two rounds are in flight), and the 16 lanes of the round read their 49 row pairs as 8-byte LDS loads: knot stride 196 dwords = 4
+//     banks, halves 98 dwords = 34 banks apart: conflict-free;
+//   * knots outside the horizon / the absent L_0: requested at the out-of-bounds offset (no traffic), their lanes take zeros.
+// The registers end up bit-identical to lpk_load_blocks' (tests run both).  `kfirst` = global knot of lanes 0, 1; valid knots are < kend.
+// (fp32 storage only: the LDS-destination loads come in 1, 2, 4, 12 and 16 bytes per lane, and a half-precision block is 24.5 x 16 bytes;
+//  fp16 storage — experimental — keeps the lane-private loads.)
+constexpr int LPK_TILE_FLOATS = 8 * NS * NS;               // one round of one wavefront
+__device__ __forceinline__ void lpk_load_blocks_lds(rsrc_t M, int kfirst, int kend, bool hasL, int lane, float* tileA, float* tileB, f2 (&Md)[7][7], f2 (&Ml)[7][7]) {
+    constexpr int ES = 4;
+    constexpr uint32_t PB = 16u;                           // bytes of a piece: 4 elements
+    constexpr uint32_t RPB = 2u * ES, CB = (uint32_t)NS * ES, BLKB = (uint32_t)(NS * NS) * ES, ROWB = (uint32_t)ROWF * ES;
+    typedef __attribute__((address_space(3))) char lds_c;
+    const int h = lane & 1, kl = (lane >> 1) & 7, myround = lane >> 4;
+    // piece i of this lane in a round: p = lane + 64 i < 392: knot p / 49 of the round, piece p % 49 of its block
+    uint32_t goff[7];                                      // byte offset from (first knot of the round, block column 0)
+    int pk[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int p = lane + 64 * i;
+        pk[i] = p / 49;
+        goff[i] = (uint32_t)pk[i] * ROWB + (uint32_t)(p - 49 * pk[i]) * PB;
+    }
+    auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto issue = [&](int r) {                              // round r -> tile r & 1
+        const int blk = r >> 2;
+        const int kr = kfirst + 8 * (r & 3);               // first knot of the round (wave-uniform)
+        const int lo = (blk == 0 && kr == 0) ? 1 : 0;      // knots lo <= pk < hi of the round exist in this block column
+        int hi = kend - kr;
+        hi = hi < 0 ? 0 : (hi > 8 ? 8 : hi);
+        if (blk == 0 && !hasL) hi = 0;
+        const uint32_t sbase = (uint32_t)kr * ROWB + (uint32_t)blk * BLKB;
+        const bool all = lo == 0 && hi == 8;               // (wave-uniform: the common case needs no per-piece test)
+        lds_c* tile = (lds_c*)((r & 1) ? tileB : tileA);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const uint32_t vo = (all || (pk[i] >= lo && pk[i] < hi)) ? goff[i] : OOB_OFF;
+            if (i < 6 || lane < 8)                         // (piece 6 exists for lanes 0..7 only: 392 = 6 x 64 + 8; the others must not write past the tile)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(M, (__attribute__((address_space(3))) void*)(tile + 64 * i * 16), 16, (int)vo, (int)sbase, 0, 0);
+        }
+    };
+    auto gather = [&](f2 (&Mx)[7][7], int r) {
+        if (myround != (r & 3)) return;
+        lds_c* tile = (lds_c*)((r & 1) ? tileB : tileA);
+        // a knot outside the horizon / the absent L_0: zeros.  (Its pieces were requested at the out-of-bounds offset, and an LDS-destination
+        // load leaves LDS UNTOUCHED for such a lane — the tile still holds an earlier round there.)
+        const int gk = kfirst + (lane >> 1);
+        if (!(gk < kend && (r >= 4 || (gk > 0 && hasL)))) {
+#pragma unroll
+            for (int s = 0; s < 7; ++s)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) Mx[s][j] = f2{0.f, 0.f};
+            return;
+        }
+        // slot s holds row pair q(h, s); columns 8h + j for j < 6 by immediate offset, column 6 + h apart
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            const int q1 = s < 3 ? s + 4 : (s == 3 ? 3 : s - 4);
+            const uint32_t b = (uint32_t)kl * BLKB + RPB * (uint32_t)(h ? q1 : s);
+            const uint32_t sb = b + CB * 8u * (uint32_t)h, sb6 = b + CB * (uint32_t)(6 + h);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const uint32_t ad = (j < 6 ? sb + CB * (uint32_t)j : sb6);
+                if constexpr (ES == 4) Mx[s][j] = *(__attribute__((address_space(3))) const volatile f2*)(tile + ad);
+                else Mx[s][j] = lpk_h2f(*(__attribute__((address_space(3))) const volatile uint32_t*)(tile + ad));
+            }
+        }
+    };
+    issue(0);
+    issue(1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r < 7) __builtin_amdgcn_s_waitcnt(0x0F77);      // vmcnt(7): everything but the younger round has landed
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        wave_sync();
+        if (r < 4) gather(Ml, r); else gather(Md, r);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the tile has been read before the next round is sent into it
+        wave_sync();
+        if (r + 2 < 8) issue(r + 2);
+    }
+}
+
 template <int NWR>
 __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
     typedef LpkLds<NWR> L;
@@ -206,9 +304,19 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
     {
         const size_t es = a.esz == 2 ? 2 : 4;
         const rsrc_t M = make_rsrc(static_cast<const char*>(isP ? a.Pinv : a.S) + (size_t)b * mstride * es, (uint32_t)(mstride * es));
+#if LPK_STAGED_LOAD
+        // (through the wavefront's two LDS tiles: one inside the iterate vectors' region, idle until the barrier below, one behind the parking area)
+        static_assert(NW * LPK_TILE_FLOATS <= L::RED, "the first load tiles alias the iterate vectors");
+        float* tileA = lds + w * LPK_TILE_FLOATS;
+        float* tileB = lds + L::TILE2 + w * LPK_TILE_FLOATS;
+        const int kfirst = 32 * wl;
+        if (a.esz == 2) lpk_load_blocks<2>(M, k, h, valid, valid && k > 0 && hasL, Md, Ml);
+        else lpk_load_blocks_lds(M, kfirst, N, hasL, lane, tileA, tileB, Md, Ml);
+#else
         const bool okD = valid, okL = valid && k > 0 && hasL;
         if (a.esz == 2) lpk_load_blocks<2>(M, k, h, okD, okL, Md, Ml);
         else lpk_load_blocks<4>(M, k, h, okD, okL, Md, Ml);
+#endif
     }
 
     // park the pairs the pass uses last (rows 4..6 of the diagonal block's seventh column) in LDS; they are fetched back inside the pass
@@ -216,6 +324,9 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
 #pragma unroll
     for (int i = 0; i < L::NPARK; ++i) park[i * NTHR] = Md[4 + i][6];
+#if LPK_STAGED_LOAD
+    lds_barrier();                                         // (every wavefront is done with its load tile: the vectors' region may be written)
+#endif
 
     // ---- stage vectors: P0 <- lambda0 (operand of the setup product), lambda <- lambda0, R0 <- gamma, everything else (pads included) <- 0 ----
     for (int e = tid; e < L::RED; e += NTHR) lds[e] = 0.f;
