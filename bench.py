@@ -945,7 +945,7 @@ def main():
                                             "kernel_family": sol1.get_option("last_kernel_family"), "kernel_waves": sol1.get_option("last_kernel_waves")}
 
     if extras and rank == 0 and world == 1 and not args.profile_mini:
-        # horizons one CU cannot hold (BASELINE config 5's N = 512, and N = 256): the clustered lane-per-block kernel, fixed
+        # horizons one CU cannot hold (BASELINE config 5's N = 512, and N = 256): the clustered lane-pair kernel, fixed
         # iteration counts = the reference's caps (settings.cuh:123-139); 256 resident systems tiled to the batch
         lh = {}
         for Nl in ((512,) if lean else (256, 512)):          # (--profile-lean: only the streaming leg below)

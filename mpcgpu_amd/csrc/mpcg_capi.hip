@@ -60,7 +60,7 @@ struct mpcg_handle {
     float* seam_qinv = nullptr;      // schur_walk: one Q^-1 per chunk seam (max_batch x chunks x 196 floats)
     size_t seam_qinv_floats = 0;
     int cluster = -1;         // workgroups per trajectory of the clustered lane-pair kernel (pcg_lpk_cluster.hip.h): 0 off, -1 auto (N > 128), G > 0 forced
-    int cluster_l2 = 1;       // clustered lane-per-block kernel: 1 = L2-resident hand-offs when a cluster's members share an XCD, 0 = always write-through
+    int cluster_l2 = 1;       // clustered lane-pair kernel: 1 = L2-resident hand-offs when a cluster's members share an XCD, 0 = always write-through
     int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
     int check_symmetry = 0;   // debug: 1 = every solve that would run a lower-triangle kernel first verifies block symmetry of S and Pinv (synchronises)
     int last_sym_violations = 0;   //   block pairs that failed the check in the last solve (then solved by a three-column kernel)
@@ -331,7 +331,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
         return MPCG_OK;
     }
     // what the last solve on this handle launched
-    if (!strcmp(key, "last_kernel_family")) { *value = h->last.family; return MPCG_OK; }      // 0 single-workgroup, 1 cluster, 2 lane-per-block
+    if (!strcmp(key, "last_kernel_family")) { *value = h->last.family; return MPCG_OK; }      // 0 single-workgroup row-pair, 3 generic, 5 row-per-lane, 6 lane-pair, 7 clustered lane-pair
     if (!strcmp(key, "last_kernel_waves")) { *value = h->last.waves; return MPCG_OK; }
     if (!strcmp(key, "last_kernel_reg_rows")) { *value = h->last.reg_rows; return MPCG_OK; }
     if (!strcmp(key, "last_kernel_lds_rows")) { *value = h->last.lds_rows; return MPCG_OK; }
@@ -546,7 +546,7 @@ static int launch_rpl(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStrea
 }
 // Automatic use (no explicit pcg_* knob): N <= 32 always (N=32: 0.150 vs 0.247 ms for one trajectory, 395 vs 277 M it/s at batch 2048;
 // N=16: 875 vs 317 M); 32 < N <= 64 for latency-sized calls only (N=64 one trajectory 0.248 vs 0.341 ms, but 170 vs 211 M it/s at
-// batch 2048, where the lane-per-block / row-pair kernels stay ahead).
+// batch 2048, where the lane-pair / row-pair kernels stay ahead).
 static bool use_rpl(const mpcg_handle* h, int esz, uint32_t batch) {
     if (esz != 4 || h->N > kRplMaxN || h->rpl == 0) return false;
     if (h->rpl == 1) return true;

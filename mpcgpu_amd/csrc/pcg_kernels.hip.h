@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256) void zero_words_kernel(unsigned long long* p, 
     if (i < count) p[i] = 0ull;
 }
 
-// Debug check behind the "check_symmetry" option: the lane-per-block / lane-pair kernels read only the left and diagonal block
+// The symmetry latch / the "check_symmetry" debug option: the lane-pair kernels read only the left and diagonal block
 // columns of S and Pinv and use L_{k+1}^T where the reference's kernel reads block (k, right).  One wavefront per (trajectory,
 // k < N-1): counts the pairs whose blocks differ by more than rel_tol x the largest entry of the pair,
 //   max_ij | M[k, right](i, j) - M[k+1, left](j, i) |  >  rel_tol * max | M[k, right], M[k+1, left] |        (NaN counts as a violation).

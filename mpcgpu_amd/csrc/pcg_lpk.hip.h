@@ -1,7 +1,7 @@
 // pcg_lpk.hip.h — "lane pair per knot" PCG kernel for gfx950 (round 3): the register-resident successor of the
-// lane-per-block kernel (pcg_lpb.hip.h) for fp32, knot_points <= 128.  TWO barriers per PCG iteration.
+// lane-per-block kernel (round 2; retired in round 4, HISTORY.md §3.1c) for fp32, knot_points <= 128.  TWO barriers per PCG iteration.
 //
-// What the lane-per-block kernel left on the table (profiles/r02_lpb_ablate.txt): of 5,812 cycles per
+// What the lane-per-block kernel left on the table (HISTORY.md §3.1c, profiles/r02_lpb_ablate.txt): of 5,812 cycles per
 // iteration only 46 % were FMA chains; the off-diagonal waves carried 196 packed FMAs per pass against 98 on the diagonal
 // waves (two of four SIMDs idle half of every pass); every pass wrote three PART vectors (yD, yL, yT) to LDS that an
 // element-wise phase of ALL waves read back, summed and wrote again — FOUR "LDS write -> barrier -> LDS read" stages per
