@@ -4,7 +4,9 @@ import os, sys, json
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from mpcgpu_amd import PcgSolver, pcg_config, synth
+from mpcgpu_amd import PcgSolver, pcg_config, synth, _lib as _L
+if os.environ.get("AB_LIB"):
+    _L.LIB_PATH = os.environ["AB_LIB"]
 dev = torch.device("cuda")
 
 
