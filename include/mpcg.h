@@ -30,7 +30,10 @@
  *     matrices later must use a fresh handle — or "check_symmetry" = 1 (debug), which verifies every solve with a blocking 8-byte copy
  *     and reports the number of offending block pairs as "last_symmetry_violations".  A caller that fills ONLY the left and diagonal block
  *     columns (the right one unwritten) says so with "assume_symmetric" = 1 before its first solve: no check, lower-triangle kernels at
- *     once.  Families 0, 3 and 5 read all three columns anyway.
+ *     once.  Families 0 and 5 read all three columns anyway; so does family 3 for floats.  DOUBLE PRECISION beyond 32 knots (family 3,
+ *     a streaming kernel) uses the same latch to skip the right block column — a third of its HBM bytes: a handle that does not know yet
+ *     checks the matrices of its first mpcg_pcg_solve_f64 call with ONE blocking 8-byte copy (never during graph capture: a captured call
+ *     on such a handle reads all three columns).
  *   - gamma, lambda: [N][n] floats per trajectory; lambda is in/out (warm start,
  *     include/mpcsim.cuh:186,267,337).
  *   - every pointer named d_* is a DEVICE pointer on the handle's device; `stream` is a hipStream_t

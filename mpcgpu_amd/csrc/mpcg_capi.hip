@@ -826,7 +826,32 @@ static int launch_f64(mpcg_handle* h, PcgArgs64 a, uint32_t batch, void* stream)
         if (h->N <= 16) return a.pcols == 3 ? launch_rpl_f64_t<4, true>(h, a, batch, st) : launch_rpl_f64_t<4, false>(h, a, batch, st);
         return a.pcols == 3 ? launch_rpl_f64_t<8, true>(h, a, batch, st) : launch_rpl_f64_t<8, false>(h, a, batch, st);
     }
-    return h->generic ? launch_generic<double, 0>(h, a, batch, stream) : launch_generic<double, 14>(h, a, batch, stream);
+    if (h->generic) return launch_generic<double, 0>(h, a, batch, stream);
+    // The streaming kernel reads a third less when it may take block (k, right) from block (k+1, left) (mpcg.h, BLOCK SYMMETRY).  Same latch as
+    // the float path; a handle that does not know yet checks THIS call's matrices once, with one blocking 8-byte copy (never during capture:
+    // a capturing call reads all three columns).
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    sym_poll(h, st, true);
+    if (h->sym_state == 0 && !h->sym_pending) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+            HIP_TRY(h, hipSetDevice(h->device));
+            unsigned long long* flag = fixup_counter(h) + 9;
+            const long items = (long)batch * ((long)h->N - 1);
+            const unsigned blocks = (unsigned)((items + 3) / 4);
+            for (const double* m : {a.S, a.pcols == 3 ? a.Pinv : (const double*)nullptr})
+                if (m) hipLaunchKernelGGL(bd_symmetry_check_kernel<double>, dim3(blocks), dim3(256), 0, st, m, (int)h->N, (int)batch, kSymRelTol, (unsigned long long*)nullptr, flag);
+            HIP_TRY(h, hipGetLastError());
+            unsigned long long v = 0;
+            HIP_TRY(h, hipMemcpyAsync(&v, flag, sizeof v, hipMemcpyDeviceToHost, st));
+            HIP_TRY(h, hipStreamSynchronize(st));
+            h->sym_state = v ? 2 : 1;
+            if (v) h->err = "warning: S / Pinv of a solve on this handle were not block-symmetric (block (k, right) != block (k+1, left)^T): the handle now "
+                            "runs kernels that read all three block columns (include/mpcg.h, BLOCK SYMMETRY)";
+        }
+    }
+    a.lower = h->sym_state == 1 ? 1 : 0;
+    return launch_generic<double, 14>(h, a, batch, stream);
 }
 // state_size != 14, float: the PcgArgs of the tuned path re-packed for the generic kernel
 static int launch_generic_f32(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {

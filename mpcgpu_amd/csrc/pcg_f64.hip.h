@@ -30,6 +30,7 @@ struct PcgArgsG {
     uint32_t* iters; uint8_t* max_iter_exit;
     int N; int max_iter; T exit_tol; int pcols;        // pcols: 3 = SS, 1 = block-Jacobi
     int n = 14;                                        // state size (used when the kernel is instantiated with NFIX = 0)
+    int lower = 0;                                     // 1: never read the right block column (S and Pinv are block-symmetric: the handle's latch says so)
 };
 typedef PcgArgsG<double> PcgArgs64;
 
@@ -64,8 +65,22 @@ __global__ __launch_bounds__(F64_THREADS) void pcg_generic_kernel(PcgArgsG<T> a)
             real acc = real(0);
             for (int s = (cols == 3 ? 0 : 1); s < (cols == 3 ? 3 : 2); ++s) {
                 if ((s == 0 && k == 0) || (s == 2 && k == N - 1)) continue;
-                const real* blk = M + ((size_t)k * 3 + s) * nn;
                 const real* xk = x + (size_t)(k + s) * n;
+                if (s == 2 && a.lower) {
+                    // block (k, right) = block (k+1, left)^T (mpcg.h, BLOCK SYMMETRY): row i of it is COLUMN i of the left block of row k + 1 —
+                    // n contiguous elements, and a block the threads of row k + 1 read in this very pass.  The same products in the same order as
+                    // from the right block itself (bit-identical on symmetric matrices); a third of the HBM bytes of a pass gone: double N=64
+                    // 11.3 -> 15.4 M it/s, N=128 5.1 -> 7.4 M (tools/_prof/f64_rate.py).
+                    const real* blt = M + ((size_t)(k + 1) * 3) * nn + (size_t)i * n;
+                    if constexpr (NFIX > 0) {
+#pragma unroll
+                        for (int c = 0; c < NFIX; ++c) acc = fma_t(blt[c], xk[c], acc);
+                    } else {
+                        for (int c = 0; c < n; ++c) acc = fma_t(blt[c], xk[c], acc);
+                    }
+                    continue;
+                }
+                const real* blk = M + ((size_t)k * 3 + s) * nn;
 if constexpr (NFIX > 0) {
 #pragma unroll
                     for (int c = 0; c < NFIX; ++c) acc = fma_t(blk[i + c * n], xk[c], acc);

@@ -111,3 +111,67 @@ def test_f64_wrappers_reject_mixed_precision():
     G, C, g, c = synth.pack_kkt_dense(k, np.float64)
     with pytest.raises(ValueError):
         sol.form_schur(dev(G.astype(np.float32)), dev(C), dev(g), dev(c), 1e-3)
+
+
+@pytest.mark.parametrize("N", [64, 128])
+def test_f64_streaming_kernel_reads_the_lower_triangle_once_the_latch_says_symmetric(orc, N):
+    """linsys_t = double beyond N = 32: block (k, right) is taken from block (k+1, left) once the handle knows the matrices are block-symmetric
+    (one blocking check on the first call).  Same products in the same order: against a solve that reads all three columns (a CAPTURED
+    solve on a fresh handle does: the check cannot run during capture) bit-identical with the block-Jacobi preconditioner — S's right blocks
+    ARE the transposed left ones — and equal to the round-off of the symmetric-stair Pinv, whose two halves are the same triple product
+    associated two ways; with NaN in every right block and "assume_symmetric" the same bits as the latched solve; a structurally asymmetric
+    Pinv is solved as given (three columns, oracle) and latches the handle the other way."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    B, K = 3, 30
+    k = synth.make_kkt(N, B, 4100 + N)
+    S, Pinv, g = synth.form_schur(k, dtype=np.float64)
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    sol = PcgSolver(N, max_batch=B)
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    sol.solve_f64(dS, dP, dg, lam, cfg)
+    torch.cuda.synchronize()
+    assert sol.get_option("symmetry_state") == 1 and sol.get_option("last_kernel_family") == 3
+    # all three columns: a fresh handle whose first solve is captured
+    sol3 = PcgSolver(N, max_batch=B)
+    lam3 = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    it3 = torch.zeros(B, dtype=torch.int32, device="cuda"); ex3 = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            sol3.solve_f64(dS, dP, dg, lam3, cfg, iters=it3, exits=ex3)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert sol3.get_option("symmetry_state") == 0
+    assert relinf(lam.cpu().numpy(), lam3.cpu().numpy()) < 1e-9
+    lamj, lamj3 = torch.zeros_like(lam), torch.zeros_like(lam)
+    sol.solve_f64(dS, dP, dg, lamj, cfg, "jacobi")
+    with torch.cuda.stream(side):
+        graphj = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graphj, stream=side):
+            sol3.solve_f64(dS, dP, dg, lamj3, cfg, "jacobi", iters=it3, exits=ex3)
+    graphj.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(lamj.cpu().numpy(), lamj3.cpu().numpy())
+    # right blocks unread
+    Sp, Pp = S.copy().reshape(B, N, 3, 196), Pinv.copy().reshape(B, N, 3, 196)
+    Sp[:, :, 2, :] = np.nan; Pp[:, :, 2, :] = np.nan
+    solp = PcgSolver(N, max_batch=B)
+    solp.set_option("assume_symmetric", 1)
+    lamp = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    solp.solve_f64(dev(Sp.reshape(B, -1)), dev(Pp.reshape(B, -1)), dg, lamp, cfg)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(lam.cpu().numpy(), lamp.cpu().numpy())
+    # asymmetric Pinv
+    Pa = Pinv.copy().reshape(B, N, 3, 196)
+    Pa[:, :-1, 2, :] *= 1.25
+    Pa = Pa.reshape(B, -1)
+    sola = PcgSolver(N, max_batch=B)
+    lama = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    sola.solve_f64(dS, dev(Pa), dg, lama, cfg)
+    torch.cuda.synchronize()
+    assert sola.get_option("symmetry_state") == 2
+    for b in range(B):
+        ref = orc.pcg(S[b], Pa[b], g[b], np.zeros(n * N), N, K, 0.0, "ss")["lam"]
+        assert relinf(lama[b].cpu().numpy(), ref) < 1e-8

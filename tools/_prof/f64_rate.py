@@ -6,7 +6,9 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench
-from mpcgpu_amd import PcgSolver, pcg_config
+from mpcgpu_amd import PcgSolver, pcg_config, _lib as _L
+if os.environ.get("AB_LIB"):
+    _L.LIB_PATH = os.environ["AB_LIB"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 dev = torch.device("cuda:0")
 for N in (16, 32, 64, 128):
