@@ -1002,6 +1002,25 @@ def main():
             del Sl, Pl, gl, ll, sl
         if lh:
             out["long_horizon"] = lh
+            # ---- linsys_t = double (USE_DOUBLES of the reference): the bench workload's own systems in double, fixed 40 iterations.  N <= 32 would run the
+            # register-resident row-per-lane kernel; N = 128 runs the streaming kernel, which reads TWO block columns once the symmetry latch allows
+            try:
+                Bd = min(B, 1024)
+                S64, P64, g64 = torch.nan_to_num(d_S[:Bd]).double(), torch.nan_to_num(d_P[:Bd]).double(), d_g[:Bd].double()
+                l64 = torch.zeros(Bd, 14 * N, dtype=torch.float64, device=dev)
+                i64 = torch.zeros(Bd, dtype=torch.int32, device=dev); x64 = torch.zeros(Bd, dtype=torch.uint8, device=dev)
+                c64 = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=40)
+                sol.solve_f64(S64, P64, g64, l64, c64, args.precond, iters=i64, exits=x64)          # (first call: the latch's one blocking check)
+                ms64 = timed(lambda: (l64.zero_(), sol.solve_f64(S64, P64, g64, l64, c64, args.precond, iters=i64, exits=x64)), 3, warm=1) - timed(lambda: l64.zero_(), 3, warm=1)
+                cols64 = 2 if sol.get_option("symmetry_state") == 1 else 3
+                by64 = 2 * cols64 * 196 * N * 8
+                out["double_precision"] = {"knot_points": N, "batch": Bd, "pcg_iters_per_solve": 40, "kernel_ms": ms64, "pcg_iterations_per_sec": Bd * 40 / (ms64 * 1e-3),
+                                           "kernel_family": sol.get_option("last_kernel_family"), "block_columns_read": cols64, "bytes_per_unit": by64,
+                                           "achieved": Bd * 40 * by64 / (ms64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": Bd * 40 * by64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "bound": "hbm (S and Pinv re-read every iteration: a double N=128 trajectory is 1.2 MB, 2.4x the register file)"}
+                del S64, P64, g64, l64
+            except Exception as e_:
+                out["double_precision"] = {"error": repr(e_)}
             # ---- the clustered kernel against the floor of ITS design ("break 0.15 or prove the floor") ----
             # Classic PCG needs two cluster-wide reductions per iteration, each behind a matrix pass, and nothing of the next half can start
             # before the reduced inner product is known.  Phase stamps of one iteration (profiles/r04_lpkc_phases.txt, N = 256, shader clocks
