@@ -801,12 +801,13 @@ static int launch_generic(mpcg_handle* h, PcgArgsG<T> a, uint32_t batch, void* s
     a.n = (int)h->n;
     const size_t lds = pcg_generic_lds_elems((int)h->N, (int)h->n) * sizeof(T);
     if (lds > kLdsMax) return fail(h, MPCG_ERR_UNSUPPORTED, "generic / double-precision kernel: the iterate vectors do not fit 160 KiB of LDS");
-    auto kern = pcg_generic_kernel<T, NFIX>;
+    const int nthr = pcg_generic_threads((int)h->N, (int)h->n);
+    void (*kern)(PcgArgsG<T>) = nthr == F64_THREADS_WIDE ? pcg_generic_kernel<T, NFIX, F64_THREADS_WIDE> : pcg_generic_kernel<T, NFIX, F64_THREADS>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(batch), dim3(F64_THREADS), lds, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, dim3(batch), dim3(nthr), lds, static_cast<hipStream_t>(stream), a);
     HIP_TRY(h, hipGetLastError());
-    h->last = LastKernel{3, F64_THREADS / 64, 0, 0, 2, 0, (int)lds, 0};      // family 3 = generic streaming kernel
+    h->last = LastKernel{3, nthr / 64, 0, 0, 2, 0, (int)lds, 0};      // family 3 = generic streaming kernel
     return MPCG_OK;
 }
 // double precision, N <= 32 (the real-time horizon): the row-per-lane kernel in double, one slot per wavefront
@@ -872,9 +873,10 @@ int mpcg_check_pcg_occupancy(mpcg_handle* h, uint32_t* resident_trajectories) {
     int per_cu = 0;
     if (h->generic) {
         const size_t lds = pcg_generic_lds_elems((int)h->N, (int)h->n) * sizeof(float);
-        auto kern = pcg_generic_kernel<float, 0>;
+        const int nthr = pcg_generic_threads((int)h->N, (int)h->n);
+        void (*kern)(PcgArgsG<float>) = nthr == F64_THREADS_WIDE ? pcg_generic_kernel<float, 0, F64_THREADS_WIDE> : pcg_generic_kernel<float, 0, F64_THREADS>;
         if (lds > 48 * 1024) HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, F64_THREADS, lds));
+        HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, nthr, lds));
     } else if (use_rpl(h, 4, h->max_batch)) {
         // mirrors launch_pcg for a throughput-sized call (batch = max_batch): the row-per-lane kernel in the shape that call would take
         int nw, rho;

@@ -34,16 +34,18 @@ struct PcgArgsG {
 };
 typedef PcgArgsG<double> PcgArgs64;
 
-constexpr int F64_THREADS = 256;
-__host__ __device__ constexpr size_t pcg_generic_lds_elems(int N, int n) { return 2 * (size_t)(N + 2) * n + 2 * (size_t)N * n + 8; }
+constexpr int F64_THREADS = 256;                   // threads per trajectory: short systems ...
+constexpr int F64_THREADS_WIDE = 1024;             // ... and from 64 x 14 rows upwards (more loads in flight per CU: double N=128 7.0 -> 8.1 M it/s)
+__host__ __device__ constexpr int pcg_generic_threads(int N, int n) { return N * n >= 64 * 14 ? F64_THREADS_WIDE : F64_THREADS; }
+__host__ __device__ constexpr size_t pcg_generic_lds_elems(int N, int n) { return 2 * (size_t)(N + 2) * n + 2 * (size_t)N * n + 16; }
 __host__ __device__ constexpr size_t pcg_f64_lds_doubles(int N) { return pcg_generic_lds_elems(N, 14); }
 
 // NFIX > 0: state size compiled in (inner products unrolled); NFIX = 0: a.n at run time.
-template <typename T, int NFIX>
-__global__ __launch_bounds__(F64_THREADS) void pcg_generic_kernel(PcgArgsG<T> a) {
+template <typename T, int NFIX, int NTHR>
+__global__ __launch_bounds__(NTHR) void pcg_generic_kernel(PcgArgsG<T> a) {
     typedef T real;
     const int n = NFIX ? NFIX : a.n, nn = n * n;
-    constexpr int NT = F64_THREADS;
+    constexpr int NT = NTHR;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     real* lds64 = reinterpret_cast<real*>(lds_raw);
     const int N = a.N, tid = threadIdx.x, b = blockIdx.x;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(F64_THREADS) void pcg_generic_kernel(PcgArgsG<T> a)
                     // block (k, right) = block (k+1, left)^T (mpcg.h, BLOCK SYMMETRY): row i of it is COLUMN i of the left block of row k + 1 —
                     // n contiguous elements, and a block the threads of row k + 1 read in this very pass.  The same products in the same order as
                     // from the right block itself (bit-identical on symmetric matrices); a third of the HBM bytes of a pass gone: double N=64
-                    // 11.3 -> 15.4 M it/s, N=128 5.1 -> 7.4 M (tools/_prof/f64_rate.py).
+                    // 11.3 -> 15.4 M it/s, N=128 5.1 -> 7.0 M (tools/_prof/f64_rate.py; 17.3 / 8.1 M with the wide workgroup).
                     const real* blt = M + ((size_t)(k + 1) * 3) * nn + (size_t)i * n;
                     if constexpr (NFIX > 0) {
 #pragma unroll

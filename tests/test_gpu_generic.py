@@ -68,4 +68,4 @@ def test_generic_state_size_vs_oracle(orc, n, N, pc):
         sol.bt_spmv(dS, dg)
     assert e.value.code == _lib.MPCG_ERR_UNSUPPORTED
     assert sol.checkPcgOccupancy() >= sol.get_option("num_cus")
-    assert sol.lib.mpcg_pcg_lds_bytes(n, N) == 4 * (2 * (N + 2) * n + 2 * N * n + 8)
+    assert sol.lib.mpcg_pcg_lds_bytes(n, N) == 4 * (2 * (N + 2) * n + 2 * N * n + 16)
