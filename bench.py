@@ -379,8 +379,17 @@ def cpu_model():
     return "unknown"
 
 
+RAMP_S = 0.02      # every timed leg first runs its function back to back for this long
+
+
 def timed(fn, reps, warm=1):
-    """Median HIP-event time (ms) of `fn` over `reps` runs on the current stream (= the stream the kernels are launched on)."""
+    """Median HIP-event time (ms) of `fn` over `reps` runs on the current stream (= the stream the kernels are launched on).
+    The function first runs back to back for RAMP_S seconds: a leg of a few sub-millisecond launches after a host-side pause is otherwise timed on a
+    GPU that has not reached its steady clocks (the timed region itself: 125-129 M it/s with 10 steps after 2, 138-140 M with 200 after 20)."""
+    t_end = time.perf_counter() + RAMP_S
+    while time.perf_counter() < t_end:
+        fn()
+        torch.cuda.synchronize()            # (bounds the ramp in GPU time: unsynchronised, 20 ms of host time enqueue seconds of work)
     ts = []
     for i in range(reps + warm):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -460,8 +469,8 @@ def plumbing_only(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)     # (0.25 s of timed steps: the GPU's steady state; 10 after 2 measure the clock ramp, see timed())
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--knots", type=int, default=128)
     ap.add_argument("--batch", type=int, default=1024, help="trajectories per GPU (--scaling weak) or in total (--scaling strong)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
