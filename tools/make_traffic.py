@@ -19,8 +19,19 @@ for name, k in pmc.items():
         key = f"bt_spmv_kernel|N{N}_B{spB}"
     elif "pcg_traj_kernel<16, 0, 2" in name:
         key = f"pcg_traj_kernel<16,0,2>|N512_B{B}_ss_it67_tol0"          # bench.py's streaming leg: N = 512, batch B, 67 fixed iterations
+    elif "generate_kkt_kernel<true>" in name:
+        key = f"generate_kkt|N{N}_B{B}"
+    elif "compute_dz_dpp_kernel" in name:
+        key = f"compute_dz|N{N}_B{B}"
+    elif "schur_walk_kernel" in name:
+        key = f"form_schur|N{N}_B{B}"
     else:
         continue
+    if key.startswith("form_schur"):      # the formation is two kernels: the walking pass + the seam kernel
+        seam = next((v for n_, v in pmc.items() if "schur_seam_kernel" in n_ and "hbm_traffic_bytes_per_launch" in v), None)
+        if seam:
+            k = dict(k, hbm_traffic_bytes_per_launch=k["hbm_traffic_bytes_per_launch"] + seam["hbm_traffic_bytes_per_launch"],
+                     fetch_bytes_corrected=k["fetch_bytes_corrected"] + seam["fetch_bytes_corrected"], write_bytes=k["write_bytes"] + seam["write_bytes"])
     out["kernels"][key] = {"kernel": name, "hbm_traffic_bytes_per_launch": k["hbm_traffic_bytes_per_launch"],
                            "fetch_bytes_corrected": k["fetch_bytes_corrected"], "write_bytes": k["write_bytes"],
                            "launches_averaged": k["FETCH_SIZE"]["launches"]}
