@@ -45,7 +45,7 @@ def test_world_size_mismatch_is_an_error():
 def test_more_ranks_than_devices_is_refused_not_degraded():
     import torch
     n = torch.cuda.device_count() + 1
-    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline", "--full-json", ""],
                        capture_output=True, text=True, timeout=300, env=_clean_env())
     assert r.returncode == 2 and "refusing to run fewer ranks" in r.stderr and '{"metric"' not in r.stdout
 
@@ -59,7 +59,7 @@ def test_self_launched_two_ranks_solve_on_the_gpu():
     if torch.cuda.device_count() < 2:
         env.update(MPCG_FORCE_DEVICE="0", MPCG_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "96", "--knots", "64", "--scaling", "strong",
-                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+                        "--no-extras", "--no-cpu-baseline", "--full-json", ""], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     out = _line(r.stdout)
     assert out["n_gpus"] == 2 and out["self_launched"] is True and out["scaling"] == "strong"

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_runs_its_collectives_over_rccl_at_world_size_one(scaling):
     env = dict(os.environ, MPCG_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "96",
-                        "--knots", "64", "--scaling", scaling, "--no-extras", "--no-cpu-baseline"],
+                        "--knots", "64", "--scaling", scaling, "--no-extras", "--no-cpu-baseline", "--full-json", ""],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
