@@ -4,6 +4,7 @@ mpcgpu_amd.PcgSolver) — against the CPU oracle and the committed golden vector
 Stated fp32 tolerance, E = |lam_hip - lam_f64|_inf / |lam_f64|_inf against the
 float64 iterate after the SAME number of iterations (exit_tol = 0):
   K <= 3  : E <= max(2e-5, 4*band), band < 5e-4 (before CG amplifies rounding: pins the arithmetic)
+  K = 10  : E <= max(1e-4, 4*band) (the tier between: a 1e-4-level arithmetic slip no longer hides under the K <= 50 floor)
   K <= 50 : E <= max(1e-3, 4*band), band = util.fp32_band = what the CPU float32 restatement does on
             the same and on 1-ulp-perturbed inputs (fp32 CG at cond ~1e5 drifts 1e-4..4e-3 by K=25-50
             whatever the summation order).
@@ -166,6 +167,26 @@ def test_pcg_first_iterations_tight(P, orc, N, pc):
             assert relinf(lam[b], r64["lam"]) <= max(2e-5, 4 * band), (K, b, relinf(lam[b], r64["lam"]), band)
 
 
+@pytest.mark.parametrize("N", [8, 32, 128, 256, 512])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+def test_pcg_ten_iterations_middle_tier(P, orc, N, pc):
+    """K = 10 (VERDICT r04 #2c): E <= max(1e-4, 4 x band) — ten times tighter than the K <= 50 floor of 1e-3, on every kernel family of the
+    default policy (N = 8 / 32: row-per-lane, 128: lane-pair, 256 / 512: clustered), cold and warm start."""
+    B = 2
+    k = synth.make_kkt(N, B, 77 + N)
+    S, Pinv, g = synth.form_schur(k, poison_unused=True)
+    rng = np.random.default_rng(10 + N)
+    for lam0 in (np.zeros((B, n * N), np.float32), rng.normal(0, 0.3, (B, n * N)).astype(np.float32)):
+        lam, it, ex = solve(P, N, S, Pinv, g, lam0, 10, 0.0, pc)
+        assert (it == 10).all() and (ex == 1).all()
+        for b in range(B):
+            Sz, Pz = np.nan_to_num(S[b]), np.nan_to_num(Pinv[b])
+            r64 = orc.pcg(Sz.astype(np.float64), Pz.astype(np.float64), g[b].astype(np.float64), lam0[b].astype(np.float64), N, 10, 0.0, pc)
+            band = fp32_band(orc, Sz, Pz, g[b], lam0[b], N, 10, pc, r64["lam"])
+            e = relinf(lam[b], r64["lam"])
+            assert e <= max(1e-4, 4 * band), (N, pc, b, e, band)
+
+
 @pytest.mark.parametrize("N", [8, 32])
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
 def test_pcg_tolerance_exit_vs_golden(P, orc, N, pc):
@@ -271,7 +292,10 @@ def test_solve_ref_twelve_argument_entry(P, orc):
     assert int(d_iters.item()) == 20 and bool(d_exit.item()) is True
     band = fp32_band(orc, G["S"], G["Pinv"], G["gamma"], np.zeros(n * N), N, 20, "ss", G["lam_ss_K20"])
     assert relinf(d_lambda.cpu().numpy(), G["lam_ss_K20"]) <= max(1e-3, 4 * band)
-    assert relinf(d_r.cpu().numpy(), r64["r"]) < 5e-2 and relinf(d_p.cpu().numpy(), r64["p"]) < 5e-2
+    # d_r / d_p = r and p of the last completed update: inside the same float32 band as lambda (tests/test_gpu_invariants.py pins them much harder,
+    # against the recurrences themselves)
+    rb = max(relinf(orc.pcg(G["S"], G["Pinv"], G["gamma"], np.zeros(n * N, np.float32), N, 20, 0.0, "ss")[k_], r64[k_]) for k_ in ("r", "p"))
+    assert relinf(d_r.cpu().numpy(), r64["r"]) <= max(1e-3, 4 * rb) and relinf(d_p.cpu().numpy(), r64["p"]) <= max(1e-3, 4 * rb)
     assert (d_v_temp == 3.0).all() and (d_eta_new_temp == 3.0).all()       # accepted, untouched
     # inputs are not modified
     np.testing.assert_array_equal(d_S.cpu().numpy(), G["S"])
