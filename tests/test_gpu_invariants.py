@@ -3,14 +3,16 @@ comparison side (VERDICT r04 #2b).  The 12-argument entry (include/pcg/sqp.cuh:1
 update; the kernels are deterministic, so a run capped at K - 1 iterations IS the state the K-iteration run passed through.  From the two
 states, with S / Pinv / gamma promoted to float64 and nothing but textbook preconditioned CG (what pcg<> computes):
 
-  step      alpha = (r' Pinv r) / (p' S p) from state K-1;   lambda_K = lambda_{K-1} + alpha p_{K-1};   r_K = r_{K-1} - alpha S p_{K-1};
-            beta = (r_K' Pinv r_K) / (r_{K-1}' Pinv r_{K-1});   p_K = Pinv r_K + beta p_{K-1}
-            — ONE iteration of float32 arithmetic against its float64 evaluation: rounding has not been amplified by CG, so the tolerance is
-            a few 1e-5 of each update's size (a 1e-4 arithmetic slip fails; the K-iterate comparisons of test_gpu_parity.py, with their
-            max(1e-3, 4 x band), would pass it);
-  gap       || d_r - (gamma - S lambda_K) || <= 16 K eps32 ||S||_inf max(||lambda||) (the classical bound on the drift of the updated residual);
-  conjugacy | p_K' S p_{K-1} | / sqrt((p_K' S p_K)(p_{K-1}' S p_{K-1})) small (local conjugacy survives finite precision);
-  orthogonality  | r_K' Pinv r_{K-1} | / sqrt(eta_K eta_{K-1}) small.
+  step      lambda_K = lambda_{K-1} + alpha p_{K-1};   r_K = r_{K-1} - alpha S p_{K-1};   p_K = Pinv r_K + beta p_{K-1}, with the alpha / beta the kernel
+            itself used (recovered from its updates), each within a few float32 ulps (u = 2^-24) of the SIZE OF ITS TERMS (|S||p|, |Pinv||r|:
+            cancellation inside the three-block sums is accounted for, so the limits are O(1) x u whatever N, K or the conditioning);
+  scalars   that alpha = (r' Pinv r) / (p' S p) and beta = (r_K' Pinv r_K) / (r_{K-1}' Pinv r_{K-1}) of the float64 evaluation, within a
+            few u x the cancellation of the inner products
+            — ONE iteration of float32 arithmetic against its float64 evaluation: rounding has not been amplified by CG, so an error of a few
+            ulps in one update fails (the K-iterate comparisons of test_gpu_parity.py, with max(1e-3, 4 x band), would pass a 1e-4 slip);
+  gap       || d_r - (gamma - S lambda_K) || <= 2 K u ||S||_inf max ||lambda|| (the classical bound on the drift of the updated residual);
+  conjugacy | p_K' S p_{K-1} | / sqrt((p_K' S p_K)(p_{K-1}' S p_{K-1})) <= 2e-3 (local conjugacy survives finite precision);
+  orthogonality  | r_K' Pinv r_{K-1} | / sqrt(eta_K eta_{K-1}) <= 2e-3.
 
 K = 10, 50, 167 for N = 32 (row-per-lane kernel), 128 (lane-pair kernel), 512 (clustered kernel); symmetric-stair and block-Jacobi Pinv."""
 import numpy as np
@@ -50,6 +52,50 @@ def state(sol, dS, dP, dg, lam0, K):
     return out
 
 
+def abs_matvec(M, x, N):
+    """|M| |x|: the size of the terms a float32 evaluation of M x rounds (cancellation inside the three-block sums shows here, not in |M x|)."""
+    return bt_matvec(np.abs(np.nan_to_num(M)), np.abs(x), N)
+
+
+def step_quantities(S, P, g, lam0, st_a, st_b, N, K):
+    """Every checked quantity DIVIDED BY the scale its float32 rounding model gives it (u = 2^-24): a correct kernel lands at O(1..30)
+    whatever N, K, the preconditioner or the conditioning; tools/_prof/inv_probe.py prints them for 96 (system, K) pairs."""
+    (lam_a, r_a, p_a), (lam_b, r_b, p_b) = st_a, st_b
+    inf = lambda x: np.abs(x).max()
+    Sp, z_a, z_b = bt_matvec(S, p_a, N), bt_matvec(P, r_a, N), bt_matvec(P, r_b, N)
+    eta_a, eta_b, v = r_a @ z_a, r_b @ z_b, p_a @ Sp
+    assert eta_a < 0 and eta_b < 0 and v < 0             # S and Pinv are stored negated (include/pcg/linsys_setup.cuh:15-19): eta = r' Pinv r < 0
+    alpha, beta = eta_a / v, eta_b / eta_a
+    # what the kernel itself used, recovered from its own updates (least squares along p_{K-1})
+    alpha_hat = ((lam_b - lam_a) @ p_a) / (p_a @ p_a)
+    beta_hat = ((p_b - z_b) @ p_a) / (p_a @ p_a)
+    # cancellation of the three inner products: sum |terms| / |sum|
+    c_eta_a = (np.abs(r_a) @ abs_matvec(P, r_a, N)) / abs(eta_a)
+    c_eta_b = (np.abs(r_b) @ abs_matvec(P, r_b, N)) / abs(eta_b)
+    c_v = (np.abs(p_a) @ abs_matvec(S, p_a, N)) / abs(v)
+    q = {
+        # the update directions, with the kernel's own scalars: pure axpy / matvec rounding
+        "lam": inf(lam_b - (lam_a + alpha_hat * p_a)) / (EPS32 * (inf(lam_b) + abs(alpha_hat) * inf(p_a))),
+        "r": inf(r_b - (r_a - alpha_hat * Sp)) / (EPS32 * (inf(r_a) + abs(alpha_hat) * inf(abs_matvec(S, p_a, N)))),
+        "p": inf(p_b - (z_b + beta_hat * p_a)) / (EPS32 * (inf(abs_matvec(P, r_b, N)) + abs(beta_hat) * inf(p_a))),
+        # the scalars: float32 inner products of ~14 N terms against their float64 values, scaled by the cancellation of the sums
+        "alpha": abs(alpha_hat / alpha - 1) / (EPS32 * (c_eta_a + c_v)),
+        "beta": abs(beta_hat / beta - 1) / (EPS32 * (c_eta_a + c_eta_b)),
+    }
+    Snorm = np.abs(np.nan_to_num(S).astype(np.float64).reshape(N, 3, n, n)).sum(axis=(1, 2)).max()      # ||S||_inf (a block row's three blocks, summed along rows)
+    true_r = g.astype(np.float64) - bt_matvec(S, lam_b, N)
+    q["gap"] = np.linalg.norm(r_b - true_r) / (K * EPS32 * Snorm * max(np.linalg.norm(lam_b), np.linalg.norm(lam0)))
+    q["conjugacy"] = abs(p_b @ Sp) / np.sqrt((p_b @ bt_matvec(S, p_b, N)) * v)
+    q["orthogonality"] = abs(r_b @ z_a) / np.sqrt(eta_a * eta_b)
+    return q
+
+
+# Worst over 96 (system, K) pairs on an MI355X (tools/_prof/inv_probe.py -> profiles/r05_invariants.txt): lam 0.89 u, r 1.67 u, p 0.95 u of their update's
+# terms; alpha 0.57, beta 1.26 u x the cancellation of their inner products; gap 0.30 of K u ||S|| ||lambda||; conjugacy 1.7e-4, orthogonality 3.4e-4.
+# The limits leave a factor 4-6: an error of a few float32 ulps in ONE update of ONE iteration fails.
+LIMITS = {"lam": 4.0, "r": 8.0, "p": 8.0, "alpha": 8.0, "beta": 8.0, "gap": 2.0, "conjugacy": 2e-3, "orthogonality": 2e-3}
+
+
 @pytest.mark.parametrize("N,family", [(32, 5), (128, 6), (512, 7)])
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
 def test_one_step_of_the_recurrences_and_the_cg_invariants(N, family, pc):
@@ -61,38 +107,11 @@ def test_one_step_of_the_recurrences_and_the_cg_invariants(N, family, pc):
     lam0 = (0.1 * rng.standard_normal(n * N)).astype(np.float32)
     sol = PcgSolver(N, max_batch=1)
     dS, dP, dg = (torch.from_numpy(a).cuda() for a in (S, P, g))
-    g64 = g.astype(np.float64)
-    Snorm = np.abs(np.nan_to_num(S).astype(np.float64).reshape(N, 3, n, n)).sum(axis=(1, 2)).max()      # ||S||_inf (rows of a block row: sum over its three blocks' columns)
-    report = []
     for K in (10, 50, 167):
-        lam_a, r_a, p_a = state(sol, dS, dP, dg, lam0, K - 1)
+        st_a = state(sol, dS, dP, dg, lam0, K - 1)
         assert sol.get_option("last_kernel_family") == family
-        lam_b, r_b, p_b = state(sol, dS, dP, dg, lam0, K)
-        Sp = bt_matvec(S, p_a, N)
-        z_a, z_b = bt_matvec(P, r_a, N), bt_matvec(P, r_b, N)
-        eta_a, eta_b, v = r_a @ z_a, r_b @ z_b, p_a @ Sp
-        alpha, beta = eta_a / v, eta_b / eta_a
-        assert eta_a < 0 and eta_b < 0 and v < 0             # S and Pinv are stored negated (include/pcg/linsys_setup.cuh:15-19): eta = r' Pinv r < 0
-        # ---- one step, float32 on the device against float64 here ----
-        inf = lambda x: np.abs(x).max()
-        e_lam = inf(lam_b - (lam_a + alpha * p_a)) / (abs(alpha) * inf(p_a))
-        e_r = inf(r_b - (r_a - alpha * Sp)) / max(abs(alpha) * inf(Sp), inf(r_a))
-        e_p = inf(p_b - (z_b + beta * p_a)) / max(inf(z_b), abs(beta) * inf(p_a))
-        # lambda is rounded to float32 at every update: its own half-ulp is part of e_lam when the update is small against lambda itself
-        lam_ulp = EPS32 * inf(lam_b) / (abs(alpha) * inf(p_a))
-        assert e_lam <= 3e-5 + 2 * lam_ulp, (N, pc, K, "lambda", e_lam, lam_ulp)
-        assert e_r <= 3e-5, (N, pc, K, "r", e_r)
-        assert e_p <= 3e-5, (N, pc, K, "p", e_p)
-        # ---- drift of the updated residual from the true one ----
-        true_r = g64 - bt_matvec(S, lam_b, N)
-        gap = np.linalg.norm(r_b - true_r)
-        bound = 16 * K * EPS32 * Snorm * max(np.linalg.norm(lam_b), np.linalg.norm(lam0))
-        assert gap <= bound, (N, pc, K, "gap", gap, bound)
-        # ---- local conjugacy / orthogonality ----
-        conj = abs(p_b @ Sp) / np.sqrt((p_b @ bt_matvec(S, p_b, N)) * v)
-        orth = abs(r_b @ z_a) / np.sqrt(eta_a * eta_b)
-        assert conj <= 2e-3, (N, pc, K, "conjugacy", conj)
-        assert orth <= 2e-3, (N, pc, K, "orthogonality", orth)
-        report.append((K, e_lam, e_r, e_p, gap / np.linalg.norm(g64), bound / np.linalg.norm(g64), conj, orth))
-    for row in report:
-        print("N=%d %s K=%d: step lambda %.1e r %.1e p %.1e | gap/|gamma| %.1e (bound %.1e) | conjugacy %.1e orthogonality %.1e" % ((N, pc) + row))
+        st_b = state(sol, dS, dP, dg, lam0, K)
+        q = step_quantities(S, P, g, lam0, st_a, st_b, N, K)
+        print(f"N={N} {pc} K={K}: " + " ".join(f"{a} {b:.2g}" for a, b in q.items()))
+        for key, lim in LIMITS.items():
+            assert q[key] <= lim, (N, pc, K, key, q[key], lim)
