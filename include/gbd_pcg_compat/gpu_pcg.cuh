@@ -18,9 +18,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
-#include <mutex>
-#include <thread>
-#include <tuple>
 #include <type_traits>
 #include <utility>
 
@@ -45,20 +42,27 @@ inline void die(const char* what, const mpcg_handle* h) {
 }
 
 // One cached handle per (host thread, device, knot_points): a handle is re-entrant per handle, not across threads, so two host threads
-// (the native multi-device driver pattern: a thread + stream + handle per device, examples/multi_gpu_pcg.cpp) never share one; the cache
-// itself is guarded by a mutex.  The solver keeps no per-call global scratch.
+// (the native multi-device driver pattern: a thread + stream + handle per device, examples/multi_gpu_pcg.cpp) never share one.  The cache
+// is THREAD-LOCAL and owns its handles: when a host thread ends, its handles — cluster scratch, dispatch order, the latch's pinned word and
+// event — are destroyed with it, so per-solve std::thread churn does not grow device memory and a reused thread::id cannot inherit
+// another thread's handle or latch state.  The solver keeps no per-call global scratch.
+struct HandleCache {
+    std::map<std::pair<int, uint32_t>, mpcg_handle*> handles;
+    ~HandleCache() {
+        for (auto& kv : handles) (void)mpcg_destroy(kv.second);
+    }
+};
+
 inline mpcg_handle* handle_for(uint32_t state_size, uint32_t knot_points) {
-    static std::mutex mu;
-    static std::map<std::tuple<std::thread::id, int, uint32_t>, mpcg_handle*> cache;
+    static thread_local HandleCache cache;
     int dev = 0;
     gpuErrchk(hipGetDevice(&dev));
-    const auto key = std::make_tuple(std::this_thread::get_id(), dev, knot_points);
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
+    const auto key = std::make_pair(dev, knot_points);
+    auto it = cache.handles.find(key);
+    if (it != cache.handles.end()) return it->second;
     mpcg_handle* h = nullptr;
     if (mpcg_create(&h, dev, state_size, knot_points, 1) != MPCG_OK) die("mpcg_create", nullptr);
-    cache[key] = h;
+    cache.handles[key] = h;
     return h;
 }
 

@@ -54,7 +54,10 @@
 extern "C" {
 #endif
 
-#define MPCG_ABI_VERSION 1
+/* 2 (round 5): the BLOCK SYMMETRY contract is checked by the handle itself (a caller that fills ONLY the left + diagonal block columns must
+ * set "assume_symmetric" = 1 — round-3 text allowed garbage in the right blocks without it); options pcg_lpb / cluster_lpb / cluster_lpk /
+ * cluster_waves / cluster_adj / schur_fma / schur_inplace are gone; mpcg_probe_hbm_read, "kkt_analytic", "pcg_variant" are new. */
+#define MPCG_ABI_VERSION 2
 
 typedef enum mpcg_status {
     MPCG_OK = 0,
@@ -250,10 +253,14 @@ int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, flo
  *   X_const [nj*36] spatial transforms parent -> link, I_spatial [nj*36] spatial inertias, Xhom_const [nj*16] homogeneous
  *   transforms link -> parent.  mpcgpu_amd/data/iiwa14_model.json carries the KUKA iiwa 14 in exactly this form.
  * The cost is the reference's end-effector tracking cost: 1/2 |ee(q_k) - goal_k|^2 (xyz of d_eePos_traj [batch][N][6]) +
- * 1/2 qd_cost |qd|^2 + 1/2 r_cost |u|^2 with its Gauss-Newton Hessian.  Derivatives of the inverse dynamics are one-sided
- * differences in float64 on the device, (ID(. + h e_j) - u) / h with h = 3e-8 — the nominal value needs no evaluation, ID(q, qd, qdd) = u
- * because qdd = Minv (u - c) — agreement of A, B with the float64 central-difference host restatement mpcgpu_amd/iiwa.py: ~2e-7, the
- * rounding of the float outputs; not GRiD's analytic recursion.  num_joints = 7 is the compiled specialisation.
+ * 1/2 qd_cost |qd|^2 + 1/2 r_cost |u|^2 with its Gauss-Newton Hessian.  Derivatives of the forward dynamics (the A, B blocks) come from the
+ * ANALYTIC gradient recursion of the inverse dynamics — what the reference computes with GRiD's forwardDynamicsAndGradient
+ * (iiwa_eepos_plant.cuh:127-155): a lane per column (7 x d/dq, 7 x d/dqd) propagates (dv, da) up the chain and dF down, next to the nominal
+ * recursion in a 15th lane (csrc/kkt_plant.hip.h) — then -Minv dID; float64 on the device, float outputs.  Option "kkt_analytic" = 0 selects
+ * the CHECKER instead: one-sided float64 differences (ID(. + h e_j) - u) / h, h = 3e-8 (the default of rounds 2-3).  Both agree with the float64
+ * central-difference host restatement (oracle/iiwa_ref.py) to ~2e-7, the rounding of the float outputs; the analytic recursion stays there for
+ * torques of any size (no (ID - u) / h term that amplifies what the explicitly inverted mass matrix leaves of ID(FD(u)) - u).
+ * num_joints = 7 is the compiled specialisation.
  * mpcg_plant_create checks what the device kernel relies on and returns MPCG_ERR_UNSUPPORTED / MPCG_ERR_INVALID otherwise: every joint
  * rotates about its own z axis (X_k(q) = blkdiag(Rz(q), Rz(q)) X_k(0), the form of GRiD's tables), the spatial inertias are symmetric and of
  * the rigid-body form [[Ibar, skew(m c)], [skew(m c)^T, m 1]], and Xhom describes the same chain as X (the end-effector position and
@@ -317,7 +324,13 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  *       kernel closes the seams between chunks; 0: the LDS kernels; same bits), "schur_chunk" (block rows per chunk: 0 = by call size, from one
  *       row per chunk for a single trajectory to 16 at 1024 x 128 knots; 1..2048 forced; same bits), "dz_dpp" (1: mpcg_compute_dz with four knots
  *       per wavefront, 0: one workgroup per knot; same bits), "block_solve_wide" (mpcg_block_solve: 1 one trajectory per wavefront, 0 four, -1 by
- *       batch size; same bits), "nt_loads" / "spmv_blocks_per_cu" (mpcg_bt_spmv), "spmv_mfma" (the MFMA experiment kernel).
+ *       batch size; same bits), "kkt_analytic" (mpcg_generate_kkt: 1 = the analytic gradient recursion of the inverse dynamics, the default;
+ *       0 = one-sided float64 differences, the checker), "nt_loads" / "spmv_blocks_per_cu" (mpcg_bt_spmv), "spmv_mfma" (the MFMA experiment kernel).
+ * "assume_symmetric" (0 / 1), "symmetry_state" (read-only; 0 unknown, 1 block-symmetric, 2 violated): see BLOCK SYMMETRY above.
+ * "pcg_variant" (0 / 1, default 0): recurrence of the clustered lane-pair kernel (knot_points > 128).  0 = the classic PCG recurrence above (two
+ *       cluster-wide reductions per iteration); 1 = the single-reduction (Chronopoulos-Gear) recurrence: the same Krylov method with both inner
+ *       products of an iteration taken in ONE reduction (one cluster-wide hand-off per iteration instead of two).  OPT-IN: its fixed-iteration
+ *       iterates drift further from the classic ones in float32 (same solution at a tolerance exit; iteration counts may differ by a few).
  * Read-only: "cluster_fixups" (trajectories re-solved by fix-up launches since mpcg_create — each costs 1.5-4.5 ms of spinning; blocking 8-byte
  *       D2H read), "last_symmetry_violations", "num_cus", "pcg_resident" (1 if the single-workgroup configuration streams nothing inside the PCG
  *       loop), "last_schur_chunk" (block rows per chunk of the last mpcg_form_schur, 0 = the LDS kernels), "last_kernel_family" (kernel of the

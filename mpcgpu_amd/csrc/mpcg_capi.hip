@@ -57,8 +57,8 @@ struct mpcg_handle {
     int kkt_analytic = 1;     // mpcg_generate_kkt: 1 = analytic gradient recursion of the inverse dynamics (as the reference's GRiD code), 0 = one-sided float64 differences (the checker)
     int dz_dpp = 1;           // 1: four-knots-per-wavefront dz recovery (schur_walk.hip.h), 0: the one-workgroup-per-knot LDS kernel
     int last_schur_chunk = 0; //   what the last mpcg_form_schur used (0: the LDS kernels)
-    float* seam_qinv = nullptr;      // schur_walk: one Q^-1 per chunk seam (max_batch x chunks x 196 floats)
-    size_t seam_qinv_floats = 0;
+    void* seam_qinv = nullptr;       // schur_walk: one Q^-1 per chunk seam (float or double; ensure_seam_buffer)
+    size_t seam_qinv_bytes = 0;
     int cluster = -1;         // workgroups per trajectory of the clustered lane-pair kernel (pcg_lpk_cluster.hip.h): 0 off, -1 auto (N > 128), G > 0 forced
     int cluster_l2 = 1;       // clustered lane-pair kernel: 1 = L2-resident hand-offs when a cluster's members share an XCD, 0 = always write-through
     int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
@@ -69,6 +69,7 @@ struct mpcg_handle {
     // call polls: no solve ever synchronises for it.  0 unknown, 1 block-symmetric (plain launches from now on), 2 violated (three-column kernels).
     int sym_state = 0;
     bool sym_pending = false;
+    unsigned long long sym_guard_seq = 0, sym_armed_seq = 0;   // guarded launches issued / the one whose flag copy is in flight (sym_poll)
     hipEvent_t sym_event = nullptr;
     unsigned long long* sym_host = nullptr;      // pinned
     unsigned long long* cluster_scratch = nullptr;
@@ -106,8 +107,19 @@ static void sym_poll(mpcg_handle* h, hipStream_t st = nullptr, bool have_stream 
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
     }
-    if (hipEventQuery(h->sym_event) != hipSuccess) return;
+    // (the query itself in relaxed capture mode: with ANOTHER stream of this thread being captured in global mode an event query is an
+    //  "unsafe" call that would invalidate that unrelated capture — mpcg_get_option("symmetry_state") passes no stream at all)
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    const hipError_t q = hipEventQuery(h->sym_event);
+    (void)hipThreadExchangeStreamCaptureMode(&mode);
+    if (q != hipSuccess) return;
     h->sym_pending = false;
+    if (*h->sym_host == 0 && h->sym_guard_seq != h->sym_armed_seq) {
+        // guarded solves were issued AFTER this copy was armed: a clean flag says nothing about their matrices.  Stay unknown — the next
+        // guarded call arms a new copy, which (the device flag is sticky) covers them all.
+        return;
+    }
     if (*h->sym_host) {
         h->sym_state = 2;
         h->err = "warning: S / Pinv of a solve on this handle were not block-symmetric (block (k, right) != block (k+1, left)^T): the handle now "
@@ -577,7 +589,7 @@ static uint32_t lpkc_resident_clusters(const mpcg_handle* h, int G) {
 // returns 1 when it does not apply.  One persistent launch for any batch: clusters draw trajectories from a queue.
 // scratch: [queue: one 128-byte line][flags: one line per trajectory of the call][cells: 1 KB per member of the launch] — what a call uses
 // is contiguous, so one small fill precedes every launch
-static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz) {
+static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz, bool guarded = false) {
     if (h->cluster == 0 || (esz != 4 && esz != 2)) return 1;
     if (h->cluster < 0 && (!h->auto_cfg || h->N <= kLpbMaxN)) return 1;     // explicit pcg_* knobs, or a horizon one CU holds
     constexpr int NWR = 2;
@@ -614,8 +626,11 @@ static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
         c.redo_flags = ca.fail_flags;
         c.redo_stride = CL_FLAG_STRIDE;
         c.redo_skip = (unsigned)G;
-        c.redo_count = fixup_counter(h);
-        const int rc = h->N <= kLpbMaxN ? launch_lpk(h, c, batch, st) : launch_traj(h, kf, c, batch, st, esz, /*record=*/false);
+        // a GUARDED call (launch_guarded: the handle does not know yet whether the caller's matrices are block-symmetric) relies on this fix-up
+        // being a three-column kernel — every completion count is 0 after a gated exit — so it is never the lower-triangle lane-pair kernel
+        // then (a forced "cluster" = G at N <= 128), and gated exits are not counted as abandoned trajectories
+        c.redo_count = guarded ? nullptr : fixup_counter(h);
+        const int rc = h->N <= kLpbMaxN && !guarded ? launch_lpk(h, c, batch, st) : launch_traj(h, kf, c, batch, st, esz, /*record=*/false);
         if (rc != MPCG_OK) return rc;
     }
     h->last = LastKernel{FAM_LPKC, 4 * NWR, 0, 0, 0, G, (int)lds, 0};
@@ -694,6 +709,7 @@ static int launch_guarded(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipS
     unsigned long long* flag = fixup_counter(h) + 9;
     const long items = (long)batch * ((long)h->N - 1);
     const unsigned blocks = (unsigned)((items + 3) / 4);
+    ++h->sym_guard_seq;
     launch_symmetry_check(h, a, batch, st, blocks, nullptr, flag);
     HIP_TRY(h, hipGetLastError());
     PcgArgs p = a;
@@ -703,7 +719,7 @@ static int launch_guarded(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipS
     const int esz = a.esz;
     if (use_lpk(h, esz)) rc = launch_lpk(h, p, batch, st);
     else {
-        rc = try_launch_cluster(h, p, batch, st, esz);
+        rc = try_launch_cluster(h, p, batch, st, esz, /*guarded=*/true);
         if (rc == 1) return 1;                                                                // (does not apply: the caller falls through)
         need_fallback = !h->cluster_fixup;
     }
@@ -726,6 +742,7 @@ static int launch_guarded(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipS
         HIP_TRY(h, hipMemcpyAsync(h->sym_host, flag, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(h, hipEventRecord(h->sym_event, st));
         h->sym_pending = true;
+        h->sym_armed_seq = h->sym_guard_seq;
     }
     return MPCG_OK;
 }
@@ -1062,6 +1079,34 @@ int mpcg_pcg_solve_ref_f64(mpcg_handle* h, double* d_S, double* d_Pinv, double* 
     return launch_f64(h, a, 1, stream);
 }
 
+}  // extern "C"
+
+// The walking Schur kernels' seam buffer (one 14 x 14 Q^-1 per chunk, float or double).  Sized ONCE, on first use, for whatever the automatic
+// chunk length can ask of this handle: chunks shorter than 16 rows are chosen only while the call has fewer than 2 x `want` rows per chunk
+// length, i.e. at most 2 x want + batch chunks; 16-row chunks beyond — so calls of different batch sizes never reallocate (a reallocation
+// inside a stream capture would leave a dangling pointer in the captured graph: ADVICE r04).  Only a FORCED short "schur_chunk" can ask for
+// more; that grows the buffer outside a capture and is refused inside one.
+static int ensure_seam_buffer(mpcg_handle* h, size_t chunks_needed, size_t elem_bytes, hipStream_t st) {
+    const size_t want = (size_t)h->num_cus * 6 * 4;
+    const size_t auto_chunks = std::max<size_t>(2 * want + h->max_batch + 4, (size_t)h->max_batch * (size_t)(((size_t)h->N - 1 + 15) / 16));
+    // (the automatic part in doubles whatever this call's type: a float call followed by a linsys_t = double call must not reallocate either)
+    const size_t need = 196 * std::max(chunks_needed * elem_bytes, auto_chunks * sizeof(double));
+    if (h->seam_qinv_bytes >= need) return MPCG_OK;
+    if (h->seam_qinv) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+            return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: a forced \"schur_chunk\" needs a larger seam buffer than the handle holds — make one such call outside the stream capture first");
+        HIP_TRY(h, hipDeviceSynchronize());          // (an earlier call's kernels may still read the old buffer)
+        HIP_TRY(h, hipFree(h->seam_qinv));
+    }
+    h->seam_qinv = nullptr; h->seam_qinv_bytes = 0;
+    HIP_TRY(h, hipMalloc(&h->seam_qinv, need));
+    h->seam_qinv_bytes = need;
+    return MPCG_OK;
+}
+
+extern "C" {
+
 int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, float* d_lambda, uint32_t batch, void* stream) {
     if (!h) return MPCG_ERR_INVALID;
     if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_block_solve: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
@@ -1113,22 +1158,14 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
             while (wL < 16 && rows / (2 * wL) >= want) wL *= 2;
         }
         const int wchunks = (N - 1 + wL - 1) / wL;
-        // seam buffer: one Q^-1 per chunk.  Sized once for whatever the automatic chunk length can ask of this handle (short chunks only while
-        // the call has fewer than 2 x `want` rows; 16-row chunks beyond), so that calls of different batch sizes do not reallocate.
-        const size_t auto_chunks = std::max<size_t>((size_t)h->num_cus * 6 * 4 * 2 + 4, (size_t)h->max_batch * (size_t)((N - 1 + 15) / 16));
-        const size_t need_s = 196 * std::max<size_t>((size_t)batch * wchunks, auto_chunks);
-        if (h->seam_qinv_floats < need_s) {       // first call (or a forced short chunk length) only — not stream-ordered: hipMalloc
-            if (h->seam_qinv) HIP_TRY(h, hipFree(h->seam_qinv));
-            h->seam_qinv = nullptr; h->seam_qinv_floats = 0;
-            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->seam_qinv), need_s * sizeof(float)));
-            h->seam_qinv_floats = need_s;
-        }
+        // seam buffer: one Q^-1 per chunk (ensure_seam_buffer: sized once for every automatic chunk length of this handle)
+        { const int rc_ = ensure_seam_buffer(h, (size_t)batch * wchunks, sizeof(float), st); if (rc_ != MPCG_OK) return rc_; }
         sw::WalkArgs w;
         w.s.G = d_G_dense; w.s.C = d_C_dense; w.s.g = d_g; w.s.c = d_c; w.s.S = d_S; w.s.Pinv = d_Pinv; w.s.gamma = d_gamma;
         w.s.Ginv_scratch = nullptr; w.s.Ginv_out = d_G_dense;
         w.s.rho = rho; w.s.n = n; w.s.m = m; w.s.N = N; w.s.batch = (int)batch; w.s.ss = precond == MPCG_PRECOND_SS; w.s.pinv = precond != MPCG_PRECOND_NONE;
         w.s.k0_only = 0;
-        w.seam_qinv = h->seam_qinv; w.L = wL; w.chunks = wchunks;
+        w.seam_qinv = static_cast<float*>(h->seam_qinv); w.L = wL; w.chunks = wchunks;
         h->last_schur_chunk = wL;
         const long capw = (long)h->num_cus * 64;
         long bw = ((long)batch * wchunks + 3) / 4;

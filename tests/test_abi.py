@@ -38,7 +38,7 @@ def test_exports_are_plain_c(hiplib):
 
 
 def test_version_and_lds_size(hiplib):
-    assert hiplib.mpcg_abi_version() == 1
+    assert hiplib.mpcg_abi_version() == 2
     assert b"gfx950" in hiplib.mpcg_build_info()
     # = the dynamic LDS of the launch a default batch-1 solve makes.  64 < N <= 128: the lane-pair-per-knot kernel, whose
     # layout is compile-time per wave count (64 or 128 knots): seven pair-major vectors of 7 x (NMAX + 4) float2, one partial per

@@ -110,6 +110,45 @@ def test_symmetry_latch_gives_an_asymmetric_pinv_the_three_column_solve_from_the
         assert int(i1.item()) == K and ok(l1.cpu().numpy(), 0)
 
 
+@pytest.mark.parametrize("N,B", [(128, 3), (96, 2)])
+def test_forced_cluster_on_a_short_horizon_keeps_the_symmetry_guarantee(orc, N, B):
+    """"cluster" = 2 forced at N <= 128 on a FRESH handle with an asymmetric caller-made Pinv.  The guarded clustered
+    launch gate-exits; its fix-up launch must then be a three-column kernel (it used to be the lower-triangle lane-pair kernel: the wrong system
+    for the first solves) and gated exits must not be counted as abandoned trajectories."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    K = 12
+    k = synth.make_kkt(N, B, 4700 + N)
+    S, Pinv, g = synth.form_schur(k, precond="ss")
+    Pa = np.array(Pinv, np.float32).reshape(B, N, 3, 196).copy()
+    Pa[:, :, 2] *= 0.9
+    Pa = Pa.reshape(B, -1)
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    sol = PcgSolver(N, max_batch=B)
+    sol.set_option("cluster", 2)
+    sol.set_option("pcg_lpk", 0)
+    sol.set_option("pcg_rpl", 0)
+    lam = torch.zeros(B, n * N, device="cuda")
+    it, ex = sol.solve(dev(S), dev(Pa), dev(g), lam, cfg, "ss")
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 7 and sol.get_option("last_kernel_cluster") == 2
+    assert (it.cpu().numpy() == K).all() and sol.get_option("cluster_fixups") == 0
+    for b in range(B):
+        ref = orc.pcg(S[b].astype(np.float64), Pa[b].astype(np.float64), g[b].astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")["lam"]
+        band = fp32_band(orc, S[b], Pa[b], g[b], np.zeros(n * N), N, K, "ss", ref)
+        assert relinf(lam[b].cpu().numpy(), ref) <= max(1e-3, 4 * band), (b, relinf(lam[b].cpu().numpy(), ref), band)
+    assert sol.get_option("symmetry_state") == 2
+    # and on the reference's own (symmetric) matrices the forced cluster still runs the clustered kernel, bit-identical before and after the latch
+    sol2 = PcgSolver(N, max_batch=B)
+    sol2.set_option("cluster", 2); sol2.set_option("pcg_lpk", 0); sol2.set_option("pcg_rpl", 0)
+    la, lb = torch.zeros(B, n * N, device="cuda"), torch.zeros(B, n * N, device="cuda")
+    sol2.solve(dev(S), dev(Pinv), dev(g), la, cfg, "ss")
+    torch.cuda.synchronize()
+    assert sol2.get_option("symmetry_state") == 1
+    sol2.solve(dev(S), dev(Pinv), dev(g), lb, cfg, "ss")
+    torch.cuda.synchronize()
+    assert torch.equal(la, lb) and sol2.get_option("last_kernel_family") == 7 and sol2.get_option("cluster_fixups") == 0
+
+
 @pytest.mark.parametrize("N,B", [(128, 3), (256, 2)])
 def test_symmetry_latch_on_reference_matrices_costs_nothing_after_the_first_calls(N, B):
     """The reference's own (block-symmetric) matrices: the guarded first solve and the plain solves after the latch give the same bits,
