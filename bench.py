@@ -37,7 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from mpcgpu_amd import PcgSolver, pcg_config, synth  # noqa: E402
 from mpcgpu_amd import dist as D  # noqa: E402
 import bench_legs as L  # noqa: E402
-from bench_legs import build_inputs  # noqa: E402,F401  (tests use bench.build_inputs)
+from bench_legs import build_inputs, load_traffic, timed  # noqa: E402,F401  (tests and tools use bench.build_inputs / bench.timed)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_PEAK_TF = 157.3  # same guide: peak fp32 vector = 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz

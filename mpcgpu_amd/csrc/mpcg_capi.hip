@@ -15,6 +15,7 @@
 #include "pcg_rpl.hip.h"
 #include "schur_kernels.hip.h"
 #include "schur_walk.hip.h"
+#include "schur_walk_f64.hip.h"
 #include "block_solve.hip.h"
 #include "pcg_f64.hip.h"
 #include "ldl_host.hpp"
@@ -1232,8 +1233,9 @@ int mpcg_compute_dz(mpcg_handle* h, uint32_t control_size, const float* d_Ginv_d
 
 
 // ---- linsys_t = double (USE_DOUBLES = 1, include/common/settings.cuh:41-49): the steps either side of the solve in double precision.
-// Functional twins (the one-wavefront-per-knot LDS kernels of schur_kernels.hip.h instantiated for double): same arithmetic order as the
-// float path, bit-identical to the oracle's double instantiation. ----
+// Round 5: the walking formation and the four-knots-per-wavefront dz recovery in double (schur_walk_f64.hip.h); options "schur_dpp" / "dz_dpp"
+// = 0 select the one-wavefront-per-knot LDS kernels of schur_kernels.hip.h instantiated for double.  Same arithmetic order as the float path,
+// bit-identical to the oracle's double instantiation either way. ----
 int mpcg_form_schur_f64(mpcg_handle* h, uint32_t control_size, double* d_G_dense, const double* d_C_dense, const double* d_g,
                         const double* d_c, double* d_S, double* d_Pinv, double* d_gamma, double rho, uint32_t batch,
                         mpcg_precond precond, void* stream) {
@@ -1249,6 +1251,39 @@ int mpcg_form_schur_f64(mpcg_handle* h, uint32_t control_size, double* d_G_dense
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = (int)h->n, m = (int)control_size, N = (int)h->N;
     const size_t Gsz = (size_t)(n * n + m * m) * N - m * m;
+    // Round 5: the register-resident formation in double (schur_walk_f64.hip.h) — the float path's design, chunk policy and seam buffer; its
+    // buffer resources carry 31-bit byte offsets: 4,704 B of S per knot => below 456 k knots per call (beyond: the LDS kernels).
+    if (h->schur_dpp && (uint64_t)batch * N * 4704u < (1ull << 31)) {
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        int wL = h->schur_chunk;
+        if (wL <= 0) {
+            const long rows = (long)batch * (N - 1), want = (long)h->num_cus * 6 * 4;
+            wL = 1;
+            while (wL < 16 && rows / (2 * wL) >= want) wL *= 2;
+        }
+        const int wchunks = (N - 1 + wL - 1) / wL;
+        { const int rc_ = ensure_seam_buffer(h, (size_t)batch * wchunks, sizeof(double), st); if (rc_ != MPCG_OK) return rc_; }
+        sw64::WalkArgs64 w;
+        w.s.G = d_G_dense; w.s.C = d_C_dense; w.s.g = d_g; w.s.c = d_c; w.s.S = d_S; w.s.Pinv = d_Pinv; w.s.gamma = d_gamma;
+        w.s.Ginv_scratch = nullptr; w.s.Ginv_out = d_G_dense;
+        w.s.rho = rho; w.s.n = n; w.s.m = m; w.s.N = N; w.s.batch = (int)batch; w.s.ss = precond == MPCG_PRECOND_SS; w.s.pinv = precond != MPCG_PRECOND_NONE;
+        w.s.k0_only = 0;
+        w.seam_qinv = static_cast<double*>(h->seam_qinv); w.L = wL; w.chunks = wchunks;
+        h->last_schur_chunk = wL;
+        const long capw = (long)h->num_cus * 64;
+        long bw = ((long)batch * wchunks + 3) / 4;
+        if (bw > capw) bw = capw;
+        hipLaunchKernelGGL(sw64::schur_walk_f64_kernel, dim3((unsigned)bw), dim3(64), 0, st, w);
+        HIP_TRY(h, hipGetLastError());
+        if (wchunks > 1) {
+            long bs = ((long)batch * (wchunks - 1) + 3) / 4;
+            if (bs > capw) bs = capw;
+            hipLaunchKernelGGL(sw64::schur_seam_f64_kernel, dim3((unsigned)bs), dim3(64), 0, st, w);
+            HIP_TRY(h, hipGetLastError());
+        }
+        return MPCG_OK;
+    }
+    h->last_schur_chunk = 0;
     const size_t need = Gsz * h->max_batch;
     if (h->ginv_scratch_f64_elems < need) {       // first call only (not stream-ordered: hipMalloc)
         if (h->ginv_scratch_f64) HIP_TRY(h, hipFree(h->ginv_scratch_f64));
@@ -1285,6 +1320,13 @@ int mpcg_compute_dz_f64(mpcg_handle* h, uint32_t control_size, const double* d_G
     DzArgsT<double> a{d_Ginv_dense, d_C_dense, d_g, d_lambda, d_dz, (int)h->n, (int)control_size, (int)h->N, (int)batch};
     long blocks = (long)batch * h->N;
     const long cap = (long)h->num_cus * 64;
+    if (h->dz_dpp && h->N >= 2 && (uint64_t)batch * h->N * 2352u < (1ull << 31)) {      // four knots per wavefront (schur_walk_f64.hip.h); 31-bit byte offsets into C
+        long bq = (blocks + 3) / 4;
+        if (bq > cap) bq = cap;
+        hipLaunchKernelGGL(sw64::compute_dz_dpp_f64_kernel, dim3((unsigned)bq), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+        HIP_TRY(h, hipGetLastError());
+        return MPCG_OK;
+    }
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((compute_dz_kernel<14, 7, double>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRY(h, hipGetLastError());

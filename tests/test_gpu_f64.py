@@ -66,22 +66,31 @@ def test_f64_tolerance_exit_warm_start_and_flags(orc):
 
 @pytest.mark.parametrize("N", [2, 3, 8, 33, 128])
 @pytest.mark.parametrize("precond", ["ss", "jacobi"])
-def test_f64_form_schur_and_dz_bit_exact_vs_oracle(orc, N, precond):
+@pytest.mark.parametrize("formation", ["auto", "walk16", "walk5", "walk1", "lds"])
+def test_f64_form_schur_and_dz_bit_exact_vs_oracle(orc, N, precond, formation):
     """linsys_t = double types the whole linear-system step of the reference (include/common/settings.cuh:41-49), not only the PCG:
     mpcg_form_schur_f64 / mpcg_compute_dz_f64 against the oracle's double instantiation, bit for bit (same operation order, contraction
     off on both sides), including which bd slots are left unwritten; then the double-precision chain KKT blocks -> Schur -> PCG -> dz
-    solves the KKT system to 1e-9."""
+    solves the KKT system to 1e-9.  Round 5: the register-resident walking formation in double (schur_walk_f64.hip.h) at every chunk length
+    — auto (L = 1 here), 16, 5 (ragged last chunk), 1 — and the four-knots-per-wavefront dz kernel; "lds" = the round-1 LDS kernels
+    ("schur_dpp" = 0, "dz_dpp" = 0)."""
     from mpcgpu_amd import PcgSolver, pcg_config
-    m, B = 7, 3
+    m, B = 7, 5                                       # (a wavefront of four chunks straddles trajectories)
     k = synth.make_kkt(N, B, 555 + N)
     G, C, g, c = synth.pack_kkt_dense(k, np.float64)
     sol = PcgSolver(N, max_batch=B)
+    if formation.startswith("walk"):
+        sol.set_option("schur_chunk", int(formation[4:]))
+    elif formation == "lds":
+        sol.set_option("schur_dpp", 0)
+        sol.set_option("dz_dpp", 0)
     dG, dC, dg, dc = dev(G), dev(C), dev(g), dev(c)
     S = torch.full((B, 3 * n * n * N), float("nan"), device="cuda", dtype=torch.float64)
     P = torch.full((B, 3 * n * n * N), float("nan"), device="cuda", dtype=torch.float64)
     gam = torch.full((B, n * N), float("nan"), device="cuda", dtype=torch.float64)
     sol.form_schur(dG, dC, dg, dc, 1e-3, precond, S=S, Pinv=P, gamma=gam)
     torch.cuda.synchronize()
+    assert sol.get_option("last_schur_chunk") == {"auto": 1, "lds": 0}.get(formation, int(formation[4:]) if formation.startswith("walk") else -1)
     Sh, Ph, gh, Gih = S.cpu().numpy(), P.cpu().numpy(), gam.cpu().numpy(), dG.cpu().numpy()
     for b in range(B):
         So, Po, go, Go = orc.form_schur(G[b], C[b], g[b], c[b], N, np.float64(1e-3), ss=(precond == "ss"))
@@ -101,6 +110,38 @@ def test_f64_form_schur_and_dz_bit_exact_vs_oracle(orc, N, precond):
         # the multipliers solve S lambda = gamma: true residual in float64
         r = orc.bt_spmv(np.nan_to_num(Sh[b]), lamh[b], N) - gh[b]
         assert np.abs(r).max() <= 1e-9 * max(1.0, np.abs(gh[b]).max()), (b, np.abs(r).max())
+
+
+def test_f64_formations_agree_at_throughput_sized_batches():
+    """The automatic chunk length of a throughput-sized double call (L = 4 at 700 x 64 knots: the grid-stride loop wraps, the last wavefront is
+    ragged, the seam buffer is the one sized at the handle's first — float — call) against one row per chunk and the LDS kernels: the same
+    bits in S, Pinv, gamma, G^-1; and both dz kernels on the result."""
+    from mpcgpu_amd import PcgSolver
+    N, B = 64, 700
+    k = synth.make_kkt(N, 50, 4242)
+    G, C, g, c = (np.tile(a, (B // 50, 1)) for a in synth.pack_kkt_dense(k, np.float64))
+    sol = PcgSolver(N, max_batch=B)
+    f32 = [dev(a[:8].astype(np.float32)) for a in (G, C, g, c)]
+    sol.form_schur(*f32, 1e-3, "ss")                                  # (a float call first: the seam buffer must serve the double calls too)
+    outs, chunks = [], []
+    lam = torch.randn(B, n * N, dtype=torch.float64, device="cuda")
+    for mode in ("auto", "one", "lds"):
+        sol.set_option("schur_dpp", 0 if mode == "lds" else 1)
+        sol.set_option("dz_dpp", 0 if mode == "lds" else 1)
+        sol.set_option("schur_chunk", 1 if mode == "one" else 0)
+        dG = dev(G)
+        S = torch.full((B, 3 * n * n * N), float("nan"), device="cuda", dtype=torch.float64)
+        P = torch.full((B, 3 * n * n * N), float("nan"), device="cuda", dtype=torch.float64)
+        gam = torch.full((B, n * N), float("nan"), device="cuda", dtype=torch.float64)
+        sol.form_schur(dG, dev(C), dev(g), dev(c), 1e-3, "ss", S=S, Pinv=P, gamma=gam)
+        dz = sol.compute_dz(dG, dev(C), dev(g), lam)
+        torch.cuda.synchronize()
+        chunks.append(sol.get_option("last_schur_chunk"))
+        outs.append([t.cpu().numpy() for t in (S, P, gam, dG, dz)])
+    assert chunks[0] > 1 and chunks[1] == 1 and chunks[2] == 0, chunks
+    for other in outs[1:]:
+        for a0, a1 in zip(outs[0], other):
+            np.testing.assert_array_equal(a0, a1)
 
 
 def test_f64_wrappers_reject_mixed_precision():
