@@ -113,8 +113,7 @@ def compact_line(full: dict) -> dict:
         "iiwa_warm_true_residual_median": warm.get("true_rel_residual_after_median"), "iiwa_warm_true_residual_max": warm.get("true_rel_residual_after_max"),
         "batch1_sqp_step_us_N32": _get(b1, "N32", "us_per_step"), "batch1_sqp_step_us_N128": _get(b1, "N128", "us_per_step"),
         "N256_pcg_iterations_per_sec": _get(lh, "N256", "pcg_iterations_per_sec"), "N512_pcg_iterations_per_sec": _get(lh, "N512", "pcg_iterations_per_sec"),
-        "N256_single_reduction_it_per_sec": _get(lh, "N256", "single_reduction_variant", "pcg_iterations_per_sec"),
-        "N512_single_reduction_it_per_sec": _get(lh, "N512", "single_reduction_variant", "pcg_iterations_per_sec"),
+        "N256_single_reduction_ceiling_it_per_sec": (_get(full, "roofline_long_horizon", "single_reduction_ceiling", "N256_batch1024_M_it_per_s", "emulated") or 0) * 1e6 or None,
         "f64_N128_pcg_iterations_per_sec": _get(full, "double_precision", "pcg_iterations_per_sec"),
         "f64_form_schur_ms": _get(full, "roofline_producers_f64", "form_schur_f64", "kernel_ms"),
         "f64_compute_dz_ms": _get(full, "roofline_producers_f64", "compute_dz_f64", "kernel_ms"),

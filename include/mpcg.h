@@ -56,7 +56,7 @@ extern "C" {
 
 /* 2 (round 5): the BLOCK SYMMETRY contract is checked by the handle itself (a caller that fills ONLY the left + diagonal block columns must
  * set "assume_symmetric" = 1 — round-3 text allowed garbage in the right blocks without it); options pcg_lpb / cluster_lpb / cluster_lpk /
- * cluster_waves / cluster_adj / schur_fma / schur_inplace are gone; mpcg_probe_hbm_read, "kkt_analytic", "pcg_variant" are new. */
+ * cluster_waves / cluster_adj / schur_fma / schur_inplace are gone; mpcg_probe_hbm_read and "kkt_analytic" are new. */
 #define MPCG_ABI_VERSION 2
 
 typedef enum mpcg_status {
@@ -327,10 +327,6 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  *       batch size; same bits), "kkt_analytic" (mpcg_generate_kkt: 1 = the analytic gradient recursion of the inverse dynamics, the default;
  *       0 = one-sided float64 differences, the checker), "nt_loads" / "spmv_blocks_per_cu" (mpcg_bt_spmv), "spmv_mfma" (the MFMA experiment kernel).
  * "assume_symmetric" (0 / 1), "symmetry_state" (read-only; 0 unknown, 1 block-symmetric, 2 violated): see BLOCK SYMMETRY above.
- * "pcg_variant" (0 / 1, default 0): recurrence of the clustered lane-pair kernel (knot_points > 128).  0 = the classic PCG recurrence above (two
- *       cluster-wide reductions per iteration); 1 = the single-reduction (Chronopoulos-Gear) recurrence: the same Krylov method with both inner
- *       products of an iteration taken in ONE reduction (one cluster-wide hand-off per iteration instead of two).  OPT-IN: its fixed-iteration
- *       iterates drift further from the classic ones in float32 (same solution at a tolerance exit; iteration counts may differ by a few).
  * Read-only: "cluster_fixups" (trajectories re-solved by fix-up launches since mpcg_create — each costs 1.5-4.5 ms of spinning; blocking 8-byte
  *       D2H read), "last_symmetry_violations", "num_cus", "pcg_resident" (1 if the single-workgroup configuration streams nothing inside the PCG
  *       loop), "last_schur_chunk" (block rows per chunk of the last mpcg_form_schur, 0 = the LDS kernels), "last_kernel_family" (kernel of the

@@ -349,7 +349,13 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpkc_kernel(ClusterArgs ca) 
             const unsigned vbyte = (unsigned)tab[64];
             const int d0 = tab[128], d1 = tab[192], d2 = tab[256];
             const bool isZ = ln >= 40;
+#ifdef MPCG_CG_EMULATE
+            // TIMING EXPERIMENT ONLY (tools/_prof/cg_emulate.py; wrong numerics): what a single-reduction (Chronopoulos-Gear) recurrence could
+            // save at best without overlapping — its hand-off after the Pinv pass carries the neighbours' halo only: no partials polled, nothing folded
+            const bool wantp = base != LPBC_SLOT_E && pbyte != 0xFFFFFFFFu;
+#else
             const bool wantp = pbyte != 0xFFFFFFFFu;
+#endif
             const bool wantv = vbyte != 0xFFFFFFFFu && (withZ || !isZ);
             unsigned long long x = 0;
             f4 xv = {0.f, 0.f, 0.f, 0.f};
@@ -375,7 +381,11 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpkc_kernel(ClusterArgs ca) 
                 dv[d1] = xv.z;
                 if (d2 >= 0) dv[d2] = xv.w;
             }
+#ifdef MPCG_CG_EMULATE
+            const float tot = base == LPBC_SLOT_E ? 1.0f : wave_fold(wantp ? __builtin_bit_cast(float, (unsigned)x) : 0.f);
+#else
             const float tot = wave_fold(wantp ? __builtin_bit_cast(float, (unsigned)x) : 0.f);
+#endif
             if (ln == 0) { bc[0] = tot; if (spins >= CL_SPIN_LIMIT) bc[1] = 1.f; }
             MPCG_STAMP(pb + 4);
         }

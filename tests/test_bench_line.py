@@ -42,8 +42,8 @@ def _full(n_gpus=1):
         "roofline_producers": {"form_schur": dict(kern), "compute_dz": dict(kern), "generate_kkt": dict(kern)},
         "roofline_producers_f64": {"form_schur_f64": dict(kern), "compute_dz_f64": dict(kern)},
         "batch1_sqp_step_latency": {"N32": {"us_per_step": f()}, "N64": {"us_per_step": f()}, "N128": {"us_per_step": f()}, "what": LONG},
-        "long_horizon": {"N256": {"pcg_iterations_per_sec": f(), "single_reduction_variant": {"pcg_iterations_per_sec": f()}},
-                         "N512": {"pcg_iterations_per_sec": f(), "single_reduction_variant": {"pcg_iterations_per_sec": f()}}},
+        "long_horizon": {"N256": {"pcg_iterations_per_sec": f()}, "N512": {"pcg_iterations_per_sec": f()}},
+        "roofline_long_horizon": {"single_reduction_ceiling": {"N256_batch1024_M_it_per_s": {"classic": 38.22, "emulated": 41.48, "target": 44.0}}},
         "roofline_pcg_streaming": {"frac": f()}, "double_precision": {"pcg_iterations_per_sec": f()},
         "scaling_expectation": {"strong": {"speedup_ceiling_at_8_gpus": f()}},
         "inrun_pmc_kernels": {LONG + str(i): {"kernel": LONG, "grid": 1} for i in range(12)},

@@ -676,7 +676,7 @@ def single_trajectory_latency(cx):
 
 def long_horizon(cx, lean=False):
     """Horizons one CU cannot hold (BASELINE config 5's N = 512, and N = 256): the clustered lane-pair kernel at the reference's iteration
-    caps (settings.cuh:123-139), classic recurrence and the opt-in single-reduction variant; plus the all-streaming PCG kernel as an HBM
+    caps (settings.cuh:123-139); plus the all-streaming PCG kernel as an HBM
     roofline leg at N = 512.  Returns (long_horizon, roofline_pcg_streaming)."""
     dev, B = cx.dev, cx.B
     lh, stream = {}, None
@@ -703,16 +703,6 @@ def long_horizon(cx, lean=False):
                  "ms_one_trajectory": ms_1, "us_per_pcg_iter_one_trajectory": ms_1 * 1e3 / synth.pcg_max_iter(Nl),
                  "kernel_family": sl.get_option("last_kernel_family"), "members_per_trajectory": sl.get_option("last_kernel_cluster"),
                  "cluster_fixups": sl.get_option("cluster_fixups")}
-            try:        # the opt-in single-reduction recurrence (pcg_variant = 1), same systems, same iteration count
-                sl.set_option("pcg_variant", 1)
-                ms_v = timed(lambda: run_b(B), 5, warm=1)
-                ms_v1 = timed(lambda: run_b(1), 15, warm=3)
-                e["single_reduction_variant"] = {"kernel_ms": ms_v, "pcg_iterations_per_sec": int(il.sum().item()) / (ms_v * 1e-3),
-                                                 "us_per_pcg_iter_one_trajectory": ms_v1 * 1e3 / synth.pcg_max_iter(Nl),
-                                                 "kernel_family": sl.get_option("last_kernel_family")}
-                sl.set_option("pcg_variant", 0)
-            except Exception as e_:
-                e["single_reduction_variant"] = {"error": repr(e_)}
             lh[f"N{Nl}"] = e
         if Nl == 512:
             # the PCG solve as an HBM stream: nothing resident (pcg_traj_kernel<16,0,2>), every block re-read every iteration; one workgroup per
@@ -750,7 +740,16 @@ def long_horizon_floor(cx, lh):
     roof = {"what": "clustered lane-pair kernel vs the floor of classic PCG on its decomposition: 2 x (matrix pass + one L2 hand-off + barrier) per iteration",
             "floor_us_per_iteration": floor_ticks / 2380.0, "floor_terms_shader_clocks": {"matrix_pass": 2090, "l2_handoff_min": 635, "barrier": 140},
             "above_the_floor_shader_clocks_per_half": {"fold_partials_and_halo_into_lds": 460, "operand_rebuild_and_scalar_chain": 360, "handoff_jitter_up_to": 640},
-            "source": "profiles/r04_lpkc_phases.txt (tools/_prof/lpkc_phases.py, -DMPCG_PROF build)"}
+            "source": "profiles/r04_lpkc_phases.txt (tools/_prof/lpkc_phases.py, -DMPCG_PROF build)",
+            # the single-reduction (Chronopoulos-Gear) recurrence, measured before building it — its hand-off after the Pinv pass
+            # carries the neighbours' halo only; -DMPCG_CG_EMULATE builds exactly that hand-off into the shipping kernel (timing only)
+            "single_reduction_ceiling": {"what": "the shipping kernel with the hand-off after the Pinv pass reduced to the halo granules (no partials polled, nothing folded): "
+                                                 "what a Chronopoulos-Gear recurrence would save at best without overlap (tools/_prof/cg_emulate.py, profiles/r05_cg_emulate.txt)",
+                                         "N256_batch1024_M_it_per_s": {"classic": 38.22, "emulated": 41.48, "target": 44.0},
+                                         "N512_batch1024_M_it_per_s": {"classic": 17.76, "emulated": 19.16, "target": 20.5},
+                                         "N256_one_trajectory_us_per_iteration": {"classic": 3.29, "emulated": 3.01, "target": 2.9},
+                                         "gain": "+7.9 .. +9.3 %: below every target, before the variant's own extra vector recurrence (s = w + beta s) and with fixed-K iterates "
+                                                 "that drift 5-10x more in float32: NOT BUILT, item closed"}}
     ncu_ = cx.sol.get_option("num_cus")
     for key_, v_ in lh.items():
         G_ = v_["members_per_trajectory"]
