@@ -1,103 +1,15 @@
-// mpcg_capi.hip — C ABI (include/mpcg.h) over the gfx950 kernels in pcg_kernels.hip.h.
-// Host side is plain C++/HIP: no torch types, no CPU fallback.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <string.h>
-#include <new>
-#include <algorithm>
-#include <string>
-
-#include "../../include/mpcg.h"
+// mpcg_pcg.hip — C ABI (include/mpcg.h) of the hot path: handle and options, the PCG launch policy (which kernel family serves a call), the
+// PCG / SpMV entry points, over the gfx950 kernels in pcg_*.hip.h.  Host side is plain C++/HIP: no torch types, no CPU fallback.
+#include "mpcg_handle.hpp"
 #include "pcg_kernels.hip.h"
 #include "pcg_lpk.hip.h"
 #include "pcg_lpk_cluster.hip.h"
 #include "pcg_rpl.hip.h"
-#include "schur_kernels.hip.h"
-#include "schur_walk.hip.h"
-#include "schur_walk_f64.hip.h"
-#include "block_solve.hip.h"
 #include "pcg_f64.hip.h"
-#include "ldl_host.hpp"
-#include "kkt_plant.hip.h"
 
 using namespace mpcg;
 
-// Launch knobs of the single-workgroup PCG kernels.  The handle holds the user's (or mpcg_create's) values; every
-// call works on a COPY that the automatic policy may adjust for that call's batch — the handle is never rewritten
-// by a solve (two calls with different batches do not see each other's choices).
-struct PcgKnobs {
-    int waves = 16;           // wavefronts per trajectory workgroup (4, 8 or 16)
-    int reg_rows = 0;         // RT: TRIPLES of block rows per matrix per wave kept in registers (compiled variants only)
-    int lds_rows = -1;        // LT: triples per matrix per wave cached in LDS; -1 = as many as fit when reg_rows > 0, else 0
-    int waves16 = 8, reg_rows16 = 6, lds_rows16 = -1;   // the same knobs for fp16 matrix storage
-    int lds_extra = -1;       // <.,.,1> kernels: single-triple LDS slots beyond the uniform cache (-1 = as many as fit, 0 = none)
-    int stream_bufs = -1;     // SB: -1 auto, else 0/1/2 register buffers for the streamed triples
-    int max_wg_per_cu = 0;    // 0 = whatever fits; k > 0 pads the LDS request so at most k workgroups share a CU
-};
-
-// What the last solve on this handle actually launched (read-only "last_kernel_*" options; tests assert on it).
-enum { FAM_NONE = -1, FAM_TRAJ = 0, /* 1, 2, 4: kernels retired in round 4 (HISTORY.md) */ FAM_GENERIC = 3, FAM_RPL = 5, FAM_LPK = 6, FAM_LPKC = 7 };
-struct LastKernel { int family = FAM_NONE, waves = 0, reg_rows = 0, lds_rows = 0, stream_bufs = 0, cluster = 0, lds_bytes = 0, lds_extra = 0; };
-
-struct mpcg_handle {
-    int device = 0;
-    uint32_t n = 0, N = 0, max_batch = 0;
-    int num_cus = 0;
-    PcgKnobs k;
-    LastKernel last;
-    int nt_loads = 1;         // non-temporal hint on the matrix stream
-    int rpl = -1;             // row-per-lane kernel (pcg_rpl.hip.h, N <= 64): -1 auto, 0 off, 1 forced
-    int rpl_waves = 0;        //   its wavefronts per trajectory: 0 auto, 4 / 8 / 16
-    int lpk = -1;             // lane-pair-per-knot kernel (pcg_lpk.hip.h, N <= 128): -1 auto (36 < N <= 128 beyond the row-per-lane kernel's calls), 0 off, 1 forced
-    int block_solve_wide = -1; // mpcg_block_solve: one trajectory per wavefront (1), four (0), by batch size (-1)
-    int schur_dpp = 1;        // 1: register-resident Schur formation (schur_walk.hip.h: the chunk-walking kernel + its seam kernel), 0: the LDS versions
-    int sched_hint = 1;       // dispatch the trajectories of a large call longest-expected-first, predicted by the previous call's iteration counts (sched_order_kernel)
-    uint32_t* sched_order = nullptr;   // [1 + max_batch] {batch it was made for, dispatch order}: written after every hinted solve, checked on the device
-    int schur_chunk = 0;      //   block rows per chunk of the walking kernel: 0 auto (by call size), 1..2048 forced
-    int kkt_analytic = 1;     // mpcg_generate_kkt: 1 = analytic gradient recursion of the inverse dynamics (as the reference's GRiD code), 0 = one-sided float64 differences (the checker)
-    int dz_dpp = 1;           // 1: four-knots-per-wavefront dz recovery (schur_walk.hip.h), 0: the one-workgroup-per-knot LDS kernel
-    int last_schur_chunk = 0; //   what the last mpcg_form_schur used (0: the LDS kernels)
-    void* seam_qinv = nullptr;       // schur_walk: one Q^-1 per chunk seam (float or double; ensure_seam_buffer)
-    size_t seam_qinv_bytes = 0;
-    int cluster = -1;         // workgroups per trajectory of the clustered lane-pair kernel (pcg_lpk_cluster.hip.h): 0 off, -1 auto (N > 128), G > 0 forced
-    int cluster_l2 = 1;       // clustered lane-pair kernel: 1 = L2-resident hand-offs when a cluster's members share an XCD, 0 = always write-through
-    int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
-    int check_symmetry = 0;   // debug: 1 = every solve that would run a lower-triangle kernel first verifies block symmetry of S and Pinv (synchronises)
-    int last_sym_violations = 0;   //   block pairs that failed the check in the last solve (then solved by a three-column kernel)
-    // The symmetry latch (default): until the handle knows, every lower-triangle solve is launched GUARDED (check kernel -> device flag ->
-    // gated lower-triangle kernel -> gated three-column kernel), and the flag travels to the host by an asynchronous copy that a later
-    // call polls: no solve ever synchronises for it.  0 unknown, 1 block-symmetric (plain launches from now on), 2 violated (three-column kernels).
-    int sym_state = 0;
-    bool sym_pending = false;
-    unsigned long long sym_guard_seq = 0, sym_armed_seq = 0;   // guarded launches issued / the one whose flag copy is in flight (sym_poll)
-    hipEvent_t sym_event = nullptr;
-    unsigned long long* sym_host = nullptr;      // pinned
-    unsigned long long* cluster_scratch = nullptr;
-    bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any valid pcg_* set_option clears this)
-    bool generic = false;     // state_size != 14: only the PCG entry points work, through pcg_generic_kernel
-    int spmv_blocks_per_cu = 3;    // (sweep at 4096 trajectories = 1.2 GB of S, a true HBM stream: profiles/r04_spmv.txt; until round 4: 4)
-    int spmv_mfma = 0;        // 1 = the MFMA experiment kernel for mpcg_bt_spmv
-    float* block_scratch = nullptr;  // W_k, z_k of mpcg_block_solve: max_batch x N x 210 floats (first call)
-    float* ginv_scratch = nullptr;   // staging for the in-place G <- G^-1 of mpcg_form_schur
-    size_t ginv_scratch_floats = 0;
-    double* ginv_scratch_f64 = nullptr;   // the same for mpcg_form_schur_f64
-    size_t ginv_scratch_f64_elems = 0;
-    std::string err;
-};
-
-static thread_local std::string g_create_err;
-
-static int fail(mpcg_handle* h, int code, const std::string& msg) {
-    if (h) h->err = msg; else g_create_err = msg;
-    return code;
-}
-#define HIP_TRY(h, expr)                                                                    \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail((h), MPCG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
+thread_local std::string mpcg_create_err;
 
 // the symmetry latch: has the asynchronous copy of the device flag landed?
 // (never while `st` is being captured into a graph: an event query is not a capturable operation and would invalidate the capture —
@@ -243,7 +155,7 @@ int mpcg_destroy(mpcg_handle* h) {
     return MPCG_OK;
 }
 
-const char* mpcg_last_error(const mpcg_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+const char* mpcg_last_error(const mpcg_handle* h) { return h ? h->err.c_str() : mpcg_create_err.c_str(); }
 
 // key -> int member of the handle (plain knobs without range checks)
 static int* knob_ptr(mpcg_handle* h, const char* key) {
@@ -1082,533 +994,8 @@ int mpcg_pcg_solve_ref_f64(mpcg_handle* h, double* d_S, double* d_Pinv, double* 
 
 }  // extern "C"
 
-// The walking Schur kernels' seam buffer (one 14 x 14 Q^-1 per chunk, float or double).  Sized ONCE, on first use, for whatever the automatic
-// chunk length can ask of this handle: chunks shorter than 16 rows are chosen only while the call has fewer than 2 x `want` rows per chunk
-// length, i.e. at most 2 x want + batch chunks; 16-row chunks beyond — so calls of different batch sizes never reallocate (a reallocation
-// inside a stream capture would leave a dangling pointer in the captured graph: ADVICE r04).  Only a FORCED short "schur_chunk" can ask for
-// more; that grows the buffer outside a capture and is refused inside one.
-static int ensure_seam_buffer(mpcg_handle* h, size_t chunks_needed, size_t elem_bytes, hipStream_t st) {
-    const size_t want = (size_t)h->num_cus * 6 * 4;
-    const size_t auto_chunks = std::max<size_t>(2 * want + h->max_batch + 4, (size_t)h->max_batch * (size_t)(((size_t)h->N - 1 + 15) / 16));
-    // (the automatic part in doubles whatever this call's type: a float call followed by a linsys_t = double call must not reallocate either)
-    const size_t need = 196 * std::max(chunks_needed * elem_bytes, auto_chunks * sizeof(double));
-    if (h->seam_qinv_bytes >= need) return MPCG_OK;
-    if (h->seam_qinv) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
-            return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: a forced \"schur_chunk\" needs a larger seam buffer than the handle holds — make one such call outside the stream capture first");
-        HIP_TRY(h, hipDeviceSynchronize());          // (an earlier call's kernels may still read the old buffer)
-        HIP_TRY(h, hipFree(h->seam_qinv));
-    }
-    h->seam_qinv = nullptr; h->seam_qinv_bytes = 0;
-    HIP_TRY(h, hipMalloc(&h->seam_qinv, need));
-    h->seam_qinv_bytes = need;
-    return MPCG_OK;
-}
-
 extern "C" {
 
-int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, float* d_lambda, uint32_t batch, void* stream) {
-    if (!h) return MPCG_ERR_INVALID;
-    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_block_solve: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
-    if (!d_S || !d_gamma || !d_lambda) return fail(h, MPCG_ERR_INVALID, "mpcg_block_solve: null device pointer");
-    if (batch == 0) return MPCG_OK;
-    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_block_solve: batch exceeds max_batch");
-    HIP_TRY(h, hipSetDevice(h->device));
-    if (!h->block_scratch)                        // first call only (not stream-ordered: hipMalloc)
-        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->block_scratch),
-                             (size_t)h->max_batch * h->N * (NS * NS + NS) * sizeof(float)));
-    BlockSolveArgs a;
-    a.S = d_S; a.gamma = d_gamma; a.lambda = d_lambda; a.work = h->block_scratch; a.N = (int)h->N; a.batch = (int)batch;
-    // few trajectories: one per wavefront (columns dealt over the four DPP rows, ~2.5x shorter critical path);
-    // many: four per wavefront.  Same bits either way.  "block_solve_wide": -1 auto, 0 / 1 forced.
-    // (N=128: one per wave 0.35 / 0.53 ms at batch 1024 / 2048 against 0.71 / 0.75; at 4096 four per wave wins, 0.88 vs 0.93)
-    const bool wide = h->block_solve_wide < 0 ? batch <= 12u * (uint32_t)h->num_cus : h->block_solve_wide != 0;
-    if (wide) hipLaunchKernelGGL(bt_block_solve_wide_kernel, dim3(batch), dim3(64), 0, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(bt_block_solve_kernel, dim3((batch + 3) / 4), dim3(64), 0, static_cast<hipStream_t>(stream), a);
-    HIP_TRY(h, hipGetLastError());
-    return MPCG_OK;
-}
-
-int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, const float* d_C_dense, const float* d_g,
-                    const float* d_c, float* d_S, float* d_Pinv, float* d_gamma, float rho, uint32_t batch,
-                    mpcg_precond precond, void* stream) {
-    if (!h) return MPCG_ERR_INVALID;
-    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
-    if (!d_G_dense || !d_C_dense || !d_g || !d_c || !d_S || (!d_Pinv && precond != MPCG_PRECOND_NONE) || !d_gamma)
-        return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: null device pointer");
-    if (control_size != 7) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur: control_size must be 7 (IIWA-14)");
-    if (precond != MPCG_PRECOND_NONE && precond != MPCG_PRECOND_JACOBI && precond != MPCG_PRECOND_SS)
-        return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: bad preconditioner");
-    if (batch == 0) return MPCG_OK;
-    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: batch exceeds max_batch");
-    if ((uint64_t)batch * h->N >= (1ull << 31)) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur: batch * knot_points must stay below 2^31");
-    HIP_TRY(h, hipSetDevice(h->device));
-    const int n = (int)h->n, m = (int)control_size, N = (int)h->N;
-    const size_t Gsz = (size_t)(n * n + m * m) * N - m * m;
-    // Register-resident formation (schur_walk.hip.h): a 16-lane row walks a chunk of L consecutive block rows, a second kernel closes the
-    // seams between chunks.  L trades parallelism against seam work: as long as a call has fewer than ~6 wavefronts of four chunks per
-    // CU the chunks are made shorter (L = 1: every row a seam — one trajectory of the MPC loop's own call; 16 at 1024 x 128 knots).
-    // (Its kernels address every array through a buffer resource with 31-bit byte offsets: 2,352 B of S per knot => below 913 k knots.)
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (h->schur_dpp && (uint64_t)batch * N * 2352u < (1ull << 31)) {
-        int wL = h->schur_chunk;
-        if (wL <= 0) {
-            const long rows = (long)batch * (N - 1), want = (long)h->num_cus * 6 * 4;
-            wL = 1;
-            while (wL < 16 && rows / (2 * wL) >= want) wL *= 2;
-        }
-        const int wchunks = (N - 1 + wL - 1) / wL;
-        // seam buffer: one Q^-1 per chunk (ensure_seam_buffer: sized once for every automatic chunk length of this handle)
-        { const int rc_ = ensure_seam_buffer(h, (size_t)batch * wchunks, sizeof(float), st); if (rc_ != MPCG_OK) return rc_; }
-        sw::WalkArgs w;
-        w.s.G = d_G_dense; w.s.C = d_C_dense; w.s.g = d_g; w.s.c = d_c; w.s.S = d_S; w.s.Pinv = d_Pinv; w.s.gamma = d_gamma;
-        w.s.Ginv_scratch = nullptr; w.s.Ginv_out = d_G_dense;
-        w.s.rho = rho; w.s.n = n; w.s.m = m; w.s.N = N; w.s.batch = (int)batch; w.s.ss = precond == MPCG_PRECOND_SS; w.s.pinv = precond != MPCG_PRECOND_NONE;
-        w.s.k0_only = 0;
-        w.seam_qinv = static_cast<float*>(h->seam_qinv); w.L = wL; w.chunks = wchunks;
-        h->last_schur_chunk = wL;
-        const long capw = (long)h->num_cus * 64;
-        long bw = ((long)batch * wchunks + 3) / 4;
-        if (bw > capw) bw = capw;
-        hipLaunchKernelGGL(sw::schur_walk_kernel, dim3((unsigned)bw), dim3(64), 0, st, w);
-        HIP_TRY(h, hipGetLastError());
-        if (wchunks > 1) {
-            long bs = ((long)batch * (wchunks - 1) + 3) / 4;
-            if (bs > capw) bs = capw;
-            hipLaunchKernelGGL(sw::schur_seam_kernel, dim3((unsigned)bs), dim3(64), 0, st, w);
-            HIP_TRY(h, hipGetLastError());
-        }
-        return MPCG_OK;
-    }
-    h->last_schur_chunk = 0;
-    // the LDS kernels (schur_kernels.hip.h; option "schur_dpp" = 0, and calls beyond the 31-bit offsets above): one wavefront per knot,
-    // G^-1 through a handle-owned staging buffer
-    const size_t need = Gsz * h->max_batch;
-    if (h->ginv_scratch_floats < need) {          // first call only (not stream-ordered: hipMalloc)
-        if (h->ginv_scratch) HIP_TRY(h, hipFree(h->ginv_scratch));
-        h->ginv_scratch = nullptr; h->ginv_scratch_floats = 0;
-        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->ginv_scratch), need * sizeof(float)));
-        h->ginv_scratch_floats = need;
-    }
-    SchurArgs a;
-    a.G = d_G_dense; a.C = d_C_dense; a.g = d_g; a.c = d_c; a.S = d_S; a.Pinv = d_Pinv; a.gamma = d_gamma;
-    a.Ginv_scratch = h->ginv_scratch; a.Ginv_out = d_G_dense;
-    a.rho = rho; a.n = n; a.m = m; a.N = N; a.batch = (int)batch; a.ss = precond == MPCG_PRECOND_SS; a.pinv = precond != MPCG_PRECOND_NONE;
-    a.k0_only = 0;
-    long blocks = (long)batch * N;
-    const long cap = (long)h->num_cus * 64;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((form_schur_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
-    HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL((complete_ss_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
-    HIP_TRY(h, hipGetLastError());
-    return MPCG_OK;
-}
-
-int mpcg_compute_dz(mpcg_handle* h, uint32_t control_size, const float* d_Ginv_dense, const float* d_C_dense,
-                    const float* d_g, const float* d_lambda, float* d_dz, uint32_t batch, void* stream) {
-    if (!h) return MPCG_ERR_INVALID;
-    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_compute_dz: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
-    if (!d_Ginv_dense || !d_C_dense || !d_g || !d_lambda || !d_dz)
-        return fail(h, MPCG_ERR_INVALID, "mpcg_compute_dz: null device pointer");
-    if (control_size != 7) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_compute_dz: control_size must be 7 (IIWA-14)");
-    if (batch == 0) return MPCG_OK;
-    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_compute_dz: batch exceeds max_batch");
-    HIP_TRY(h, hipSetDevice(h->device));
-    DzArgs a{d_Ginv_dense, d_C_dense, d_g, d_lambda, d_dz, (int)h->n, (int)control_size, (int)h->N, (int)batch};
-    long blocks = (long)batch * h->N;
-    const long cap = (long)h->num_cus * 64;
-    if (blocks > cap) blocks = cap;
-    if (h->dz_dpp && h->N >= 2 && (uint64_t)batch * h->N * 1176u < (1ull << 31)) {     // (31-bit byte offsets into C)
-        long b4 = ((long)batch * h->N + 3) / 4;
-        if (b4 > cap * 4) b4 = cap * 4;
-        hipLaunchKernelGGL(sw::compute_dz_dpp_kernel, dim3((unsigned)b4), dim3(64), 0, static_cast<hipStream_t>(stream), a);
-    } else {
-        hipLaunchKernelGGL((compute_dz_kernel<14, 7>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
-    }
-    HIP_TRY(h, hipGetLastError());
-    return MPCG_OK;
-}
-
-
-// ---- linsys_t = double (USE_DOUBLES = 1, include/common/settings.cuh:41-49): the steps either side of the solve in double precision.
-// Round 5: the walking formation and the four-knots-per-wavefront dz recovery in double (schur_walk_f64.hip.h); options "schur_dpp" / "dz_dpp"
-// = 0 select the one-wavefront-per-knot LDS kernels of schur_kernels.hip.h instantiated for double.  Same arithmetic order as the float path,
-// bit-identical to the oracle's double instantiation either way. ----
-int mpcg_form_schur_f64(mpcg_handle* h, uint32_t control_size, double* d_G_dense, const double* d_C_dense, const double* d_g,
-                        const double* d_c, double* d_S, double* d_Pinv, double* d_gamma, double rho, uint32_t batch,
-                        mpcg_precond precond, void* stream) {
-    if (!h) return MPCG_ERR_INVALID;
-    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur_f64: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
-    if (!d_G_dense || !d_C_dense || !d_g || !d_c || !d_S || (!d_Pinv && precond != MPCG_PRECOND_NONE) || !d_gamma)
-        return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur_f64: null device pointer");
-    if (control_size != 7) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur_f64: control_size must be 7 (IIWA-14)");
-    if (precond != MPCG_PRECOND_NONE && precond != MPCG_PRECOND_JACOBI && precond != MPCG_PRECOND_SS)
-        return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur_f64: bad preconditioner");
-    if (batch == 0) return MPCG_OK;
-    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur_f64: batch exceeds max_batch");
-    HIP_TRY(h, hipSetDevice(h->device));
-    const int n = (int)h->n, m = (int)control_size, N = (int)h->N;
-    const size_t Gsz = (size_t)(n * n + m * m) * N - m * m;
-    // Round 5: the register-resident formation in double (schur_walk_f64.hip.h) — the float path's design, chunk policy and seam buffer; its
-    // buffer resources carry 31-bit byte offsets: 4,704 B of S per knot => below 456 k knots per call (beyond: the LDS kernels).
-    if (h->schur_dpp && (uint64_t)batch * N * 4704u < (1ull << 31)) {
-        hipStream_t st = static_cast<hipStream_t>(stream);
-        int wL = h->schur_chunk;
-        if (wL <= 0) {
-            const long rows = (long)batch * (N - 1), want = (long)h->num_cus * 6 * 4;
-            wL = 1;
-            while (wL < 16 && rows / (2 * wL) >= want) wL *= 2;
-        }
-        const int wchunks = (N - 1 + wL - 1) / wL;
-        { const int rc_ = ensure_seam_buffer(h, (size_t)batch * wchunks, sizeof(double), st); if (rc_ != MPCG_OK) return rc_; }
-        sw64::WalkArgs64 w;
-        w.s.G = d_G_dense; w.s.C = d_C_dense; w.s.g = d_g; w.s.c = d_c; w.s.S = d_S; w.s.Pinv = d_Pinv; w.s.gamma = d_gamma;
-        w.s.Ginv_scratch = nullptr; w.s.Ginv_out = d_G_dense;
-        w.s.rho = rho; w.s.n = n; w.s.m = m; w.s.N = N; w.s.batch = (int)batch; w.s.ss = precond == MPCG_PRECOND_SS; w.s.pinv = precond != MPCG_PRECOND_NONE;
-        w.s.k0_only = 0;
-        w.seam_qinv = static_cast<double*>(h->seam_qinv); w.L = wL; w.chunks = wchunks;
-        h->last_schur_chunk = wL;
-        const long capw = (long)h->num_cus * 64;
-        long bw = ((long)batch * wchunks + 3) / 4;
-        if (bw > capw) bw = capw;
-        hipLaunchKernelGGL(sw64::schur_walk_f64_kernel, dim3((unsigned)bw), dim3(64), 0, st, w);
-        HIP_TRY(h, hipGetLastError());
-        if (wchunks > 1) {
-            long bs = ((long)batch * (wchunks - 1) + 3) / 4;
-            if (bs > capw) bs = capw;
-            hipLaunchKernelGGL(sw64::schur_seam_f64_kernel, dim3((unsigned)bs), dim3(64), 0, st, w);
-            HIP_TRY(h, hipGetLastError());
-        }
-        return MPCG_OK;
-    }
-    h->last_schur_chunk = 0;
-    const size_t need = Gsz * h->max_batch;
-    if (h->ginv_scratch_f64_elems < need) {       // first call only (not stream-ordered: hipMalloc)
-        if (h->ginv_scratch_f64) HIP_TRY(h, hipFree(h->ginv_scratch_f64));
-        h->ginv_scratch_f64 = nullptr; h->ginv_scratch_f64_elems = 0;
-        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->ginv_scratch_f64), need * sizeof(double)));
-        h->ginv_scratch_f64_elems = need;
-    }
-    SchurArgsT<double> a;
-    a.G = d_G_dense; a.C = d_C_dense; a.g = d_g; a.c = d_c; a.S = d_S; a.Pinv = d_Pinv; a.gamma = d_gamma;
-    a.Ginv_scratch = h->ginv_scratch_f64; a.Ginv_out = d_G_dense;
-    a.rho = rho; a.n = n; a.m = m; a.N = N; a.batch = (int)batch; a.ss = precond == MPCG_PRECOND_SS; a.pinv = precond != MPCG_PRECOND_NONE;
-    a.k0_only = 0;
-    long blocks = (long)batch * N;
-    const long cap = (long)h->num_cus * 64;
-    if (blocks > cap) blocks = cap;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL((form_schur_kernel<14, 7, double>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
-    HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL((complete_ss_kernel<14, 7, double>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, st, a);
-    HIP_TRY(h, hipGetLastError());
-    return MPCG_OK;
-}
-
-int mpcg_compute_dz_f64(mpcg_handle* h, uint32_t control_size, const double* d_Ginv_dense, const double* d_C_dense,
-                        const double* d_g, const double* d_lambda, double* d_dz, uint32_t batch, void* stream) {
-    if (!h) return MPCG_ERR_INVALID;
-    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_compute_dz_f64: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
-    if (!d_Ginv_dense || !d_C_dense || !d_g || !d_lambda || !d_dz)
-        return fail(h, MPCG_ERR_INVALID, "mpcg_compute_dz_f64: null device pointer");
-    if (control_size != 7) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_compute_dz_f64: control_size must be 7 (IIWA-14)");
-    if (batch == 0) return MPCG_OK;
-    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_compute_dz_f64: batch exceeds max_batch");
-    HIP_TRY(h, hipSetDevice(h->device));
-    DzArgsT<double> a{d_Ginv_dense, d_C_dense, d_g, d_lambda, d_dz, (int)h->n, (int)control_size, (int)h->N, (int)batch};
-    long blocks = (long)batch * h->N;
-    const long cap = (long)h->num_cus * 64;
-    if (h->dz_dpp && h->N >= 2 && (uint64_t)batch * h->N * 2352u < (1ull << 31)) {      // four knots per wavefront (schur_walk_f64.hip.h); 31-bit byte offsets into C
-        long bq = (blocks + 3) / 4;
-        if (bq > cap) bq = cap;
-        hipLaunchKernelGGL(sw64::compute_dz_dpp_f64_kernel, dim3((unsigned)bq), dim3(64), 0, static_cast<hipStream_t>(stream), a);
-        HIP_TRY(h, hipGetLastError());
-        return MPCG_OK;
-    }
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((compute_dz_kernel<14, 7, double>), dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
-    HIP_TRY(h, hipGetLastError());
-    return MPCG_OK;
-}
-
-int mpcg_prep_csr(mpcg_handle* h, int32_t* d_col_ptr, int32_t* d_row_ind, void* stream) {
-    if (!h) return MPCG_ERR_INVALID;
-    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_prep_csr: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
-    if (!d_col_ptr || !d_row_ind) return fail(h, MPCG_ERR_INVALID, "mpcg_prep_csr: null device pointer");
-    HIP_TRY(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(prep_csr_kernel, dim3(h->N), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), (int)h->n, (int)h->N,
-                       d_col_ptr, d_row_ind);
-    HIP_TRY(h, hipGetLastError());
-    return MPCG_OK;
-}
-
-int mpcg_bd_to_csr_lowertri(mpcg_handle* h, const float* d_S, float* d_val, float mult, uint32_t batch, void* stream) {
-    if (!h) return MPCG_ERR_INVALID;
-    if (h->generic) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_bd_to_csr_lowertri: state_size = 14 only (other state sizes: PCG entry points through the generic kernel)");
-    if (!d_S || !d_val) return fail(h, MPCG_ERR_INVALID, "mpcg_bd_to_csr_lowertri: null device pointer");
-    if (batch == 0) return MPCG_OK;
-    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_bd_to_csr_lowertri: batch exceeds max_batch");
-    HIP_TRY(h, hipSetDevice(h->device));
-    CsrArgs a{d_S, d_val, mult, (int)h->n, (int)h->N, (int)batch};
-    long blocks = (long)batch * h->N;
-    const long cap = (long)h->num_cus * 64;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(bd_to_csr_kernel, dim3((unsigned)blocks), dim3(SCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
-    HIP_TRY(h, hipGetLastError());
-    return MPCG_OK;
-}
-
-// ---- the producer of the path's inputs: KKT block assembly with the robot as data (kkt_plant.hip.h) ----
-struct mpcg_plant { int device = 0; PlantDev* d = nullptr; };
-
-int mpcg_plant_create(mpcg_plant** out, int device, uint32_t num_joints, const double* X_const, const double* I_spatial, const double* Xhom_const,
-                      const int32_t* X_trig_idx, const double* X_trig_coef, const int32_t* X_trig_j, uint32_t n_X_trig,
-                      const int32_t* Xhom_trig_idx, const double* Xhom_trig_coef, const int32_t* Xhom_trig_j, uint32_t n_Xhom_trig) {
-    if (!out) return MPCG_ERR_INVALID;
-    *out = nullptr;
-    if (num_joints != (uint32_t)PJ) return fail(nullptr, MPCG_ERR_UNSUPPORTED, "mpcg_plant_create: the compiled specialisation has 7 joints (IIWA-14)");
-    if (!X_const || !I_spatial || !Xhom_const || (n_X_trig && (!X_trig_idx || !X_trig_coef || !X_trig_j)) ||
-        (n_Xhom_trig && (!Xhom_trig_idx || !Xhom_trig_coef || !Xhom_trig_j)))
-        return fail(nullptr, MPCG_ERR_INVALID, "mpcg_plant_create: null table");
-    PlantDev* hp = new (std::nothrow) PlantDev();
-    if (!hp) return MPCG_ERR_NOMEM;
-    memset(hp, 0, sizeof(PlantDev));
-    // The tables as given: X_k(q_k) = [[E, 0], [B, E]] with E = E0 + Es sin q_k + Ec cos q_k (likewise B), homogeneous transforms
-    // R = R0 + Rs sin + Rc cos and translation p.  Tables are column-major (6x6 / 4x4), these are row-major 3x3 blocks.
-    struct Given { double E0[PJ][9], Es[PJ][9], Ec[PJ][9], B0[PJ][9], Bs[PJ][9], Bc[PJ][9], R0[PJ][9], Rs[PJ][9], Rc[PJ][9], p[PJ][3], I[PJ][36]; };
-    Given* gv = new (std::nothrow) Given();
-    if (!gv) { delete hp; return MPCG_ERR_NOMEM; }
-    memset(gv, 0, sizeof(Given));
-    auto place = [&](int k, int r, int c, double v, int which /*0 const, 1 sin, 2 cos*/) -> bool {
-        double(*E)[9] = which == 0 ? gv->E0 : (which == 1 ? gv->Es : gv->Ec);
-        double(*B)[9] = which == 0 ? gv->B0 : (which == 1 ? gv->Bs : gv->Bc);
-        if (r < 3 && c < 3) { E[k][3 * r + c] = v; return true; }
-        if (r >= 3 && c < 3) { B[k][3 * (r - 3) + c] = v; return true; }
-        return v == 0.0 || (r >= 3 && c >= 3);             // upper-right block must be zero; lower-right repeats E
-    };
-    bool ok = true;
-    for (int k = 0; k < PJ; ++k) {
-        for (int c = 0; c < 6; ++c)
-            for (int r = 0; r < 6; ++r) {
-                ok = ok && place(k, r, c, X_const[k * 36 + c * 6 + r], 0);
-                gv->I[k][6 * r + c] = I_spatial[k * 36 + c * 6 + r];
-            }
-        for (int c = 0; c < 3; ++c)
-            for (int r = 0; r < 3; ++r) gv->R0[k][3 * r + c] = Xhom_const[k * 16 + c * 4 + r];
-        for (int r = 0; r < 3; ++r) gv->p[k][r] = Xhom_const[k * 16 + 12 + r];
-    }
-    for (uint32_t t = 0; t < n_X_trig && ok; ++t) {
-        const int idx = X_trig_idx[t], k = idx / 36, c = (idx % 36) / 6, r = idx % 6, j = X_trig_j[t];
-        if (idx < 0 || k >= PJ || j < 0 || j >= 2 * PJ || j % PJ != k) { ok = false; break; }     // joint k's transform depends on q_k only
-        // a trig entry REPLACES the constant at that position (load_update_XImats_helpers overwrites it)
-        place(k, r, c, 0.0, 0);
-        ok = place(k, r, c, X_trig_coef[t], j < PJ ? 1 : 2);
-    }
-    for (uint32_t t = 0; t < n_Xhom_trig && ok; ++t) {
-        const int idx = Xhom_trig_idx[t], k = idx / 16, c = (idx % 16) / 4, r = idx % 4, j = Xhom_trig_j[t];
-        if (idx < 0 || k >= PJ || j < 0 || j >= 2 * PJ || j % PJ != k || r >= 3 || c >= 3) { ok = false; break; }
-        gv->R0[k][3 * r + c] = 0.0;
-        (j < PJ ? gv->Rs : gv->Rc)[k][3 * r + c] = Xhom_trig_coef[t];
-    }
-    if (!ok) { delete hp; delete gv; return fail(nullptr, MPCG_ERR_INVALID, "mpcg_plant_create: tables do not describe a serial chain of revolute joints (X = [[E, 0], [B, E]], joint k depends on q_k)"); }
-    // The kernel applies X_k(q) as blkdiag(Rz, Rz) Xtree, Rz = [[c, s, 0], [-s, c, 0], [0, 0, 1]] (a revolute joint about its own z axis,
-    // the convention of GRiD's tables): row 0 = c T0 + s T1, row 1 = -s T0 + c T1, row 2 = T2 with T = E0 + Ec the transform at q = 0.
-    // Verify that the given constant / sin / cos parts have exactly that form.
-    double scale = 0.0;
-    for (int k = 0; k < PJ; ++k)
-        for (int e = 0; e < 9; ++e) {
-            hp->ET[k][e] = gv->E0[k][e] + gv->Ec[k][e];
-            hp->BT[k][e] = gv->B0[k][e] + gv->Bc[k][e];
-            scale = fmax(scale, fmax(fabs(hp->ET[k][e]), fabs(hp->BT[k][e])));
-        }
-    auto rotz_form = [&](const double* T, const double* c0, const double* cs, const double* cc) {
-        double worst = 0.0;
-        for (int c = 0; c < 3; ++c) {
-            worst = fmax(worst, fabs(cc[c] - T[c]) + fabs(cc[3 + c] - T[3 + c]) + fabs(cc[6 + c]));                 // cos part: rows 0, 1 of T
-            worst = fmax(worst, fabs(cs[c] - T[3 + c]) + fabs(cs[3 + c] + T[c]) + fabs(cs[6 + c]));                 // sin part: T1, -T0
-            worst = fmax(worst, fabs(c0[c]) + fabs(c0[3 + c]) + fabs(c0[6 + c] - T[6 + c]));                        // constant part: row 2
-        }
-        return worst;
-    };
-    double dev = 0.0;
-    for (int k = 0; k < PJ; ++k) {
-        dev = fmax(dev, rotz_form(hp->ET[k], gv->E0[k], gv->Es[k], gv->Ec[k]));
-        dev = fmax(dev, rotz_form(hp->BT[k], gv->B0[k], gv->Bs[k], gv->Bc[k]));
-    }
-    if (!(dev <= 1e-12 * fmax(scale, 1.0))) {
-        delete hp; delete gv;
-        return fail(nullptr, MPCG_ERR_UNSUPPORTED, "mpcg_plant_create: every joint must rotate about its own z axis, X_k(q) = blkdiag(Rz(q), Rz(q)) X_k(0) (the form of GRiD's tables)");
-    }
-    // Spatial inertias: the kernel multiplies with the rigid-body form [[Ibar, skew(h)], [skew(h)^T, m 1]] (ten numbers).
-    for (int k = 0; k < PJ; ++k) {
-        const double* Ik = gv->I[k];
-        double sc = 0.0, asym = 0.0;
-        for (int r = 0; r < 6; ++r)
-            for (int c = 0; c < 6; ++c) { sc = fmax(sc, fabs(Ik[6 * r + c])); asym = fmax(asym, fabs(Ik[6 * r + c] - Ik[6 * c + r])); }
-        if (!(asym <= 1e-12 * fmax(1.0, sc))) {
-            delete hp; delete gv;
-            return fail(nullptr, MPCG_ERR_INVALID, "mpcg_plant_create: spatial inertias must be symmetric");
-        }
-        const double mass = Ik[6 * 3 + 3], h[3] = {Ik[6 * 2 + 4], Ik[6 * 0 + 5], Ik[6 * 1 + 3]};      // skew(h) = [[0, -hz, hy], [hz, 0, -hx], [-hy, hx, 0]]
-        const double sk[9] = {0, -h[2], h[1], h[2], 0, -h[0], -h[1], h[0], 0};
-        double devI = 0.0;
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) {
-                devI = fmax(devI, fabs(Ik[6 * r + 3 + c] - sk[3 * r + c]));
-                devI = fmax(devI, fabs(Ik[6 * (3 + r) + 3 + c] - (r == c ? mass : 0.0)));
-            }
-        if (!(devI <= 1e-12 * fmax(1.0, sc))) {
-            delete hp; delete gv;
-            return fail(nullptr, MPCG_ERR_UNSUPPORTED, "mpcg_plant_create: spatial inertias must have the rigid-body form [[Ibar, skew(m c)], [skew(m c)^T, m 1]]");
-        }
-        const double ib[10] = {Ik[0], Ik[1], Ik[2], Ik[7], Ik[8], Ik[14], h[0], h[1], h[2], mass};
-        memcpy(hp->Ib[k], ib, sizeof(ib));
-    }
-    // The end-effector position and Jacobian come out of the spatial transforms on the device (kkt_plant.hip.h, round 0); the reference
-    // takes them from the homogeneous transforms.  Both tables describe the same chain: check it at three configurations.
-    {
-        const double qs[3][PJ] = {{0, 0, 0, 0, 0, 0, 0}, {0.3, -0.7, 1.1, 0.5, -1.3, 0.9, 0.2}, {-2.1, 1.4, -0.6, 1.9, 0.8, -1.7, 2.5}};
-        double worst = 0.0;
-        for (int t = 0; t < 3; ++t) {
-            double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pos[3] = {0, 0, 0};
-            double W[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, V[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};       // motion vectors [e_i; 0] pushed through the chain
-            for (int k = 0; k < PJ; ++k) {
-                const double sn = sin(qs[t][k]), cs = cos(qs[t][k]);
-                double H[9], Rn[9];
-                for (int e = 0; e < 9; ++e) H[e] = gv->R0[k][e] + gv->Rs[k][e] * sn + gv->Rc[k][e] * cs;
-                for (int r = 0; r < 3; ++r) {
-                    pos[r] += R[3 * r] * gv->p[k][0] + R[3 * r + 1] * gv->p[k][1] + R[3 * r + 2] * gv->p[k][2];
-                    for (int c = 0; c < 3; ++c) Rn[3 * r + c] = R[3 * r] * H[c] + R[3 * r + 1] * H[3 + c] + R[3 * r + 2] * H[6 + c];
-                }
-                memcpy(R, Rn, sizeof(R));
-                for (int i = 0; i < 3; ++i) {
-                    double tw[3], tu[3];
-                    for (int r = 0; r < 3; ++r) {
-                        tw[r] = hp->ET[k][3 * r] * W[i][0] + hp->ET[k][3 * r + 1] * W[i][1] + hp->ET[k][3 * r + 2] * W[i][2];
-                        tu[r] = hp->BT[k][3 * r] * W[i][0] + hp->BT[k][3 * r + 1] * W[i][1] + hp->BT[k][3 * r + 2] * W[i][2] +
-                                hp->ET[k][3 * r] * V[i][0] + hp->ET[k][3 * r + 1] * V[i][1] + hp->ET[k][3 * r + 2] * V[i][2];
-                    }
-                    W[i][0] = cs * tw[0] + sn * tw[1]; W[i][1] = cs * tw[1] - sn * tw[0]; W[i][2] = tw[2];
-                    V[i][0] = cs * tu[0] + sn * tu[1]; V[i][1] = cs * tu[1] - sn * tu[0]; V[i][2] = tu[2];
-                }
-            }
-            const double ee[3] = {-(W[2][0] * V[1][0] + W[2][1] * V[1][1] + W[2][2] * V[1][2]), W[2][0] * V[0][0] + W[2][1] * V[0][1] + W[2][2] * V[0][2],
-                                  -(W[1][0] * V[0][0] + W[1][1] * V[0][1] + W[1][2] * V[0][2])};
-            for (int r = 0; r < 3; ++r) worst = fmax(worst, fabs(ee[r] - pos[r]));
-        }
-        if (!(worst <= 1e-9)) {
-            delete hp; delete gv;
-            return fail(nullptr, MPCG_ERR_INVALID, "mpcg_plant_create: the homogeneous transforms (Xhom) and the spatial transforms (X) describe different chains");
-        }
-    }
-    delete gv;
-    mpcg_plant* pl = new (std::nothrow) mpcg_plant();
-    if (!pl) { delete hp; return MPCG_ERR_NOMEM; }
-    if (device < 0 && hipGetDevice(&device) != hipSuccess) { delete hp; delete pl; return fail(nullptr, MPCG_ERR_HIP, "mpcg_plant_create: no HIP device"); }
-    pl->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&pl->d), sizeof(PlantDev)) != hipSuccess ||
-        hipMemcpy(pl->d, hp, sizeof(PlantDev), hipMemcpyHostToDevice) != hipSuccess) {
-        delete hp; delete pl;
-        return fail(nullptr, MPCG_ERR_HIP, "mpcg_plant_create: cannot place the model on the device");
-    }
-    delete hp;
-    *out = pl;
-    return MPCG_OK;
-}
-
-// The KUKA LBR iiwa 14 the reference is built for, from the tables compiled into the library (csrc/iiwa14_model.inc): what
-// gato_plant::initializeDynamicsConstMem<T>() returns in the reference (include/dynamics/iiwa/iiwa_eepos_plant.cuh:63-66).
-#include "iiwa14_model.inc"
-int mpcg_plant_create_iiwa14(mpcg_plant** out, int device) {
-    return mpcg_plant_create(out, device, 7, kIiwa14_X_const, kIiwa14_I, kIiwa14_Xhom_const, kIiwa14_X_trig_idx, kIiwa14_X_trig_coef, kIiwa14_X_trig_j,
-                             (uint32_t)(sizeof(kIiwa14_X_trig_idx) / sizeof(int32_t)), kIiwa14_Xhom_trig_idx, kIiwa14_Xhom_trig_coef, kIiwa14_Xhom_trig_j,
-                             (uint32_t)(sizeof(kIiwa14_Xhom_trig_idx) / sizeof(int32_t)));
-}
-
-int mpcg_plant_destroy(mpcg_plant* p) {
-    if (p && p->d) { (void)hipSetDevice(p->device); (void)hipFree(p->d); }
-    delete p;
-    return MPCG_OK;
-}
-
-int mpcg_generate_kkt(mpcg_handle* h, const mpcg_plant* plant, uint32_t control_size, float timestep, const float* d_eePos_traj,
-                      const float* d_xs, const float* d_xu, float qd_cost, float r_cost, float* d_G_dense, float* d_C_dense,
-                      float* d_g, float* d_c, uint32_t batch, void* stream) {
-    if (!h || !plant) return MPCG_ERR_INVALID;
-    if (!d_eePos_traj || !d_xs || !d_xu || !d_G_dense || !d_C_dense || !d_g || !d_c)
-        return fail(h, MPCG_ERR_INVALID, "mpcg_generate_kkt: null device pointer");
-    if (control_size != (uint32_t)PJ || h->n != 2u * PJ) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_generate_kkt: state_size 14 / control_size 7 (IIWA-14) only");
-    if (plant->device != h->device) return fail(h, MPCG_ERR_INVALID, "mpcg_generate_kkt: plant and handle live on different devices");
-    if (batch == 0) return MPCG_OK;
-    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_generate_kkt: batch exceeds max_batch");
-    HIP_TRY(h, hipSetDevice(h->device));
-    KktArgs a;
-    a.plant = plant->d; a.eePos_traj = d_eePos_traj; a.xs = d_xs; a.xu = d_xu;
-    a.G = d_G_dense; a.C = d_C_dense; a.g = d_g; a.c = d_c;
-    a.N = (int)h->N; a.batch = (int)batch; a.dt = timestep; a.qd_cost = qd_cost; a.r_cost = r_cost;
-    a.analytic = h->kkt_analytic;
-    long blocks = ((long)batch * (h->N - 1) + KKT_ITEMS - 1) / KKT_ITEMS;      // one wavefront per KKT_ITEMS (trajectory, knot) pairs
-    const long cap = (long)h->num_cus * 32;
-    if (blocks > cap) blocks = cap;
-    if (h->kkt_analytic) hipLaunchKernelGGL(generate_kkt_kernel<true>, dim3((unsigned)blocks), dim3(KKT_THREADS), 0, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(generate_kkt_kernel<false>, dim3((unsigned)blocks), dim3(KKT_THREADS), 0, static_cast<hipStream_t>(stream), a);
-    HIP_TRY(h, hipGetLastError());
-    return MPCG_OK;
-}
-
-// ---- LINSYS_SOLVE == 0: the reference's CPU LDL^T path as a selectable solver (ldl_host.hpp) ----
-struct mpcg_ldl { mpcg_ldl_host::Ldl w; std::string err; };
-
-int mpcg_ldl_create(mpcg_ldl** out, uint32_t state_size, uint32_t knot_points) {
-    if (!out) return MPCG_ERR_INVALID;
-    *out = nullptr;
-    if (state_size == 0 || knot_points == 0 || (uint64_t)state_size * knot_points > (1u << 24)) return MPCG_ERR_INVALID;
-    mpcg_ldl* l = new (std::nothrow) mpcg_ldl();
-    if (!l) return MPCG_ERR_NOMEM;
-    if (mpcg_ldl_host::setup(l->w, (int)state_size, (int)knot_points) != 0) { delete l; return MPCG_ERR_INVALID; }
-    *out = l;
-    return MPCG_OK;
-}
-
-int mpcg_ldl_destroy(mpcg_ldl* l) { delete l; return MPCG_OK; }
-
-int mpcg_ldl_pattern(const mpcg_ldl* l, const int32_t** h_col_ptr, const int32_t** h_row_ind, uint32_t* nnz, uint32_t* sum_lnz) {
-    if (!l) return MPCG_ERR_INVALID;
-    if (h_col_ptr) *h_col_ptr = l->w.Ap.data();
-    if (h_row_ind) *h_row_ind = l->w.Ai.data();
-    if (nnz) *nnz = (uint32_t)l->w.Ai.size();
-    if (sum_lnz) *sum_lnz = (uint32_t)l->w.sumLnz;
-    return MPCG_OK;
-}
-
-int mpcg_ldl_solve(mpcg_ldl* l, const float* h_val, const float* h_gamma, float* h_lambda) {
-    if (!l || !h_val || !h_gamma || !h_lambda) return MPCG_ERR_INVALID;
-    if (mpcg_ldl_host::factor(l->w, h_val) < 0) { l->err = "mpcg_ldl_solve: zero pivot"; return MPCG_ERR_INVALID; }
-    if (h_lambda != h_gamma) memcpy(h_lambda, h_gamma, sizeof(float) * (size_t)l->w.An);
-    mpcg_ldl_host::solve(l->w, h_lambda);
-    return MPCG_OK;
-}
-
-int mpcg_qdldl_solve_schur(mpcg_handle* h, mpcg_ldl* l, const float* d_val, const float* d_gamma, float* d_lambda, void* stream) {
-    if (!h || !l) return MPCG_ERR_INVALID;
-    if (!d_val || !d_gamma || !d_lambda) return fail(h, MPCG_ERR_INVALID, "mpcg_qdldl_solve_schur: null device pointer");
-    if ((uint32_t)l->w.n != h->n || (uint32_t)l->w.N != h->N) return fail(h, MPCG_ERR_INVALID, "mpcg_qdldl_solve_schur: pattern and handle differ in shape");
-    HIP_TRY(h, hipSetDevice(h->device));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    // the reference's timed region (include/qdldl/sqp.cuh:268-273): D2H values + gamma, factor + solve, H2D lambda
-    HIP_TRY(h, hipMemcpyAsync(l->w.val.data(), d_val, sizeof(float) * l->w.val.size(), hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipMemcpyAsync(l->w.rhs.data(), d_gamma, sizeof(float) * (size_t)l->w.An, hipMemcpyDeviceToHost, st));
-    HIP_TRY(h, hipStreamSynchronize(st));
-    const int rc = mpcg_ldl_solve(l, l->w.val.data(), l->w.rhs.data(), l->w.sol.data());
-    if (rc != MPCG_OK) return fail(h, rc, "mpcg_qdldl_solve_schur: zero pivot in the LDL^T factorisation");
-    HIP_TRY(h, hipMemcpyAsync(d_lambda, l->w.sol.data(), sizeof(float) * (size_t)l->w.An, hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipStreamSynchronize(st));
-    return MPCG_OK;
-}
-
-// diagnostic: copy the first `count` u64 words of the cluster scratch (fail flags first) to the host; synchronises the device
 int mpcg_debug_read_cluster_scratch(mpcg_handle* h, unsigned long long* out, int count) {
     if (!h || !out || count < 0 || (size_t)count > cluster_alloc_words(h)) return MPCG_ERR_INVALID;
     if (hipDeviceSynchronize() != hipSuccess) return MPCG_ERR_HIP;

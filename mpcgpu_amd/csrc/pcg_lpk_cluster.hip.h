@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpkc_kernel(ClusterArgs ca) 
     const int g = jx % G;
     const int cl = (jx / G) * 8 + xcd;
     if ((unsigned)cl >= nclusters) return;
-    // gate of the symmetry latch (mpcg_capi.hip: launch_guarded): every member reads the same word and leaves at once when it says the
+    // gate of the symmetry latch (mpcg_pcg.hip: launch_guarded): every member reads the same word and leaves at once when it says the
     // matrices are not block-symmetric — no trajectory is drawn, every completion count stays 0, and the fix-up launch solves them all
     if (a.redo_flags && __hip_atomic_load(a.redo_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.redo_skip) return;
     const int k0 = (int)(((long)g * N) / G), k1 = (int)(((long)(g + 1) * N) / G);

@@ -34,7 +34,8 @@ def disassemble(lib):
         cos = [os.path.join(tmp, f) for f in os.listdir(tmp) if "amdgcn" in f]
         if not cos:
             raise RuntimeError("no amdgcn code object found in " + lib)
-        return subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", cos[0]], check=True, capture_output=True, text=True).stdout
+        # one code object per translation unit of the library (mpcg_pcg / mpcg_producers / mpcg_plant / mpcg_ldl): all of them
+        return "\n".join(subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout for co in sorted(cos))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -3,7 +3,7 @@
 # then on the GPU box:  for m in 0 1 3 7; do AB_LIB=tools/_prof/ab/libmpcg_lpk_abl$m.so python tools/lpk_quick.py 128x1024 128x1; done
 mkdir -p tools/_prof/ab
 for m in 0 1 3 7; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-function -DMPCG_ABLATE_LPK=$m mpcgpu_amd/csrc/mpcg_capi.hip -o tools/_prof/ab/libmpcg_lpk_abl$m.so &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-function -DMPCG_ABLATE_LPK=$m mpcgpu_amd/csrc/mpcg_*.hip -o tools/_prof/ab/libmpcg_lpk_abl$m.so &
 done
 wait
 ls -la tools/_prof/ab/ | grep lpk
