@@ -30,7 +30,7 @@ struct PcgKnobs {
 };
 
 // What the last solve on this handle actually launched (read-only "last_kernel_*" options; tests assert on it).
-enum { FAM_NONE = -1, FAM_TRAJ = 0, /* 1, 2, 4: kernels retired in round 4 (HISTORY.md) */ FAM_GENERIC = 3, FAM_RPL = 5, FAM_LPK = 6, FAM_LPKC = 7 };
+enum { FAM_NONE = -1, FAM_TRAJ = 0, /* 1, 2, 4: kernels retired in round 4 (HISTORY.md) */ FAM_GENERIC = 3, FAM_RPL = 5, FAM_LPK = 6, FAM_LPKC = 7, FAM_RPLC64 = 8 };
 struct LastKernel { int family = FAM_NONE, waves = 0, reg_rows = 0, lds_rows = 0, stream_bufs = 0, cluster = 0, lds_bytes = 0, lds_extra = 0; };
 
 struct mpcg_handle {
@@ -67,6 +67,7 @@ struct mpcg_handle {
     hipEvent_t sym_event = nullptr;
     unsigned long long* sym_host = nullptr;      // pinned
     unsigned long long* cluster_scratch = nullptr;
+    unsigned long long* cluster64_scratch = nullptr;   // the clustered row-per-lane kernel in double (pcg_rpl_cluster_f64.hip.h): queue | flags | cells, first use
     bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any valid pcg_* set_option clears this)
     bool generic = false;     // state_size != 14: only the PCG entry points work, through pcg_generic_kernel
     int spmv_blocks_per_cu = 3;    // (sweep at 4096 trajectories = 1.2 GB of S, a true HBM stream: profiles/r04_spmv.txt; until round 4: 4)

@@ -5,6 +5,7 @@
 #include "pcg_lpk.hip.h"
 #include "pcg_lpk_cluster.hip.h"
 #include "pcg_rpl.hip.h"
+#include "pcg_rpl_cluster_f64.hip.h"
 #include "pcg_f64.hip.h"
 
 using namespace mpcg;
@@ -149,6 +150,7 @@ int mpcg_destroy(mpcg_handle* h) {
         if (h->sym_host) (void)hipHostFree(h->sym_host);
         if (h->ginv_scratch_f64) (void)hipFree(h->ginv_scratch_f64);
         if (h->cluster_scratch) (void)hipFree(h->cluster_scratch);
+        if (h->cluster64_scratch) (void)hipFree(h->cluster64_scratch);
         if (h->sched_order) (void)hipFree(h->sched_order);
     }
     delete h;
@@ -256,7 +258,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
         return MPCG_OK;
     }
     // what the last solve on this handle launched
-    if (!strcmp(key, "last_kernel_family")) { *value = h->last.family; return MPCG_OK; }      // 0 single-workgroup row-pair, 3 generic, 5 row-per-lane, 6 lane-pair, 7 clustered lane-pair
+    if (!strcmp(key, "last_kernel_family")) { *value = h->last.family; return MPCG_OK; }      // 0 single-workgroup row-pair, 3 generic, 5 row-per-lane, 6 lane-pair, 7 clustered lane-pair, 8 clustered row-per-lane (double)
     if (!strcmp(key, "last_kernel_waves")) { *value = h->last.waves; return MPCG_OK; }
     if (!strcmp(key, "last_kernel_reg_rows")) { *value = h->last.reg_rows; return MPCG_OK; }
     if (!strcmp(key, "last_kernel_lds_rows")) { *value = h->last.lds_rows; return MPCG_OK; }
@@ -750,6 +752,59 @@ static int launch_rpl_f64_t(mpcg_handle* h, const PcgArgs64& a, uint32_t batch, 
     h->last = LastKernel{FAM_RPL, NW, 1, 0, 0, 0, (int)lds, 0};
     return MPCG_OK;
 }
+// ---- linsys_t = double, 32 < N <= 256: the row-per-lane kernel across G = ceil(N / 32) CUs of one XCD (pcg_rpl_cluster_f64.hip.h) ----
+// Same launch shape as the clustered lane-pair kernel (persistent clusters pinned to XCDs, one fill of queue + flags + cells in front, a fix-up
+// launch behind: here the streaming kernel, gated on the completion counts).  Returns 1 when it does not apply.
+static int rplc64_members(const mpcg_handle* h) {
+    const int G = h->cluster > 0 ? h->cluster : ((int)h->N + RPLC_KMAX - 1) / RPLC_KMAX;
+    if (G < 2 || G > RPLC_MAX_G || G > h->num_cus || G > (int)h->N) return 0;
+    if (((int)h->N + G - 1) / G > RPLC_KMAX) return 0;
+    return G;
+}
+static size_t cluster64_alloc_words(const mpcg_handle* h) {
+    return CL_FLAG_STRIDE + (size_t)h->max_batch * CL_FLAG_STRIDE + (size_t)h->num_cus * RPLC_WG_WORDS + 16;
+}
+template <typename T, int NFIX>
+static int launch_generic(mpcg_handle* h, PcgArgsG<T> a, uint32_t batch, void* stream);
+static int try_launch_cluster_f64(mpcg_handle* h, const PcgArgs64& a, uint32_t batch, hipStream_t st) {
+    if (h->cluster == 0 || h->generic) return 1;
+    const int G = rplc64_members(h);
+    if (G == 0) return 1;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "batch exceeds max_batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->cluster64_scratch) {                       // first use (not stream-ordered: hipMalloc)
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->cluster64_scratch), cluster64_alloc_words(h) * sizeof(unsigned long long)));
+        HIP_TRY(h, hipMemset(h->cluster64_scratch, 0, cluster64_alloc_words(h) * sizeof(unsigned long long)));
+    }
+    const uint32_t resident = lpkc_resident_clusters(h, G);
+    const uint32_t clusters = batch < resident ? batch : resident;
+    const size_t lds = pcg_rplc_lds_doubles() * sizeof(double);
+    void (*kern)(ClusterArgs64) = a.pcols == 3 ? pcg_rplc_f64_kernel<true> : pcg_rplc_f64_kernel<false>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ClusterArgs64 ca;
+    ca.p = a;
+    ca.queue = h->cluster64_scratch;
+    ca.fail_flags = ca.queue + CL_FLAG_STRIDE;
+    ca.scratch = ca.fail_flags + (size_t)batch * CL_FLAG_STRIDE;
+    ca.G = G; ca.batch = (int)batch; ca.clusters = (int)clusters; ca.l2_handoff = h->cluster_l2;
+    const size_t zw = CL_FLAG_STRIDE + (size_t)batch * CL_FLAG_STRIDE + (size_t)clusters * G * RPLC_WG_WORDS;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster64_scratch, zw);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(kern, dim3(((clusters + 7) / 8) * 8 * (unsigned)G), dim3(RPLC_NW * 64), lds, st, ca);
+    HIP_TRY(h, hipGetLastError());
+    if (h->cluster_fixup) {                             // trajectories whose cluster gave up: the streaming kernel, all three block columns
+        PcgArgs64 c = a;
+        c.lower = 0;
+        c.redo_flags = ca.fail_flags; c.redo_stride = CL_FLAG_STRIDE; c.redo_skip = (unsigned long long)G;
+        c.redo_count = fixup_counter(h);
+        const int rc = launch_generic<double, 14>(h, c, batch, st);
+        if (rc != MPCG_OK) return rc;
+    }
+    h->last = LastKernel{FAM_RPLC64, RPLC_NW, 0, 0, 0, G, (int)lds, 0};
+    return MPCG_OK;
+}
+
 static int launch_f64(mpcg_handle* h, PcgArgs64 a, uint32_t batch, void* stream) {
     if (!h->generic && h->N <= kRplMaxN64 && h->rpl != 0 && (h->rpl == 1 || h->auto_cfg)) {
         HIP_TRY(h, hipSetDevice(h->device));
@@ -758,6 +813,10 @@ static int launch_f64(mpcg_handle* h, PcgArgs64 a, uint32_t batch, void* stream)
         return a.pcols == 3 ? launch_rpl_f64_t<8, true>(h, a, batch, st) : launch_rpl_f64_t<8, false>(h, a, batch, st);
     }
     if (h->generic) return launch_generic<double, 0>(h, a, batch, stream);
+    {   // 32 < N <= 256: clusters of ceil(N / 32) CUs keep S and Pinv in registers ("cluster" = 0: the streaming kernel below)
+        const int rc = try_launch_cluster_f64(h, a, batch, static_cast<hipStream_t>(stream));
+        if (rc != 1) return rc;
+    }
     // The streaming kernel reads a third less when it may take block (k, right) from block (k+1, left) (mpcg.h, BLOCK SYMMETRY).  Same latch as
     // the float path; a handle that does not know yet checks THIS call's matrices once, with one blocking 8-byte copy (never during capture:
     // a capturing call reads all three columns).

@@ -31,6 +31,11 @@ struct PcgArgsG {
     int N; int max_iter; T exit_tol; int pcols;        // pcols: 3 = SS, 1 = block-Jacobi
     int n = 14;                                        // state size (used when the kernel is instantiated with NFIX = 0)
     int lower = 0;                                     // 1: never read the right block column (S and Pinv are block-symmetric: the handle's latch says so)
+    // fix-up launches (behind the clustered double kernel): trajectory b is skipped when redo_flags[b * redo_stride] == redo_skip
+    const unsigned long long* redo_flags = nullptr;
+    unsigned long long redo_skip = 0;
+    int redo_stride = 0;
+    unsigned long long* redo_count = nullptr;         // incremented once per trajectory a fix-up launch actually solves ("cluster_fixups")
 };
 typedef PcgArgsG<double> PcgArgs64;
 
@@ -49,6 +54,8 @@ __global__ __launch_bounds__(NTHR) void pcg_generic_kernel(PcgArgsG<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     real* lds64 = reinterpret_cast<real*>(lds_raw);
     const int N = a.N, tid = threadIdx.x, b = blockIdx.x;
+    if (a.redo_flags && __hip_atomic_load(a.redo_flags + (size_t)b * a.redo_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.redo_skip) return;
+    if (a.redo_count && tid == 0) __hip_atomic_fetch_add(a.redo_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     real* xp = lds64;                                  // p, knot j at (j+1)*n, zero knot either side
     real* xr = xp + (size_t)(N + 2) * n;             // r likewise
     real* lam = xr + (size_t)(N + 2) * n;

@@ -169,12 +169,14 @@ def test_f64_streaming_kernel_reads_the_lower_triangle_once_the_latch_says_symme
     cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
     dS, dP, dg = dev(S), dev(Pinv), dev(g)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("cluster", 0)                       # (the streaming kernel: since round 5 the default beyond N = 32 is the clustered row-per-lane kernel)
     lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
     sol.solve_f64(dS, dP, dg, lam, cfg)
     torch.cuda.synchronize()
     assert sol.get_option("symmetry_state") == 1 and sol.get_option("last_kernel_family") == 3
     # all three columns: a fresh handle whose first solve is captured
     sol3 = PcgSolver(N, max_batch=B)
+    sol3.set_option("cluster", 0)
     lam3 = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
     it3 = torch.zeros(B, dtype=torch.int32, device="cuda"); ex3 = torch.zeros(B, dtype=torch.uint8, device="cuda")
     side = torch.cuda.Stream()
@@ -199,6 +201,7 @@ def test_f64_streaming_kernel_reads_the_lower_triangle_once_the_latch_says_symme
     Sp, Pp = S.copy().reshape(B, N, 3, 196), Pinv.copy().reshape(B, N, 3, 196)
     Sp[:, :, 2, :] = np.nan; Pp[:, :, 2, :] = np.nan
     solp = PcgSolver(N, max_batch=B)
+    solp.set_option("cluster", 0)
     solp.set_option("assume_symmetric", 1)
     lamp = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
     solp.solve_f64(dev(Sp.reshape(B, -1)), dev(Pp.reshape(B, -1)), dg, lamp, cfg)
@@ -209,6 +212,7 @@ def test_f64_streaming_kernel_reads_the_lower_triangle_once_the_latch_says_symme
     Pa[:, :-1, 2, :] *= 1.25
     Pa = Pa.reshape(B, -1)
     sola = PcgSolver(N, max_batch=B)
+    sola.set_option("cluster", 0)
     lama = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
     sola.solve_f64(dS, dev(Pa), dg, lama, cfg)
     torch.cuda.synchronize()
@@ -216,3 +220,92 @@ def test_f64_streaming_kernel_reads_the_lower_triangle_once_the_latch_says_symme
     for b in range(B):
         ref = orc.pcg(S[b], Pa[b], g[b], np.zeros(n * N), N, K, 0.0, "ss")["lam"]
         assert relinf(lama[b].cpu().numpy(), ref) < 1e-8
+
+
+@pytest.mark.parametrize("N", [33, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("precond", ["ss", "jacobi"])
+def test_f64_clustered_row_per_lane_kernel_vs_oracle(orc, N, precond):
+    """linsys_t = double beyond N = 32 (round 5): the row-per-lane kernel across ceil(N / 32) CUs of one XCD (pcg_rpl_cluster_f64.hip.h) —
+    S and Pinv stay in registers, members exchange their boundary knots' entries and the wave partials once per pass.  Fixed iteration counts
+    against the oracle's float64 iterate (cold and warm start), the tolerance exit, and the semantics of every other kernel: flags, counts,
+    lambda untouched when converged, run-to-run determinism."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    B, K = 3, 30
+    k = synth.make_kkt(N, B, 6100 + N)
+    S, Pinv, g = synth.form_schur(k, precond=precond, dtype=np.float64, poison_unused=True)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    sol = PcgSolver(N, max_batch=B)
+    rng = np.random.default_rng(N)
+    G = (N + 31) // 32
+    for lam0 in (np.zeros((B, n * N)), 0.1 * rng.standard_normal((B, n * N))):
+        lam = dev(lam0.copy())
+        it, ex = sol.solve_f64(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), precond)
+        torch.cuda.synchronize()
+        assert sol.get_option("last_kernel_family") == 8 and sol.get_option("last_kernel_cluster") == G
+        assert sol.get_option("cluster_fixups") == 0          # (solved by the clusters themselves, not by the streaming fix-up behind them)
+        assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all()
+        lamh = lam.cpu().numpy()
+        for b in range(B):
+            ref = orc.pcg(np.nan_to_num(S[b]), np.nan_to_num(Pinv[b]), g[b], lam0[b], N, K, 0.0, precond)["lam"]
+            assert relinf(lamh[b], ref) < 1e-9, (b, relinf(lamh[b], ref))
+        lam2 = dev(lam0.copy())
+        sol.solve_f64(dS, dP, dg, lam2, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), precond)
+        torch.cuda.synchronize()
+        assert torch.equal(lam, lam2)                    # run-to-run determinism
+    # tolerance exit: the oracle's count (+- the plateau), flag 0; then already converged: no update, lambda untouched
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    it, ex = sol.solve_f64(dS, dP, dg, lam, pcg_config(pcg_exit_tol=1e-10, pcg_max_iter=5000), precond)
+    torch.cuda.synchronize()
+    itn = it.cpu().numpy()
+    assert (ex.cpu().numpy() == 0).all()
+    for b in range(B):
+        ref = orc.pcg(np.nan_to_num(S[b]), np.nan_to_num(Pinv[b]), g[b], np.zeros(n * N), N, 5000, 1e-10, precond)
+        assert abs(int(itn[b]) - ref["iters"]) <= max(2, ref["iters"] // 8), (b, int(itn[b]), ref["iters"])
+    lamh = lam.cpu().numpy().copy()
+    it2, ex2 = sol.solve_f64(dS, dP, dg, lam, pcg_config(pcg_exit_tol=1e-8, pcg_max_iter=5000), precond)
+    torch.cuda.synchronize()
+    assert (it2.cpu().numpy() == 0).all() and (ex2.cpu().numpy() == 0).all()
+    np.testing.assert_array_equal(lam.cpu().numpy(), lamh)
+
+
+@pytest.mark.parametrize("N,B", [(64, 300), (128, 150)])
+def test_f64_clustered_kernel_draws_trajectories_from_the_queue(orc, N, B):
+    """More trajectories than resident clusters (128 at N = 64, 64 at N = 128): the persistent clusters draw from the queue; copies of one system
+    solve to the same bits wherever they land; against the streaming kernel ("cluster" = 0) to round-off; no trajectory left to the fix-up."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    K = 25
+    k = synth.make_kkt(N, 5, 6200 + N)
+    S5, P5, g5 = synth.form_schur(k, dtype=np.float64)
+    rep = (B + 4) // 5
+    S, Pinv, g = (np.tile(a_, (rep, 1))[:B] for a_ in (S5, P5, g5))
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    sol = PcgSolver(N, max_batch=B)
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    it, ex = sol.solve_f64(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 8 and (it.cpu().numpy() == K).all() and sol.get_option("cluster_fixups") == 0
+    lamh = lam.cpu().numpy()
+    for b in range(5, B):
+        np.testing.assert_array_equal(lamh[b], lamh[b % 5])
+    sol.set_option("cluster", 0)
+    lam_s = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    sol.solve_f64(dS, dP, dg, lam_s, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 3
+    assert relinf(lamh[:5], lam_s.cpu().numpy()[:5]) < 1e-9
+
+
+def test_f64_clustered_kernel_without_fixup_reports_abandoned_trajectories_only_when_there_are_any():
+    """ "cluster_fixup" = 0: no streaming launch behind the clusters — an undisturbed call still solves everything itself (iteration counts,
+    not the 0xFFFFFFFF / flag 2 of an abandoned trajectory), which is what says the clusters did the work."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, B, K = 128, 70, 12
+    k = synth.make_kkt(N, B, 6300)
+    S, Pinv, g = synth.form_schur(k, dtype=np.float64)
+    sol = PcgSolver(N, max_batch=B)
+    sol.set_option("cluster_fixup", 0)
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    it, ex = sol.solve_f64(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 8
+    assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all() and torch.isfinite(lam).all()

@@ -11,7 +11,7 @@ if os.environ.get("AB_LIB"):
     _L.LIB_PATH = os.environ["AB_LIB"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 dev = torch.device("cuda:0")
-for N in (16, 32, 64, 128):
+for N in (16, 32, 64, 128, 256):
     sol = PcgSolver(N, max_batch=B)
     S, P, g = bench.build_inputs(sol, N, B, 7, "ss", dev, chunk=64)
     S64, P64, g64 = torch.nan_to_num(S).double(), torch.nan_to_num(P).double(), g.double()
