@@ -309,7 +309,10 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  *       ("cluster_l2" = 0: always write-through), so all members of a cluster must be resident: the launch holds as many clusters as fit the
  *       chip and each draws trajectories from a queue (any batch = one launch).  A cluster that cannot make progress (a peer not resident:
  *       another stream holds its CU) gives up after a bounded spin and the follow-up launch of a single-workgroup kernel re-solves its
- *       trajectory ("cluster_fixup" = 0: no follow-up launch, d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for such a trajectory);
+ *       trajectory ("cluster_fixup" = 0: no follow-up launch, d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for such a trajectory).
+ *       linsys_t = double (mpcg_pcg_solve_f64 / _ref_f64): the same option governs the clustered row-per-lane kernel, automatic for 32 < knot_points
+ *       <= 256 with G = ceil(N / 32) members (full block rows of S and Pinv in the registers of G CUs; all three block columns are read, no symmetry
+ *       contract); "cluster" = 0 selects the streaming kernel, which is also its fix-up;
  *   otherwise (explicit pcg_* knobs, the fix-up launches, fp16 storage at N <= 36) the single-workgroup row-pair kernel: "pcg_waves" (4, 8 or 16
  *       wavefronts per trajectory workgroup), "pcg_reg_rows" (TRIPLES of block rows per matrix and wave kept in registers for the whole
  *       solve; only compiled (waves, rows) pairs are accepted at launch), "pcg_lds_rows" (triples per matrix and wave cached in LDS, -1 =
@@ -330,8 +333,8 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * Read-only: "cluster_fixups" (trajectories re-solved by fix-up launches since mpcg_create — each costs 1.5-4.5 ms of spinning; blocking 8-byte
  *       D2H read), "last_symmetry_violations", "num_cus", "pcg_resident" (1 if the single-workgroup configuration streams nothing inside the PCG
  *       loop), "last_schur_chunk" (block rows per chunk of the last mpcg_form_schur, 0 = the LDS kernels), "last_kernel_family" (kernel of the
- *       last solve: 0 single-workgroup row-pair, 3 generic, 5 row-per-lane, 6 lane-pair-per-knot, 7 clustered lane-pair; 1, 2, 4 were kernels
- *       retired in round 4), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
+ *       last solve: 0 single-workgroup row-pair, 3 generic, 5 row-per-lane, 6 lane-pair-per-knot, 7 clustered lane-pair, 8 clustered row-per-lane
+ *       (double); 1, 2, 4 were kernels retired in round 4), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
  * WHICH kernel family serves a call depends on knot_points AND on the call's batch (e.g. 32 < N <= 64: row-per-lane kernel up to one
  * trajectory per CU, lane-pair kernel beyond; N <= 32: 8 waves x 1 slot or 4 x 2 by batch).  Families sum the inner products in different
  * orders, so the SAME trajectory solved alone and inside a large batch may differ in the last fp32 bits (and, near the tolerance, by an

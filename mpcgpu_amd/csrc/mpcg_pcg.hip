@@ -85,6 +85,7 @@ size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
 size_t mpcg_pcg_lds_bytes_f64(uint32_t state_size, uint32_t knot_points) {
     if (!shape_supported(state_size, knot_points) && !generic_shape_supported(state_size, knot_points)) return 0;
     if (state_size == NS && knot_points <= 32) return pcg_rpl_lds_floats((int)knot_points, knot_points <= 16 ? 4 : 8) * sizeof(double);   // row-per-lane kernel
+    if (state_size == NS && knot_points <= (uint32_t)(RPLC_KMAX * RPLC_MAX_G)) return pcg_rplc_lds_doubles() * sizeof(double);         // a member of the clustered row-per-lane kernel
     const size_t b = pcg_generic_lds_elems((int)knot_points, (int)state_size) * sizeof(double);
     return b <= kLdsMax ? b : 0;
 }

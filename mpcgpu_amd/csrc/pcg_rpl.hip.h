@@ -55,10 +55,28 @@ __device__ __forceinline__ float rpl_wave_fold(float part) {
     const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(pb, 48));
     return ((part + r1) + r2) + r3;
 }
-__device__ __forceinline__ double rpl_wave_fold(double part) {      // (no 64-bit row shifts in DPP: the LDS crossbar)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
-    return part;
+// double: 64-bit operations have no row shifts in DPP (row_newbcast only) — but a shift only MOVES data, so the two halves travel as 32-bit
+// DPP moves and the add is a plain v_add_f64: four steps inside the 16-lane rows (lanes shifted in from outside a row read +0.0), then the four
+// row sums through v_readlane.  (Until round 5 this was six __shfl_down round trips through the LDS crossbar: ~600 clocks per fold, twice per
+// iteration.)  Fixed order, the float version's.
+template <int CTRL>
+__device__ __forceinline__ double rpl_dpp_shift_add(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
+    return v + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double rpl_readlane(double v, int l) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double rpl_wave_fold(double part) {
+    part = rpl_dpp_shift_add<0x108>(part);             // row_shl:8
+    part = rpl_dpp_shift_add<0x104>(part);
+    part = rpl_dpp_shift_add<0x102>(part);
+    part = rpl_dpp_shift_add<0x101>(part);
+    return ((part + rpl_readlane(part, 16)) + rpl_readlane(part, 32)) + rpl_readlane(part, 48);
 }
 // column c of all three blocks of a row: three independent chains, interleaved (a v_fmac's result is ready after ~2 issue slots)
 template <int C, typename T>

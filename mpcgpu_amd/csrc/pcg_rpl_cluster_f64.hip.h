@@ -64,7 +64,7 @@ __global__ __launch_bounds__(RPLC_NW * 64, 2) void pcg_rplc_f64_kernel(ClusterAr
     real* xr1 = lds + 3 * VS;
     real* xt = lds + 4 * VS;
     real* xu = lds + 5 * VS;
-    real* red = lds + 6 * VS;                           // [64] the cluster's wave partials of the current hand-off
+    real* red = lds + 6 * VS;                           // [0] the cluster-wide inner product of the current hand-off
     real* bc = red + 64;                                // [0] timeout flag  [1] trajectory index (as int)  [2] same-XCD (as int)
     gu64* my_words = (gu64*)ca.scratch + ((size_t)cl * G + g) * RPLC_WG_WORDS;
     gu64* cl_words = (gu64*)ca.scratch + (size_t)cl * G * RPLC_WG_WORDS;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(RPLC_NW * 64, 2) void pcg_rplc_f64_kernel(ClusterAr
 
     // One hand-off: every wave publishes its partial, the rows of the first / last own knot publish their entries of two vectors (va -> the
     // neighbour's halo of bufA, vb -> of bufB); wave 0 polls the cluster's partials and the neighbours' groups, drops the halo entries into the
-    // local vectors and the partials into `red`; ONE barrier; every thread sums the partials in the same fixed order.
+    // local vectors and folds the partials into ONE value; ONE barrier.
     auto exchange = [&](real* bufA, real va, real* bufB, real vb, real wave_part) -> real {
         ++epoch;
         const unsigned sb = (epoch & 1u) * (unsigned)RPLC_SLOT;           // word offset of this hand-off's slot
@@ -154,8 +154,10 @@ __global__ __launch_bounds__(RPLC_NW * 64, 2) void pcg_rplc_f64_kernel(ClusterAr
                 real* dst = e < 14 ? bufA : bufB;
                 dst[(fromL ? 0 : KL + 1) * NS + (e < 14 ? e : e - 14)] = halo;
             }
-            red[lane] = wantp ? partial : real(0);
-            if (lane == 0 && spins >= CL_SPIN_LIMIT) bc[0] = 1.0;
+            // the cluster-wide inner product: the G NW partials sit in lanes 0 .. G NW - 1 of this wavefront — folded here, in one fixed order that is
+            // the same in every member (lane l = member l / NW, wave l % NW), one value for the workgroup
+            const real tot_ = rpl_wave_fold(wantp ? partial : real(0));
+            if (lane == 0) { red[0] = tot_; if (spins >= CL_SPIN_LIMIT) bc[0] = 1.0; }
 #ifdef RPLC_DEBUG
             if (spins >= CL_SPIN_LIMIT) {
                 double* d = ca.p.lambda + g * 256 + lane * 4;
@@ -166,17 +168,7 @@ __global__ __launch_bounds__(RPLC_NW * 64, 2) void pcg_rplc_f64_kernel(ClusterAr
         }
         lds_barrier();
         if (bc[0] != 0.0) failed = true;
-        real t[8];                                       // member by member, the waves of a member pairwise (all_sum's order), then the members in order
-        real tot = real(0);
-        for (int m = 0; m < G; ++m) {
-#pragma unroll
-            for (int c = 0; c < NW; ++c) t[c] = red[m * NW + c];
-#pragma unroll
-            for (int h = NW / 2; h >= 1; h /= 2)
-#pragma unroll
-                for (int c = 0; c < h; ++c) t[c] = t[2 * c] + t[2 * c + 1];
-            tot += t[0];
-        }
+        const real tot = red[0];
         return tot;
     };
 

@@ -44,7 +44,7 @@ def _full(n_gpus=1):
         "batch1_sqp_step_latency": {"N32": {"us_per_step": f()}, "N64": {"us_per_step": f()}, "N128": {"us_per_step": f()}, "what": LONG},
         "long_horizon": {"N256": {"pcg_iterations_per_sec": f()}, "N512": {"pcg_iterations_per_sec": f()}},
         "roofline_long_horizon": {"single_reduction_ceiling": {"N256_batch1024_M_it_per_s": {"classic": 38.22, "emulated": 41.48, "target": 44.0}}},
-        "roofline_pcg_streaming": {"frac": f()}, "double_precision": {"pcg_iterations_per_sec": f()},
+        "roofline_pcg_streaming": {"frac": f()}, "double_precision": {"pcg_iterations_per_sec": f(), "streaming_kernel": {"pcg_iterations_per_sec": f(), "frac": f()}},
         "scaling_expectation": {"strong": {"speedup_ceiling_at_8_gpus": f()}},
         "inrun_pmc_kernels": {LONG + str(i): {"kernel": LONG, "grid": 1} for i in range(12)},
         "cpu_baseline": {"value": f(), "unit": "linsolves/s", "cores": 1, "kind": "port", "ms_per_linsolve": f(), "sample": LONG, "cpu_model": LONG, "host_cpus": 256,

@@ -763,21 +763,38 @@ def long_horizon_floor(cx, lh):
 
 
 def double_precision(cx):
-    """linsys_t = double (USE_DOUBLES of the reference): the bench workload's own systems in double, fixed 40 iterations."""
+    """linsys_t = double (USE_DOUBLES of the reference): the bench workload's own systems in double, fixed 40 iterations.  Default policy beyond
+    N = 32: the row-per-lane kernel across ceil(N / 32) CUs per trajectory (family 8, matrices resident in registers); "cluster" = 0: the streaming
+    kernel (family 3; two block columns once the symmetry latch allows), whose HBM roofline is reported next to it."""
     sol, dev, N, args = cx.sol, cx.dev, cx.N, cx.args
     Bd = min(cx.B, 1024)
     S64, P64, g64 = torch.nan_to_num(cx.d_S[:Bd]).double(), torch.nan_to_num(cx.d_P[:Bd]).double(), cx.d_g[:Bd].double()
     l64 = torch.zeros(Bd, 14 * N, dtype=torch.float64, device=dev)
     i64 = torch.zeros(Bd, dtype=torch.int32, device=dev); x64 = torch.zeros(Bd, dtype=torch.uint8, device=dev)
     c64 = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=40)
-    sol.solve_f64(S64, P64, g64, l64, c64, args.precond, iters=i64, exits=x64)          # (first call: the latch's one blocking check)
-    ms64 = timed(lambda: (l64.zero_(), sol.solve_f64(S64, P64, g64, l64, c64, args.precond, iters=i64, exits=x64)), 3, warm=1) - timed(lambda: l64.zero_(), 3, warm=1)
-    cols64 = 2 if sol.get_option("symmetry_state") == 1 else 3
-    by64 = 2 * cols64 * 196 * N * 8
-    return {"knot_points": N, "batch": Bd, "pcg_iters_per_solve": 40, "kernel_ms": ms64, "pcg_iterations_per_sec": Bd * 40 / (ms64 * 1e-3),
-            "kernel_family": sol.get_option("last_kernel_family"), "block_columns_read": cols64, "bytes_per_unit": by64,
-            "achieved": Bd * 40 * by64 / (ms64 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": Bd * 40 * by64 / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "bound": "hbm (S and Pinv re-read every iteration: a double N=128 trajectory is 1.2 MB, 2.4x the register file)"}
+    go = lambda: (l64.zero_(), sol.solve_f64(S64, P64, g64, l64, c64, args.precond, iters=i64, exits=x64))
+    t_zero = timed(lambda: l64.zero_(), 3, warm=1)
+    out = {"knot_points": N, "batch": Bd, "pcg_iters_per_solve": 40}
+    go()
+    ms = timed(go, 3, warm=1) - t_zero
+    fam = sol.get_option("last_kernel_family")
+    out.update({"kernel_ms": ms, "pcg_iterations_per_sec": Bd * 40 / (ms * 1e-3), "kernel_family": fam, "members_per_trajectory": sol.get_option("last_kernel_cluster"),
+                "cluster_fixups": sol.get_option("cluster_fixups"),
+                "bound": "two cluster-wide hand-offs per iteration (S and Pinv resident in the registers of ceil(N / 32) CUs)" if fam == 8 else "hbm"})
+    try:
+        sol.set_option("cluster", 0)
+        go()                                                                     # (first streaming call: the latch's one blocking check)
+        ms_s = timed(go, 3, warm=1) - t_zero
+        cols64 = 2 if sol.get_option("symmetry_state") == 1 else 3
+        by64 = 2 * cols64 * 196 * N * 8
+        out["streaming_kernel"] = {"kernel_ms": ms_s, "pcg_iterations_per_sec": Bd * 40 / (ms_s * 1e-3), "kernel_family": sol.get_option("last_kernel_family"),
+                                   "block_columns_read": cols64, "bytes_per_unit": by64, "achieved": Bd * 40 * by64 / (ms_s * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": Bd * 40 * by64 / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "bound": "hbm (S and Pinv re-read every iteration)"}
+        out["speedup_over_streaming"] = ms_s / ms
+    finally:
+        sol.set_option("cluster", -1)
+    return out
 
 
 def scaling_expectation(cx):
