@@ -248,6 +248,14 @@ class PcgSolver:
                                                 _ptr(d_pcg_iters), _ptr(d_pcg_exit),
                                                 int(pcg_max_iter), float(pcg_exit_tol), _stream()))
 
+    def solve_ref_f64(self, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp,
+                      d_pcg_iters, d_pcg_exit, pcg_max_iter: int, pcg_exit_tol: float):
+        """The reference kernel's argument list with linsys_t = double (pcg<double, n, N>; include/pcg/sqp.cuh:137-150)."""
+        self._check(self.lib.mpcg_pcg_solve_ref_f64(self._h, _ptr(d_S), _ptr(d_Pinv), _ptr(d_gamma), _ptr(d_lambda),
+                                                    _ptr(d_r), _ptr(d_p), _ptr(d_v_temp), _ptr(d_eta_new_temp),
+                                                    _ptr(d_pcg_iters), _ptr(d_pcg_exit),
+                                                    int(pcg_max_iter), float(pcg_exit_tol), _stream()))
+
     def block_solve(self, S, gamma, lam=None):
         """Batched block-tridiagonal direct solve (the GPU counterpart of qdldl_solve_schur,
         include/qdldl/sqp.cuh:22-49).  S: [B, 3*n*n*N], gamma: [B, n*N]; returns lambda [B, n*N]."""

@@ -26,10 +26,13 @@ n = 14
 EPS32 = 2.0 ** -24
 
 
+HP = [np.float64]          # the host's evaluation precision: float64 for the float kernels, the x87 80-bit long double for the double kernels
+
+
 def bt_matvec(M, x, N):
-    """Block-tridiagonal product from the bd layout in float64 (numpy): y_k = M[k,0] x_{k-1} + M[k,1] x_k + M[k,2] x_{k+1}, blocks column-major."""
-    B = np.nan_to_num(np.asarray(M, np.float64)).reshape(N, 3, n, n).transpose(0, 1, 3, 2)       # [k][col] as row-major matrices
-    X = np.asarray(x, np.float64).reshape(N, n)
+    """Block-tridiagonal product from the bd layout in HP[0] precision (numpy): y_k = M[k,0] x_{k-1} + M[k,1] x_k + M[k,2] x_{k+1}, blocks column-major."""
+    B = np.nan_to_num(np.asarray(M, HP[0])).reshape(N, 3, n, n).transpose(0, 1, 3, 2)       # [k][col] as row-major matrices
+    X = np.asarray(x, HP[0]).reshape(N, n)
     y = np.einsum("kij,kj->ki", B[:, 1], X)
     y[1:] += np.einsum("kij,kj->ki", B[1:, 0], X[:-1])
     y[:-1] += np.einsum("kij,kj->ki", B[:-1, 2], X[1:])
@@ -38,16 +41,17 @@ def bt_matvec(M, x, N):
 
 def state(sol, dS, dP, dg, lam0, K):
     N = sol.N
+    dt = dS.dtype                                          # float32, or float64 = linsys_t double (the same checks at u = 2^-53)
     d_lam = torch.from_numpy(lam0.copy()).cuda()
-    d_r = torch.full((n * N,), float("nan"), device="cuda")
-    d_p = torch.full((n * N,), float("nan"), device="cuda")
-    scratch = torch.zeros(N, device="cuda")
+    d_r = torch.full((n * N,), float("nan"), device="cuda", dtype=dt)
+    d_p = torch.full((n * N,), float("nan"), device="cuda", dtype=dt)
+    scratch = torch.zeros(N, device="cuda", dtype=dt)
     d_it = torch.zeros(1, dtype=torch.int32, device="cuda")
     d_ex = torch.zeros(1, dtype=torch.bool, device="cuda")
-    sol.solve_ref(dS, dP, dg, d_lam, d_r, d_p, scratch, scratch, d_it, d_ex, K, 0.0)
+    (sol.solve_ref if dt == torch.float32 else sol.solve_ref_f64)(dS, dP, dg, d_lam, d_r, d_p, scratch, scratch, d_it, d_ex, K, 0.0)
     torch.cuda.synchronize()
     assert int(d_it.item()) == K and bool(d_ex.item()) is True
-    out = [t.cpu().numpy().astype(np.float64) for t in (d_lam, d_r, d_p)]
+    out = [t.cpu().numpy().astype(HP[0]) for t in (d_lam, d_r, d_p)]
     assert all(np.isfinite(v).all() for v in out)
     return out
 
@@ -57,7 +61,7 @@ def abs_matvec(M, x, N):
     return bt_matvec(np.abs(np.nan_to_num(M)), np.abs(x), N)
 
 
-def step_quantities(S, P, g, lam0, st_a, st_b, N, K):
+def step_quantities(S, P, g, lam0, st_a, st_b, N, K, EPS32=EPS32):
     """Every checked quantity DIVIDED BY the scale its float32 rounding model gives it (u = 2^-24): a correct kernel lands at O(1..30)
     whatever N, K, the preconditioner or the conditioning; tools/_prof/inv_probe.py prints them for 96 (system, K) pairs."""
     (lam_a, r_a, p_a), (lam_b, r_b, p_b) = st_a, st_b
@@ -82,12 +86,13 @@ def step_quantities(S, P, g, lam0, st_a, st_b, N, K):
         "alpha": abs(alpha_hat / alpha - 1) / (EPS32 * (c_eta_a + c_v)),
         "beta": abs(beta_hat / beta - 1) / (EPS32 * (c_eta_a + c_eta_b)),
     }
-    Snorm = np.abs(np.nan_to_num(S).astype(np.float64).reshape(N, 3, n, n)).sum(axis=(1, 2)).max()      # ||S||_inf (a block row's three blocks, summed along rows)
-    true_r = g.astype(np.float64) - bt_matvec(S, lam_b, N)
-    q["gap"] = np.linalg.norm(r_b - true_r) / (K * EPS32 * Snorm * max(np.linalg.norm(lam_b), np.linalg.norm(lam0)))
+    Snorm = float(np.abs(np.nan_to_num(S).astype(np.float64).reshape(N, 3, n, n)).sum(axis=(1, 2)).max())      # ||S||_inf (a block row's three blocks, summed along rows)
+    true_r = g.astype(HP[0]) - bt_matvec(S, lam_b, N)
+    nrm = lambda x: float(np.sqrt(float(x @ x)))
+    q["gap"] = nrm(r_b - true_r) / (K * EPS32 * Snorm * max(nrm(lam_b), nrm(np.asarray(lam0, HP[0]))))
     q["conjugacy"] = abs(p_b @ Sp) / np.sqrt((p_b @ bt_matvec(S, p_b, N)) * v)
     q["orthogonality"] = abs(r_b @ z_a) / np.sqrt(eta_a * eta_b)
-    return q
+    return {k_: float(v_) for k_, v_ in q.items()}
 
 
 # Worst over 96 (system, K) pairs on an MI355X (tools/_prof/inv_probe.py -> profiles/r05_invariants.txt): lam 0.89 u, r 1.67 u, p 0.95 u of their update's
@@ -115,3 +120,39 @@ def test_one_step_of_the_recurrences_and_the_cg_invariants(N, family, pc):
         print(f"N={N} {pc} K={K}: " + " ".join(f"{a} {b:.2g}" for a, b in q.items()))
         for key, lim in LIMITS.items():
             assert q[key] <= lim, (N, pc, K, key, q[key], lim)
+
+
+@pytest.mark.parametrize("N,family", [(32, 5), (64, 8), (128, 8)])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+def test_the_same_invariants_in_double(N, family, pc):
+    """linsys_t = double: the row-per-lane kernel (N = 32) and its clustered form across 2 / 4 CUs (N = 64 / 128, round 5) against the same
+    recurrences at u = 2^-53, the host side evaluated in the x87 80-bit long double (u = 2^-64; numpy's longdouble on x86-64) so that it is
+    again the more precise side; same limits as the float test."""
+    from mpcgpu_amd import PcgSolver
+    k = synth.make_kkt(N, 1, 9100 + N)
+    S, P, g = synth.form_schur(k, precond=pc, dtype=np.float64)
+    S, P, g = S[0], P[0], g[0]
+    rng = np.random.default_rng(N)
+    lam0 = 0.1 * rng.standard_normal(n * N)
+    sol = PcgSolver(N, max_batch=1)
+    dS, dP, dg = (torch.from_numpy(a).cuda() for a in (S, P, g))
+    U64 = 2.0 ** -53
+    if np.finfo(np.longdouble).eps > 2.0 ** -60:
+        pytest.skip("no extended-precision long double on this host")
+    HP[0] = np.longdouble
+    try:
+        _double_invariants(sol, dS, dP, dg, S, P, g, lam0, N, family, pc, U64)
+    finally:
+        HP[0] = np.float64
+
+
+def _double_invariants(sol, dS, dP, dg, S, P, g, lam0, N, family, pc, U64):
+    for K in (10, 50, 167):
+        st_a = state(sol, dS, dP, dg, lam0, K - 1)
+        assert sol.get_option("last_kernel_family") == family and sol.get_option("cluster_fixups") == 0
+        st_b = state(sol, dS, dP, dg, lam0, K)
+        q = step_quantities(S, P, g, lam0, st_a, st_b, N, K, EPS32=U64)
+        print(f"double N={N} {pc} K={K}: " + " ".join(f"{a} {b:.2g}" for a, b in q.items()))
+        for key, lim in LIMITS.items():
+            scale = 1.0 if key in ("lam", "r", "p", "alpha", "beta", "gap") else 2.0 ** -29      # (conjugacy / orthogonality scale with u: float32's limit x 2^-29)
+            assert q[key] <= lim * scale, (N, pc, K, key, q[key], lim * scale)
