@@ -314,7 +314,7 @@ def main():
     cfg = pcg_config(pcg_exit_tol=args.exit_tol, pcg_max_iter=max_iter)
 
     sol = PcgSolver(N, max_batch=max(B, args.spmv_batch if not args.no_extras else B), device=local_rank)
-    d_S, d_P, d_g = L.build_inputs(sol, N, B, seed0, args.precond, dev, chunk=B if args.profile_mini else 128)
+    d_S, d_P, d_g = L.build_inputs(sol, N, B, seed0, args.precond, dev, chunk=B if args.profile_lean else 128)      # (PMC passes: one launch shape per kernel)
     ns = min(32, B)
     S_h, P_h, g_h = (t[:ns].cpu().numpy() for t in (d_S, d_P, d_g))     # host copies of the CPU-baseline sample
     d_lam = torch.zeros(B, 14 * N, device=dev)

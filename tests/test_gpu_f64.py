@@ -309,3 +309,36 @@ def test_f64_clustered_kernel_without_fixup_reports_abandoned_trajectories_only_
     torch.cuda.synchronize()
     assert sol.get_option("last_kernel_family") == 8
     assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all() and torch.isfinite(lam).all()
+
+
+def test_f64_clusters_that_cannot_get_their_cus_fall_to_the_streaming_fixup(orc):
+    """Members of a cluster must be co-resident.  With another stream holding the chip (4,000-iteration float solves on every CU) a 4-member double
+    cluster may not find its CUs: its members give up after the bounded spin, leave lambda alone, and the streaming kernel behind the launch solves
+    exactly the trajectories whose completion count is short ("cluster_fixups" counts them).  Either way the caller gets the oracle's answer."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, B, K = 128, 4, 10
+    k = synth.make_kkt(N, B, 6400)
+    S, Pinv, g = synth.form_schur(k, dtype=np.float64)
+    sol = PcgSolver(N, max_batch=B)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    blocker = torch.cuda.Stream()
+    ncu = sol.get_option("num_cus")
+    big = PcgSolver(128, max_batch=4 * ncu)
+    kb = synth.make_kkt(128, 2, 3)
+    Sb, Pb, gb = synth.form_schur(kb, precond="ss")
+    bS, bP, bg = (dev(a).repeat(2 * ncu, 1).contiguous() for a in (Sb, Pb, gb))
+    bl = torch.zeros(4 * ncu, n * 128, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(blocker):
+        for _ in range(3):
+            big.solve(bS, bP, bg, bl, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=4000), "ss")
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    it, ex = sol.solve_f64(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
+    torch.cuda.synchronize()
+    fixed = sol.get_option("cluster_fixups")
+    assert sol.get_option("last_kernel_family") == 8 and 0 <= fixed <= B
+    assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all()
+    lamh = lam.cpu().numpy()
+    for b in range(B):
+        ref = orc.pcg(S[b], Pinv[b], g[b], np.zeros(n * N), N, K, 0.0, "ss")["lam"]
+        assert relinf(lamh[b], ref) < 1e-9, (b, fixed, relinf(lamh[b], ref))
