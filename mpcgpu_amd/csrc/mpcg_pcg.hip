@@ -74,6 +74,7 @@ static size_t cluster_alloc_words(const mpcg_handle* h) {
            + 16;                         // + one line for the "cluster_fixups" counter (never re-zeroed by a launch)
 }
 static unsigned long long* fixup_counter(const mpcg_handle* h) { return h->cluster_scratch + cluster_alloc_words(h) - 16; }
+static size_t cluster64_alloc_words(const mpcg_handle* h);
 
 size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
     if (generic_shape_supported(state_size, knot_points)) return pcg_generic_lds_elems((int)knot_points, (int)state_size) * sizeof(float);
@@ -129,6 +130,16 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
         (void)hipFree(h->cluster_scratch);
         delete h;
         return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the dispatch-order buffer");
+    }
+    // the clustered double kernel's queue + flags + cells (0.5 MB at max_batch 4096), here for the same reason: a fresh handle's first
+    // mpcg_pcg_solve_f64 may be a captured one
+    if (!generic && knot_points > 32 && knot_points <= (uint32_t)(RPLC_KMAX * RPLC_MAX_G)) {
+        if (hipMalloc(reinterpret_cast<void**>(&h->cluster64_scratch), cluster64_alloc_words(h) * sizeof(unsigned long long)) != hipSuccess) {
+            (void)hipFree(h->cluster_scratch); (void)hipFree(h->sched_order);
+            delete h;
+            return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the double-precision cluster scratch");
+        }
+        (void)hipMemset(h->cluster64_scratch, 0, cluster64_alloc_words(h) * sizeof(unsigned long long));
     }
     if (hipEventCreateWithFlags(&h->sym_event, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&h->sym_host), sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {

@@ -342,3 +342,35 @@ def test_f64_clusters_that_cannot_get_their_cus_fall_to_the_streaming_fixup(orc)
     for b in range(B):
         ref = orc.pcg(S[b], Pinv[b], g[b], np.zeros(n * N), N, K, 0.0, "ss")["lam"]
         assert relinf(lamh[b], ref) < 1e-9, (b, fixed, relinf(lamh[b], ref))
+
+
+def test_f64_clustered_kernel_in_a_graph_captured_on_a_fresh_handle():
+    """The first double solve of a fresh handle may be a captured one: the clustered kernel's scratch is allocated by mpcg_create, the launch is
+    three kernel nodes (fill, clusters, gated streaming fix-up); replays reproduce the eager solve bit for bit."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, B, K = 128, 6, 20
+    k = synth.make_kkt(N, B, 6500)
+    S, Pinv, g = synth.form_schur(k, dtype=np.float64)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    sol = PcgSolver(N, max_batch=B)
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    it = torch.zeros(B, dtype=torch.int32, device="cuda"); ex = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            lam.zero_()
+            sol.solve_f64(dS, dP, dg, lam, cfg, iters=it, exits=ex)
+    outs = []
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        outs.append(lam.clone())
+    assert sol.get_option("last_kernel_family") == 8 and sol.get_option("cluster_fixups") == 0 and (it.cpu().numpy() == K).all()
+    eager = PcgSolver(N, max_batch=B)
+    lam_e = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    eager.solve_f64(dS, dP, dg, lam_e, cfg)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, lam_e)
