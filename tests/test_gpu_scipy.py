@@ -1,0 +1,75 @@
+"""GPU: the PCG kernels against THIRD-PARTY code directly — scipy.sparse.linalg.cg (float64, M = the preconditioner, every iterate captured by the
+callback) — with no same-author restatement in between (the oracle and the goldens are same-author; tests/test_oracle.py pins the
+oracle on scipy, this file pins the kernels on it).  S and Pinv are stored negated (negative definite): scipy gets A = -S, M = -Pinv, b = -gamma,
+the same system and the same recurrences (include/pcg/sqp.cuh:137-150 semantics).
+  * linsys_t = double — the row-per-lane kernel (N = 32), its clustered form (N = 64, 128: two / four CUs per trajectory) and the streaming kernel:
+    the iterate after K = 1 .. 40 iterations within 1e-10 of scipy's (cond ~1e5 amplifies the last bits of two float64 summation orders);
+  * float — every kernel family of the default policy at K = 1, 2, 3, before CG has amplified float32 rounding: within 2e-4."""
+import numpy as np
+import pytest
+import torch
+
+from mpcgpu_amd import synth
+from util import relinf
+
+pytestmark = pytest.mark.gpu
+n = 14
+
+
+def scipy_iterates(S, P, g, lam0, N, pc, KM):
+    import scipy.sparse.linalg as sla
+    Sd = synth.bd_to_dense(np.nan_to_num(S).astype(np.float64), N)
+    Pd = synth.bd_to_dense(np.nan_to_num(P).astype(np.float64), N)
+    if pc == "jacobi":
+        Pd = Pd * np.kron(np.eye(N), np.ones((n, n)))
+    xs = []
+    sla.cg(sla.aslinearoperator(-Sd), -g.astype(np.float64), x0=lam0.astype(np.float64).copy(), rtol=0.0, atol=0.0, maxiter=KM, M=sla.aslinearoperator(-Pd),
+           callback=lambda xk: xs.append(xk.copy()))
+    assert len(xs) == KM
+    return xs
+
+
+@pytest.mark.parametrize("N,family,cluster", [(32, 5, -1), (64, 8, -1), (128, 8, -1), (64, 3, 0)])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+def test_double_kernels_against_scipy_cg_at_every_iteration(N, family, cluster, pc):
+    from mpcgpu_amd import PcgSolver, pcg_config
+    k = synth.make_kkt(N, 1, 8000 + N)
+    S, P, g = (a[0] for a in synth.form_schur(k, precond=pc, dtype=np.float64))
+    rng = np.random.default_rng(N)
+    lam0 = 0.1 * rng.standard_normal(n * N)
+    KM = 40
+    xs = scipy_iterates(S, P, g, lam0, N, pc, KM)
+    sol = PcgSolver(N, max_batch=1)
+    sol.set_option("cluster", cluster)
+    dS, dP, dg = (torch.from_numpy(a.reshape(1, -1).copy()).cuda() for a in (S, P, g))
+    worst = 0.0
+    for K in range(1, KM + 1):
+        lam = torch.from_numpy(lam0.reshape(1, -1).copy()).cuda()
+        it, ex = sol.solve_f64(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), pc)
+        torch.cuda.synchronize()
+        assert sol.get_option("last_kernel_family") == family and int(it.item()) == K
+        e = relinf(lam.cpu().numpy()[0], xs[K - 1])
+        worst = max(worst, e)
+        assert e < 1e-10, (N, pc, K, e)            # (measured worst: 2e-12)
+    print(f"double N={N} {pc} family {family}: worst distance from scipy's iterate over K = 1..{KM}: {worst:.2e}")
+
+
+@pytest.mark.parametrize("N,family", [(8, 5), (32, 5), (128, 6), (256, 7), (512, 7)])
+@pytest.mark.parametrize("pc", ["ss", "jacobi"])
+def test_float_kernels_against_scipy_cg_first_iterations(N, family, pc):
+    from mpcgpu_amd import PcgSolver, pcg_config
+    k = synth.make_kkt(N, 1, 8100 + N)
+    S, P, g = (a[0] for a in synth.form_schur(k, precond=pc))
+    rng = np.random.default_rng(N)
+    lam0 = (0.3 * rng.standard_normal(n * N)).astype(np.float32)
+    xs = scipy_iterates(S, P, g, lam0, N, pc, 3)
+    sol = PcgSolver(N, max_batch=1)
+    dS, dP, dg = (torch.from_numpy(a.reshape(1, -1).copy()).cuda() for a in (S, P, g))
+    for K in (1, 2, 3):
+        lam = torch.from_numpy(lam0.reshape(1, -1).copy()).cuda()
+        it, ex = sol.solve(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), pc)
+        torch.cuda.synchronize()
+        assert sol.get_option("last_kernel_family") == family and int(it.item()) == K
+        e = relinf(lam.cpu().numpy()[0], xs[K - 1])
+        print(f"float N={N} {pc} K={K}: {e:.2e}")
+        assert e < 2e-4, (N, pc, K, e)             # (measured worst: 5.4e-5 — float32 rounding through the cancellation of alpha on a random warm start; a wrong block, row, sign or reduction shows as O(1))
