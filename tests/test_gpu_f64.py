@@ -374,3 +374,46 @@ def test_f64_clustered_kernel_in_a_graph_captured_on_a_fresh_handle():
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(o, lam_e)
+
+
+@pytest.mark.parametrize("N,rho", [(16, 1e-1), (64, 1e-2), (128, 1e-3)])
+def test_f64_kkt_to_step_pipeline_vs_dense_kkt_solve(N, rho):
+    """The whole linear-system step in double against the DEFINITION — numpy's dense solve of the regularised KKT system
+    [G C^T; C 0][dz; lam] = [g; c] (sign conventions of include/common/dz.cuh / linsys_setup.cuh), no restatement of the Schur algebra on the
+    comparison side: KKT blocks -> mpcg_form_schur_f64 (walking kernel) -> mpcg_pcg_solve_f64 (row-per-lane kernel, clustered beyond N = 32) ->
+    mpcg_compute_dz_f64, to 1e-7 of the dense solution (cond up to 1e7 at rho = 1e-3) and C dz = c to 1e-9."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    m, B = 7, 2
+    k = synth.make_kkt(N, B, 31337 + N)
+    G, C, g, c = synth.pack_kkt_dense(k, np.float64)
+    sol = PcgSolver(N, max_batch=B)
+    dG, dC, dg, dc = dev(G), dev(C), dev(g), dev(c)
+    S, P, gam = sol.form_schur(dG, dC, dg, dc, rho, "ss")
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    it, ex = sol.solve_f64(S, P, gam, lam, pcg_config(pcg_exit_tol=1e-26, pcg_max_iter=20000), "ss")
+    dz = sol.compute_dz(dG, dC, dg, lam)
+    torch.cuda.synchronize()
+    assert (ex.cpu().numpy() == 0).all() and sol.get_option("cluster_fixups") == 0
+    assert sol.get_option("last_kernel_family") == (5 if N <= 32 else 8)
+    dz, lam = dz.cpu().numpy(), lam.cpu().numpy()
+    nz = (n + m) * N - m
+    for b in range(B):
+        Cm, Gm, gz = np.zeros((n * N, nz)), np.zeros((nz, nz)), np.zeros(nz)
+        Cm[:n, :n] = np.eye(n)
+        for kk in range(N):
+            o = kk * (n + m)
+            Gm[o:o + n, o:o + n] = k.Q[b, kk] + rho * np.eye(n)
+            gz[o:o + n] = k.q[b, kk]
+            if kk < N - 1:
+                Gm[o + n:o + n + m, o + n:o + n + m] = k.R[b, kk] + rho * np.eye(m)
+                gz[o + n:o + n + m] = k.r[b, kk]
+            if kk > 0:
+                po = (kk - 1) * (n + m)
+                Cm[kk * n:(kk + 1) * n, po:po + n] = -k.A[b, kk - 1]
+                Cm[kk * n:(kk + 1) * n, po + n:po + n + m] = -k.Bm[b, kk - 1]
+                Cm[kk * n:(kk + 1) * n, o:o + n] = np.eye(n)
+        K = np.block([[Gm, Cm.T], [Cm, np.zeros((n * N, n * N))]])
+        sol64 = np.linalg.solve(K, np.concatenate([gz, k.c[b].reshape(-1)]))
+        assert relinf(lam[b], sol64[nz:]) < 1e-7, (b, relinf(lam[b], sol64[nz:]))
+        assert relinf(dz[b], sol64[:nz]) < 1e-7, (b, relinf(dz[b], sol64[:nz]))
+        assert np.abs(Cm @ dz[b] - k.c[b].reshape(-1)).max() < 1e-9 * max(1.0, np.abs(dz[b]).max())
