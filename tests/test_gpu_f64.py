@@ -417,3 +417,33 @@ def test_f64_kkt_to_step_pipeline_vs_dense_kkt_solve(N, rho):
         assert relinf(lam[b], sol64[nz:]) < 1e-7, (b, relinf(lam[b], sol64[nz:]))
         assert relinf(dz[b], sol64[:nz]) < 1e-7, (b, relinf(dz[b], sol64[:nz]))
         assert np.abs(Cm @ dz[b] - k.c[b].reshape(-1)).max() < 1e-9 * max(1.0, np.abs(dz[b]).max())
+
+
+def test_f64_seeded_fuzz_of_the_double_kernels(orc):
+    """80 random (N in 2..256, batch, preconditioner, warm start, iteration cap) double solves on the default policy — row-per-lane kernel up to
+    N = 32, its clustered form beyond (ragged member sizes: N = 33 -> 16 + 17 knots, 97 -> 24 + 24 + 24 + 25, ...) — against the oracle's float64
+    iterate; nothing left to the fix-up."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    rng = np.random.default_rng(20250930)
+    fam = {}
+    for case in range(80):
+        N = int(rng.choice([rng.integers(2, 33), rng.integers(33, 129), rng.integers(129, 257)], p=[0.2, 0.5, 0.3]))
+        B = int(rng.integers(1, 6))
+        pc = str(rng.choice(["ss", "jacobi"]))
+        K = int(rng.integers(1, min(35, 14 * N)))
+        k = synth.make_kkt(N, B, int(rng.integers(1 << 30)))
+        S, P, g = synth.form_schur(k, precond=pc, dtype=np.float64, poison_unused=True)
+        lam0 = 0.1 * rng.standard_normal((B, n * N)) if rng.random() < 0.5 else np.zeros((B, n * N))
+        sol = PcgSolver(N, max_batch=B)
+        lam = dev(lam0.copy())
+        it, ex = sol.solve_f64(dev(S), dev(P), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), pc)
+        torch.cuda.synchronize()
+        f = sol.get_option("last_kernel_family")
+        fam[f] = fam.get(f, 0) + 1
+        assert f == (5 if N <= 32 else 8), (N, f)
+        assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all() and sol.get_option("cluster_fixups") == 0
+        lamh = lam.cpu().numpy()
+        for b in range(B):
+            ref = orc.pcg(np.nan_to_num(S[b]), np.nan_to_num(P[b]), g[b], lam0[b], N, K, 0.0, pc)["lam"]
+            assert relinf(lamh[b], ref) < 1e-9, (case, N, B, pc, K, b, relinf(lamh[b], ref))
+    assert fam.get(5, 0) >= 8 and fam.get(8, 0) >= 40, fam
