@@ -64,7 +64,7 @@ __global__ __launch_bounds__(RPLC_NW * 64, 2) void pcg_rplc_f64_kernel(ClusterAr
     real* xr1 = lds + 3 * VS;
     real* xt = lds + 4 * VS;
     real* xu = lds + 5 * VS;
-    real* red = lds + 6 * VS;                           // [0] the cluster-wide inner product of the current hand-off
+    real* red = lds + 6 * VS;                           // [0], [1] the cluster-wide inner product of the current hand-off, by epoch parity
     real* bc = red + 64;                                // [0] timeout flag  [1] trajectory index (as int)  [2] same-XCD (as int)
     gu64* my_words = (gu64*)ca.scratch + ((size_t)cl * G + g) * RPLC_WG_WORDS;
     gu64* cl_words = (gu64*)ca.scratch + (size_t)cl * G * RPLC_WG_WORDS;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(RPLC_NW * 64, 2) void pcg_rplc_f64_kernel(ClusterAr
             // the cluster-wide inner product: the G NW partials sit in lanes 0 .. G NW - 1 of this wavefront — folded here, in one fixed order that is
             // the same in every member (lane l = member l / NW, wave l % NW), one value for the workgroup
             const real tot_ = rpl_wave_fold(wantp ? partial : real(0));
-            if (lane == 0) { red[0] = tot_; if (spins >= CL_SPIN_LIMIT) bc[0] = 1.0; }
+            if (lane == 0) { red[epoch & 1u] = tot_; if (spins >= CL_SPIN_LIMIT) bc[0] = 1.0; }
 #ifdef RPLC_DEBUG
             if (spins >= CL_SPIN_LIMIT) {
                 double* d = ca.p.lambda + g * 256 + lane * 4;
@@ -168,7 +168,9 @@ __global__ __launch_bounds__(RPLC_NW * 64, 2) void pcg_rplc_f64_kernel(ClusterAr
         }
         lds_barrier();
         if (bc[0] != 0.0) failed = true;
-        const real tot = red[0];
+        // (two cells by epoch parity.  One would do: the next hand-off's poll cannot complete before every wavefront of this member has published its
+        //  next partial, i.e. after it has read this value — the second cell only makes that independence of timing local to these lines)
+        const real tot = red[epoch & 1u];
         return tot;
     };
 
