@@ -29,7 +29,7 @@ SHIM_PCG   := $(INC)/gbd_pcg_compat/gpu_pcg.cuh $(INC)/gbd_pcg_compat/gpuassert.
 SHIM_STEPS := $(INC)/mpcgpu_compat/linsys_steps.cuh
 SHIM_SIM   := $(INC)/mpcsim.cuh $(INC)/pcg/sqp.cuh $(INC)/qdldl/sqp.cuh $(INC)/mpcgpu_compat/sqp_stages.cuh $(SHIM_STEPS) $(SHIM_PCG)
 
-EXAMPLES := examples/sqp_pcg_callsite examples/sqp_pcg_callsite_f64 examples/sqp_linsys_chain examples/sqp_linsys_chain_f64 \
+EXAMPLES := examples/sqp_pcg_callsite examples/sqp_pcg_callsite_f64 examples/sqp_pcg_callsite_f64_n128 examples/sqp_linsys_chain examples/sqp_linsys_chain_f64 \
             examples/mpcsim_shim_demo_pcg examples/mpcsim_shim_demo_qdldl examples/mpcsim_iiwa_demo_pcg examples/mpcsim_iiwa_demo_qdldl \
             examples/bd_utils_probe examples/multi_gpu_pcg
 
@@ -51,6 +51,8 @@ examples/sqp_pcg_callsite: examples/sqp_pcg_callsite.cpp $(LIB) $(SHIM_PCG)
 	$(HIPCC) $(EXFLAGS) -I$(INC)/gbd_pcg_compat $< $(LINKLIB) -lpthread -o $@
 examples/sqp_pcg_callsite_f64: examples/sqp_pcg_callsite.cpp $(LIB) $(SHIM_PCG)
 	$(HIPCC) $(EXFLAGS) -DUSE_DOUBLES -I$(INC)/gbd_pcg_compat $< $(LINKLIB) -lpthread -o $@
+examples/sqp_pcg_callsite_f64_n128: examples/sqp_pcg_callsite.cpp $(LIB) $(SHIM_PCG)
+	$(HIPCC) $(EXFLAGS) -DUSE_DOUBLES -DKNOT_POINTS=128 -I$(INC)/gbd_pcg_compat $< $(LINKLIB) -lpthread -o $@
 examples/sqp_linsys_chain: examples/sqp_linsys_chain.cpp $(LIB) $(SHIM_PCG) $(SHIM_STEPS)
 	$(HIPCC) $(EXFLAGS) -I$(INC)/gbd_pcg_compat -I$(INC)/mpcgpu_compat $< $(LINKLIB) -o $@
 examples/sqp_linsys_chain_f64: examples/sqp_linsys_chain.cpp $(LIB) $(SHIM_PCG) $(SHIM_STEPS)

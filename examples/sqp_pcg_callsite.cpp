@@ -13,7 +13,9 @@
 #include "gpu_pcg.cuh"
 
 #define STATE_SIZE 14
+#ifndef KNOT_POINTS           // (-DKNOT_POINTS=128 -DUSE_DOUBLES: pcg<double, 14, 128> — the clustered row-per-lane kernel behind the same call site)
 #define KNOT_POINTS 32
+#endif
 #define PCG_NUM_THREADS 128
 #ifdef USE_DOUBLES            // linsys_t = double, include/common/settings.cuh:41-49
 typedef double T;

@@ -21,6 +21,7 @@ def _ex(name):
 
 
 EXAMPLE_BIN, EXAMPLE_BIN64 = _ex("sqp_pcg_callsite"), _ex("sqp_pcg_callsite_f64")
+EXAMPLE_BIN64_N128 = _ex("sqp_pcg_callsite_f64_n128")
 CHAIN_BIN, CHAIN_BIN64 = _ex("sqp_linsys_chain"), _ex("sqp_linsys_chain_f64")
 DEMO_BINS = {1: _ex("mpcsim_shim_demo_pcg"), 0: _ex("mpcsim_shim_demo_qdldl")}
 IIWA_DEMO_BINS = {1: _ex("mpcsim_iiwa_demo_pcg"), 0: _ex("mpcsim_iiwa_demo_qdldl")}
@@ -89,6 +90,12 @@ def build_example_f64(force: bool = False, verbose: bool = False) -> str:
     """The same call site compiled with -DUSE_DOUBLES (linsys_t = double): pcg<double, n, N> over the shim."""
     _build_bins([EXAMPLE_BIN64], force, verbose)
     return EXAMPLE_BIN64
+
+
+def build_example_f64_n128(force: bool = False, verbose: bool = False) -> str:
+    """The call site with -DUSE_DOUBLES -DKNOT_POINTS=128: pcg<double, 14, 128> — the clustered row-per-lane kernel behind the shim."""
+    _build_bins([EXAMPLE_BIN64_N128], force, verbose)
+    return EXAMPLE_BIN64_N128
 
 
 def build_chain_example(force: bool = False, verbose: bool = False) -> str:

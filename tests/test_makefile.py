@@ -27,7 +27,7 @@ def test_make_all_names_the_library_and_every_example():
     link = [ln for ln in out.splitlines() if "-shared" in ln and "-o mpcgpu_amd/libmpcg_hip.so" in ln]
     assert len(link) == 1
     from mpcgpu_amd import build
-    bins = [build.EXAMPLE_BIN, build.EXAMPLE_BIN64, build.CHAIN_BIN, build.CHAIN_BIN64, *build.DEMO_BINS.values(), *build.IIWA_DEMO_BINS.values(),
+    bins = [build.EXAMPLE_BIN, build.EXAMPLE_BIN64, build.EXAMPLE_BIN64_N128, build.CHAIN_BIN, build.CHAIN_BIN64, *build.DEMO_BINS.values(), *build.IIWA_DEMO_BINS.values(),
             build.MULTI_BIN, build.UTILS_BIN]
     for b in bins:
         assert f"-o {os.path.relpath(b, ROOT)}" in out, b
