@@ -120,7 +120,6 @@ __device__ __forceinline__ void invert(double (&A)[NN], double (&I)[NN], int lr)
 
 // ---- memory: buffer resources, one 32-bit byte offset per lane (as schur_walk.hip.h); SW_OOB drops a store ----
 __device__ __forceinline__ double bld(rsrc_t r, uint32_t off) {
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
 }
 __device__ __forceinline__ void bst(rsrc_t r, uint32_t off, double v) {
