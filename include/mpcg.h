@@ -309,7 +309,9 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  *       ("cluster_l2" = 0: always write-through), so all members of a cluster must be resident: the launch holds as many clusters as fit the
  *       chip and each draws trajectories from a queue (any batch = one launch).  A cluster that cannot make progress (a peer not resident:
  *       another stream holds its CU) gives up after a bounded spin and the follow-up launch of a single-workgroup kernel re-solves its
- *       trajectory ("cluster_fixup" = 0: no follow-up launch, d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for such a trajectory).
+ *       trajectory ("cluster_fixup" = 0: no follow-up launch, d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for such a trajectory).  The
+ *       follow-up launch warm-starts from the handle's own copy of d_lambda, made in front of the cluster launch: members that did finish such a
+ *       trajectory have written their knots by then.  ("cluster_test_fail" = 1, tests only: one member gives up at its first write-back.)
  *       linsys_t = double (mpcg_pcg_solve_f64 / _ref_f64): the same option governs the clustered row-per-lane kernel, automatic for 32 < knot_points
  *       <= 256 with G = ceil(N / 32) members (full block rows of S and Pinv in the registers of G CUs; all three block columns are read, no symmetry
  *       contract); "cluster" = 0 selects the streaming kernel, which is also its fix-up;

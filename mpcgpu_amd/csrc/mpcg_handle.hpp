@@ -56,6 +56,7 @@ struct mpcg_handle {
     int cluster = -1;         // workgroups per trajectory of the clustered lane-pair kernel (pcg_lpk_cluster.hip.h): 0 off, -1 auto (N > 128), G > 0 forced
     int cluster_l2 = 1;       // clustered lane-pair kernel: 1 = L2-resident hand-offs when a cluster's members share an XCD, 0 = always write-through
     int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
+    int cluster_test_fail = 0; // tests only: the last member of cluster 0 gives up at the write-back of its first trajectory (ClusterArgs::test_fail)
     int check_symmetry = 0;   // debug: 1 = every solve that would run a lower-triangle kernel first verifies block symmetry of S and Pinv (synchronises)
     int last_sym_violations = 0;   //   block pairs that failed the check in the last solve (then solved by a three-column kernel)
     // The symmetry latch (default): until the handle knows, every lower-triangle solve is launched GUARDED (check kernel -> device flag ->
@@ -67,6 +68,9 @@ struct mpcg_handle {
     hipEvent_t sym_event = nullptr;
     unsigned long long* sym_host = nullptr;      // pinned
     unsigned long long* cluster_scratch = nullptr;
+    // the handle's copy of the caller's lambda ([batch][N][n]) made in front of every cluster launch: what the fix-up launch warm-starts from
+    void* lam_backup = nullptr;
+    size_t lam_backup_bytes = 0;
     unsigned long long* cluster64_scratch = nullptr;   // the clustered row-per-lane kernel in double (pcg_rpl_cluster_f64.hip.h): queue | flags | cells, first use
     bool auto_cfg = true;     // launch knobs still at mpcg_create's choice (any valid pcg_* set_option clears this)
     bool generic = false;     // state_size != 14: only the PCG entry points work, through pcg_generic_kernel

@@ -74,6 +74,28 @@ static size_t cluster_alloc_words(const mpcg_handle* h) {
            + 16;                         // + one line for the "cluster_fixups" counter (never re-zeroed by a launch)
 }
 static unsigned long long* fixup_counter(const mpcg_handle* h) { return h->cluster_scratch + cluster_alloc_words(h) - 16; }
+// The handle's copy of lambda0 (mpcg_handle::lam_backup).  mpcg_create sizes it for every horizon the automatic policy gives to a cluster kernel;
+// a forced "cluster" = G on a shorter horizon allocates at its first launch (hipMalloc: not inside a stream capture).
+static int ensure_lam_backup(mpcg_handle* h, size_t bytes) {
+    if (h->lam_backup_bytes >= bytes) return MPCG_OK;
+    if (h->lam_backup) { HIP_TRY(h, hipFree(h->lam_backup)); h->lam_backup = nullptr; h->lam_backup_bytes = 0; }
+    HIP_TRY(h, hipMalloc(&h->lam_backup, bytes));
+    h->lam_backup_bytes = bytes;
+    return MPCG_OK;
+}
+// queue + flags + cells zeroed and lambda copied, one launch (cluster_prologue_kernel)
+static int launch_cluster_prologue(mpcg_handle* h, unsigned long long* words, size_t zw, const void* lambda, size_t lam_bytes, hipStream_t st) {
+    const int rc = ensure_lam_backup(h, lam_bytes);
+    if (rc != MPCG_OK) return rc;
+    const size_t work = zw > lam_bytes / 16 ? zw : lam_bytes / 16;
+    size_t blocks = (work + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks * 256 < zw) blocks = (zw + 255) / 256;
+    hipLaunchKernelGGL(cluster_prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, st, words, zw, static_cast<const uint32_t*>(lambda),
+                       static_cast<uint32_t*>(h->lam_backup), lam_bytes / 4);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
 static size_t cluster64_alloc_words(const mpcg_handle* h);
 
 size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
@@ -141,10 +163,21 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
         }
         (void)hipMemset(h->cluster64_scratch, 0, cluster64_alloc_words(h) * sizeof(unsigned long long));
     }
+    // the copy of lambda0 that cluster fix-up launches start from: float clusters beyond one CU's horizon, double clusters beyond N = 32
+    if (!generic && knot_points > 32) {
+        const size_t esz = knot_points <= (uint32_t)(RPLC_KMAX * RPLC_MAX_G) ? sizeof(double) : sizeof(float);
+        if (knot_points > kLpbMaxN || esz == sizeof(double)) {
+            const size_t bytes = (size_t)max_batch * knot_points * state_size * esz;
+            if (hipMalloc(&h->lam_backup, bytes) != hipSuccess) {
+                (void)mpcg_destroy(h);
+                return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the copy of lambda the cluster fix-up starts from");
+            }
+            h->lam_backup_bytes = bytes;
+        }
+    }
     if (hipEventCreateWithFlags(&h->sym_event, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&h->sym_host), sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
-        (void)hipFree(h->cluster_scratch); (void)hipFree(h->sched_order);
-        delete h;
+        (void)mpcg_destroy(h);
         return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the symmetry latch");
     }
     *h->sym_host = 0;
@@ -153,8 +186,9 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
 }
 
 int mpcg_destroy(mpcg_handle* h) {
-    if (h && (h->ginv_scratch || h->ginv_scratch_f64 || h->cluster_scratch || h->block_scratch)) {
+    if (h) {
         (void)hipSetDevice(h->device);
+        if (h->lam_backup) (void)hipFree(h->lam_backup);
         if (h->block_scratch) (void)hipFree(h->block_scratch);
         if (h->ginv_scratch) (void)hipFree(h->ginv_scratch);
         if (h->seam_qinv) (void)hipFree(h->seam_qinv);
@@ -214,6 +248,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "nt_loads")) { h->nt_loads = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_fixup")) { h->cluster_fixup = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_l2")) { h->cluster_l2 = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "cluster_test_fail")) { h->cluster_test_fail = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "check_symmetry")) { h->check_symmetry = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "assume_symmetric")) {      // 1: the caller vouches (or fills only the lower block triangle): no check; 0: back to "unknown"
         h->sym_state = value ? 1 : 0; h->sym_pending = false; return MPCG_OK;
@@ -542,10 +577,17 @@ static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
     ca.batch = (int)batch;
     ca.clusters = (int)clusters;
     ca.l2_handoff = h->cluster_l2;
-    // one fill: the queue counter, this call's flags and the cells of this launch (their tags restart at 1 every launch)
+    ca.test_fail = h->cluster_test_fail;
+    // one launch in front: the queue counter, this call's flags and the cells of this launch zeroed (their tags restart at 1 every launch) and,
+    // when a fix-up launch follows, lambda0 copied for it
     const size_t zw = CL_FLAG_STRIDE + (size_t)batch * CL_FLAG_STRIDE + (size_t)clusters * G * LPBC_WG_WORDS;
-    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster_scratch, zw);
-    HIP_TRY(h, hipGetLastError());
+    if (fixup) {
+        const int rc = launch_cluster_prologue(h, h->cluster_scratch, zw, a.lambda, (size_t)batch * h->N * NS * sizeof(float), st);
+        if (rc != MPCG_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster_scratch, zw);
+        HIP_TRY(h, hipGetLastError());
+    }
     hipLaunchKernelGGL(kern, dim3(((clusters + 7) / 8) * 8 * (unsigned)G), dim3(NWR * 256), lds, st, ca);
     HIP_TRY(h, hipGetLastError());
     if (fixup) {
@@ -557,6 +599,7 @@ static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
         // being a three-column kernel — every completion count is 0 after a gated exit — so it is never the lower-triangle lane-pair kernel
         // then (a forced "cluster" = G at N <= 128), and gated exits are not counted as abandoned trajectories
         c.redo_count = guarded ? nullptr : fixup_counter(h);
+        c.lam0 = static_cast<const float*>(h->lam_backup);     // (members that finished a trajectory their cluster did not have written their knots of lambda)
         const int rc = h->N <= kLpbMaxN && !guarded ? launch_lpk(h, c, batch, st) : launch_traj(h, kf, c, batch, st, esz, /*record=*/false);
         if (rc != MPCG_OK) return rc;
     }
@@ -800,9 +843,15 @@ static int try_launch_cluster_f64(mpcg_handle* h, const PcgArgs64& a, uint32_t b
     ca.fail_flags = ca.queue + CL_FLAG_STRIDE;
     ca.scratch = ca.fail_flags + (size_t)batch * CL_FLAG_STRIDE;
     ca.G = G; ca.batch = (int)batch; ca.clusters = (int)clusters; ca.l2_handoff = h->cluster_l2;
+    ca.test_fail = h->cluster_test_fail;
     const size_t zw = CL_FLAG_STRIDE + (size_t)batch * CL_FLAG_STRIDE + (size_t)clusters * G * RPLC_WG_WORDS;
-    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster64_scratch, zw);
-    HIP_TRY(h, hipGetLastError());
+    if (h->cluster_fixup) {
+        const int rc = launch_cluster_prologue(h, h->cluster64_scratch, zw, a.lambda, (size_t)batch * h->N * NS * sizeof(double), st);
+        if (rc != MPCG_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster64_scratch, zw);
+        HIP_TRY(h, hipGetLastError());
+    }
     hipLaunchKernelGGL(kern, dim3(((clusters + 7) / 8) * 8 * (unsigned)G), dim3(RPLC_NW * 64), lds, st, ca);
     HIP_TRY(h, hipGetLastError());
     if (h->cluster_fixup) {                             // trajectories whose cluster gave up: the streaming kernel, all three block columns
@@ -810,6 +859,7 @@ static int try_launch_cluster_f64(mpcg_handle* h, const PcgArgs64& a, uint32_t b
         c.lower = 0;
         c.redo_flags = ca.fail_flags; c.redo_stride = CL_FLAG_STRIDE; c.redo_skip = (unsigned long long)G;
         c.redo_count = fixup_counter(h);
+        c.lam0 = static_cast<const double*>(h->lam_backup);
         const int rc = launch_generic<double, 14>(h, c, batch, st);
         if (rc != MPCG_OK) return rc;
     }

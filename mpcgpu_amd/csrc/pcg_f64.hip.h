@@ -36,6 +36,7 @@ struct PcgArgsG {
     unsigned long long redo_skip = 0;
     int redo_stride = 0;
     unsigned long long* redo_count = nullptr;         // incremented once per trajectory a fix-up launch actually solves ("cluster_fixups")
+    const T* lam0 = nullptr;                           // fix-up launches: the warm start ([batch][N][n], the handle's copy of lambda made in front of the cluster launch); nullptr: `lambda`
 };
 typedef PcgArgsG<double> PcgArgs64;
 
@@ -117,7 +118,7 @@ if constexpr (NFIX > 0) {
     for (int e = tid; e < (N + 2) * n; e += NT) { xp[e] = real(0); xr[e] = real(0); }
     __syncthreads();
     for (int e = tid; e < N * n; e += NT) {
-        const real l0 = lam_g[e];
+        const real l0 = a.lam0 ? a.lam0[(size_t)b * n * N + e] : lam_g[e];
         xp[n + e] = l0; lam[e] = l0; xr[n + e] = gam[e];
     }
     __syncthreads();

@@ -190,6 +190,9 @@ struct PcgArgs {
     int redo_stride = 0;
     unsigned redo_skip = 0;
     unsigned long long* redo_count = nullptr;   // fix-up launches: += 1 per trajectory they re-solve (the handle's "cluster_fixups" counter)
+    // fix-up launches: the warm start is read from here ([batch][N][n], the handle's copy of lambda made in front of the cluster launch) — the
+    // members of a cluster that DID finish a trajectory have written their knots of `lambda` already.  nullptr: from `lambda` itself.
+    const float* lam0 = nullptr;
     // dispatch order (pcg_lpk_kernel, pcg_lpkc_kernel, ...): workgroup / draw q solves trajectory sched_pick(order, q, order_tag) (nullptr: q
     // itself).  See sched_order_kernel.
     const uint32_t* order = nullptr;
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(NW * 64, (RT == 0 ? 4 : (NW == 4 && RT <= 3 ? 2 : N
     for (int e = tid; e < (N + 2) * NS; e += NTHR) { xp[e] = 0.f; xr[e] = 0.f; }
     lds_barrier();
     for (int e = tid; e < N * NS; e += NTHR) {
-        const float l0 = lam_g[e];
+        const float l0 = a.lam0 ? a.lam0[(size_t)b * vstride + e] : lam_g[e];
         xp[NS + e] = l0;
         lam[e] = l0;
         xr[NS + e] = gam[e];
@@ -715,6 +718,7 @@ struct ClusterArgs {
     int batch = 0;                       // trajectories of the call
     int clusters = 0;                    // clusters of the launch (the grid holds 8 ceil(clusters / 8) of them)
     int l2_handoff = 1;                  // 1 = hand-offs through the XCD's L2 when all members of a cluster share an XCD (verified in the kernel)
+    int test_fail = 0;                   // tests only ("cluster_test_fail"): the last member of cluster 0 gives up at the write-back of its first trajectory
 };
 
 // Zero-fill of the cluster scratch (flags + hand-off cells) in front of every cluster launch.  A kernel of our own
@@ -724,6 +728,20 @@ struct ClusterArgs {
 __global__ __launch_bounds__(256) void zero_words_kernel(unsigned long long* p, size_t count) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < count) p[i] = 0ull;
+}
+// The same fill + the handle's copy of the caller's lambda ([batch][N][n], n32 dwords): what a fix-up launch warm-starts from (PcgArgs::lam0).
+// One launch in front of every cluster launch.
+__global__ __launch_bounds__(256) void cluster_prologue_kernel(unsigned long long* p, size_t count, const uint32_t* src, uint32_t* dst, size_t n32) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    for (size_t j = i; j < count; j += stride) p[j] = 0ull;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        const size_t n4 = n32 / 4;
+        for (size_t j = i; j < n4; j += stride) reinterpret_cast<u4v*>(dst)[j] = reinterpret_cast<const u4v*>(src)[j];
+        for (size_t j = 4 * n4 + i; j < n32; j += stride) dst[j] = src[j];
+    } else {
+        for (size_t j = i; j < n32; j += stride) dst[j] = src[j];
+    }
 }
 
 // The symmetry latch / the "check_symmetry" debug option: the lane-pair kernels read only the left and diagonal block

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
     lds_barrier();
     for (int e = tid; e < N * NS; e += NTHR) {
         const int kk = e / NS, i = e - kk * NS;
-        const float l0 = lam_g[e];
+        const float l0 = a.lam0 ? a.lam0[(size_t)b * vstride + e] : lam_g[e];      // (a fix-up launch behind a forced cluster: PcgArgs::lam0)
         lds[L::P0 + L::at(kk, i)] = l0;
         lds[L::LAM + L::at(kk, i)] = l0;
         lds[L::R0 + L::at(kk, i)] = gam[e];

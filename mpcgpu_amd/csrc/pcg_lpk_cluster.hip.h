@@ -563,6 +563,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpkc_kernel(ClusterArgs ca) 
         // ---- write back own knots (a member that gave up leaves lambda alone: its trajectory's count stays short of G, the fix-up launch re-solves it) ----
         kargp_t k_out = kp;
         asm volatile("" : "+s"(k_out));
+        if (ca.test_fail && cl == 0 && g == G - 1 && seq == 1) failed = true;      // ("cluster_test_fail": a member that gives up when its peers are past their last hand-off)
         if (failed) {
             if (tid == 0) { k_out->p.iters[b] = 0xFFFFFFFFu; k_out->p.max_iter_exit[b] = 2; }
             break;

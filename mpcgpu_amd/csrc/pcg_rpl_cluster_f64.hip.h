@@ -33,6 +33,7 @@ struct ClusterArgs64 {
     unsigned long long* fail_flags;      // [batch][CL_FLAG_STRIDE], zeroed before the launch: members that finished the trajectory
     unsigned long long* queue;           // next trajectory to hand out (zeroed before the launch)
     int G, batch, clusters, l2_handoff;
+    int test_fail = 0;                   // tests only ("cluster_test_fail"): the last member of cluster 0 gives up at the write-back of its first trajectory
 };
 
 // LDS (doubles): six vectors [KL + 2][14] with a halo knot either side | 64 partials of the cluster | {timeout flag, trajectory index, same-XCD}
@@ -322,7 +323,9 @@ __global__ __launch_bounds__(RPLC_NW * 64, 2) void pcg_rplc_f64_kernel(ClusterAr
                     eta = eta_new;
                 }
             }
-            // ---- write back (a member that gave up leaves lambda alone: the trajectory's count stays short of G, the fix-up launch re-solves it) ----
+            // ---- write back (a member that gave up leaves lambda alone: the trajectory's count stays short of G, the fix-up launch re-solves it
+            //      from the handle's copy of lambda0 — its peers may be past their last hand-off and have written their knots) ----
+            if (ca.test_fail && cl == 0 && g == G - 1 && seq == 1) failed = true;
             if (failed) {
                 if (tid == 0) { kp->p.iters[b] = 0xFFFFFFFFu; kp->p.max_iter_exit[b] = 2; }
                 break;

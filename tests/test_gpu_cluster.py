@@ -226,3 +226,46 @@ def test_cluster_falls_back_when_peers_are_not_resident(orc):
     it2, ex2 = sol.solve(dS, dP, dg, lam2, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
     torch.cuda.synchronize()
     assert int(it2.item()) == K and relinf(lam2.cpu().numpy()[0], r64["lam"]) <= max(1e-3, 4 * band)
+
+
+@pytest.mark.parametrize("precision", ["float", "double"])
+def test_fixup_starts_from_the_callers_lambda_even_if_some_members_finished(orc, precision):
+    """A member that gives up AFTER its peers passed their last hand-off ("cluster_test_fail": the last member of cluster 0, at the write-back of
+    its first trajectory): the peers have written their knots of lambda, the trajectory's completion count is short of G, the fix-up launch
+    re-solves it — from the handle's copy of lambda0 (PcgArgs::lam0), not from the half-written array.  Warm start, few iterations: a wrong
+    start would be far outside the band.  The peers then wait for the member that left, give up on their next trajectory: two fix-ups."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    dbl = precision == "double"
+    N, B, K = (128, 70, 6) if dbl else (256, 140, 6)          # more trajectories than resident clusters (64 / 128): the queue is in use
+    k = synth.make_kkt(N, 3, 8800 + N)
+    S3, P3, g3 = synth.form_schur(k, dtype=np.float64 if dbl else np.float32)
+    rep = (B + 2) // 3
+    S, Pinv, g = (np.tile(a_, (rep, 1))[:B] for a_ in (S3, P3, g3))
+    lam0 = np.random.default_rng(5).normal(0, 0.3, (B, n * N)).astype(S.dtype)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    sol = PcgSolver(N, max_batch=B)
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    solve = sol.solve_f64 if dbl else sol.solve
+    lam_ok = dev(lam0.copy())
+    solve(dS, dP, dg, lam_ok, cfg)
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == (8 if dbl else 7) and sol.get_option("cluster_fixups") == 0
+    sol.set_option("cluster_test_fail", 1)
+    lam = dev(lam0.copy())
+    it, ex = solve(dS, dP, dg, lam, cfg)
+    torch.cuda.synchronize()
+    fixed = sol.get_option("cluster_fixups")
+    assert 1 <= fixed <= 2, fixed
+    assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all()
+    lamh, okh = lam.cpu().numpy(), lam_ok.cpu().numpy()
+    changed = [b for b in range(B) if not np.array_equal(lamh[b], okh[b])]
+    assert 0 in changed and len(changed) <= fixed, changed     # (re-solved by another kernel: other bits; everything else untouched)
+    for b in changed:
+        r64 = orc.pcg(S[b].astype(np.float64), Pinv[b].astype(np.float64), g[b].astype(np.float64), lam0[b].astype(np.float64), N, K, 0.0, "ss")
+        tol = 1e-9 if dbl else max(2e-5, 4 * fp32_band(orc, S[b], Pinv[b], g[b], lam0[b], N, K, "ss", r64["lam"], trials=2))
+        assert relinf(lamh[b], r64["lam"]) <= tol, (b, relinf(lamh[b], r64["lam"]), tol)
+    sol.set_option("cluster_test_fail", 0)
+    lam2 = dev(lam0.copy())
+    solve(dS, dP, dg, lam2, cfg)
+    torch.cuda.synchronize()
+    assert torch.equal(lam2, lam_ok) and sol.get_option("cluster_fixups") == fixed

@@ -9,7 +9,8 @@ from mpcgpu_amd import PcgSolver, pcg_config, _lib as _L
 if os.environ.get("AB_LIB"):
     _L.LIB_PATH = os.environ["AB_LIB"]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-for B in (1024, 1):
+BATCHES = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1024, 1]
+for B in BATCHES:
     sol = PcgSolver(N, max_batch=B)
     dS, dP, dg = bench.build_inputs(sol, N, B, 0, "ss", torch.device("cuda", 0))
     lam = torch.zeros(B, 14 * N, device="cuda")
