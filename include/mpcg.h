@@ -39,6 +39,10 @@
  *   - every pointer named d_* is a DEVICE pointer on the handle's device; `stream` is a hipStream_t
  *     passed as void* (NULL = default stream).  Calls are stream-ordered and never synchronise.
  *   - batched entry points take `batch` independent trajectories stored back to back.
+ *   - GRAPH CAPTURE.  Every compute entry point is pure stream work and may be captured into a hipGraph.  What the PCG entry points need is
+ *     allocated by mpcg_create; mpcg_form_schur(_f64), mpcg_block_solve and a FORCED "cluster" on a horizon the automatic policy gives to one
+ *     CU allocate a handle-owned work buffer at their first call (hipMalloc is not stream work): make that call once outside the capture — a
+ *     first call on a capturing stream returns MPCG_ERR_INVALID with a message and leaves the capture intact.
  *
  * All functions return MPCG_OK (0) or a negative mpcg_status; mpcg_last_error() gives the text.
  * Nothing here falls back to a CPU implementation: without a gfx950 device every compute entry

@@ -97,3 +97,11 @@ static inline int fail(mpcg_handle* h, int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                               \
             return fail((h), MPCG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// Buffers the handle allocates at the first call that needs them (hipMalloc is not stream work): a call that would have to allocate while its
+// stream is being captured is refused — message, MPCG_ERR_INVALID, capture intact — instead of failing inside the capture.  (mpcg.h, GRAPH CAPTURE)
+static inline int alloc_allowed(mpcg_handle* h, hipStream_t st, const char* what) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) return MPCG_OK;
+    return fail(h, MPCG_ERR_INVALID, std::string(what) + ": the handle allocates a work buffer at the first such call — make one outside the stream capture first");
+}

@@ -76,8 +76,9 @@ static size_t cluster_alloc_words(const mpcg_handle* h) {
 static unsigned long long* fixup_counter(const mpcg_handle* h) { return h->cluster_scratch + cluster_alloc_words(h) - 16; }
 // The handle's copy of lambda0 (mpcg_handle::lam_backup).  mpcg_create sizes it for every horizon the automatic policy gives to a cluster kernel;
 // a forced "cluster" = G on a shorter horizon allocates at its first launch (hipMalloc: not inside a stream capture).
-static int ensure_lam_backup(mpcg_handle* h, size_t bytes) {
+static int ensure_lam_backup(mpcg_handle* h, size_t bytes, hipStream_t st) {
     if (h->lam_backup_bytes >= bytes) return MPCG_OK;
+    { const int rc = alloc_allowed(h, st, "a forced \"cluster\" on a horizon the automatic policy gives to one CU"); if (rc != MPCG_OK) return rc; }
     if (h->lam_backup) { HIP_TRY(h, hipFree(h->lam_backup)); h->lam_backup = nullptr; h->lam_backup_bytes = 0; }
     HIP_TRY(h, hipMalloc(&h->lam_backup, bytes));
     h->lam_backup_bytes = bytes;
@@ -85,7 +86,7 @@ static int ensure_lam_backup(mpcg_handle* h, size_t bytes) {
 }
 // queue + flags + cells zeroed and lambda copied, one launch (cluster_prologue_kernel)
 static int launch_cluster_prologue(mpcg_handle* h, unsigned long long* words, size_t zw, const void* lambda, size_t lam_bytes, hipStream_t st) {
-    const int rc = ensure_lam_backup(h, lam_bytes);
+    const int rc = ensure_lam_backup(h, lam_bytes, st);
     if (rc != MPCG_OK) return rc;
     const size_t work = zw > lam_bytes / 16 ? zw : lam_bytes / 16;
     size_t blocks = (work + 255) / 256;
@@ -827,7 +828,8 @@ static int try_launch_cluster_f64(mpcg_handle* h, const PcgArgs64& a, uint32_t b
     if (G == 0) return 1;
     if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "batch exceeds max_batch");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (!h->cluster64_scratch) {                       // first use (not stream-ordered: hipMalloc)
+    if (!h->cluster64_scratch) {                       // (mpcg_create made it for every horizon this kernel serves)
+        { const int rc = alloc_allowed(h, st, "mpcg_pcg_solve_f64"); if (rc != MPCG_OK) return rc; }
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->cluster64_scratch), cluster64_alloc_words(h) * sizeof(unsigned long long)));
         HIP_TRY(h, hipMemset(h->cluster64_scratch, 0, cluster64_alloc_words(h) * sizeof(unsigned long long)));
     }

@@ -20,10 +20,8 @@ static int ensure_seam_buffer(mpcg_handle* h, size_t chunks_needed, size_t elem_
     // (the automatic part in doubles whatever this call's type: a float call followed by a linsys_t = double call must not reallocate either)
     const size_t need = 196 * std::max(chunks_needed * elem_bytes, auto_chunks * sizeof(double));
     if (h->seam_qinv_bytes >= need) return MPCG_OK;
+    { const int rc = alloc_allowed(h, st, "mpcg_form_schur (the seam buffer; a forced short \"schur_chunk\" needs a larger one)"); if (rc != MPCG_OK) return rc; }
     if (h->seam_qinv) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
-            return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur: a forced \"schur_chunk\" needs a larger seam buffer than the handle holds — make one such call outside the stream capture first");
         HIP_TRY(h, hipDeviceSynchronize());          // (an earlier call's kernels may still read the old buffer)
         HIP_TRY(h, hipFree(h->seam_qinv));
     }
@@ -42,7 +40,10 @@ int mpcg_block_solve(mpcg_handle* h, const float* d_S, const float* d_gamma, flo
     if (batch == 0) return MPCG_OK;
     if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_block_solve: batch exceeds max_batch");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (!h->block_scratch)                        // first call only (not stream-ordered: hipMalloc)
+    if (!h->block_scratch) {                      // first call only (not stream-ordered: hipMalloc)
+        const int rc = alloc_allowed(h, static_cast<hipStream_t>(stream), "mpcg_block_solve"); if (rc != MPCG_OK) return rc;
+    }
+    if (!h->block_scratch)
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->block_scratch),
                              (size_t)h->max_batch * h->N * (14 * 14 + 14) * sizeof(float)));       // W_k (14 x 14) + z_k per knot
     BlockSolveArgs a;
@@ -113,6 +114,7 @@ int mpcg_form_schur(mpcg_handle* h, uint32_t control_size, float* d_G_dense, con
     // G^-1 through a handle-owned staging buffer
     const size_t need = Gsz * h->max_batch;
     if (h->ginv_scratch_floats < need) {          // first call only (not stream-ordered: hipMalloc)
+        { const int rc = alloc_allowed(h, st, "mpcg_form_schur (\"schur_dpp\" = 0)"); if (rc != MPCG_OK) return rc; }
         if (h->ginv_scratch) HIP_TRY(h, hipFree(h->ginv_scratch));
         h->ginv_scratch = nullptr; h->ginv_scratch_floats = 0;
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->ginv_scratch), need * sizeof(float)));
@@ -213,6 +215,7 @@ int mpcg_form_schur_f64(mpcg_handle* h, uint32_t control_size, double* d_G_dense
     h->last_schur_chunk = 0;
     const size_t need = Gsz * h->max_batch;
     if (h->ginv_scratch_f64_elems < need) {       // first call only (not stream-ordered: hipMalloc)
+        { const int rc = alloc_allowed(h, static_cast<hipStream_t>(stream), "mpcg_form_schur_f64 (\"schur_dpp\" = 0)"); if (rc != MPCG_OK) return rc; }
         if (h->ginv_scratch_f64) HIP_TRY(h, hipFree(h->ginv_scratch_f64));
         h->ginv_scratch_f64 = nullptr; h->ginv_scratch_f64_elems = 0;
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->ginv_scratch_f64), need * sizeof(double)));

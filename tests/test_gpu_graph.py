@@ -101,3 +101,52 @@ def test_capture_while_the_symmetry_latch_is_still_pending(N):
         torch.cuda.synchronize()
         np.testing.assert_array_equal(lam.cpu().numpy(), want.cpu().numpy())
     assert sol.get_option("symmetry_state") in (0, 1)
+
+
+def test_first_call_allocations_are_refused_inside_a_capture_and_leave_it_intact():
+    """mpcg_form_schur and mpcg_block_solve allocate a handle-owned work buffer at their first call (hipMalloc: not stream work).  On a fresh
+    handle whose stream is being captured they return MPCG_ERR_INVALID with a message (include/mpcg.h, GRAPH CAPTURE) instead of failing inside
+    the capture; the capture stays usable — the PCG solve captured next to them replays — and after one eager call the same calls capture."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, B = 32, 3
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=12)
+    G, C, g, c = (dev(a) for a in synth.pack_kkt_dense(synth.make_kkt(N, B, 4242), np.float32))
+    ref = PcgSolver(N, max_batch=B)
+    z = lambda: torch.zeros(B, 3 * n * n * N, device="cuda")       # (blocks (0, left) and (N-1, right) are never written: zeros on both sides)
+    S, P, gam = ref.form_schur(G.clone(), C, g, c, 1e-3, "ss", S=z(), Pinv=z(), gamma=torch.zeros(B, n * N, device="cuda"))
+    lam_want = torch.zeros(B, n * N, device="cuda")
+    ref.solve(S, P, gam, lam_want, cfg, "ss")
+    torch.cuda.synchronize()
+
+    sol = PcgSolver(N, max_batch=B)                     # fresh: no seam buffer, no block-solve scratch
+    S2, P2, gam2 = torch.empty_like(S), torch.empty_like(P), torch.empty_like(gam)
+    lam = torch.empty(B, n * N, device="cuda")
+    lam_d = torch.empty(B, n * N, device="cuda")
+    it = torch.zeros(B, dtype=torch.int32, device="cuda"); ex = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    dG = G.clone()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        with pytest.raises(RuntimeError, match="outside the stream capture"):
+            sol.form_schur(dG, C, g, c, 1e-3, "ss", S=S2, Pinv=P2, gamma=gam2)
+        with pytest.raises(RuntimeError, match="outside the stream capture"):
+            sol.block_solve(S, gam, lam_d)
+        lam.zero_()
+        sol.solve(S, P, gam, lam, cfg, "ss", iters=it, exits=ex)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(lam, lam_want)
+    # one eager call each, then the same calls capture and replay
+    sol.form_schur(G.clone(), C, g, c, 1e-3, "ss", S=S2, Pinv=P2, gamma=gam2)
+    sol.block_solve(S, gam, lam_d)
+    torch.cuda.synchronize()
+    want_d = lam_d.clone()
+    S2.zero_(); P2.zero_(); lam_d.zero_()
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2):
+        dG.copy_(G)
+        sol.form_schur(dG, C, g, c, 1e-3, "ss", S=S2, Pinv=P2, gamma=gam2)
+        sol.block_solve(S2, gam2, lam_d)
+    graph2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(S2, S) and torch.equal(P2, P) and torch.equal(lam_d, want_d)
