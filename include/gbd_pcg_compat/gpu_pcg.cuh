@@ -10,8 +10,9 @@
 //   cudaLaunchCooperativeKernel(pcg_kernel, N, threads, args, smem)   include/pcg/sqp.cuh:230
 //                                                        -> mpcgLaunchPcg(pcg_kernel, N, threads, args, smem)
 //                                                           (the ONE line of sqp.cuh that changes)
-// T = float (linsys_t with USE_DOUBLES=0, include/common/settings.cuh:41-49) is the tuned path; T = double
-// (USE_DOUBLES=1) is served by the library's functional double-precision kernel.  STATE_SIZE = 14.
+// T = float (linsys_t with USE_DOUBLES=0, include/common/settings.cuh:41-49) is the headline path; T = double (USE_DOUBLES=1) runs the
+// row-per-lane kernel in double to 32 knots, its clustered form (ceil(N / 32) CUs per trajectory) to 256, the streaming kernel beyond.
+// STATE_SIZE = 14.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>

@@ -79,7 +79,11 @@ static unsigned long long* fixup_counter(const mpcg_handle* h) { return h->clust
 static int ensure_lam_backup(mpcg_handle* h, size_t bytes, hipStream_t st) {
     if (h->lam_backup_bytes >= bytes) return MPCG_OK;
     { const int rc = alloc_allowed(h, st, "a forced \"cluster\" on a horizon the automatic policy gives to one CU"); if (rc != MPCG_OK) return rc; }
-    if (h->lam_backup) { HIP_TRY(h, hipFree(h->lam_backup)); h->lam_backup = nullptr; h->lam_backup_bytes = 0; }
+    if (h->lam_backup) {
+        HIP_TRY(h, hipDeviceSynchronize());              // (an earlier call's fix-up launch may still read the old copy)
+        HIP_TRY(h, hipFree(h->lam_backup));
+        h->lam_backup = nullptr; h->lam_backup_bytes = 0;
+    }
     HIP_TRY(h, hipMalloc(&h->lam_backup, bytes));
     h->lam_backup_bytes = bytes;
     return MPCG_OK;

@@ -781,6 +781,10 @@ def double_precision(cx):
     out.update({"kernel_ms": ms, "pcg_iterations_per_sec": Bd * 40 / (ms * 1e-3), "kernel_family": fam, "members_per_trajectory": sol.get_option("last_kernel_cluster"),
                 "cluster_fixups": sol.get_option("cluster_fixups"),
                 "bound": "two cluster-wide hand-offs per iteration (S and Pinv resident in the registers of ceil(N / 32) CUs)" if fam == 8 else "hbm"})
+    # useful flop of one trajectory-iteration (bench.py's count for the headline kernel): two block-tridiagonal products + 2 inner products + 3 axpys
+    flop = 2 * 196 * ((3 * N - 2) + ((3 * N - 2) if args.precond == "ss" else N)) + 10 * 14 * N
+    out.update({"flop_per_iteration": flop, "achieved_tflops": out["pcg_iterations_per_sec"] * flop / 1e12,
+                "frac_of_fp64_valu_peak": out["pcg_iterations_per_sec"] * flop / 1e12 / FP64_VALU_PEAK_TF})
     try:
         sol.set_option("cluster", 0)
         go()                                                                     # (first streaming call: the latch's one blocking check)
