@@ -30,7 +30,7 @@ struct PcgKnobs {
 };
 
 // What the last solve on this handle actually launched (read-only "last_kernel_*" options; tests assert on it).
-enum { FAM_NONE = -1, FAM_TRAJ = 0, /* 1, 2, 4: kernels retired in round 4 (HISTORY.md) */ FAM_GENERIC = 3, FAM_RPL = 5, FAM_LPK = 6, FAM_LPKC = 7, FAM_RPLC64 = 8 };
+enum { FAM_NONE = -1, FAM_TRAJ = 0, /* 1, 2, 4: kernels retired in round 4 (HISTORY.md) */ FAM_GENERIC = 3, FAM_RPL = 5, FAM_LPK = 6, FAM_LPKC = 7, FAM_RPLC64 = 8, FAM_LQK64 = 9 };
 struct LastKernel { int family = FAM_NONE, waves = 0, reg_rows = 0, lds_rows = 0, stream_bufs = 0, cluster = 0, lds_bytes = 0, lds_extra = 0; };
 
 struct mpcg_handle {
@@ -42,6 +42,7 @@ struct mpcg_handle {
     int nt_loads = 1;         // non-temporal hint on the matrix stream
     int rpl = -1;             // row-per-lane kernel (pcg_rpl.hip.h, N <= 64): -1 auto, 0 off, 1 forced
     int rpl_waves = 0;        //   its wavefronts per trajectory: 0 auto, 4 / 8 / 16
+    int lqk = -1;             // lane-quad-per-knot kernel in double (pcg_lqk_f64.hip.h, N <= 64): -1 auto (32 < N <= 64 once the latch says block-symmetric), 0 off, 1 forced
     int lpk = -1;             // lane-pair-per-knot kernel (pcg_lpk.hip.h, N <= 128): -1 auto (36 < N <= 128 beyond the row-per-lane kernel's calls), 0 off, 1 forced
     int block_solve_wide = -1; // mpcg_block_solve: one trajectory per wavefront (1), four (0), by batch size (-1)
     int schur_dpp = 1;        // 1: register-resident Schur formation (schur_walk.hip.h: the chunk-walking kernel + its seam kernel), 0: the LDS versions

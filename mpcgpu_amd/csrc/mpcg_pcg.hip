@@ -6,6 +6,7 @@
 #include "pcg_lpk_cluster.hip.h"
 #include "pcg_rpl.hip.h"
 #include "pcg_rpl_cluster_f64.hip.h"
+#include "pcg_lqk_f64.hip.h"
 #include "pcg_f64.hip.h"
 
 using namespace mpcg;
@@ -57,6 +58,7 @@ static constexpr uint32_t kLpbMaxN = 128;         // one block per lane: 8 waves
 
 static int stream_bufs_for(const mpcg_handle* h, const PcgKnobs& k, int nw, int esz);
 static void choose_auto(const mpcg_handle* h, PcgKnobs& k, uint32_t batch, int esz);
+static constexpr uint32_t kLqkMaxN = 64;      // linsys_t = double: knots one CU holds as lane quads (pcg_lqk_f64.hip.h)
 static size_t default_launch_lds_bytes(uint32_t N, int num_cus);
 
 extern "C" {
@@ -113,6 +115,7 @@ size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
 size_t mpcg_pcg_lds_bytes_f64(uint32_t state_size, uint32_t knot_points) {
     if (!shape_supported(state_size, knot_points) && !generic_shape_supported(state_size, knot_points)) return 0;
     if (state_size == NS && knot_points <= 32) return pcg_rpl_lds_floats((int)knot_points, knot_points <= 16 ? 4 : 8) * sizeof(double);   // row-per-lane kernel
+    if (state_size == NS && knot_points <= kLqkMaxN) return pcg_lqk_lds_doubles(8) * sizeof(double);                                   // lane-quad kernel (block-symmetric matrices: the reference's)
     if (state_size == NS && knot_points <= (uint32_t)(RPLC_KMAX * RPLC_MAX_G)) return pcg_rplc_lds_doubles() * sizeof(double);         // a member of the clustered row-per-lane kernel
     const size_t b = pcg_generic_lds_elems((int)knot_points, (int)state_size) * sizeof(double);
     return b <= kLdsMax ? b : 0;
@@ -244,6 +247,11 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
         if (value != 0 && value != 4 && value != 8 && value != 16) return fail(h, MPCG_ERR_INVALID, "rpl_waves must be 0 (auto), 4, 8 or 16");
         h->rpl_waves = value; return MPCG_OK;
     }
+    if (!strcmp(key, "pcg_lqk")) {
+        if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "pcg_lqk must be -1 (auto), 0 (off) or 1 (forced)");
+        if (value == 1 && h->N > kLqkMaxN) return fail(h, MPCG_ERR_UNSUPPORTED, "pcg_lqk: the lane-quad kernel holds knot_points <= 64");
+        h->lqk = value; return MPCG_OK;
+    }
     if (!strcmp(key, "pcg_lpk")) {
         if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "pcg_lpk must be -1 (auto), 0 (off) or 1 (forced)");
         if (value == 1 && h->N > kLpbMaxN) return fail(h, MPCG_ERR_UNSUPPORTED, "pcg_lpk: the lane-pair kernel holds knot_points <= 128");
@@ -280,6 +288,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "pcg_waves")) { *value = h->k.waves; return MPCG_OK; }
     if (!strcmp(key, "pcg_max_wg_per_cu")) { *value = h->k.max_wg_per_cu; return MPCG_OK; }
     if (!strcmp(key, "pcg_lpk")) { *value = h->lpk; return MPCG_OK; }
+    if (!strcmp(key, "pcg_lqk")) { *value = h->lqk; return MPCG_OK; }
     if (!strcmp(key, "pcg_rpl")) { *value = h->rpl; return MPCG_OK; }
     if (!strcmp(key, "rpl_waves")) { *value = h->rpl_waves; return MPCG_OK; }
     if (const int* p = knob_ptr(const_cast<mpcg_handle*>(h), key)) { *value = *p; return MPCG_OK; }
@@ -873,40 +882,67 @@ static int try_launch_cluster_f64(mpcg_handle* h, const PcgArgs64& a, uint32_t b
     return MPCG_OK;
 }
 
+// The double kernels that read only the left + diagonal block columns use the float path's latch (mpcg.h, BLOCK SYMMETRY): a handle that does not
+// know yet checks THIS call's matrices once, with one blocking 8-byte copy (never during capture: a capturing call on such a handle runs a
+// kernel that reads all three columns).
+static int f64_symmetry_latch(mpcg_handle* h, const PcgArgs64& a, uint32_t batch, hipStream_t st) {
+    sym_poll(h, st, true);
+    if (h->sym_state != 0 || h->sym_pending) return MPCG_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return MPCG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    unsigned long long* flag = fixup_counter(h) + 9;
+    const long items = (long)batch * ((long)h->N - 1);
+    const unsigned blocks = (unsigned)((items + 3) / 4);
+    for (const double* m : {a.S, a.pcols == 3 ? a.Pinv : (const double*)nullptr})
+        if (m) hipLaunchKernelGGL(bd_symmetry_check_kernel<double>, dim3(blocks), dim3(256), 0, st, m, (int)h->N, (int)batch, kSymRelTol, (unsigned long long*)nullptr, flag);
+    HIP_TRY(h, hipGetLastError());
+    unsigned long long v = 0;
+    HIP_TRY(h, hipMemcpyAsync(&v, flag, sizeof v, hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    h->sym_state = v ? 2 : 1;
+    if (v) h->err = "warning: S / Pinv of a solve on this handle were not block-symmetric (block (k, right) != block (k+1, left)^T): the handle now "
+                    "runs kernels that read all three block columns (include/mpcg.h, BLOCK SYMMETRY)";
+    return MPCG_OK;
+}
+// linsys_t = double, N <= 64: a lane quad per knot, the lower block triangle in the registers of ONE CU (pcg_lqk_f64.hip.h)
+template <int NWR>
+static int launch_lqk_f64_t(mpcg_handle* h, const PcgArgs64& a, uint32_t batch, hipStream_t st) {
+    const size_t lds = pcg_lqk_lds_doubles(4 * NWR) * sizeof(double);
+    void (*kern)(PcgArgs64) = pcg_lqk_f64_kernel<NWR>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(batch), dim3(NWR * 256), lds, st, a);
+    HIP_TRY(h, hipGetLastError());
+    h->last = LastKernel{FAM_LQK64, 4 * NWR, 0, 0, 0, 0, (int)lds, 0};
+    return MPCG_OK;
+}
+
 static int launch_f64(mpcg_handle* h, PcgArgs64 a, uint32_t batch, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // 32 < N <= 64 (or "pcg_lqk" = 1 at any N <= 64): the lane-quad kernel, once the latch says the matrices are block-symmetric
+    if (!h->generic && h->N <= kLqkMaxN && h->lqk != 0 && (h->lqk == 1 || (h->auto_cfg && h->N > kRplMaxN64 && h->cluster < 0))) {
+        const int rc = f64_symmetry_latch(h, a, batch, st);
+        if (rc != MPCG_OK) return rc;
+        if (h->sym_state == 1) {
+            HIP_TRY(h, hipSetDevice(h->device));
+            return h->N <= 32 ? launch_lqk_f64_t<1>(h, a, batch, st) : launch_lqk_f64_t<2>(h, a, batch, st);
+        }
+    }
     if (!h->generic && h->N <= kRplMaxN64 && h->rpl != 0 && (h->rpl == 1 || h->auto_cfg)) {
         HIP_TRY(h, hipSetDevice(h->device));
-        hipStream_t st = static_cast<hipStream_t>(stream);
         if (h->N <= 16) return a.pcols == 3 ? launch_rpl_f64_t<4, true>(h, a, batch, st) : launch_rpl_f64_t<4, false>(h, a, batch, st);
         return a.pcols == 3 ? launch_rpl_f64_t<8, true>(h, a, batch, st) : launch_rpl_f64_t<8, false>(h, a, batch, st);
     }
     if (h->generic) return launch_generic<double, 0>(h, a, batch, stream);
     {   // 32 < N <= 256: clusters of ceil(N / 32) CUs keep S and Pinv in registers ("cluster" = 0: the streaming kernel below)
-        const int rc = try_launch_cluster_f64(h, a, batch, static_cast<hipStream_t>(stream));
+        const int rc = try_launch_cluster_f64(h, a, batch, st);
         if (rc != 1) return rc;
     }
-    // The streaming kernel reads a third less when it may take block (k, right) from block (k+1, left) (mpcg.h, BLOCK SYMMETRY).  Same latch as
-    // the float path; a handle that does not know yet checks THIS call's matrices once, with one blocking 8-byte copy (never during capture:
-    // a capturing call reads all three columns).
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    sym_poll(h, st, true);
-    if (h->sym_state == 0 && !h->sym_pending) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
-            HIP_TRY(h, hipSetDevice(h->device));
-            unsigned long long* flag = fixup_counter(h) + 9;
-            const long items = (long)batch * ((long)h->N - 1);
-            const unsigned blocks = (unsigned)((items + 3) / 4);
-            for (const double* m : {a.S, a.pcols == 3 ? a.Pinv : (const double*)nullptr})
-                if (m) hipLaunchKernelGGL(bd_symmetry_check_kernel<double>, dim3(blocks), dim3(256), 0, st, m, (int)h->N, (int)batch, kSymRelTol, (unsigned long long*)nullptr, flag);
-            HIP_TRY(h, hipGetLastError());
-            unsigned long long v = 0;
-            HIP_TRY(h, hipMemcpyAsync(&v, flag, sizeof v, hipMemcpyDeviceToHost, st));
-            HIP_TRY(h, hipStreamSynchronize(st));
-            h->sym_state = v ? 2 : 1;
-            if (v) h->err = "warning: S / Pinv of a solve on this handle were not block-symmetric (block (k, right) != block (k+1, left)^T): the handle now "
-                            "runs kernels that read all three block columns (include/mpcg.h, BLOCK SYMMETRY)";
-        }
+    // The streaming kernel reads a third less when it may take block (k, right) from block (k+1, left) (mpcg.h, BLOCK SYMMETRY)
+    {
+        const int rc = f64_symmetry_latch(h, a, batch, st);
+        if (rc != MPCG_OK) return rc;
     }
     a.lower = h->sym_state == 1 ? 1 : 0;
     return launch_generic<double, 14>(h, a, batch, stream);

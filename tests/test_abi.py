@@ -55,8 +55,11 @@ def test_version_and_lds_size(hiplib):
     for N in (129, 256, 512):
         assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (7 * 7 * 132 * 2 + 4 + 5 * 64 + 3 * 2 * 8 * 64) == 65328
     assert hiplib.mpcg_pcg_lds_bytes_f64(14, 32) == 8 * (6 * r4((32 + 2) * 14) + 16)          # N <= 32: the row-per-lane kernel in double
-    # 32 < N <= 256 (round 5): a member of the clustered row-per-lane kernel — six vectors of 32 + 2 knots, the cluster's partial, three control words
-    for N in (33, 64, 128, 256):
+    # 32 < N <= 64 (round 5): the lane-quad kernel — seven pair-major vectors of 64 + 2 knot slots, eight wave partials, five parked values per lane
+    for N in (33, 64):
+        assert hiplib.mpcg_pcg_lds_bytes_f64(14, N) == 8 * (7 * 7 * 66 * 2 + 8 + 5 * 512) == 72288
+    # 64 < N <= 256 (round 5): a member of the clustered row-per-lane kernel — six vectors of 32 + 2 knots, the cluster's partial, three control words
+    for N in (65, 128, 256):
         assert hiplib.mpcg_pcg_lds_bytes_f64(14, N) == 8 * (6 * r4((32 + 2) * 14) + 64 + 8)
     assert hiplib.mpcg_pcg_lds_bytes_f64(14, 300) == 8 * ((300 + 2) * 14 * 2 + 300 * 14 * 2 + 16)   # beyond: the generic streaming kernel (vectors + 16 wave partials)
     assert hiplib.mpcg_pcg_lds_bytes(12, 128) == 4 * (2 * 130 * 12 + 2 * 128 * 12 + 16)   # n != 14: the generic kernel's vectors

@@ -235,6 +235,7 @@ def test_f64_clustered_row_per_lane_kernel_vs_oracle(orc, N, precond):
     S, Pinv, g = synth.form_schur(k, precond=precond, dtype=np.float64, poison_unused=True)
     dS, dP, dg = dev(S), dev(Pinv), dev(g)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("pcg_lqk", 0)                         # (N <= 64 would run the lane-quad kernel of one CU, tests/test_gpu_lqk64.py)
     rng = np.random.default_rng(N)
     G = (N + 31) // 32
     for lam0 in (np.zeros((B, n * N)), 0.1 * rng.standard_normal((B, n * N))):
@@ -280,6 +281,7 @@ def test_f64_clustered_kernel_draws_trajectories_from_the_queue(orc, N, B):
     S, Pinv, g = (np.tile(a_, (rep, 1))[:B] for a_ in (S5, P5, g5))
     dS, dP, dg = dev(S), dev(Pinv), dev(g)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("pcg_lqk", 0)
     lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
     it, ex = sol.solve_f64(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
     torch.cuda.synchronize()
@@ -380,7 +382,7 @@ def test_f64_clustered_kernel_in_a_graph_captured_on_a_fresh_handle():
 def test_f64_kkt_to_step_pipeline_vs_dense_kkt_solve(N, rho):
     """The whole linear-system step in double against the DEFINITION — numpy's dense solve of the regularised KKT system
     [G C^T; C 0][dz; lam] = [g; c] (sign conventions of include/common/dz.cuh / linsys_setup.cuh), no restatement of the Schur algebra on the
-    comparison side: KKT blocks -> mpcg_form_schur_f64 (walking kernel) -> mpcg_pcg_solve_f64 (row-per-lane kernel, clustered beyond N = 32) ->
+    comparison side: KKT blocks -> mpcg_form_schur_f64 (walking kernel) -> mpcg_pcg_solve_f64 (row-per-lane kernel, lane-quad kernel to N = 64, clusters beyond) ->
     mpcg_compute_dz_f64, to 1e-7 of the dense solution (cond up to 1e7 at rho = 1e-3) and C dz = c to 1e-9."""
     from mpcgpu_amd import PcgSolver, pcg_config
     m, B = 7, 2
@@ -394,7 +396,7 @@ def test_f64_kkt_to_step_pipeline_vs_dense_kkt_solve(N, rho):
     dz = sol.compute_dz(dG, dC, dg, lam)
     torch.cuda.synchronize()
     assert (ex.cpu().numpy() == 0).all() and sol.get_option("cluster_fixups") == 0
-    assert sol.get_option("last_kernel_family") == (5 if N <= 32 else 8)
+    assert sol.get_option("last_kernel_family") == (5 if N <= 32 else 9 if N <= 64 else 8)
     dz, lam = dz.cpu().numpy(), lam.cpu().numpy()
     nz = (n + m) * N - m
     for b in range(B):
@@ -421,13 +423,13 @@ def test_f64_kkt_to_step_pipeline_vs_dense_kkt_solve(N, rho):
 
 def test_f64_seeded_fuzz_of_the_double_kernels(orc):
     """80 random (N in 2..256, batch, preconditioner, warm start, iteration cap) double solves on the default policy — row-per-lane kernel up to
-    N = 32, its clustered form beyond (ragged member sizes: N = 33 -> 16 + 17 knots, 97 -> 24 + 24 + 24 + 25, ...) — against the oracle's float64
+    N = 32, the lane-quad kernel up to 64, the clustered row-per-lane kernel beyond (ragged member sizes: N = 33 -> 16 + 17 knots, 97 -> 24 + 24 + 24 + 25, ...) — against the oracle's float64
     iterate; nothing left to the fix-up."""
     from mpcgpu_amd import PcgSolver, pcg_config
     rng = np.random.default_rng(20250930)
     fam = {}
     for case in range(80):
-        N = int(rng.choice([rng.integers(2, 33), rng.integers(33, 129), rng.integers(129, 257)], p=[0.2, 0.5, 0.3]))
+        N = int(rng.choice([rng.integers(2, 33), rng.integers(33, 65), rng.integers(65, 129), rng.integers(129, 257)], p=[0.2, 0.25, 0.3, 0.25]))
         B = int(rng.integers(1, 6))
         pc = str(rng.choice(["ss", "jacobi"]))
         K = int(rng.integers(1, min(35, 14 * N)))
@@ -440,7 +442,7 @@ def test_f64_seeded_fuzz_of_the_double_kernels(orc):
         torch.cuda.synchronize()
         f = sol.get_option("last_kernel_family")
         fam[f] = fam.get(f, 0) + 1
-        assert f == (5 if N <= 32 else 8), (N, f)
+        assert f == (5 if N <= 32 else 9 if N <= 64 else 8), (N, f)
         assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all() and sol.get_option("cluster_fixups") == 0
         lamh = lam.cpu().numpy()
         for b in range(B):
@@ -451,4 +453,4 @@ def test_f64_seeded_fuzz_of_the_double_kernels(orc):
                 pert = lambda a_: a_ * (1 + 1.1e-16 * rng.standard_normal(a_.shape))
                 band = max(relinf(orc.pcg(pert(Sz), Pz, pert(g[b]), pert(lam0[b]), N, K, 0.0, pc)["lam"], ref) for _ in range(8))
                 assert e <= 20 * band, (case, N, B, pc, K, b, e, band)
-    assert fam.get(5, 0) >= 8 and fam.get(8, 0) >= 40, fam
+    assert fam.get(5, 0) >= 8 and fam.get(9, 0) >= 10 and fam.get(8, 0) >= 25, fam

@@ -122,10 +122,11 @@ def test_one_step_of_the_recurrences_and_the_cg_invariants(N, family, pc):
             assert q[key] <= lim, (N, pc, K, key, q[key], lim)
 
 
-@pytest.mark.parametrize("N,family", [(32, 5), (64, 8), (128, 8)])
+@pytest.mark.parametrize("N,family", [(32, 5), (64, 9), (64, 8), (128, 8)])
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
 def test_the_same_invariants_in_double(N, family, pc):
-    """linsys_t = double: the row-per-lane kernel (N = 32) and its clustered form across 2 / 4 CUs (N = 64 / 128, round 5) against the same
+    """linsys_t = double: the row-per-lane kernel (N = 32), the lane-quad kernel (N = 64) and the clustered row-per-lane kernel across 2 / 4 CUs
+    (N = 64 / 128) against the same
     recurrences at u = 2^-53, the host side evaluated in the x87 80-bit long double (u = 2^-64; numpy's longdouble on x86-64) so that it is
     again the more precise side; same limits as the float test."""
     from mpcgpu_amd import PcgSolver
@@ -135,6 +136,8 @@ def test_the_same_invariants_in_double(N, family, pc):
     rng = np.random.default_rng(N)
     lam0 = 0.1 * rng.standard_normal(n * N)
     sol = PcgSolver(N, max_batch=1)
+    if family == 8 and N <= 64:
+        sol.set_option("pcg_lqk", 0)                      # (the clustered row-per-lane kernel instead of the lane-quad kernel)
     dS, dP, dg = (torch.from_numpy(a).cuda() for a in (S, P, g))
     U64 = 2.0 ** -53
     if np.finfo(np.longdouble).eps > 2.0 ** -60:

@@ -29,7 +29,7 @@ def scipy_iterates(S, P, g, lam0, N, pc, KM):
     return xs
 
 
-@pytest.mark.parametrize("N,family,cluster", [(32, 5, -1), (64, 8, -1), (128, 8, -1), (64, 3, 0)])
+@pytest.mark.parametrize("N,family,cluster", [(32, 5, -1), (64, 9, -1), (64, 8, 2), (128, 8, -1), (64, 3, 0)])
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
 def test_double_kernels_against_scipy_cg_at_every_iteration(N, family, cluster, pc):
     from mpcgpu_amd import PcgSolver, pcg_config
