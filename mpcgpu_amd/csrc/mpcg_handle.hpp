@@ -30,7 +30,7 @@ struct PcgKnobs {
 };
 
 // What the last solve on this handle actually launched (read-only "last_kernel_*" options; tests assert on it).
-enum { FAM_NONE = -1, FAM_TRAJ = 0, /* 1, 2, 4: kernels retired in round 4 (HISTORY.md) */ FAM_GENERIC = 3, FAM_RPL = 5, FAM_LPK = 6, FAM_LPKC = 7, FAM_RPLC64 = 8, FAM_LQK64 = 9 };
+enum { FAM_NONE = -1, FAM_TRAJ = 0, /* 1, 2, 4: kernels retired in round 4 (HISTORY.md) */ FAM_GENERIC = 3, FAM_RPL = 5, FAM_LPK = 6, FAM_LPKC = 7, FAM_RPLC64 = 8, FAM_LQK64 = 9, FAM_LQKC64 = 10 };
 struct LastKernel { int family = FAM_NONE, waves = 0, reg_rows = 0, lds_rows = 0, stream_bufs = 0, cluster = 0, lds_bytes = 0, lds_extra = 0; };
 
 struct mpcg_handle {

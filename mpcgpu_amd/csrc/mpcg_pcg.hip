@@ -7,6 +7,7 @@
 #include "pcg_rpl.hip.h"
 #include "pcg_rpl_cluster_f64.hip.h"
 #include "pcg_lqk_f64.hip.h"
+#include "pcg_lqk_cluster_f64.hip.h"
 #include "pcg_f64.hip.h"
 
 using namespace mpcg;
@@ -59,6 +60,7 @@ static constexpr uint32_t kLpbMaxN = 128;         // one block per lane: 8 waves
 static int stream_bufs_for(const mpcg_handle* h, const PcgKnobs& k, int nw, int esz);
 static void choose_auto(const mpcg_handle* h, PcgKnobs& k, uint32_t batch, int esz);
 static constexpr uint32_t kLqkMaxN = 64;      // linsys_t = double: knots one CU holds as lane quads (pcg_lqk_f64.hip.h)
+static constexpr uint32_t kCluster64MaxN = 64 * LQKC_MAX_G;      // linsys_t = double: the longest horizon a cluster kernel holds (eight members of 64 knots)
 static size_t default_launch_lds_bytes(uint32_t N, int num_cus);
 
 extern "C" {
@@ -116,7 +118,7 @@ size_t mpcg_pcg_lds_bytes_f64(uint32_t state_size, uint32_t knot_points) {
     if (!shape_supported(state_size, knot_points) && !generic_shape_supported(state_size, knot_points)) return 0;
     if (state_size == NS && knot_points <= 32) return pcg_rpl_lds_floats((int)knot_points, knot_points <= 16 ? 4 : 8) * sizeof(double);   // row-per-lane kernel
     if (state_size == NS && knot_points <= kLqkMaxN) return pcg_lqk_lds_doubles(8) * sizeof(double);                                   // lane-quad kernel (block-symmetric matrices: the reference's)
-    if (state_size == NS && knot_points <= (uint32_t)(RPLC_KMAX * RPLC_MAX_G)) return pcg_rplc_lds_doubles() * sizeof(double);         // a member of the clustered row-per-lane kernel
+    if (state_size == NS && knot_points <= kCluster64MaxN) return pcg_lqkc_lds_doubles() * sizeof(double);                             // a member of the clustered lane-quad kernel
     const size_t b = pcg_generic_lds_elems((int)knot_points, (int)state_size) * sizeof(double);
     return b <= kLdsMax ? b : 0;
 }
@@ -163,7 +165,7 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     }
     // the clustered double kernel's queue + flags + cells (0.5 MB at max_batch 4096), here for the same reason: a fresh handle's first
     // mpcg_pcg_solve_f64 may be a captured one
-    if (!generic && knot_points > 32 && knot_points <= (uint32_t)(RPLC_KMAX * RPLC_MAX_G)) {
+    if (!generic && knot_points > 32 && knot_points <= kCluster64MaxN) {
         if (hipMalloc(reinterpret_cast<void**>(&h->cluster64_scratch), cluster64_alloc_words(h) * sizeof(unsigned long long)) != hipSuccess) {
             (void)hipFree(h->cluster_scratch); (void)hipFree(h->sched_order);
             delete h;
@@ -173,7 +175,7 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
     }
     // the copy of lambda0 that cluster fix-up launches start from: float clusters beyond one CU's horizon, double clusters beyond N = 32
     if (!generic && knot_points > 32) {
-        const size_t esz = knot_points <= (uint32_t)(RPLC_KMAX * RPLC_MAX_G) ? sizeof(double) : sizeof(float);
+        const size_t esz = knot_points <= kCluster64MaxN ? sizeof(double) : sizeof(float);
         if (knot_points > kLpbMaxN || esz == sizeof(double)) {
             const size_t bytes = (size_t)max_batch * knot_points * state_size * esz;
             if (hipMalloc(&h->lam_backup, bytes) != hipSuccess) {
@@ -882,6 +884,64 @@ static int try_launch_cluster_f64(mpcg_handle* h, const PcgArgs64& a, uint32_t b
     return MPCG_OK;
 }
 
+// ---- linsys_t = double, 64 < N <= 512, block-symmetric matrices: the lane-quad kernel across G = ceil(N / 64) CUs of one XCD (pcg_lqk_cluster_f64.hip.h).
+// Launch shape, scratch and fix-up of try_launch_cluster_f64.  Returns 1 when it does not apply.
+static int lqkc_members(const mpcg_handle* h) {
+    const int nmax = 64;
+    const int G = h->cluster > 0 ? h->cluster : ((int)h->N + nmax - 1) / nmax;
+    if (G < 2 || G > LQKC_MAX_G || G > h->num_cus || G > (int)h->N) return 0;
+    if (((int)h->N + G - 1) / G > nmax) return 0;
+    return G;
+}
+static int try_launch_cluster_lqk_f64(mpcg_handle* h, const PcgArgs64& a, uint32_t batch, hipStream_t st) {
+    if (h->cluster == 0 || h->generic || h->lqk == 0) return 1;
+    const int G = lqkc_members(h);
+    if (G == 0) return 1;
+    if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "batch exceeds max_batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->cluster64_scratch) {                       // (mpcg_create made it for every horizon this kernel serves by default)
+        { const int rc = alloc_allowed(h, st, "mpcg_pcg_solve_f64"); if (rc != MPCG_OK) return rc; }
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->cluster64_scratch), cluster64_alloc_words(h) * sizeof(unsigned long long)));
+        HIP_TRY(h, hipMemset(h->cluster64_scratch, 0, cluster64_alloc_words(h) * sizeof(unsigned long long)));
+    }
+    const uint32_t resident = lpkc_resident_clusters(h, G);
+    const uint32_t clusters = batch < resident ? batch : resident;
+    const size_t lds = pcg_lqkc_lds_doubles() * sizeof(double);
+    void (*kern)(ClusterArgs64) = pcg_lqkc_f64_kernel<2>;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ClusterArgs64 ca;
+    ca.p = a;
+    ca.queue = h->cluster64_scratch;
+    ca.fail_flags = ca.queue + CL_FLAG_STRIDE;
+    ca.scratch = ca.fail_flags + (size_t)batch * CL_FLAG_STRIDE;
+    ca.G = G; ca.batch = (int)batch; ca.clusters = (int)clusters; ca.l2_handoff = h->cluster_l2;
+    ca.test_fail = h->cluster_test_fail;
+    const size_t zw = CL_FLAG_STRIDE + (size_t)batch * CL_FLAG_STRIDE + (size_t)clusters * G * LQKC_WG_WORDS;
+    // (the fix-up is the streaming kernel: beyond the horizon whose iterate vectors fit its LDS — N = 350 in double — an abandoned trajectory is
+    //  reported, d_iters = 0xFFFFFFFF / d_max_iter_exit = 2, as with "cluster_fixup" = 0)
+    const bool fixup = h->cluster_fixup && pcg_generic_lds_elems((int)h->N, (int)h->n) * sizeof(double) <= kLdsMax;
+    if (fixup) {
+        const int rc = launch_cluster_prologue(h, h->cluster64_scratch, zw, a.lambda, (size_t)batch * h->N * NS * sizeof(double), st);
+        if (rc != MPCG_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((zw + 255) / 256)), dim3(256), 0, st, h->cluster64_scratch, zw);
+        HIP_TRY(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(kern, dim3(((clusters + 7) / 8) * 8 * (unsigned)G), dim3(512), lds, st, ca);
+    HIP_TRY(h, hipGetLastError());
+    if (fixup) {                                        // trajectories whose cluster gave up: the streaming kernel (two block columns: the latch says symmetric)
+        PcgArgs64 c = a;
+        c.lower = 1;
+        c.redo_flags = ca.fail_flags; c.redo_stride = CL_FLAG_STRIDE; c.redo_skip = (unsigned long long)G;
+        c.redo_count = fixup_counter(h);
+        c.lam0 = static_cast<const double*>(h->lam_backup);
+        const int rc = launch_generic<double, 14>(h, c, batch, st);
+        if (rc != MPCG_OK) return rc;
+    }
+    h->last = LastKernel{FAM_LQKC64, 8, 0, 0, 0, G, (int)lds, 0};
+    return MPCG_OK;
+}
+
 // The double kernels that read only the left + diagonal block columns use the float path's latch (mpcg.h, BLOCK SYMMETRY): a handle that does not
 // know yet checks THIS call's matrices once, with one blocking 8-byte copy (never during capture: a capturing call on such a handle runs a
 // kernel that reads all three columns).
@@ -935,7 +995,16 @@ static int launch_f64(mpcg_handle* h, PcgArgs64 a, uint32_t batch, void* stream)
         return a.pcols == 3 ? launch_rpl_f64_t<8, true>(h, a, batch, st) : launch_rpl_f64_t<8, false>(h, a, batch, st);
     }
     if (h->generic) return launch_generic<double, 0>(h, a, batch, stream);
-    {   // 32 < N <= 256: clusters of ceil(N / 32) CUs keep S and Pinv in registers ("cluster" = 0: the streaming kernel below)
+    // 64 < N <= 512, block-symmetric matrices: lane-quad clusters of ceil(N / 64) CUs
+    if (h->N > kRplMaxN64 && h->cluster != 0 && h->lqk != 0 && lqkc_members(h) > 0) {
+        const int rcl = f64_symmetry_latch(h, a, batch, st);
+        if (rcl != MPCG_OK) return rcl;
+        if (h->sym_state == 1) {
+            const int rc = try_launch_cluster_lqk_f64(h, a, batch, st);
+            if (rc != 1) return rc;
+        }
+    }
+    {   // 32 < N <= 256: clusters of ceil(N / 32) CUs keep full block rows of S and Pinv in registers ("cluster" = 0: the streaming kernel below)
         const int rc = try_launch_cluster_f64(h, a, batch, st);
         if (rc != 1) return rc;
     }

@@ -58,10 +58,10 @@ def test_version_and_lds_size(hiplib):
     # 32 < N <= 64 (round 5): the lane-quad kernel — seven pair-major vectors of 64 + 2 knot slots, eight wave partials, five parked values per lane
     for N in (33, 64):
         assert hiplib.mpcg_pcg_lds_bytes_f64(14, N) == 8 * (7 * 7 * 66 * 2 + 8 + 5 * 512) == 72288
-    # 64 < N <= 256 (round 5): a member of the clustered row-per-lane kernel — six vectors of 32 + 2 knots, the cluster's partial, three control words
-    for N in (65, 128, 256):
-        assert hiplib.mpcg_pcg_lds_bytes_f64(14, N) == 8 * (6 * r4((32 + 2) * 14) + 64 + 8)
-    assert hiplib.mpcg_pcg_lds_bytes_f64(14, 300) == 8 * ((300 + 2) * 14 * 2 + 300 * 14 * 2 + 16)   # beyond: the generic streaming kernel (vectors + 16 wave partials)
+    # 64 < N <= 512 (round 5): a member of the clustered lane-quad kernel — the same seven vectors, broadcast cell, three hand-off tables of 64 ints, ten parked values per lane
+    for N in (65, 128, 256, 300, 512):
+        assert hiplib.mpcg_pcg_lds_bytes_f64(14, N) == 8 * (7 * 7 * 66 * 2 + 4 + 3 * 32 + 10 * 512) == 93504
+    assert hiplib.mpcg_pcg_lds_bytes_f64(14, 513) == 0          # beyond: the streaming kernel's vectors would not fit 160 KiB of LDS in double
     assert hiplib.mpcg_pcg_lds_bytes(12, 128) == 4 * (2 * 130 * 12 + 2 * 128 * 12 + 16)   # n != 14: the generic kernel's vectors
     assert hiplib.mpcg_pcg_lds_bytes(65, 8) == 0            # state sizes beyond 64 are not served
     assert hiplib.mpcg_pcg_lds_bytes(14, 1024) == 0         # vectors would not fit 160 KiB LDS

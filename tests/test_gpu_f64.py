@@ -297,8 +297,10 @@ def test_f64_clustered_kernel_draws_trajectories_from_the_queue(orc, N, B):
     assert relinf(lamh[:5], lam_s.cpu().numpy()[:5]) < 1e-9
 
 
-def test_f64_clustered_kernel_without_fixup_reports_abandoned_trajectories_only_when_there_are_any():
-    """ "cluster_fixup" = 0: no streaming launch behind the clusters — an undisturbed call still solves everything itself (iteration counts,
+@pytest.mark.parametrize("family", [10, 8])
+def test_f64_clustered_kernel_without_fixup_reports_abandoned_trajectories_only_when_there_are_any(family):
+    """(family 10: the lane-quad clusters of two CUs, the default at N = 128; 8: the row-per-lane clusters of four, "pcg_lqk" = 0.)
+    "cluster_fixup" = 0: no streaming launch behind the clusters — an undisturbed call still solves everything itself (iteration counts,
     not the 0xFFFFFFFF / flag 2 of an abandoned trajectory), which is what says the clusters did the work."""
     from mpcgpu_amd import PcgSolver, pcg_config
     N, B, K = 128, 70, 12
@@ -306,14 +308,16 @@ def test_f64_clustered_kernel_without_fixup_reports_abandoned_trajectories_only_
     S, Pinv, g = synth.form_schur(k, dtype=np.float64)
     sol = PcgSolver(N, max_batch=B)
     sol.set_option("cluster_fixup", 0)
+    sol.set_option("pcg_lqk", -1 if family == 10 else 0)
     lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
     it, ex = sol.solve_f64(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
     torch.cuda.synchronize()
-    assert sol.get_option("last_kernel_family") == 8
+    assert sol.get_option("last_kernel_family") == family
     assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all() and torch.isfinite(lam).all()
 
 
-def test_f64_clusters_that_cannot_get_their_cus_fall_to_the_streaming_fixup(orc):
+@pytest.mark.parametrize("family", [10, 8])
+def test_f64_clusters_that_cannot_get_their_cus_fall_to_the_streaming_fixup(orc, family):
     """Members of a cluster must be co-resident.  With another stream holding the chip (4,000-iteration float solves on every CU) a 4-member double
     cluster may not find its CUs: its members give up after the bounded spin, leave lambda alone, and the streaming kernel behind the launch solves
     exactly the trajectories whose completion count is short ("cluster_fixups" counts them).  Either way the caller gets the oracle's answer."""
@@ -322,7 +326,10 @@ def test_f64_clusters_that_cannot_get_their_cus_fall_to_the_streaming_fixup(orc)
     k = synth.make_kkt(N, B, 6400)
     S, Pinv, g = synth.form_schur(k, dtype=np.float64)
     sol = PcgSolver(N, max_batch=B)
+    sol.set_option("pcg_lqk", -1 if family == 10 else 0)
     dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    if family == 10:                                     # (the latch's one blocking check happens on an undisturbed first call)
+        sol.solve_f64(dS, dP, dg, torch.zeros(B, n * N, dtype=torch.float64, device="cuda"), pcg_config(pcg_exit_tol=0.0, pcg_max_iter=1))
     blocker = torch.cuda.Stream()
     ncu = sol.get_option("num_cus")
     big = PcgSolver(128, max_batch=4 * ncu)
@@ -338,7 +345,7 @@ def test_f64_clusters_that_cannot_get_their_cus_fall_to_the_streaming_fixup(orc)
     it, ex = sol.solve_f64(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
     torch.cuda.synchronize()
     fixed = sol.get_option("cluster_fixups")
-    assert sol.get_option("last_kernel_family") == 8 and 0 <= fixed <= B
+    assert sol.get_option("last_kernel_family") == family and 0 <= fixed <= B
     assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all()
     lamh = lam.cpu().numpy()
     for b in range(B):
@@ -371,6 +378,7 @@ def test_f64_clustered_kernel_in_a_graph_captured_on_a_fresh_handle():
         outs.append(lam.clone())
     assert sol.get_option("last_kernel_family") == 8 and sol.get_option("cluster_fixups") == 0 and (it.cpu().numpy() == K).all()
     eager = PcgSolver(N, max_batch=B)
+    eager.set_option("pcg_lqk", 0)                          # (the captured call could not run the latch's check: the kernel that reads all three columns)
     lam_e = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
     eager.solve_f64(dS, dP, dg, lam_e, cfg)
     torch.cuda.synchronize()
@@ -396,7 +404,7 @@ def test_f64_kkt_to_step_pipeline_vs_dense_kkt_solve(N, rho):
     dz = sol.compute_dz(dG, dC, dg, lam)
     torch.cuda.synchronize()
     assert (ex.cpu().numpy() == 0).all() and sol.get_option("cluster_fixups") == 0
-    assert sol.get_option("last_kernel_family") == (5 if N <= 32 else 9 if N <= 64 else 8)
+    assert sol.get_option("last_kernel_family") == (5 if N <= 32 else 9 if N <= 64 else 10)
     dz, lam = dz.cpu().numpy(), lam.cpu().numpy()
     nz = (n + m) * N - m
     for b in range(B):
@@ -423,7 +431,7 @@ def test_f64_kkt_to_step_pipeline_vs_dense_kkt_solve(N, rho):
 
 def test_f64_seeded_fuzz_of_the_double_kernels(orc):
     """80 random (N in 2..256, batch, preconditioner, warm start, iteration cap) double solves on the default policy — row-per-lane kernel up to
-    N = 32, the lane-quad kernel up to 64, the clustered row-per-lane kernel beyond (ragged member sizes: N = 33 -> 16 + 17 knots, 97 -> 24 + 24 + 24 + 25, ...) — against the oracle's float64
+    N = 32, the lane-quad kernel up to 64, its clustered form beyond (ragged member sizes: N = 33 -> 16 + 17 knots, 97 -> 24 + 24 + 24 + 25, ...) — against the oracle's float64
     iterate; nothing left to the fix-up."""
     from mpcgpu_amd import PcgSolver, pcg_config
     rng = np.random.default_rng(20250930)
@@ -442,7 +450,7 @@ def test_f64_seeded_fuzz_of_the_double_kernels(orc):
         torch.cuda.synchronize()
         f = sol.get_option("last_kernel_family")
         fam[f] = fam.get(f, 0) + 1
-        assert f == (5 if N <= 32 else 9 if N <= 64 else 8), (N, f)
+        assert f == (5 if N <= 32 else 9 if N <= 64 else 10), (N, f)
         assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all() and sol.get_option("cluster_fixups") == 0
         lamh = lam.cpu().numpy()
         for b in range(B):
@@ -453,4 +461,4 @@ def test_f64_seeded_fuzz_of_the_double_kernels(orc):
                 pert = lambda a_: a_ * (1 + 1.1e-16 * rng.standard_normal(a_.shape))
                 band = max(relinf(orc.pcg(pert(Sz), Pz, pert(g[b]), pert(lam0[b]), N, K, 0.0, pc)["lam"], ref) for _ in range(8))
                 assert e <= 20 * band, (case, N, B, pc, K, b, e, band)
-    assert fam.get(5, 0) >= 8 and fam.get(9, 0) >= 10 and fam.get(8, 0) >= 25, fam
+    assert fam.get(5, 0) >= 8 and fam.get(9, 0) >= 10 and fam.get(10, 0) >= 25, fam

@@ -122,7 +122,7 @@ def test_one_step_of_the_recurrences_and_the_cg_invariants(N, family, pc):
             assert q[key] <= lim, (N, pc, K, key, q[key], lim)
 
 
-@pytest.mark.parametrize("N,family", [(32, 5), (64, 9), (64, 8), (128, 8)])
+@pytest.mark.parametrize("N,family", [(32, 5), (64, 9), (64, 8), (128, 10), (128, 8)])
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
 def test_the_same_invariants_in_double(N, family, pc):
     """linsys_t = double: the row-per-lane kernel (N = 32), the lane-quad kernel (N = 64) and the clustered row-per-lane kernel across 2 / 4 CUs
@@ -136,7 +136,7 @@ def test_the_same_invariants_in_double(N, family, pc):
     rng = np.random.default_rng(N)
     lam0 = 0.1 * rng.standard_normal(n * N)
     sol = PcgSolver(N, max_batch=1)
-    if family == 8 and N <= 64:
+    if family == 8:
         sol.set_option("pcg_lqk", 0)                      # (the clustered row-per-lane kernel instead of the lane-quad kernel)
     dS, dP, dg = (torch.from_numpy(a).cuda() for a in (S, P, g))
     U64 = 2.0 ** -53

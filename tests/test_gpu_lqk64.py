@@ -199,3 +199,90 @@ def test_graph_capture_before_and_after_the_latch_knows():
         g2.replay(); torch.cuda.synchronize()
         assert torch.equal(lam, lam_e) and (it.cpu().numpy() == K).all()
     assert relinf(first.cpu().numpy(), lam_e.cpu().numpy()) < 1e-9
+
+
+# ---- the same kernel across G = ceil(N / 64) CUs of one XCD (pcg_lqk_cluster_f64.hip.h, family 10) ----
+
+@pytest.mark.parametrize("N", [65, 100, 128, 200, 256, 300, 512])
+@pytest.mark.parametrize("precond", ["ss", "jacobi"])
+@pytest.mark.parametrize("l2", [1, 0])
+def test_clustered_lane_quad_kernel_vs_oracle(orc, N, precond, l2):
+    """64 < N <= 512, ragged member sizes (65 -> 32 + 33 knots, 300 -> five members of 60), L2-resident and write-through hand-offs: fixed
+    iteration counts against the oracle's float64 iterate (cold and warm start), nothing left to the fix-up, the tolerance exit, determinism."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    if l2 == 0 and N not in (100, 256):
+        pytest.skip("write-through hand-offs: two horizons")
+    B, K = 3, 25
+    k = synth.make_kkt(N, B, 7700 + N)
+    S, Pinv, g = synth.form_schur(k, precond=precond, dtype=np.float64, poison_unused=True)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    sol = PcgSolver(N, max_batch=B)
+    sol.set_option("cluster_l2", l2)
+    rng = np.random.default_rng(N)
+    G = (N + 63) // 64
+    for lam0 in (np.zeros((B, n * N)), 0.1 * rng.standard_normal((B, n * N))):
+        lam = dev(lam0.copy())
+        it, ex = sol.solve_f64(dS, dP, dg, lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), precond)
+        torch.cuda.synchronize()
+        assert sol.get_option("last_kernel_family") == 10 and sol.get_option("last_kernel_cluster") == G and sol.get_option("cluster_fixups") == 0
+        assert sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes_f64(14, N)
+        assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all()
+        for b in range(B):
+            ref = orc.pcg(np.nan_to_num(S[b]), np.nan_to_num(Pinv[b]), g[b], lam0[b], N, K, 0.0, precond)["lam"]
+            assert relinf(lam.cpu().numpy()[b], ref) < 1e-9, (b, relinf(lam.cpu().numpy()[b], ref))
+        lam2 = dev(lam0.copy())
+        sol.solve_f64(dS, dP, dg, lam2, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), precond)
+        torch.cuda.synchronize()
+        assert torch.equal(lam, lam2)
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    it, ex = sol.solve_f64(dS, dP, dg, lam, pcg_config(pcg_exit_tol=1e-10, pcg_max_iter=5000), precond)
+    torch.cuda.synchronize()
+    assert (ex.cpu().numpy() == 0).all()
+    ref = orc.pcg(np.nan_to_num(S[0]), np.nan_to_num(Pinv[0]), g[0], np.zeros(n * N), N, 5000, 1e-10, precond)
+    assert abs(int(it.cpu().numpy()[0]) - ref["iters"]) <= max(2, ref["iters"] // 8)
+    lamh = lam.cpu().numpy().copy()
+    it2, ex2 = sol.solve_f64(dS, dP, dg, lam, pcg_config(pcg_exit_tol=1e-8, pcg_max_iter=5000), precond)
+    torch.cuda.synchronize()
+    assert (it2.cpu().numpy() == 0).all() and (ex2.cpu().numpy() == 0).all()
+    np.testing.assert_array_equal(lam.cpu().numpy(), lamh)
+
+
+def test_clustered_lane_quad_kernel_queue_outputs_and_cross_checks(orc):
+    """N = 128, 300 trajectories (128 clusters of two CUs fit the chip: the queue is in use): copies of five systems solve to the same bits wherever
+    they land; the reference kernel's argument list gives d_r / d_p; the clustered row-per-lane kernel ("pcg_lqk" = 0) and the streaming kernel
+    ("cluster" = 0) agree to round-off."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, B, K = 128, 300, 20
+    k = synth.make_kkt(N, 5, 7800)
+    S5, P5, g5 = synth.form_schur(k, dtype=np.float64)
+    rep = (B + 4) // 5
+    S, Pinv, g = (np.tile(a_, (rep, 1))[:B] for a_ in (S5, P5, g5))
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    sol = PcgSolver(N, max_batch=B)
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    it, ex = sol.solve_f64(dS, dP, dg, lam, cfg)
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 10 and (it.cpu().numpy() == K).all() and sol.get_option("cluster_fixups") == 0
+    lamh = lam.cpu().numpy()
+    for b in range(5, B):
+        np.testing.assert_array_equal(lamh[b], lamh[b % 5])
+    lam0 = 0.1 * np.random.default_rng(1).standard_normal(n * N)
+    d_lam = dev(lam0.copy())
+    d_r, d_p, scr = (torch.zeros(n * N, dtype=torch.float64, device="cuda") for _ in range(3))
+    d_it = torch.zeros(1, dtype=torch.int32, device="cuda"); d_ex = torch.zeros(1, dtype=torch.uint8, device="cuda")
+    sol.solve_ref_f64(dS[:1], dP[:1], dg[:1], d_lam, d_r, d_p, scr, scr, d_it, d_ex, K, 0.0)
+    torch.cuda.synchronize()
+    ref = orc.pcg(S[0], Pinv[0], g[0], lam0, N, K, 0.0, "ss")
+    scale = np.abs(g[0] - synth.bd_to_dense(S[0], N) @ lam0).max()
+    assert sol.get_option("last_kernel_family") == 10 and int(d_it.item()) == K
+    assert relinf(d_lam.cpu().numpy(), ref["lam"]) < 1e-9
+    assert np.abs(d_r.cpu().numpy() - ref["r"]).max() < 1e-9 * scale
+    assert np.abs(d_p.cpu().numpy() - ref["p"]).max() < 1e-9 * max(scale, np.abs(ref["p"]).max())
+    for opt, fam in (("pcg_lqk", 8), ("cluster", 3)):
+        sol.set_option(opt, 0)
+        lam_o = torch.zeros(5, n * N, dtype=torch.float64, device="cuda")
+        sol.solve_f64(dS[:5], dP[:5], dg[:5], lam_o, cfg)
+        torch.cuda.synchronize()
+        assert sol.get_option("last_kernel_family") == fam
+        assert relinf(lam_o.cpu().numpy(), lamh[:5]) < 1e-9

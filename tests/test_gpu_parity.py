@@ -369,13 +369,13 @@ def test_cpp_callsite_over_shim_headers():
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["pcg_exit"] == 0 and 0 < out["pcg_iters"] < 200 and out["rel_residual"] < 1e-4 and out["smem"] > 0
-    # ... and at the BASELINE horizon: pcg<double, 14, 128> = the row-per-lane kernel across four CUs behind the same call site (round 5)
+    # ... and at the BASELINE horizon: pcg<double, 14, 128> = the lane-quad kernel across two CUs behind the same call site (round 5)
     exe128 = build.EXAMPLE_BIN64_N128 if os.path.exists(build.EXAMPLE_BIN64_N128) else build.build_example_f64_n128()
     r = subprocess.run([exe128], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["pcg_exit"] == 0 and out["pcg_iters"] > 0 and out["rel_residual"] < 1e-4 and out["two_threads_two_streams_same_bits"] == 1
-    assert out["smem"] == 8 * (6 * ((32 + 2) * 14) + 64 + 8)      # a member of the clustered kernel (mpcg_pcg_lds_bytes_f64)
+    assert out["smem"] == 93504                                   # a member of the clustered lane-quad kernel (mpcg_pcg_lds_bytes_f64)
 
 
 @pytest.mark.parametrize("waves,reg_rows,lds_rows", [(16, 1, -1), (16, 1, 0), (16, 2, -1), (8, 2, 0), (8, 2, 1), (8, 3, -1), (4, 4, -1), (4, 6, 2), (4, 7, -1)])

@@ -9,7 +9,8 @@ n = 14
 def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 def relinf(a, b): return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 worst = 0.0
-for N in (64, 33, 40, 57, 32, 16, 5):
+NS_ = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [64, 33, 40, 57, 32, 16, 5]
+for N in NS_:
     for pc in ("ss", "jacobi"):
         B, K = 3, 30
         k = synth.make_kkt(N, B, 6100 + N)
@@ -29,5 +30,5 @@ for N in (64, 33, 40, 57, 32, 16, 5):
                 ref = orc.pcg(S[b], Pinv[b], g[b], lam0[b], N, K, 0.0, pc)
                 e = max(e, relinf(lam.cpu().numpy()[b], ref["lam"]))
             worst = max(worst, e)
-            print(f"N={N} {pc} fam={fam} iters={it.cpu().numpy()} exits={ex.cpu().numpy()} relinf={e:.2e}", flush=True)
+            print(f"N={N} {pc} fam={fam} G={sol.get_option('last_kernel_cluster')} fixups={sol.get_option('cluster_fixups')} iters={it.cpu().numpy()} exits={ex.cpu().numpy()} relinf={e:.2e}", flush=True)
 print("worst", worst)
