@@ -391,7 +391,11 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lqkc_f64_kernel(ClusterArgs6
         const real* lam_in = kp->p.lambda + (size_t)b * vstride;
         {
             const rsrc_t M = make_rsrc(static_cast<const char*>(static_cast<const void*>(isP ? kp->p.Pinv : kp->p.S)) + (size_t)b * mstride * 8, (uint32_t)(mstride * 8));
-            lqk_load_blocks(M, k0 + i, h, g, valid, valid && k0 + i > 0 && hasL, Md, Ml);
+            // (lane constants made opaque per trajectory: hoisted out of the trajectory loop, the load addresses are 40 registers this kernel
+            //  does not have — spilled once, reloaded between the loads of every trajectory, each reload waiting for all loads in flight)
+            int i_st = i, h_st = h, g_st = g;
+            asm volatile("" : "+v"(i_st), "+v"(h_st), "+v"(g_st));
+            lqk_load_blocks(M, k0 + i_st, h_st, g_st, valid, valid && k0 + i_st > 0 && hasL, Md, Ml);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
 #pragma unroll

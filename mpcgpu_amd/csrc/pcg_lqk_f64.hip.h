@@ -76,6 +76,9 @@ __device__ __forceinline__ void lqk_load_blocks(rsrc_t M, int k, int h, int g, b
         bD6[s] = okD ? bs + CB * (uint32_t)(6 + h) + BLKB : OOB_OFF;
     }
     auto ld = [&](uint32_t off) -> double {
+#ifdef LQK_ABLATE_LOAD                                    // (timing experiment only: no matrix traffic, wrong results)
+        return (double)off * 1e-30;
+#endif
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
         const u2 v = __builtin_amdgcn_raw_buffer_load_b64(M, (int)off, 0, 0);
         return __builtin_bit_cast(double, v);

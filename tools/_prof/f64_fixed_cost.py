@@ -5,7 +5,9 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench
-from mpcgpu_amd import PcgSolver, pcg_config
+from mpcgpu_amd import PcgSolver, pcg_config, _lib as _L
+if os.environ.get("AB_LIB"):
+    _L.LIB_PATH = os.environ["AB_LIB"]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 BATCHES = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1024, 1]
 opts = [a.split("=") for a in sys.argv[3:]]
