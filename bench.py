@@ -116,6 +116,9 @@ def compact_line(full: dict) -> dict:
         "N256_single_reduction_ceiling_it_per_sec": (_get(full, "roofline_long_horizon", "single_reduction_ceiling", "N256_batch1024_M_it_per_s", "emulated") or 0) * 1e6 or None,
         "f64_N128_pcg_iterations_per_sec": _get(full, "double_precision", "pcg_iterations_per_sec"),
         "f64_N128_frac_of_fp64_valu_peak": _get(full, "double_precision", "frac_of_fp64_valu_peak"),
+        "f64_N128_it_per_sec_at_167_iterations": _get(full, "double_precision", "at_iteration_cap", "pcg_iterations_per_sec"),
+        "f64_N128_row_per_lane_clusters_it_per_sec": _get(full, "double_precision", "row_per_lane_clusters", "pcg_iterations_per_sec"),
+        "f64_N64_pcg_iterations_per_sec": _get(full, "double_precision", "N64", "pcg_iterations_per_sec"),
         "f64_N128_streaming_it_per_sec": _get(full, "double_precision", "streaming_kernel", "pcg_iterations_per_sec"),
         "f64_N128_streaming_frac_of_hbm": _get(full, "double_precision", "streaming_kernel", "frac"),
         "f64_form_schur_ms": _get(full, "roofline_producers_f64", "form_schur_f64", "kernel_ms"),

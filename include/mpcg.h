@@ -30,10 +30,11 @@
  *     matrices later must use a fresh handle — or "check_symmetry" = 1 (debug), which verifies every solve with a blocking 8-byte copy
  *     and reports the number of offending block pairs as "last_symmetry_violations".  A caller that fills ONLY the left and diagonal block
  *     columns (the right one unwritten) says so with "assume_symmetric" = 1 before its first solve: no check, lower-triangle kernels at
- *     once.  Families 0 and 5 read all three columns anyway; so does family 3 for floats.  DOUBLE PRECISION beyond 32 knots (family 3,
- *     a streaming kernel) uses the same latch to skip the right block column — a third of its HBM bytes: a handle that does not know yet
- *     checks the matrices of its first mpcg_pcg_solve_f64 call with ONE blocking 8-byte copy (never during graph capture: a captured call
- *     on such a handle reads all three columns).
+ *     once.  Families 0 and 5 read all three columns anyway; so does family 3 for floats.  DOUBLE PRECISION beyond 32 knots uses the same
+ *     latch: the lane-quad kernels (families 9, 10: the lower block triangle in registers) and the streaming kernel (family 3: skips the right
+ *     block column, a third of its HBM bytes) run once it says symmetric.  A handle that does not know yet checks the matrices of its first
+ *     mpcg_pcg_solve_f64 call with ONE blocking 8-byte copy (never during graph capture: a captured call on such a handle runs a kernel that
+ *     reads all three columns — family 8 up to 256 knots, family 3 beyond).
  *   - gamma, lambda: [N][n] floats per trajectory; lambda is in/out (warm start,
  *     include/mpcsim.cuh:186,267,337).
  *   - every pointer named d_* is a DEVICE pointer on the handle's device; `stream` is a hipStream_t
@@ -316,9 +317,13 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  *       trajectory ("cluster_fixup" = 0: no follow-up launch, d_iters = 0xFFFFFFFF and d_max_iter_exit = 2 for such a trajectory).  The
  *       follow-up launch warm-starts from the handle's own copy of d_lambda, made in front of the cluster launch: members that did finish such a
  *       trajectory have written their knots by then.  ("cluster_test_fail" = 1, tests only: one member gives up at its first write-back.)
- *       linsys_t = double (mpcg_pcg_solve_f64 / _ref_f64): the same option governs the clustered row-per-lane kernel, automatic for 32 < knot_points
- *       <= 256 with G = ceil(N / 32) members (full block rows of S and Pinv in the registers of G CUs; all three block columns are read, no symmetry
- *       contract); "cluster" = 0 selects the streaming kernel, which is also its fix-up;
+ *       linsys_t = double (mpcg_pcg_solve_f64 / _ref_f64): knot_points <= 32 the row-per-lane kernel in double; beyond, with block-symmetric
+ *       matrices (the latch), "pcg_lqk" (-1 auto / 0 / 1): the lane-quad-per-knot kernel — the lower block triangle of 64 knots in the registers of
+ *       one CU (32 < knot_points <= 64; = 1 forces it below) — and for 64 < knot_points <= 512 its clustered form, G = ceil(N / 64) CUs per
+ *       trajectory under the same "cluster" option and hand-off machinery; "pcg_lqk" = 0, a latch that says not symmetric or a capturing first
+ *       call: the clustered row-per-lane kernel (32 < knot_points <= 256, G = ceil(N / 32) members, full block rows, all three block columns);
+ *       "cluster" = 0 selects the streaming kernel, which is also the clusters' fix-up (up to 350 knots: beyond, its iterate vectors do not fit
+ *       LDS and an abandoned trajectory is reported as with "cluster_fixup" = 0);
  *   otherwise (explicit pcg_* knobs, the fix-up launches, fp16 storage at N <= 36) the single-workgroup row-pair kernel: "pcg_waves" (4, 8 or 16
  *       wavefronts per trajectory workgroup), "pcg_reg_rows" (TRIPLES of block rows per matrix and wave kept in registers for the whole
  *       solve; only compiled (waves, rows) pairs are accepted at launch), "pcg_lds_rows" (triples per matrix and wave cached in LDS, -1 =
@@ -340,7 +345,7 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  *       D2H read), "last_symmetry_violations", "num_cus", "pcg_resident" (1 if the single-workgroup configuration streams nothing inside the PCG
  *       loop), "last_schur_chunk" (block rows per chunk of the last mpcg_form_schur, 0 = the LDS kernels), "last_kernel_family" (kernel of the
  *       last solve: 0 single-workgroup row-pair, 3 generic, 5 row-per-lane, 6 lane-pair-per-knot, 7 clustered lane-pair, 8 clustered row-per-lane
- *       (double); 1, 2, 4 were kernels retired in round 4), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
+ *       (double), 9 lane-quad-per-knot (double), 10 clustered lane-quad (double); 1, 2, 4 were kernels retired in round 4), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
  * WHICH kernel family serves a call depends on knot_points AND on the call's batch (e.g. 32 < N <= 64: row-per-lane kernel up to one
  * trajectory per CU, lane-pair kernel beyond; N <= 32: 8 waves x 1 slot or 4 x 2 by batch).  Families sum the inner products in different
  * orders, so the SAME trajectory solved alone and inside a large batch may differ in the last fp32 bits (and, near the tolerance, by an

@@ -763,41 +763,65 @@ def long_horizon_floor(cx, lh):
 
 
 def double_precision(cx):
-    """linsys_t = double (USE_DOUBLES of the reference): the bench workload's own systems in double, fixed 40 iterations.  Default policy beyond
-    N = 32: the row-per-lane kernel across ceil(N / 32) CUs per trajectory (family 8, matrices resident in registers); "cluster" = 0: the streaming
-    kernel (family 3; two block columns once the symmetry latch allows), whose HBM roofline is reported next to it."""
+    """linsys_t = double (USE_DOUBLES of the reference): the bench workload's own systems in double.  Default policy beyond N = 32 with block-symmetric
+    matrices: the lane-quad kernel (family 9: one CU to N = 64; family 10: ceil(N / 64) CUs of one XCD beyond) — the lower block triangle resident in
+    registers; "pcg_lqk" = 0: the clustered row-per-lane kernel (family 8, full block rows on ceil(N / 32) CUs); "cluster" = 0: the streaming kernel
+    (family 3), whose HBM roofline is reported next to it.  40 iterations per solve (a warm-started solve) and the reference's cap."""
     sol, dev, N, args = cx.sol, cx.dev, cx.N, cx.args
     Bd = min(cx.B, 1024)
     S64, P64, g64 = torch.nan_to_num(cx.d_S[:Bd]).double(), torch.nan_to_num(cx.d_P[:Bd]).double(), cx.d_g[:Bd].double()
     l64 = torch.zeros(Bd, 14 * N, dtype=torch.float64, device=dev)
     i64 = torch.zeros(Bd, dtype=torch.int32, device=dev); x64 = torch.zeros(Bd, dtype=torch.uint8, device=dev)
-    c64 = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=40)
-    go = lambda: (l64.zero_(), sol.solve_f64(S64, P64, g64, l64, c64, args.precond, iters=i64, exits=x64))
     t_zero = timed(lambda: l64.zero_(), 3, warm=1)
+
+    def rate(K, reps=3):
+        c64 = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+        go = lambda: (l64.zero_(), sol.solve_f64(S64, P64, g64, l64, c64, args.precond, iters=i64, exits=x64))
+        go()
+        ms = timed(go, reps, warm=1) - t_zero
+        return ms, Bd * K / (ms * 1e-3)
+
     out = {"knot_points": N, "batch": Bd, "pcg_iters_per_solve": 40}
-    go()
-    ms = timed(go, 3, warm=1) - t_zero
+    ms, r40 = rate(40)
     fam = sol.get_option("last_kernel_family")
-    out.update({"kernel_ms": ms, "pcg_iterations_per_sec": Bd * 40 / (ms * 1e-3), "kernel_family": fam, "members_per_trajectory": sol.get_option("last_kernel_cluster"),
-                "cluster_fixups": sol.get_option("cluster_fixups"),
-                "bound": "two cluster-wide hand-offs per iteration (S and Pinv resident in the registers of ceil(N / 32) CUs)" if fam == 8 else "hbm"})
+    bound = {10: "two cluster-wide hand-offs per iteration (lower block triangle of S and Pinv resident in the registers of ceil(N / 64) CUs)",
+             9: "fp64 VALU issue / per-half latency, one active wavefront per SIMD (lower block triangle resident in one CU)",
+             8: "two cluster-wide hand-offs per iteration (full block rows resident in the registers of ceil(N / 32) CUs)"}.get(fam, "hbm")
+    out.update({"kernel_ms": ms, "pcg_iterations_per_sec": r40, "kernel_family": fam, "members_per_trajectory": sol.get_option("last_kernel_cluster"),
+                "cluster_fixups": sol.get_option("cluster_fixups"), "bound": bound})
     # useful flop of one trajectory-iteration (bench.py's count for the headline kernel): two block-tridiagonal products + 2 inner products + 3 axpys
     flop = 2 * 196 * ((3 * N - 2) + ((3 * N - 2) if args.precond == "ss" else N)) + 10 * 14 * N
-    out.update({"flop_per_iteration": flop, "achieved_tflops": out["pcg_iterations_per_sec"] * flop / 1e12,
-                "frac_of_fp64_valu_peak": out["pcg_iterations_per_sec"] * flop / 1e12 / FP64_VALU_PEAK_TF})
+    ms_cap, r_cap = rate(cx.max_iter, reps=2)
+    out.update({"flop_per_iteration": flop, "achieved_tflops": r40 * flop / 1e12, "frac_of_fp64_valu_peak": r40 * flop / 1e12 / FP64_VALU_PEAK_TF,
+                "at_iteration_cap": {"pcg_iters_per_solve": cx.max_iter, "kernel_ms": ms_cap, "pcg_iterations_per_sec": r_cap,
+                                     "frac_of_fp64_valu_peak": r_cap * flop / 1e12 / FP64_VALU_PEAK_TF}})
     try:
+        if fam in (9, 10):
+            sol.set_option("pcg_lqk", 0)
+            ms_r, r_r = rate(40)
+            out["row_per_lane_clusters"] = {"kernel_ms": ms_r, "pcg_iterations_per_sec": r_r, "kernel_family": sol.get_option("last_kernel_family"),
+                                            "members_per_trajectory": sol.get_option("last_kernel_cluster")}
         sol.set_option("cluster", 0)
-        go()                                                                     # (first streaming call: the latch's one blocking check)
-        ms_s = timed(go, 3, warm=1) - t_zero
+        ms_s, r_s = rate(40)                                                     # (first streaming call of a handle that does not know yet: the latch's one blocking check)
         cols64 = 2 if sol.get_option("symmetry_state") == 1 else 3
         by64 = 2 * cols64 * 196 * N * 8
-        out["streaming_kernel"] = {"kernel_ms": ms_s, "pcg_iterations_per_sec": Bd * 40 / (ms_s * 1e-3), "kernel_family": sol.get_option("last_kernel_family"),
-                                   "block_columns_read": cols64, "bytes_per_unit": by64, "achieved": Bd * 40 * by64 / (ms_s * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": Bd * 40 * by64 / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "bound": "hbm (S and Pinv re-read every iteration)"}
+        out["streaming_kernel"] = {"kernel_ms": ms_s, "pcg_iterations_per_sec": r_s, "kernel_family": sol.get_option("last_kernel_family"),
+                                   "block_columns_read": cols64, "bytes_per_unit": by64, "achieved": r_s * by64 / 1e9, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": r_s * by64 / 1e9 / HBM_PEAK_GBS, "bound": "hbm (S and Pinv re-read every iteration)"}
         out["speedup_over_streaming"] = ms_s / ms
     finally:
-        sol.set_option("cluster", -1)
+        sol.set_option("cluster", -1); sol.set_option("pcg_lqk", -1)
+    # the longest horizon one CU holds in double
+    if N > 64:
+        sol64 = PcgSolver(64, max_batch=Bd, device=dev.index)
+        S_, P_, g_ = (t.view(Bd, N, -1)[:, :64].reshape(Bd, -1).contiguous() for t in (S64, P64, g64))
+        l_ = torch.zeros(Bd, 14 * 64, dtype=torch.float64, device=dev)
+        c40 = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=40)
+        go64 = lambda: (l_.zero_(), sol64.solve_f64(S_, P_, g_, l_, c40, args.precond, iters=i64, exits=x64))
+        go64()
+        ms64 = timed(go64, 3, warm=1) - t_zero
+        out["N64"] = {"kernel_ms": ms64, "pcg_iterations_per_sec": Bd * 40 / (ms64 * 1e-3), "kernel_family": sol64.get_option("last_kernel_family"),
+                      "note": "the first 64 knots of the same systems (a leading principal block: still symmetric negative definite)"}
     return out
 
 
