@@ -286,3 +286,24 @@ def test_clustered_lane_quad_kernel_queue_outputs_and_cross_checks(orc):
         torch.cuda.synchronize()
         assert sol.get_option("last_kernel_family") == fam
         assert relinf(lam_o.cpu().numpy(), lamh[:5]) < 1e-9
+
+
+@pytest.mark.parametrize("N,G", [(33, 2), (40, 8), (64, 3), (128, 4), (128, 8), (200, 7), (512, 8)])
+def test_forced_member_counts(orc, N, G):
+    """ "cluster" = G: more members than the horizon needs — members of 5 knots (N = 40 over eight CUs: most wavefronts of a member hold no knot),
+    ragged splits (200 over seven), a single-CU horizon on three CUs — against the oracle and, bit for bit, against nothing else: every member count
+    sums the inner products in its own order."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    B, K = 3, 20
+    k = synth.make_kkt(N, B, 7900 + N + G)
+    S, Pinv, g = synth.form_schur(k, dtype=np.float64)
+    lam0 = 0.1 * np.random.default_rng(N + G).standard_normal((B, n * N))
+    sol = PcgSolver(N, max_batch=B)
+    sol.set_option("cluster", G)
+    lam = dev(lam0.copy())
+    it, ex = sol.solve_f64(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K))
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 10 and sol.get_option("last_kernel_cluster") == G and sol.get_option("cluster_fixups") == 0
+    assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all()
+    for b in range(B):
+        assert relinf(lam.cpu().numpy()[b], orc.pcg(S[b], Pinv[b], g[b], lam0[b], N, K, 0.0, "ss")["lam"]) < 1e-9
