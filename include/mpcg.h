@@ -319,7 +319,8 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  *       trajectory have written their knots by then.  ("cluster_test_fail" = 1, tests only: one member gives up at its first write-back.)
  *       linsys_t = double (mpcg_pcg_solve_f64 / _ref_f64): knot_points <= 32 the row-per-lane kernel in double; beyond, with block-symmetric
  *       matrices (the latch), "pcg_lqk" (-1 auto / 0 / 1): the lane-quad-per-knot kernel — the lower block triangle of 64 knots in the registers of
- *       one CU (32 < knot_points <= 64; = 1 forces it below) — and for 64 < knot_points <= 512 its clustered form, G = ceil(N / 64) CUs per
+ *       one CU (32 < knot_points <= 64, and 16 < knot_points <= 32 for calls of at least four trajectories per CU; = 1 forces it at any
+ *       knot_points <= 64) — and for 64 < knot_points <= 512 its clustered form, G = ceil(N / 64) CUs per
  *       trajectory under the same "cluster" option and hand-off machinery; "pcg_lqk" = 0, a latch that says not symmetric or a capturing first
  *       call: the clustered row-per-lane kernel (32 < knot_points <= 256, G = ceil(N / 32) members, full block rows, all three block columns);
  *       "cluster" = 0 selects the streaming kernel, which is also the clusters' fix-up (up to 350 knots: beyond, its iterate vectors do not fit

@@ -980,8 +980,12 @@ static int launch_lqk_f64_t(mpcg_handle* h, const PcgArgs64& a, uint32_t batch, 
 
 static int launch_f64(mpcg_handle* h, PcgArgs64 a, uint32_t batch, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // 32 < N <= 64 (or "pcg_lqk" = 1 at any N <= 64): the lane-quad kernel, once the latch says the matrices are block-symmetric
-    if (!h->generic && h->N <= kLqkMaxN && h->lqk != 0 && (h->lqk == 1 || (h->auto_cfg && h->N > kRplMaxN64 && h->cluster < 0))) {
+    // 32 < N <= 64 (or "pcg_lqk" = 1 at any N <= 64): the lane-quad kernel, once the latch says the matrices are block-symmetric.  Also 16 < N <= 32
+    // when the call brings at least four trajectories per CU: two 32-knot workgroups per CU take 4.2 us per iteration of 1,024 trajectories at
+    // every such N and 30-39 us to start, the row-per-lane kernel 4.4 us and 38-64 us — 40-iteration solves of 1,024 trajectories: 200-205 against
+    // 218-246 us (tools/_prof/f64_fixed_cost.py); below that batch the row-per-lane kernel's 1.0-1.1 us per iteration of ONE trajectory wins (1.7).
+    const bool lqk_short = h->N > 16 && batch >= 4u * (uint32_t)h->num_cus;
+    if (!h->generic && h->N <= kLqkMaxN && h->lqk != 0 && (h->lqk == 1 || (h->auto_cfg && (h->N > kRplMaxN64 || lqk_short) && h->cluster < 0))) {
         const int rc = f64_symmetry_latch(h, a, batch, st);
         if (rc != MPCG_OK) return rc;
         if (h->sym_state == 1) {

@@ -307,3 +307,37 @@ def test_forced_member_counts(orc, N, G):
     assert (it.cpu().numpy() == K).all() and (ex.cpu().numpy() == 1).all()
     for b in range(B):
         assert relinf(lam.cpu().numpy()[b], orc.pcg(S[b], Pinv[b], g[b], lam0[b], N, K, 0.0, "ss")["lam"]) < 1e-9
+
+
+def test_short_horizons_take_the_lane_quad_kernel_only_for_throughput_sized_batches(orc):
+    """16 < N <= 32: a call with at least four trajectories per CU runs two 32-knot lane-quad workgroups per CU (family 9), anything smaller the
+    row-per-lane kernel (family 5) — a sub-batch of the same systems therefore comes from another kernel and agrees to round-off, not to the bit."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, K = 24, 20
+    sol = PcgSolver(N, max_batch=4096)
+    B = 4 * sol.get_option("num_cus")
+    k = synth.make_kkt(N, 4, 8100)
+    S4, P4, g4 = synth.form_schur(k, dtype=np.float64)
+    S, Pinv, g = (np.tile(a_, (B // 4, 1)) for a_ in (S4, P4, g4))
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    it, ex = sol.solve_f64(dS, dP, dg, lam, cfg)
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 9 and sol.get_option("last_kernel_waves") == 4 and (it.cpu().numpy() == K).all()
+    lamh = lam.cpu().numpy()
+    for b in range(4, B):
+        np.testing.assert_array_equal(lamh[b], lamh[b % 4])
+    for b in range(4):
+        assert relinf(lamh[b], orc.pcg(S4[b], P4[b], g4[b], np.zeros(n * N), N, K, 0.0, "ss")["lam"]) < 1e-9
+    lam_s = torch.zeros(B - 1, n * N, dtype=torch.float64, device="cuda")
+    sol.solve_f64(dS[:B - 1], dP[:B - 1], dg[:B - 1], lam_s, cfg)
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 5
+    assert relinf(lam_s.cpu().numpy()[:4], lamh[:4]) < 1e-9
+    sol16 = PcgSolver(16, max_batch=B)                       # N <= 16: the row-per-lane kernel at every batch (twice the lane-quad kernel's rate)
+    k16 = synth.make_kkt(16, 2, 8101)
+    S2, P2, g2 = (np.tile(a_, (B // 2, 1)) for a_ in synth.form_schur(k16, dtype=np.float64))
+    sol16.solve_f64(dev(S2), dev(P2), dev(g2), torch.zeros(B, n * 16, dtype=torch.float64, device="cuda"), cfg)
+    torch.cuda.synchronize()
+    assert sol16.get_option("last_kernel_family") == 5
