@@ -386,13 +386,15 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpkc_kernel(ClusterArgs ca) 
 #else
             const float tot = wave_fold(wantp ? __builtin_bit_cast(float, (unsigned)x) : 0.f);
 #endif
-            if (ln == 0) { bc[0] = tot; if (spins >= CL_SPIN_LIMIT) bc[1] = 1.f; }
+            if (ln == 0) { bc[(epoch & 1u) ? 3 : 0] = tot; if (spins >= CL_SPIN_LIMIT) bc[1] = 1.f; }
             MPCG_STAMP(pb + 4);
         }
         lds_barrier();
         MPCG_STAMP(pb + 5);
         if (bc[1] != 0.f) failed = true;
-        return bc[0];
+        // (two cells by epoch parity: the next hand-off's poller — another wavefront of this workgroup — may finish before a wavefront that takes no
+        //  part in the next pass has read this value; with one cell that would be a race, however unlikely a wavefront lags a whole pass)
+        return bc[(epoch & 1u) ? 3 : 0];
     };
 
     if (tid == 0) { bc[0] = 0.f; bc[1] = 0.f; bc[3] = 0.f; }

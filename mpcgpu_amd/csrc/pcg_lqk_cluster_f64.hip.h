@@ -65,7 +65,7 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lqkc_f64_kernel(ClusterArgs6
     if ((unsigned)cl >= nclusters) return;
     const int k0 = (int)(((long)gm * N) / G), k1 = (int)(((long)(gm + 1) * N) / G);
     const int KL = k1 - k0;                             // own knots (launcher: 1 <= KL <= NMAX)
-    real* bc = lds + L::BC;                             // [0] cluster-wide sum, [1] sticky timeout flag, [2] trajectory index / same-XCD (int)
+    real* bc = lds + L::BC;                             // [0] / [3] cluster-wide sum of even / odd hand-offs, [1] sticky timeout flag, [2] trajectory index / same-XCD (int)
 
     const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;
     gu64* my_words = (gu64*)ca.scratch + ((size_t)cl * G + gm) * LQKC_WG_WORDS;
@@ -312,11 +312,13 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lqkc_f64_kernel(ClusterArgs6
             if (wantv) (lds + (isZ ? ZV : TV))[dst] = __builtin_bit_cast(real, ((unsigned long long)xv.y << 32) | (unsigned long long)xv.x);
             const real partial = __builtin_bit_cast(real, ((unsigned long long)xp.y << 32) | (unsigned long long)xp.x);
             const real tot = rpl_wave_fold(wantp ? partial : real(0));
-            if (ln == 0) { bc[0] = tot; if (spins >= CL_SPIN_LIMIT) bc[1] = 1.0; }
+            if (ln == 0) { bc[(epoch & 1u) ? 3 : 0] = tot; if (spins >= CL_SPIN_LIMIT) bc[1] = 1.0; }
         }
         lds_barrier();
         if (bc[1] != 0.0) failed = true;
-        return bc[0];
+        // (two cells by epoch parity: the next hand-off's poller — another wavefront of this workgroup — may finish before a wavefront that takes no
+        //  part in the next pass has read this value; with one cell that would be a race, however unlikely a wavefront lags a whole pass)
+        return bc[(epoch & 1u) ? 3 : 0];
     };
 
     if (tid == 0) { bc[0] = 0.0; bc[1] = 0.0; bc[2] = 0.0; bc[3] = 0.0; }
