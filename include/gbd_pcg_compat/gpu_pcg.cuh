@@ -11,7 +11,7 @@
 //                                                        -> mpcgLaunchPcg(pcg_kernel, N, threads, args, smem)
 //                                                           (the ONE line of sqp.cuh that changes)
 // T = float (linsys_t with USE_DOUBLES=0, include/common/settings.cuh:41-49) is the headline path; T = double (USE_DOUBLES=1) runs the
-// row-per-lane kernel in double to 32 knots, its clustered form (ceil(N / 32) CUs per trajectory) to 256, the streaming kernel beyond.
+// row-per-lane kernel in double to 32 knots and the lane-quad kernels beyond (one CU to 64 knots, ceil(N / 64) CUs to 512).
 // STATE_SIZE = 14.
 #pragma once
 #include <hip/hip_runtime.h>
