@@ -68,7 +68,7 @@ extern "C" {
 int mpcg_abi_version(void) { return MPCG_ABI_VERSION; }
 
 const char* mpcg_build_info(void) {
-    return "libmpcg_hip gfx950 fp32 n=14 (row-per-lane DPP PCG for short horizons, lane-pair register-resident PCG to N = 128, clustered lane-pair PCG beyond, wave64 row-triple streaming PCG; chunk-walking Schur formation; IIWA-14 KKT blocks with the analytic inverse-dynamics gradient)";
+    return "libmpcg_hip gfx950 fp32 n=14 (row-per-lane DPP PCG for short horizons, lane-pair register-resident PCG to N = 128, clustered lane-pair PCG beyond, wave64 row-triple streaming PCG; linsys_t = double: row-per-lane to N = 32, lane-quad register-resident PCG to N = 64, clustered to 512; chunk-walking Schur formation in float and double; IIWA-14 KKT blocks with the analytic inverse-dynamics gradient)";
 }
 
 // device scratch of the clustered kernel: [queue line][flags: one 128-byte line per trajectory of the CALL, up to max_batch][cells: 1 KB
