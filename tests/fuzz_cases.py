@@ -23,6 +23,7 @@ def run(cases=120, seed=7, verbose=True):
     f16_count = collections.Counter()
     worst16 = 0.0
     f16_bitwise = 0
+    f16_chaotic = 0
     warm_cases = 0
     t0 = time.time()
     for ci in range(cases):
@@ -82,7 +83,15 @@ def run(cases=120, seed=7, verbose=True):
             cpu32 = orc.pcg(Sr[b], Pr[b], g[b], lam0[b], N, K, 0.0, pc)["lam"]
             if not np.isfinite(cpu32).all():
                 continue
-            ref = orc.pcg(Sr[b].astype(np.float64), Pr[b].astype(np.float64), g[b].astype(np.float64), lam0[b].astype(np.float64), N, K, 0.0, pc)["lam"]
+            r64 = orc.pcg(Sr[b].astype(np.float64), Pr[b].astype(np.float64), g[b].astype(np.float64), lam0[b].astype(np.float64), N, K, 0.0, pc, hist=True)
+            ref = r64["lam"]
+            # Rounding to fp16 can make S or Pinv INDEFINITE (profiles/r05_fuzz.txt: case 2143 of seed 4041, N = 4: largest eigenvalue of the rounded
+            # -S +0.15).  CG then passes near-breakdowns — eta grows by orders of magnitude in one iteration, in float64 too — and the iterates behind
+            # one are not comparable between any two arithmetics (the CPU float32 and float64 restatements differ by 38 % there): inconclusive.
+            eh = np.abs(np.asarray(r64["eta_hist"], np.float64))
+            if len(eh) > 1 and (eh[1:] > 30.0 * np.maximum(eh[:-1], 1e-300)).any():
+                f16_chaotic += 1
+                continue
             band = fp32_band(orc, Sr[b], Pr[b], g[b], lam0[b], N, K, pc, ref)
             e = relinf(a16[b], ref)
             # the ROUNDED system can be much worse conditioned than the caller's (rho = 1e-3: entries lose 11 bits): where the CPU float32 restatement
@@ -97,4 +106,4 @@ def run(cases=120, seed=7, verbose=True):
             if verbose: print(f"MISMATCH case {ci}: N={N} B={B} {pc} K={K} family {fam}: iters {it_h.tolist()} exit {ex_h.tolist()} finite {bool(np.isfinite(lam_h).all())}", flush=True)
     return {"cases": cases, "seed": seed, "seconds": time.time() - t0, "families": dict(sorted(fam_count.items())), "worst_error_over_tolerance": worst,
             "marginal_trajectories": marginal, "breakdown_skipped": breakdown, "f16_families": dict(sorted(f16_count.items())), "f16_bitwise_cases": f16_bitwise,
-            "f16_worst_error_over_tolerance": worst16, "warm_start_cases": warm_cases, "mismatches": bad}
+            "f16_worst_error_over_tolerance": worst16, "f16_near_breakdown_skipped": f16_chaotic, "warm_start_cases": warm_cases, "mismatches": bad}
