@@ -308,7 +308,9 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * Kernel selection of a float solve (state_size 14):
  *   "pcg_rpl" (-1 auto / 0 / 1): the row-per-lane kernel for knot_points <= 64 — a DPP row per knot, vectors in registers; automatic for
  *       knot_points <= 32 and for calls of at most one trajectory per CU up to 64; "rpl_waves" (its wavefronts per trajectory: 0 auto, 4, 8, 16);
- *   "pcg_lpk" (-1 auto / 0 / 1): the lane-pair-per-knot kernel, knot_points <= 128 — everything in registers; automatic for 36 < knot_points <= 128;
+ *   "pcg_lpk" (-1 auto / 0 / 1): the lane-pair-per-knot kernel, knot_points <= 128 — everything in registers; automatic for 36 < knot_points <= 128
+ *       and, in its half build (one wavefront per matrix, four workgroups per CU), for 16 < knot_points <= 32 when the call brings at least 2.5
+ *       trajectories per CU;
  *   "cluster" (-1 auto / 0 off / G = 2..8 forced): workgroups (= CUs of one XCD) per trajectory of the clustered lane-pair kernel, automatic
  *       for knot_points > 128 (G = ceil(N / 128)).  Members exchange inner-product partials and boundary knots through the XCD's L2
  *       ("cluster_l2" = 0: always write-through), so all members of a cluster must be resident: the launch holds as many clusters as fit the
@@ -348,7 +350,8 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  *       last solve: 0 single-workgroup row-pair, 3 generic, 5 row-per-lane, 6 lane-pair-per-knot, 7 clustered lane-pair, 8 clustered row-per-lane
  *       (double), 9 lane-quad-per-knot (double), 10 clustered lane-quad (double); 1, 2, 4 were kernels retired in round 4), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
  * WHICH kernel family serves a call depends on knot_points AND on the call's batch (e.g. 32 < N <= 64: row-per-lane kernel up to one
- * trajectory per CU, lane-pair kernel beyond; N <= 32: 8 waves x 1 slot or 4 x 2 by batch).  Families sum the inner products in different
+ * trajectory per CU, lane-pair kernel beyond; N <= 32: 8 waves x 1 slot or 4 x 2 by batch, 16 < N <= 32: the lane-pair kernel's half build
+ * from 2.5 trajectories per CU).  Families sum the inner products in different
  * orders, so the SAME trajectory solved alone and inside a large batch may differ in the last fp32 bits (and, near the tolerance, by an
  * iteration); within one family results are bitwise reproducible run to run and independent of batch composition.  Pin a family with
  * "pcg_rpl" / "pcg_lpk" / "rpl_waves" when bit-stability across batch sizes matters.  None of the residency knobs changes results within a

@@ -484,24 +484,31 @@ static void choose_auto(const mpcg_handle* h, PcgKnobs& k, uint32_t batch, int e
 // ---- lane-pair-per-knot kernel (pcg_lpk.hip.h): everything register-resident, N <= 128 ----
 template <int NWR>
 static int launch_lpk_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
-    const size_t lds = pcg_lpk_lds_floats(4 * NWR) * sizeof(float);
+    const size_t lds = pcg_lpk_lds_floats(LpkLds<NWR>::NW) * sizeof(float);
     auto kern = pcg_lpk_kernel<NWR>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(batch), dim3(NWR * 256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(batch), dim3(LpkLds<NWR>::NW * 64), lds, st, a);
     HIP_TRY(h, hipGetLastError());
-    h->last = LastKernel{FAM_LPK, 4 * NWR, 0, 0, 0, 0, (int)lds, 0};
+    h->last = LastKernel{FAM_LPK, LpkLds<NWR>::NW, 0, 0, 0, 0, (int)lds, 0};
     return MPCG_OK;
 }
 static int launch_lpk(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    if (h->N <= 32) return launch_lpk_t<0>(h, a, batch, st);          // the half build: one wavefront per matrix, four workgroups per CU
     return h->N <= 64 ? launch_lpk_t<1>(h, a, batch, st) : launch_lpk_t<2>(h, a, batch, st);
 }
 // Automatic use: 36 < N <= 128 (where the row-per-lane kernel has not taken the call).  Its per-lane work does not shrink with the horizon
 // (a lane pair per knot whatever N), so up to N = 36 — where the row-pair kernel <4,3,0> fits two trajectories per CU — that one stays
 // ahead in throughput (N=36: 292 vs 222 M it/s at batch 2048); beyond it the order flips (HISTORY.md §3.1c).
-static bool use_lpk(const mpcg_handle* h, int esz) {
+// ... and, round 5, 16 < N <= 32 for calls of at least 2.5 trajectories per CU: the HALF build (one wavefront per matrix, 32 knots, four workgroups
+// per CU) takes 1.45-1.55 us per iteration for up to four trajectories per CU, the row-per-lane kernel 1.26 us for two, 2.1 for three, 2.5-2.7 for
+// four: N = 32, batch 1024 / 4096: 378 / 434 -> 661 / 629 M it/s (tools/_prof/lpk_half.py); at N <= 16 the row-per-lane kernel stays ahead (780-920 M).
+static bool lpk_half(const mpcg_handle* h, int esz, uint32_t batch) {
+    return esz == 4 && h->lpk != 0 && h->rpl != 1 && h->auto_cfg && h->cluster <= 0 && h->N > 16 && h->N <= 32 && 2ull * batch >= 5ull * (uint32_t)h->num_cus;
+}
+static bool use_lpk(const mpcg_handle* h, int esz, uint32_t batch) {
     if ((esz != 4 && esz != 2) || h->N > kLpbMaxN || h->lpk == 0) return false;     // (fp16 storage: converted once at the load)
-    return h->lpk == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 36);
+    return h->lpk == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 36) || lpk_half(h, esz, batch);
 }
 
 // ---- row-per-lane kernel (pcg_rpl.hip.h): short horizons, NW wavefronts x RHO slots of four knots ----
@@ -541,6 +548,7 @@ static bool use_rpl(const mpcg_handle* h, int esz, uint32_t batch) {
     if (esz != 4 || h->N > kRplMaxN || h->rpl == 0) return false;
     if (h->rpl == 1) return true;
     if (h->lpk == 1) return false;
+    if (lpk_half(h, esz, batch)) return false;
     return h->auto_cfg && h->cluster <= 0 && (h->N <= 32 || batch <= (uint32_t)h->num_cus);
 }
 
@@ -703,7 +711,7 @@ static int launch_guarded(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipS
     bool need_fallback = true;
     int rc;
     const int esz = a.esz;
-    if (use_lpk(h, esz)) rc = launch_lpk(h, p, batch, st);
+    if (use_lpk(h, esz, batch)) rc = launch_lpk(h, p, batch, st);
     else {
         rc = try_launch_cluster(h, p, batch, st, esz, /*guarded=*/true);
         if (rc == 1) return 1;                                                                // (does not apply: the caller falls through)
@@ -746,13 +754,13 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a_in, uint32_t batch, hipSt
     // Verify the precondition on this call's matrices; a call that violates it is solved by a kernel that reads all three columns.
     bool lower_ok = true;
     h->last_sym_violations = 0;
-    if (h->check_symmetry && (use_lpk(h, esz) || (h->cluster != 0 && (h->cluster > 0 || h->N > kLpbMaxN)))) {
+    if (h->check_symmetry && (use_lpk(h, esz, batch) || (h->cluster != 0 && (h->cluster > 0 || h->N > kLpbMaxN)))) {
         int v = 0;
         const int rc = symmetry_violations(h, a, batch, st, &v);
         if (rc != MPCG_OK) return rc;
         h->last_sym_violations = v;
         lower_ok = v == 0;
-    } else if (a.redo_flags == nullptr && (use_lpk(h, esz) || (h->cluster != 0 && (h->cluster > 0 || (h->auto_cfg && h->N > kLpbMaxN))))) {
+    } else if (a.redo_flags == nullptr && (use_lpk(h, esz, batch) || (h->cluster != 0 && (h->cluster > 0 || (h->auto_cfg && h->N > kLpbMaxN))))) {
         // the symmetry latch (see launch_guarded): no synchronisation, no per-solve D2H
         sym_poll(h, st, true);
         if (h->sym_state == 2) lower_ok = false;
@@ -762,7 +770,7 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a_in, uint32_t batch, hipSt
         }
     }
     if (lower_ok) {
-        if (use_lpk(h, esz)) return launch_lpk(h, a, batch, st);
+        if (use_lpk(h, esz, batch)) return launch_lpk(h, a, batch, st);
         const int rc = try_launch_cluster(h, a, batch, st, esz);
         if (rc != 1) return rc;
     } else if (esz == 4 && h->N <= kRplMaxN && h->rpl != 0) {
@@ -1051,9 +1059,10 @@ int mpcg_check_pcg_occupancy(mpcg_handle* h, uint32_t* resident_trajectories) {
 #define X(NW_, RHO_) if (nw == NW_ && rho == RHO_) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_rpl_kernel<NW_, RHO_, true>, NW_ * 64, lds));
         MPCG_RPL_VARIANTS(X)
 #undef X
-    } else if (use_lpk(h, 4)) {
-        const size_t lds = pcg_lpk_lds_floats(h->N <= 64 ? 4 : 8) * sizeof(float);
-        if (h->N <= 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpk_kernel<1>, 256, lds));
+    } else if (use_lpk(h, 4, h->max_batch)) {
+        const size_t lds = pcg_lpk_lds_floats(h->N <= 32 ? 2 : h->N <= 64 ? 4 : 8) * sizeof(float);
+        if (h->N <= 32) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpk_kernel<0>, 128, lds));
+        else if (h->N <= 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpk_kernel<1>, 256, lds));
         else {
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pcg_lpk_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpk_kernel<2>, 512, lds));

@@ -51,7 +51,7 @@ namespace mpcg {
 // The first version used knot-major [knot][16 floats]: 8- to 16-way conflicts on every access made the LDS pipe the bottleneck
 // (profiles/r03_lpk_phases.txt).
 template <int NWR> struct LpkLds {
-    static constexpr int NMAX = 64 * NWR, NW = 4 * NWR;
+    static constexpr int NMAX = NWR ? 64 * NWR : 32, NW = NWR ? 4 * NWR : 2;      // (NWR = 0: the HALF build — one wavefront per matrix, 32 knots, four workgroups per CU)
     static constexpr int KN = NMAX + 4;                        // knot slots per row pair: NMAX + 2 rounded up to 4 (mod 8)
     static_assert(KN % 8 == 4, "row pairs q and q + 4 must sit 32 banks apart");
     static constexpr int VS = 7 * KN * 2;                      // floats per vector
@@ -66,7 +66,7 @@ template <int NWR> struct LpkLds {
     __host__ __device__ static constexpr int at(int k, int i) { return 2 * ((i >> 1) * KN + k + 1) + (i & 1); }
 };
 __host__ __device__ constexpr size_t pcg_lpk_lds_floats(int NW) {
-    return NW == 4 ? (size_t)LpkLds<1>::TOTAL : (size_t)LpkLds<2>::TOTAL;
+    return NW == 2 ? (size_t)LpkLds<0>::TOTAL : NW == 4 ? (size_t)LpkLds<1>::TOTAL : (size_t)LpkLds<2>::TOTAL;
 }
 
 __device__ __forceinline__ f2 buf_load2(rsrc_t r, uint32_t voff) {
@@ -266,9 +266,9 @@ __device__ __forceinline__ void lpk_load_blocks_lds(rsrc_t M, int kfirst, int ke
 }
 
 template <int NWR>
-__global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
+__global__ __launch_bounds__(NWR ? NWR * 256 : 128, 2) void pcg_lpk_kernel(PcgArgs a) {
     typedef LpkLds<NWR> L;
-    constexpr int NW = 4 * NWR, NTHR = NW * 64;
+    constexpr int NW = L::NW, NTHR = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int N = a.N;
     const int tid = threadIdx.x;
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
     float* lam_g = a.lambda + (size_t)b * vstride;
 
     // ---- role of this wave, knot and column half of this lane ----
-    const bool isP = w >= 2 * NWR;                         // wave-uniform
-    const int wl = w - (isP ? 2 * NWR : 0);                // wave of its matrix: 0 .. 2 NWR - 1
+    const bool isP = w >= NW / 2;                          // wave-uniform
+    const int wl = w - (isP ? NW / 2 : 0);                 // wave of its matrix: 0 .. NW / 2 - 1
     const int li = 64 * wl + lane;
     const int k = li >> 1, h = li & 1;
     const bool p3 = a.pcols == 3;
@@ -366,9 +366,11 @@ __global__ __launch_bounds__(NWR * 256, 2) void pcg_lpk_kernel(PcgArgs a) {
         if constexpr (NW == 8) {
             const f4 v = *reinterpret_cast<const f4*>(red);
             return ((v.x + v.y) + v.z) + v.w;
-        } else {
+        } else if constexpr (NW == 4) {
             const f2 v = *reinterpret_cast<const f2*>(red);
             return v.x + v.y;
+        } else {
+            return red[0];
         }
     };
     struct Own { f2 v[4]; };

@@ -37,6 +37,8 @@ def run(cases=120, seed=7, verbose=True):
         warm_cases += int(warm)
         lam0 = (0.1 * rng.standard_normal((B, 14 * N))).astype(np.float32) if warm else np.zeros((B, 14 * N), np.float32)
         sol = PcgSolver(N, max_batch=B)
+        if N <= 32 and rng.random() < 0.25:
+            sol.set_option("pcg_lpk", 1)                   # the lane-pair kernel's half build (the policy's choice for throughput-sized calls at 16 < N <= 32)
         lam = dev(lam0.copy())
         it, ex = sol.solve(dev(S), dev(P), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), pc)
         torch.cuda.synchronize()

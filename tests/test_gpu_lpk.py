@@ -52,7 +52,7 @@ def lpk_solve(P, N, S, Pinv, g, lam0, max_iter, tol, pc="ss"):
     lam = dev(np.asarray(lam0, np.float32))
     it, ex = sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=tol, pcg_max_iter=max_iter), pc)
     torch.cuda.synchronize()
-    assert sol.get_option("last_kernel_family") == 6 and sol.get_option("last_kernel_waves") == (4 if N <= 64 else 8)
+    assert sol.get_option("last_kernel_family") == 6 and sol.get_option("last_kernel_waves") == (2 if N <= 32 else 4 if N <= 64 else 8)
     assert N <= 64 or sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes(14, N)
     return lam.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy()
 
@@ -248,3 +248,42 @@ def test_batch_composition_independence(P):
     lam_s, it_s, _ = lpk_solve(P, N, S[sub], Pinv[sub], g[sub], np.zeros((3, n * N)), *cfg)
     np.testing.assert_array_equal(lam_s, lam[sub])
     np.testing.assert_array_equal(it_s, it[sub])
+
+
+def test_half_build_policy_on_short_horizons(P, orc):
+    """16 < N <= 32 (round 5): calls of at least 2.5 trajectories per CU run the lane-pair kernel's HALF build (family 6, two wavefronts, four
+    workgroups per CU), smaller ones and N <= 16 the row-per-lane kernel (family 5).  Copies of four systems solve to the same bits wherever
+    they land; a sub-batch below the threshold comes from the other kernel and agrees inside the float32 band."""
+    PcgSolver, pcg_config = P
+    N, K = 24, 20
+    sol = PcgSolver(N, max_batch=4096)
+    ncu = sol.get_option("num_cus")
+    B = (5 * ncu + 1) // 2
+    k = synth.make_kkt(N, 4, 515)
+    S4, P4, g4 = synth.form_schur(k)
+    rep = (B + 3) // 4
+    S, Pinv, g = (np.tile(a_, (rep, 1))[:B] for a_ in (S4, P4, g4))
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    lam = torch.zeros(B, n * N, device="cuda")
+    it, ex = sol.solve(dS, dP, dg, lam, cfg, "ss")
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 6 and sol.get_option("last_kernel_waves") == 2 and (it.cpu().numpy() == K).all()
+    lamh = lam.cpu().numpy()
+    for b in range(4, B):
+        np.testing.assert_array_equal(lamh[b], lamh[b % 4])
+    for b in range(4):
+        r64 = orc.pcg(S4[b].astype(np.float64), P4[b].astype(np.float64), g4[b].astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")["lam"]
+        band = fp32_band(orc, S4[b], P4[b], g4[b], np.zeros(n * N, np.float32), N, K, "ss", r64)
+        assert relinf(lamh[b], r64) <= max(1e-3, 4 * band)
+    lam_s = torch.zeros(B - 1, n * N, device="cuda")
+    sol.solve(dS[:B - 1], dP[:B - 1], dg[:B - 1], lam_s, cfg, "ss")
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == 5
+    assert relinf(lam_s.cpu().numpy()[:4], lamh[:4]) < 2e-3
+    sol16 = PcgSolver(16, max_batch=B)
+    k16 = synth.make_kkt(16, 2, 516)
+    S2, P2, g2 = (np.tile(a_, ((B + 1) // 2, 1))[:B] for a_ in synth.form_schur(k16))
+    sol16.solve(dev(S2), dev(P2), dev(g2), torch.zeros(B, n * 16, device="cuda"), cfg, "ss")
+    torch.cuda.synchronize()
+    assert sol16.get_option("last_kernel_family") == 5

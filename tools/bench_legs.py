@@ -537,7 +537,8 @@ def producers_f64(cx):
 
 
 def short_horizon(cx):
-    """The short-horizon regime in throughput mode (N = 32, the reference's real-time horizon; row-per-lane kernel)."""
+    """The short-horizon regime in throughput mode (N = 32, the reference's real-time horizon, 2048 trajectories: the lane-pair kernel's half build —
+    one wavefront per matrix, four workgroups per CU; the row-per-lane kernel serves latency-sized calls and N <= 16)."""
     sh = {}
     for pc_ in ("ss", "jacobi"):
         Ns, Bs = 32, 2048
