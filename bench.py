@@ -114,6 +114,7 @@ def compact_line(full: dict) -> dict:
         "batch1_sqp_step_us_N32": _get(b1, "N32", "us_per_step"), "batch1_sqp_step_us_N128": _get(b1, "N128", "us_per_step"),
         "N256_pcg_iterations_per_sec": _get(lh, "N256", "pcg_iterations_per_sec"), "N512_pcg_iterations_per_sec": _get(lh, "N512", "pcg_iterations_per_sec"),
         "N256_single_reduction_ceiling_it_per_sec": (_get(full, "roofline_long_horizon", "single_reduction_ceiling", "N256_batch1024_M_it_per_s", "emulated") or 0) * 1e6 or None,
+        "N32_batch2048_pcg_iterations_per_sec": _get(full, "short_horizon", "ss", "pcg_iterations_per_sec"),
         "f64_N128_pcg_iterations_per_sec": _get(full, "double_precision", "pcg_iterations_per_sec"),
         "f64_N128_frac_of_fp64_valu_peak": _get(full, "double_precision", "frac_of_fp64_valu_peak"),
         "f64_N128_it_per_sec_at_167_iterations": _get(full, "double_precision", "at_iteration_cap", "pcg_iterations_per_sec"),
