@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <set>
 #include <type_traits>
 #include <utility>
 
@@ -67,6 +68,17 @@ inline mpcg_handle* handle_for(uint32_t state_size, uint32_t knot_points) {
     return h;
 }
 
+// The library's lower-triangle kernels need block-symmetric S / Pinv (include/mpcg.h, BLOCK SYMMETRY — the reference's construction is); a handle
+// whose latch found a violation solves with three-column kernels from then on and says so in mpcg_last_error() only.  Surface it once per
+// handle: a maintainer who swaps in a hand-made Pinv should see why the solve got slower.  (Host-side state only: no synchronisation.)
+inline void warn_once_if_not_block_symmetric(mpcg_handle* h) {
+    static thread_local std::set<mpcg_handle*> warned;
+    int state = 0;
+    if (mpcg_get_option(h, "symmetry_state", &state) == MPCG_OK && state == 2 && warned.insert(h).second)
+        fprintf(stderr, "mpcg: %s\n", "S / Pinv of a solve on this handle were not block-symmetric (block (k, right) != block (k+1, left)^T): "
+                                       "three-column kernels from now on (include/mpcg.h, BLOCK SYMMETRY)");
+}
+
 // the stream the next pcg<> launch of THIS host thread goes to (mpcgLaunchPcg's optional last argument sets it around the call; the
 // reference's own call site runs on the default stream, include/pcg/sqp.cuh:225-236)
 inline hipStream_t& launch_stream() {
@@ -109,6 +121,7 @@ void pcg(T* d_S, T* d_Pinv, T* d_gamma, T* d_lambda, T* d_r, T* d_p, T* d_v_temp
         rc = mpcg_pcg_solve_ref_f64(h, d_S, d_Pinv, d_gamma, d_lambda, d_r, d_p, d_v_temp, d_eta_new_temp, d_iters,
                                     reinterpret_cast<uint8_t*>(d_max_iter_exit), max_iter, exit_tol, mpcg_compat::launch_stream());
     if (rc != MPCG_OK) mpcg_compat::die("pcg", h);
+    mpcg_compat::warn_once_if_not_block_symmetric(h);
 }
 
 // Replaces cudaLaunchCooperativeKernel at include/pcg/sqp.cuh:230.  `kernel` is the void* the call

@@ -40,10 +40,13 @@
  *   - every pointer named d_* is a DEVICE pointer on the handle's device; `stream` is a hipStream_t
  *     passed as void* (NULL = default stream).  Calls are stream-ordered and never synchronise.
  *   - batched entry points take `batch` independent trajectories stored back to back.
- *   - GRAPH CAPTURE.  Every compute entry point is pure stream work and may be captured into a hipGraph.  What the PCG entry points need is
- *     allocated by mpcg_create; mpcg_form_schur(_f64), mpcg_block_solve and a FORCED "cluster" on a horizon the automatic policy gives to one
+ *   - GRAPH CAPTURE.  Every compute entry point is pure stream work and may be captured into a hipGraph.  What the float PCG entry points need
+ *     is allocated by mpcg_create; mpcg_form_schur(_f64), mpcg_block_solve and a FORCED "cluster" on a horizon the automatic policy gives to one
  *     CU allocate a handle-owned work buffer at their first call (hipMalloc is not stream work): make that call once outside the capture — a
- *     first call on a capturing stream returns MPCG_ERR_INVALID with a message and leaves the capture intact.
+ *     first call on a capturing stream returns MPCG_ERR_INVALID with a message and leaves the capture intact.  linsys_t = double beyond 32
+ *     knots (mpcg_pcg_solve_f64 / _ref_f64: cluster kernels with a queue + flags buffer and a double-sized copy of lambda0): mpcg_create makes
+ *     those buffers while they are small (max_batch x knot_points x state_size x 8 B <= 8 MB — every handle of the C++ shim), larger handles at
+ *     their first double solve outside a capture or when the caller sets "reserve_f64" = 1 ahead of it (float-only callers never pay for them).
  *
  * All functions return MPCG_OK (0) or a negative mpcg_status; mpcg_last_error() gives the text.
  * Nothing here falls back to a CPU implementation: without a gfx950 device every compute entry
@@ -61,7 +64,13 @@ extern "C" {
 
 /* 2 (round 5): the BLOCK SYMMETRY contract is checked by the handle itself (a caller that fills ONLY the left + diagonal block columns must
  * set "assume_symmetric" = 1 — round-3 text allowed garbage in the right blocks without it); options pcg_lpb / cluster_lpb / cluster_lpk /
- * cluster_waves / cluster_adj / schur_fma / schur_inplace are gone; mpcg_probe_hbm_read and "kkt_analytic" are new. */
+ * cluster_waves / cluster_adj / schur_fma / schur_inplace are gone; mpcg_probe_hbm_read and "kkt_analytic" are new.
+ * This reaches the reference's real-time horizon too: float 16 < N <= 32 at >= 2.5 trajectories per CU runs a lower-triangle kernel since
+ * round 5 (below that batch, and at N <= 16, the row-per-lane kernel reads all three columns as before) — such calls are launched GUARDED
+ * (check kernel + two gated kernels) until the handle's latch resolves, for good on a handle whose matrices violated the contract, and results
+ * differ bitwise between batch sizes either side of the threshold.  mpcg_get_option("symmetry_state") = 2 / the warning in mpcg_last_error()
+ * say when a handle has been sent to the three-column kernels; the C++ shim prints that warning once per handle to stderr.
+ * Round 6, same ABI: "reserve_f64" (below, GRAPH CAPTURE); a latch that resolved on block-Jacobi calls re-opens at the first SS call. */
 #define MPCG_ABI_VERSION 2
 
 typedef enum mpcg_status {

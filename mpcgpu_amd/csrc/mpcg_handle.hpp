@@ -66,6 +66,11 @@ struct mpcg_handle {
     int sym_state = 0;
     bool sym_pending = false;
     unsigned long long sym_guard_seq = 0, sym_armed_seq = 0;   // guarded launches issued / the one whose flag copy is in flight (sym_poll)
+    // Pinv has off-diagonal blocks only in SS calls: a latch that resolved on block-Jacobi calls alone has never seen a Pinv.  sym_pinv_guarded:
+    // some guarded check so far included Pinv (the device flag is sticky: an armed copy covers every check issued before it);
+    // sym_armed_pinv: its value when the copy in flight was armed; sym_pinv_ok: state 1 covers Pinv too (else the first SS call re-opens the latch).
+    bool sym_pinv_guarded = false, sym_armed_pinv = false, sym_pinv_ok = false;
+    bool sym_flag_reset = false;   // "assume_symmetric" = 0 after a violation: the sticky device flag is cleared by the next solve, on its stream
     hipEvent_t sym_event = nullptr;
     unsigned long long* sym_host = nullptr;      // pinned
     unsigned long long* cluster_scratch = nullptr;

@@ -42,6 +42,7 @@ static void sym_poll(mpcg_handle* h, hipStream_t st = nullptr, bool have_stream 
                  "runs kernels that read all three block columns (include/mpcg.h, BLOCK SYMMETRY)";
     } else {
         h->sym_state = 1;
+        h->sym_pinv_ok = h->sym_armed_pinv;
     }
 }
 
@@ -78,11 +79,23 @@ static size_t cluster_alloc_words(const mpcg_handle* h) {
            + 16;                         // + one line for the "cluster_fixups" counter (never re-zeroed by a launch)
 }
 static unsigned long long* fixup_counter(const mpcg_handle* h) { return h->cluster_scratch + cluster_alloc_words(h) - 16; }
+// A handle whose latch resolved on block-Jacobi calls knows S only: the first SS call (Pinv has off-diagonal blocks) re-opens it, so that its
+// Pinv goes through a check before a lower-triangle kernel reads it.  Also where a pending reset of the device flag is issued.
+static int sym_prepare(mpcg_handle* h, int pcols, hipStream_t st) {
+    if (h->sym_state == 1 && pcols == 3 && !h->sym_pinv_ok) h->sym_state = 0;
+    if (h->sym_flag_reset) {
+        hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, fixup_counter(h) + 9, (size_t)1);
+        HIP_TRY(h, hipGetLastError());
+        h->sym_flag_reset = false;
+    }
+    return MPCG_OK;
+}
 // The handle's copy of lambda0 (mpcg_handle::lam_backup).  mpcg_create sizes it for every horizon the automatic policy gives to a cluster kernel;
 // a forced "cluster" = G on a shorter horizon allocates at its first launch (hipMalloc: not inside a stream capture).
 static int ensure_lam_backup(mpcg_handle* h, size_t bytes, hipStream_t st) {
     if (h->lam_backup_bytes >= bytes) return MPCG_OK;
-    { const int rc = alloc_allowed(h, st, "a forced \"cluster\" on a horizon the automatic policy gives to one CU"); if (rc != MPCG_OK) return rc; }
+    { const int rc = alloc_allowed(h, st, "a cluster launch whose copy of lambda mpcg_create did not size (a forced \"cluster\" on a horizon the automatic policy gives to one CU; a "
+                                          "first double solve on a handle created with more than 8 MB of double iterates: \"reserve_f64\")"); if (rc != MPCG_OK) return rc; }
     if (h->lam_backup) {
         HIP_TRY(h, hipDeviceSynchronize());              // (an earlier call's fix-up launch may still read the old copy)
         HIP_TRY(h, hipFree(h->lam_backup));
@@ -105,7 +118,35 @@ static int launch_cluster_prologue(mpcg_handle* h, unsigned long long* words, si
     HIP_TRY(h, hipGetLastError());
     return MPCG_OK;
 }
+// no fix-up launch behind a cluster launch: report the trajectories whose completion count is short of G (cluster_report_kernel)
+static int launch_cluster_report(mpcg_handle* h, const unsigned long long* flags, int G, uint32_t batch, uint32_t* iters, uint8_t* exits, hipStream_t st) {
+    hipLaunchKernelGGL(cluster_report_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, flags, (int)CL_FLAG_STRIDE, (unsigned long long)G, (int)batch, iters, exits);
+    HIP_TRY(h, hipGetLastError());
+    return MPCG_OK;
+}
 static size_t cluster64_alloc_words(const mpcg_handle* h);
+static constexpr size_t kEagerF64Bytes = (size_t)8 << 20;
+// the double cluster kernels' buffers: queue + flags + cells, and the double-sized copy of lambda0 their fix-up launch starts from.  Blocking
+// (hipMalloc): mpcg_create for small handles, "reserve_f64" = 1, or the first double cluster solve outside a capture.
+static int reserve_f64(mpcg_handle* h) {
+    if (h->generic || h->N <= 32 || h->N > kCluster64MaxN) return MPCG_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->cluster64_scratch) {
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->cluster64_scratch), cluster64_alloc_words(h) * sizeof(unsigned long long)));
+        HIP_TRY(h, hipMemset(h->cluster64_scratch, 0, cluster64_alloc_words(h) * sizeof(unsigned long long)));
+    }
+    const size_t bytes = (size_t)h->max_batch * h->N * h->n * sizeof(double);
+    if (h->lam_backup_bytes < bytes) {
+        if (h->lam_backup) {
+            HIP_TRY(h, hipDeviceSynchronize());              // (an earlier call's fix-up launch may still read the old copy)
+            HIP_TRY(h, hipFree(h->lam_backup));
+            h->lam_backup = nullptr; h->lam_backup_bytes = 0;
+        }
+        HIP_TRY(h, hipMalloc(&h->lam_backup, bytes));
+        h->lam_backup_bytes = bytes;
+    }
+    return MPCG_OK;
+}
 
 size_t mpcg_pcg_lds_bytes(uint32_t state_size, uint32_t knot_points) {
     if (generic_shape_supported(state_size, knot_points)) return pcg_generic_lds_elems((int)knot_points, (int)state_size) * sizeof(float);
@@ -163,21 +204,18 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
         delete h;
         return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the dispatch-order buffer");
     }
-    // the clustered double kernel's queue + flags + cells (0.5 MB at max_batch 4096), here for the same reason: a fresh handle's first
-    // mpcg_pcg_solve_f64 may be a captured one
-    if (!generic && knot_points > 32 && knot_points <= kCluster64MaxN) {
-        if (hipMalloc(reinterpret_cast<void**>(&h->cluster64_scratch), cluster64_alloc_words(h) * sizeof(unsigned long long)) != hipSuccess) {
-            (void)hipFree(h->cluster_scratch); (void)hipFree(h->sched_order);
-            delete h;
-            return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the double-precision cluster scratch");
-        }
-        (void)hipMemset(h->cluster64_scratch, 0, cluster64_alloc_words(h) * sizeof(unsigned long long));
-    }
-    // the copy of lambda0 that cluster fix-up launches start from: float clusters beyond one CU's horizon, double clusters beyond N = 32
+    // linsys_t = double beyond N = 32 runs cluster kernels with a queue + flags + cells buffer of their own and a DOUBLE-sized copy of lambda0.
+    // A float caller never needs either (N = 128, max_batch 4096 = 59 MB per handle for nothing), so mpcg_create makes them only
+    // while they are small (<= 8 MB of double iterates: every handle of the C++ shim, max_batch = 1) — then a fresh handle's first
+    // mpcg_pcg_solve_f64 may still be a captured one; larger handles allocate at the first double solve, outside a capture, or when the caller
+    // sets "reserve_f64" = 1 (mpcg.h, GRAPH CAPTURE).  Float clusters (N > 128) get their float-sized copy here as before.
     if (!generic && knot_points > 32) {
-        const size_t esz = knot_points <= kCluster64MaxN ? sizeof(double) : sizeof(float);
-        if (knot_points > kLpbMaxN || esz == sizeof(double)) {
-            const size_t bytes = (size_t)max_batch * knot_points * state_size * esz;
+        const size_t bytes64 = (size_t)max_batch * knot_points * state_size * sizeof(double);
+        if (knot_points <= kCluster64MaxN && bytes64 <= kEagerF64Bytes) {
+            const int rc = reserve_f64(h);
+            if (rc != MPCG_OK) { const std::string e = h->err; (void)mpcg_destroy(h); return fail(nullptr, rc, "mpcg_create: " + e); }
+        } else if (knot_points > kLpbMaxN) {
+            const size_t bytes = (size_t)max_batch * knot_points * state_size * sizeof(float);
             if (hipMalloc(&h->lam_backup, bytes) != hipSuccess) {
                 (void)mpcg_destroy(h);
                 return fail(nullptr, MPCG_ERR_NOMEM, "mpcg_create: cannot allocate the copy of lambda the cluster fix-up starts from");
@@ -263,10 +301,15 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "nt_loads")) { h->nt_loads = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_fixup")) { h->cluster_fixup = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster_l2")) { h->cluster_l2 = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "reserve_f64")) { return value ? reserve_f64(h) : MPCG_OK; }
     if (!strcmp(key, "cluster_test_fail")) { h->cluster_test_fail = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "check_symmetry")) { h->check_symmetry = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "assume_symmetric")) {      // 1: the caller vouches (or fills only the lower block triangle): no check; 0: back to "unknown"
-        h->sym_state = value ? 1 : 0; h->sym_pending = false; return MPCG_OK;
+        // (1 vouches for Pinv too.  0 also forgets a violation: the sticky device flag is cleared by the next solve, on its stream)
+        h->sym_state = value ? 1 : 0; h->sym_pending = false; h->sym_pinv_ok = value != 0;
+        h->sym_pinv_guarded = h->sym_armed_pinv = false;
+        if (!value) h->sym_flag_reset = true;
+        return MPCG_OK;
     }
     if (!strcmp(key, "schur_dpp")) { h->schur_dpp = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "schur_chunk")) { if (value < 0 || value > 2048) return fail(h, MPCG_ERR_INVALID, "schur_chunk must be 0 (auto) or 1..2048 block rows"); h->schur_chunk = value; return MPCG_OK; }
@@ -626,6 +669,9 @@ static int try_launch_cluster(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
         c.lam0 = static_cast<const float*>(h->lam_backup);     // (members that finished a trajectory their cluster did not have written their knots of lambda)
         const int rc = h->N <= kLpbMaxN && !guarded ? launch_lpk(h, c, batch, st) : launch_traj(h, kf, c, batch, st, esz, /*record=*/false);
         if (rc != MPCG_OK) return rc;
+    } else {
+        const int rc = launch_cluster_report(h, ca.fail_flags, G, batch, a.iters, a.max_iter_exit, st);
+        if (rc != MPCG_OK) return rc;
     }
     h->last = LastKernel{FAM_LPKC, 4 * NWR, 0, 0, 0, G, (int)lds, 0};
     return MPCG_OK;
@@ -667,6 +713,9 @@ static int launch_generic_f32(mpcg_handle* h, const PcgArgs& a, uint32_t batch, 
 // in float — measured on the bench's systems: 2.5e-5 of the largest entry in the median, 6e-5 at worst, more on worse-conditioned blocks —
 // so the check looks for STRUCTURAL asymmetry (a caller-made Pinv), not for rounding.
 static constexpr float kSymRelTol = 1e-2f;
+// (double: the two associations agree to ~1e-13; anything at the 1e-6 level is a different matrix, and a lower-triangle kernel would solve a
+//  different system than the caller's without a word — ADVICE r05)
+static constexpr double kSymRelTol64 = 1e-6;
 
 // block pairs of S and (SS only) Pinv that fail the check.  Blocking: waits for `st`.
 // S (and Pinv when it has off-diagonal blocks) of one call through bd_symmetry_check_kernel, in the call's storage type
@@ -704,6 +753,7 @@ static int launch_guarded(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipS
     const long items = (long)batch * ((long)h->N - 1);
     const unsigned blocks = (unsigned)((items + 3) / 4);
     ++h->sym_guard_seq;
+    if (a.pcols == 3) h->sym_pinv_guarded = true;
     launch_symmetry_check(h, a, batch, st, blocks, nullptr, flag);
     HIP_TRY(h, hipGetLastError());
     PcgArgs p = a;
@@ -737,6 +787,7 @@ static int launch_guarded(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipS
         HIP_TRY(h, hipEventRecord(h->sym_event, st));
         h->sym_pending = true;
         h->sym_armed_seq = h->sym_guard_seq;
+        h->sym_armed_pinv = h->sym_pinv_guarded;
     }
     return MPCG_OK;
 }
@@ -763,6 +814,7 @@ static int launch_pcg(mpcg_handle* h, const PcgArgs& a_in, uint32_t batch, hipSt
     } else if (a.redo_flags == nullptr && (use_lpk(h, esz, batch) || (h->cluster != 0 && (h->cluster > 0 || (h->auto_cfg && h->N > kLpbMaxN))))) {
         // the symmetry latch (see launch_guarded): no synchronisation, no per-solve D2H
         sym_poll(h, st, true);
+        { const int rc = sym_prepare(h, a.pcols, st); if (rc != MPCG_OK) return rc; }
         if (h->sym_state == 2) lower_ok = false;
         else if (h->sym_state == 0) {
             const int rc = launch_guarded(h, a, batch, st);
@@ -851,10 +903,10 @@ static int try_launch_cluster_f64(mpcg_handle* h, const PcgArgs64& a, uint32_t b
     if (G == 0) return 1;
     if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "batch exceeds max_batch");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (!h->cluster64_scratch) {                       // (mpcg_create made it for every horizon this kernel serves)
-        { const int rc = alloc_allowed(h, st, "mpcg_pcg_solve_f64"); if (rc != MPCG_OK) return rc; }
-        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->cluster64_scratch), cluster64_alloc_words(h) * sizeof(unsigned long long)));
-        HIP_TRY(h, hipMemset(h->cluster64_scratch, 0, cluster64_alloc_words(h) * sizeof(unsigned long long)));
+    if (!h->cluster64_scratch || (h->cluster_fixup && h->lam_backup_bytes < (size_t)h->max_batch * h->N * NS * sizeof(double))) {
+        // (mpcg_create made them for handles with <= 8 MB of double iterates; "reserve_f64" = 1 makes them ahead of a capture)
+        { const int rc = alloc_allowed(h, st, "mpcg_pcg_solve_f64 (or set \"reserve_f64\" = 1 first)"); if (rc != MPCG_OK) return rc; }
+        { const int rc = reserve_f64(h); if (rc != MPCG_OK) return rc; }
     }
     const uint32_t resident = lpkc_resident_clusters(h, G);
     const uint32_t clusters = batch < resident ? batch : resident;
@@ -887,6 +939,9 @@ static int try_launch_cluster_f64(mpcg_handle* h, const PcgArgs64& a, uint32_t b
         c.lam0 = static_cast<const double*>(h->lam_backup);
         const int rc = launch_generic<double, 14>(h, c, batch, st);
         if (rc != MPCG_OK) return rc;
+    } else {
+        const int rc = launch_cluster_report(h, ca.fail_flags, G, batch, a.iters, a.max_iter_exit, st);
+        if (rc != MPCG_OK) return rc;
     }
     h->last = LastKernel{FAM_RPLC64, RPLC_NW, 0, 0, 0, G, (int)lds, 0};
     return MPCG_OK;
@@ -907,10 +962,10 @@ static int try_launch_cluster_lqk_f64(mpcg_handle* h, const PcgArgs64& a, uint32
     if (G == 0) return 1;
     if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "batch exceeds max_batch");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (!h->cluster64_scratch) {                       // (mpcg_create made it for every horizon this kernel serves by default)
-        { const int rc = alloc_allowed(h, st, "mpcg_pcg_solve_f64"); if (rc != MPCG_OK) return rc; }
-        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->cluster64_scratch), cluster64_alloc_words(h) * sizeof(unsigned long long)));
-        HIP_TRY(h, hipMemset(h->cluster64_scratch, 0, cluster64_alloc_words(h) * sizeof(unsigned long long)));
+    if (!h->cluster64_scratch || (h->cluster_fixup && h->lam_backup_bytes < (size_t)h->max_batch * h->N * NS * sizeof(double))) {
+        // (mpcg_create made them for handles with <= 8 MB of double iterates; "reserve_f64" = 1 makes them ahead of a capture)
+        { const int rc = alloc_allowed(h, st, "mpcg_pcg_solve_f64 (or set \"reserve_f64\" = 1 first)"); if (rc != MPCG_OK) return rc; }
+        { const int rc = reserve_f64(h); if (rc != MPCG_OK) return rc; }
     }
     const uint32_t resident = lpkc_resident_clusters(h, G);
     const uint32_t clusters = batch < resident ? batch : resident;
@@ -945,6 +1000,9 @@ static int try_launch_cluster_lqk_f64(mpcg_handle* h, const PcgArgs64& a, uint32
         c.lam0 = static_cast<const double*>(h->lam_backup);
         const int rc = launch_generic<double, 14>(h, c, batch, st);
         if (rc != MPCG_OK) return rc;
+    } else {
+        const int rc = launch_cluster_report(h, ca.fail_flags, G, batch, a.iters, a.max_iter_exit, st);
+        if (rc != MPCG_OK) return rc;
     }
     h->last = LastKernel{FAM_LQKC64, 8, 0, 0, 0, G, (int)lds, 0};
     return MPCG_OK;
@@ -955,20 +1013,27 @@ static int try_launch_cluster_lqk_f64(mpcg_handle* h, const PcgArgs64& a, uint32
 // kernel that reads all three columns).
 static int f64_symmetry_latch(mpcg_handle* h, const PcgArgs64& a, uint32_t batch, hipStream_t st) {
     sym_poll(h, st, true);
-    if (h->sym_state != 0 || h->sym_pending) return MPCG_OK;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return MPCG_OK;
+    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    if (h->sym_state == 1 && a.pcols == 3 && !h->sym_pinv_ok) {
+        // latched on block-Jacobi calls: this call's Pinv has never been looked at.  (A capturing call cannot check: it runs a three-column kernel.)
+        h->sym_state = 0;
+    }
+    if (h->sym_state != 0 || h->sym_pending) return MPCG_OK;
+    if (capturing) return MPCG_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    { const int rc = sym_prepare(h, a.pcols, st); if (rc != MPCG_OK) return rc; }
     unsigned long long* flag = fixup_counter(h) + 9;
     const long items = (long)batch * ((long)h->N - 1);
     const unsigned blocks = (unsigned)((items + 3) / 4);
     for (const double* m : {a.S, a.pcols == 3 ? a.Pinv : (const double*)nullptr})
-        if (m) hipLaunchKernelGGL(bd_symmetry_check_kernel<double>, dim3(blocks), dim3(256), 0, st, m, (int)h->N, (int)batch, kSymRelTol, (unsigned long long*)nullptr, flag);
+        if (m) hipLaunchKernelGGL(bd_symmetry_check_kernel<double>, dim3(blocks), dim3(256), 0, st, m, (int)h->N, (int)batch, (float)kSymRelTol64, (unsigned long long*)nullptr, flag);
     HIP_TRY(h, hipGetLastError());
     unsigned long long v = 0;
     HIP_TRY(h, hipMemcpyAsync(&v, flag, sizeof v, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     h->sym_state = v ? 2 : 1;
+    h->sym_pinv_ok = !v && a.pcols == 3;
     if (v) h->err = "warning: S / Pinv of a solve on this handle were not block-symmetric (block (k, right) != block (k+1, left)^T): the handle now "
                     "runs kernels that read all three block columns (include/mpcg.h, BLOCK SYMMETRY)";
     return MPCG_OK;

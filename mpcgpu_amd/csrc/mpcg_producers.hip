@@ -2,6 +2,9 @@
 // recovery (float and linsys_t = double), the CSR emitter of the QDLDL path and the block-tridiagonal direct solve, over the gfx950 kernels
 // in schur_kernels.hip.h / schur_walk.hip.h / schur_walk_f64.hip.h / block_solve.hip.h.
 #include "mpcg_handle.hpp"
+#ifndef MPCG_DZ64_CAPMUL
+#define MPCG_DZ64_CAPMUL 4      // (grid cap of compute_dz_dpp_f64_kernel in units of 64 workgroups per CU; tools/_prof/dz64_ab.py)
+#endif
 #include "schur_kernels.hip.h"
 #include "schur_walk.hip.h"
 #include "schur_walk_f64.hip.h"
@@ -177,6 +180,7 @@ int mpcg_form_schur_f64(mpcg_handle* h, uint32_t control_size, double* d_G_dense
         return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur_f64: bad preconditioner");
     if (batch == 0) return MPCG_OK;
     if (batch > h->max_batch) return fail(h, MPCG_ERR_INVALID, "mpcg_form_schur_f64: batch exceeds max_batch");
+    if ((uint64_t)batch * h->N >= (1ull << 31)) return fail(h, MPCG_ERR_UNSUPPORTED, "mpcg_form_schur_f64: batch * knot_points must stay below 2^31");     // (as mpcg_form_schur: the LDS kernels index knots with int)
     HIP_TRY(h, hipSetDevice(h->device));
     const int n = (int)h->n, m = (int)control_size, N = (int)h->N;
     const size_t Gsz = (size_t)(n * n + m * m) * N - m * m;
@@ -251,8 +255,11 @@ int mpcg_compute_dz_f64(mpcg_handle* h, uint32_t control_size, const double* d_G
     long blocks = (long)batch * h->N;
     const long cap = (long)h->num_cus * 64;
     if (h->dz_dpp && h->N >= 2 && (uint64_t)batch * h->N * 2352u < (1ull << 31)) {      // four knots per wavefront (schur_walk_f64.hip.h); 31-bit byte offsets into C
+        // (grid-stride over quads of knots, capped like the float kernel at 4 x cap one-wavefront workgroups.  Round 5 capped this one at cap —
+        //  126 VGPRs, four wavefronts per SIMD against the float kernel's seven — which left the 1024 x 128 call two quads per workgroup:
+        //  0.1165-0.1175 ms against 0.1126-0.1128 with the float kernel's cap, tools/_prof/dz64_ab.py)
         long bq = (blocks + 3) / 4;
-        if (bq > cap) bq = cap;
+        if (bq > cap * MPCG_DZ64_CAPMUL) bq = cap * MPCG_DZ64_CAPMUL;
         hipLaunchKernelGGL(sw64::compute_dz_dpp_f64_kernel, dim3((unsigned)bq), dim3(64), 0, static_cast<hipStream_t>(stream), a);
         HIP_TRY(h, hipGetLastError());
         return MPCG_OK;

@@ -729,6 +729,20 @@ __global__ __launch_bounds__(256) void zero_words_kernel(unsigned long long* p, 
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < count) p[i] = 0ull;
 }
+// Behind a cluster launch that NO fix-up launch follows ("cluster_fixup" = 0, or a horizon the fix-up kernel cannot hold): every trajectory
+// whose completion count is short of G is REPORTED here — d_iters = 0xFFFFFFFF, d_max_iter_exit = 2 — whatever the members themselves stored.
+// A member that gives up writes that pair itself, but member 0 may still pass its last hand-off (the failed peer published before it timed
+// out) and store a valid-looking count over it, and a cluster that gives up stops drawing from the queue: trajectories it would have drawn
+// get no store at all.  The completion counts know both.
+__global__ __launch_bounds__(256) void cluster_report_kernel(const unsigned long long* flags, int stride, unsigned long long G, int batch,
+                                                             uint32_t* iters, uint8_t* max_iter_exit) {
+    const int b = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (b >= batch) return;
+    if (__hip_atomic_load(flags + (size_t)b * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != G) {
+        iters[b] = 0xFFFFFFFFu;
+        max_iter_exit[b] = 2;
+    }
+}
 // The same fill + the handle's copy of the caller's lambda ([batch][N][n], n32 dwords): what a fix-up launch warm-starts from (PcgArgs::lam0).
 // One launch in front of every cluster launch.
 __global__ __launch_bounds__(256) void cluster_prologue_kernel(unsigned long long* p, size_t count, const uint32_t* src, uint32_t* dst, size_t n32) {
@@ -763,7 +777,9 @@ __global__ __launch_bounds__(256) void bd_symmetry_check_kernel(const MT* __rest
     for (int e = lane; e < NS * NS; e += 64) {
         const int i = e % NS, j = e / NS;
         const float x = (float)R[j * NS + i], y = (float)Lt[i * NS + j];
-        const float d = fabsf(x - y);
+        float d;
+        if constexpr (sizeof(MT) == 8) d = (float)fabs((double)R[j * NS + i] - (double)Lt[i * NS + j]);      // (the difference in the storage type: the double tolerance is 1e-6)
+        else d = fabsf(x - y);
         bad |= !(d == d);
         dmax = fmaxf(dmax, d);
         amax = fmaxf(amax, fmaxf(fabsf(x), fabsf(y)));

@@ -271,3 +271,49 @@ def test_fixup_starts_from_the_callers_lambda_even_if_some_members_finished(orc,
     solve(dS, dP, dg, lam2, cfg)
     torch.cuda.synchronize()
     assert torch.equal(lam2, lam_ok) and sol.get_option("cluster_fixups") == fixed
+
+
+@pytest.mark.parametrize("precision,N", [("float", 256), ("double", 128), ("double-rpl", 128), ("double", 384)])
+def test_without_a_fixup_launch_an_abandoned_trajectory_is_always_reported(precision, N):
+    """No fix-up launch behind the clusters ("cluster_fixup" = 0; double N > 350: the streaming kernel cannot hold the horizon, so there is none
+    either): a trajectory whose completion count is short of G must come back as d_iters = 0xFFFFFFFF / d_max_iter_exit = 2 — also when member 0
+    passed its last hand-off and stored a valid-looking count (the member that "fails" here does so at its write-back, after every hand-off), and
+    also when the cluster that would have drawn it has stopped drawing.  Everything else is solved and bit-identical to the
+    undisturbed call."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    dbl = precision != "float"
+    B, K = 140 if N < 384 else 48, 6
+    k = synth.make_kkt(N, 3, 8900 + N)
+    S3, P3, g3 = synth.form_schur(k, dtype=np.float64 if dbl else np.float32)
+    rep = (B + 2) // 3
+    S, Pinv, g = (np.tile(a_, (rep, 1))[:B] for a_ in (S3, P3, g3))
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    sol = PcgSolver(N, max_batch=B)
+    if precision == "double-rpl":
+        sol.set_option("pcg_lqk", 0)
+    if N < 384:
+        sol.set_option("cluster_fixup", 0)                # (N = 384 in double: on, but no fix-up kernel exists for that horizon)
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    solve = sol.solve_f64 if dbl else sol.solve
+    dt = torch.float64 if dbl else torch.float32
+    lam_ok = torch.zeros(B, n * N, dtype=dt, device="cuda")
+    it0, ex0 = solve(dS, dP, dg, lam_ok, cfg)
+    torch.cuda.synchronize()
+    assert sol.get_option("last_kernel_family") == {"float": 7, "double": 10, "double-rpl": 8}[precision]
+    assert (it0.cpu().numpy() == K).all() and (ex0.cpu().numpy() == 1).all()
+    sol.set_option("cluster_test_fail", 1)
+    lam = torch.zeros(B, n * N, dtype=dt, device="cuda")
+    it, ex = solve(dS, dP, dg, lam, cfg)
+    torch.cuda.synchronize()
+    ith, exh = it.cpu().numpy().view(np.uint32), ex.cpu().numpy()          # (d_iters is uint32_t: 0xFFFFFFFF, not -1)
+    gone = np.flatnonzero(ith == np.uint32(0xFFFFFFFF))
+    assert 1 <= len(gone) <= 2 and 0 in gone, gone         # the trajectory the member left + the one its peers then wait on
+    assert (exh[gone] == 2).all() and (np.delete(exh, gone) == 1).all() and (np.delete(ith, gone) == K).all()
+    keep = np.setdiff1d(np.arange(B), gone)
+    assert torch.equal(lam[keep], lam_ok[keep])
+    assert sol.get_option("cluster_fixups") == 0
+    sol.set_option("cluster_test_fail", 0)
+    lam2 = torch.zeros(B, n * N, dtype=dt, device="cuda")
+    it2, _ = solve(dS, dP, dg, lam2, cfg)
+    torch.cuda.synchronize()
+    assert (it2.cpu().numpy() == K).all() and torch.equal(lam2, lam_ok)

@@ -334,3 +334,72 @@ def test_hbm_read_probe_contract():
     assert sink.item() == 7.0
     with pytest.raises(RuntimeError):
         sol.probe_hbm_read(src[1:], sink)                   # 4-byte aligned only
+
+
+@pytest.mark.parametrize("precision", ["float", "double"])
+def test_a_latch_that_resolved_on_block_jacobi_calls_reopens_at_the_first_ss_call(orc, precision):
+    """block-Jacobi calls never show the handle a Pinv with off-diagonal blocks.  A handle whose latch resolved to "symmetric" on such
+    calls must not hand a later SS call with a caller-made, structurally asymmetric Pinv to a lower-triangle kernel unchecked: the first SS
+    call re-opens the latch, gets the three-column solve, and the handle ends up "violated".  "assume_symmetric" = 0 then forgets the violation
+    (the sticky device flag is cleared by the next solve): the same handle latches symmetric again on the reference's own matrices."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    dbl = precision == "double"
+    N, B, K = 128, 3, 12
+    dt = np.float64 if dbl else np.float32
+    k = synth.make_kkt(N, B, 4700)
+    S, Pinv, g = synth.form_schur(k, precond="ss", dtype=dt)
+    Pa = np.array(Pinv, dt).reshape(B, N, 3, 196).copy()
+    Pa[:, :, 2] *= 0.9
+    Pa = Pa.reshape(B, -1)
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    dS, dP, dPa, dg = dev(S), dev(Pinv), dev(Pa), dev(g)
+    sol = PcgSolver(N, max_batch=B)
+    solve = sol.solve_f64 if dbl else sol.solve
+    z = lambda: torch.zeros(B, n * N, dtype=torch.float64 if dbl else torch.float32, device="cuda")
+    for _ in range(3):                                    # block-Jacobi calls: the latch resolves on S alone
+        solve(dS, dP, dg, z(), cfg, "jacobi")
+        torch.cuda.synchronize()
+    assert sol.get_option("symmetry_state") == 1
+    lam = z()
+    it, ex = solve(dS, dPa, dg, lam, cfg, "ss")
+    torch.cuda.synchronize()
+    assert (it.cpu().numpy() == K).all()
+    for b in (0, B - 1):
+        ref = orc.pcg(S[b].astype(np.float64), Pa[b].astype(np.float64), g[b].astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")["lam"]
+        tol = 1e-9 if dbl else max(1e-3, 4 * fp32_band(orc, S[b], Pa[b], g[b], np.zeros(n * N), N, K, "ss", ref))
+        assert relinf(lam[b].cpu().numpy(), ref) <= tol, (b, relinf(lam[b].cpu().numpy(), ref), tol)
+    solve(dS, dPa, dg, z(), cfg, "ss")
+    torch.cuda.synchronize()
+    assert sol.get_option("symmetry_state") == 2 and "block-symmetric" in sol.last_error()
+    # forget it: back to "unknown", the device flag is cleared by the next solve; the reference's matrices latch symmetric again
+    sol.set_option("assume_symmetric", 0)
+    assert sol.get_option("symmetry_state") == 0
+    lam_ok = z()
+    for _ in range(3):
+        lam_ok.zero_()
+        solve(dS, dP, dg, lam_ok, cfg, "ss")
+        torch.cuda.synchronize()
+    assert sol.get_option("symmetry_state") == 1
+    assert sol.get_option("last_kernel_family") == (10 if dbl else 6)
+    ref = orc.pcg(S[0].astype(np.float64), Pinv[0].astype(np.float64), g[0].astype(np.float64), np.zeros(n * N), N, K, 0.0, "ss")["lam"]
+    assert relinf(lam_ok[0].cpu().numpy(), ref) <= (1e-9 if dbl else max(1e-3, 4 * fp32_band(orc, S[0], Pinv[0], g[0], np.zeros(n * N), N, K, "ss", ref)))
+
+
+def test_double_symmetry_check_uses_a_double_tolerance(orc):
+    """the float path's 1 % tolerance let a double S that is asymmetric at the 1e-3 level through to a lower-triangle kernel, which then
+    solves a different system than the caller's.  The double check looks at 1e-6 of the pair's largest entry."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, B, K = 64, 2, 10
+    k = synth.make_kkt(N, B, 4800)
+    S, Pinv, g = synth.form_schur(k, precond="ss", dtype=np.float64)
+    Pa = np.array(Pinv).reshape(B, N, 3, 196).copy()
+    Pa[:, :, 2] *= 1.0 + 1e-3
+    Pa = Pa.reshape(B, -1)
+    sol = PcgSolver(N, max_batch=B)
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    sol.solve_f64(dev(S), dev(Pa), dev(g), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), "ss")
+    torch.cuda.synchronize()
+    assert sol.get_option("symmetry_state") == 2 and sol.get_option("last_kernel_family") != 9
+    for b in range(B):
+        ref = orc.pcg(S[b], Pa[b], g[b], np.zeros(n * N), N, K, 0.0, "ss")["lam"]
+        assert relinf(lam[b].cpu().numpy(), ref) <= 1e-9

@@ -150,3 +150,49 @@ def test_first_call_allocations_are_refused_inside_a_capture_and_leave_it_intact
     graph2.replay()
     torch.cuda.synchronize()
     assert torch.equal(S2, S) and torch.equal(P2, P) and torch.equal(lam_d, want_d)
+
+
+def test_a_large_handles_first_double_solve_needs_reserve_f64_before_a_capture():
+    """Handles with more than 8 MB of double iterates do not get the double cluster kernels' buffers from mpcg_create (a float caller would pay
+    59 MB per handle at N = 128, max_batch 4096 for nothing — ADVICE r05): their first mpcg_pcg_solve_f64 allocates, so inside a capture it is
+    refused with a message and leaves the capture intact; "reserve_f64" = 1 makes the buffers ahead of it, and then the captured first call
+    replays the eager answer bit for bit."""
+    from mpcgpu_amd import PcgSolver, pcg_config
+    N, B, K = 128, 4, 8
+    big = 1024                                           # max_batch: 1024 x 128 x 14 x 8 B = 14.7 MB > 8 MB
+    k = synth.make_kkt(N, B, 6600)
+    S, Pinv, g = synth.form_schur(k, dtype=np.float64)
+    dS, dP, dg = dev(S), dev(Pinv), dev(g)
+    cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
+    eager = PcgSolver(N, max_batch=big)
+    eager.set_option("pcg_lqk", 0)                       # (a capturing first call cannot run the latch's check: the three-column cluster kernel)
+    want = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    eager.solve_f64(dS, dP, dg, want, cfg)
+    torch.cuda.synchronize()
+    assert eager.get_option("last_kernel_family") == 8
+
+    sol = PcgSolver(N, max_batch=big)
+    lam = torch.zeros(B, n * N, dtype=torch.float64, device="cuda")
+    lam32 = torch.zeros(B, n * N, device="cuda")
+    it = torch.zeros(B, dtype=torch.int32, device="cuda"); ex = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    S32, P32, g32 = dS.float(), dP.float(), dg.float()
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        with pytest.raises(RuntimeError, match="reserve_f64"):
+            sol.solve_f64(dS, dP, dg, lam, cfg, iters=it, exits=ex)
+        sol.solve(S32, P32, g32, lam32, cfg, "ss")       # the capture is intact: a float solve captured next to the refused call replays
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(lam32).all() and float(lam32.abs().max()) > 0
+
+    sol2 = PcgSolver(N, max_batch=big)
+    sol2.set_option("reserve_f64", 1)
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2):
+        lam.zero_()
+        sol2.solve_f64(dS, dP, dg, lam, cfg, iters=it, exits=ex)
+    graph2.replay()
+    torch.cuda.synchronize()
+    assert sol2.get_option("last_kernel_family") == 8 and (it.cpu().numpy() == K).all()
+    assert torch.equal(lam, want)
