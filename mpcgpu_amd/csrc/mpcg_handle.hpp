@@ -30,7 +30,7 @@ struct PcgKnobs {
 };
 
 // What the last solve on this handle actually launched (read-only "last_kernel_*" options; tests assert on it).
-enum { FAM_NONE = -1, FAM_TRAJ = 0, /* 1, 2, 4: kernels retired in round 4 (HISTORY.md) */ FAM_GENERIC = 3, FAM_RPL = 5, FAM_LPK = 6, FAM_LPKC = 7, FAM_RPLC64 = 8, FAM_LQK64 = 9, FAM_LQKC64 = 10 };
+enum { FAM_NONE = -1, FAM_TRAJ = 0, /* 1, 2, 4: kernels retired in round 4 (HISTORY.md) */ FAM_GENERIC = 3, FAM_RPL = 5, FAM_LPK = 6, FAM_LPKC = 7, FAM_RPLC64 = 8, FAM_LQK64 = 9, FAM_LQKC64 = 10, FAM_LQB = 11 };
 struct LastKernel { int family = FAM_NONE, waves = 0, reg_rows = 0, lds_rows = 0, stream_bufs = 0, cluster = 0, lds_bytes = 0, lds_extra = 0; };
 
 struct mpcg_handle {
@@ -56,6 +56,7 @@ struct mpcg_handle {
     size_t seam_qinv_bytes = 0;
     int cluster = -1;         // workgroups per trajectory of the clustered lane-pair kernel (pcg_lpk_cluster.hip.h): 0 off, -1 auto (N > 128), G > 0 forced
     int cluster_l2 = 1;       // clustered lane-pair kernel: 1 = L2-resident hand-offs when a cluster's members share an XCD, 0 = always write-through
+    int lqb = -1;             // the float lane-quad kernel (pcg_lqb.hip.h) in place of the lane-pair kernel: -1 auto, 0 off, 1 wherever the lane-pair kernel would run
     int cluster_fixup = 1;    // 1: a trajectory whose cluster gave up (bounded spin) is re-solved by the single-workgroup kernel
     int cluster_test_fail = 0; // tests only: the last member of cluster 0 gives up at the write-back of its first trajectory (ClusterArgs::test_fail)
     int check_symmetry = 0;   // debug: 1 = every solve that would run a lower-triangle kernel first verifies block symmetry of S and Pinv (synchronises)

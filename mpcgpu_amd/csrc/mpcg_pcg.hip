@@ -3,6 +3,7 @@
 #include "mpcg_handle.hpp"
 #include "pcg_kernels.hip.h"
 #include "pcg_lpk.hip.h"
+#include "pcg_lqb.hip.h"
 #include "pcg_lpk_cluster.hip.h"
 #include "pcg_rpl.hip.h"
 #include "pcg_rpl_cluster_f64.hip.h"
@@ -292,6 +293,10 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
         if (value == 1 && h->N > kLqkMaxN) return fail(h, MPCG_ERR_UNSUPPORTED, "pcg_lqk: the lane-quad kernel holds knot_points <= 64");
         h->lqk = value; return MPCG_OK;
     }
+    if (!strcmp(key, "pcg_lqb")) {
+        if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "pcg_lqb must be -1 (auto), 0 (off) or 1 (in place of the lane-pair kernel)");
+        h->lqb = value; return MPCG_OK;
+    }
     if (!strcmp(key, "pcg_lpk")) {
         if (value < -1 || value > 1) return fail(h, MPCG_ERR_INVALID, "pcg_lpk must be -1 (auto), 0 (off) or 1 (forced)");
         if (value == 1 && h->N > kLpbMaxN) return fail(h, MPCG_ERR_UNSUPPORTED, "pcg_lpk: the lane-pair kernel holds knot_points <= 128");
@@ -333,6 +338,7 @@ int mpcg_get_option(const mpcg_handle* h, const char* key, int* value) {
     if (!strcmp(key, "pcg_waves")) { *value = h->k.waves; return MPCG_OK; }
     if (!strcmp(key, "pcg_max_wg_per_cu")) { *value = h->k.max_wg_per_cu; return MPCG_OK; }
     if (!strcmp(key, "pcg_lpk")) { *value = h->lpk; return MPCG_OK; }
+    if (!strcmp(key, "pcg_lqb")) { *value = h->lqb; return MPCG_OK; }
     if (!strcmp(key, "pcg_lqk")) { *value = h->lqk; return MPCG_OK; }
     if (!strcmp(key, "pcg_rpl")) { *value = h->rpl; return MPCG_OK; }
     if (!strcmp(key, "rpl_waves")) { *value = h->rpl_waves; return MPCG_OK; }
@@ -536,7 +542,24 @@ static int launch_lpk_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStr
     h->last = LastKernel{FAM_LPK, LpkLds<NWR>::NW, 0, 0, 0, 0, (int)lds, 0};
     return MPCG_OK;
 }
+// ---- lane-quad-per-knot kernel, both matrices in every wavefront (pcg_lqb.hip.h): the lane-pair kernel's contract, two working wavefronts per SIMD ----
+template <int NMAXQ>
+static int launch_lqb_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    const size_t lds = pcg_lqb_lds_floats(NMAXQ) * sizeof(float);
+    auto kern = pcg_lqb_kernel<NMAXQ>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(batch), dim3(NMAXQ * 4), lds, st, a);
+    HIP_TRY(h, hipGetLastError());
+    h->last = LastKernel{FAM_LQB, NMAXQ / 16, 0, 0, 0, 0, (int)lds, 0};
+    return MPCG_OK;
+}
+static bool use_lqb(const mpcg_handle* h, int esz) { return esz == 4 && h->lqb == 1; }
 static int launch_lpk(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
+    if (use_lqb(h, a.esz)) {
+        if (h->N <= 32) return launch_lqb_t<32>(h, a, batch, st);
+        return h->N <= 64 ? launch_lqb_t<64>(h, a, batch, st) : launch_lqb_t<128>(h, a, batch, st);
+    }
     if (h->N <= 32) return launch_lpk_t<0>(h, a, batch, st);          // the half build: one wavefront per matrix, four workgroups per CU
     return h->N <= 64 ? launch_lpk_t<1>(h, a, batch, st) : launch_lpk_t<2>(h, a, batch, st);
 }
