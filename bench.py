@@ -373,7 +373,7 @@ def main():
     t_local = time.perf_counter() - t0
     t_all = D.max_over_ranks(t_local, dev)
 
-    fam = {0: "pcg_traj_kernel", 3: "pcg_generic_kernel", 5: "pcg_rpl_kernel", 6: "pcg_lpk_kernel", 7: "pcg_lpkc_kernel"}[sol.get_option("last_kernel_family")]
+    fam = {0: "pcg_traj_kernel", 3: "pcg_generic_kernel", 5: "pcg_rpl_kernel", 6: "pcg_lpk_kernel", 7: "pcg_lpkc_kernel", 11: "pcg_lqb_kernel"}[sol.get_option("last_kernel_family")]
     kdesc = {"family": fam, **{k: sol.get_option("last_kernel_" + k) for k in ("waves", "reg_rows", "lds_rows", "stream_bufs", "cluster", "lds_bytes")}}
     it_host = h_it.numpy().astype(np.int64)          # what the timed region's last step copied back
     ex_host = h_ex.numpy().copy()

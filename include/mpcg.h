@@ -14,8 +14,8 @@
  *     (N-1,col 2) are never written by the reference (:97,118) and are never read here.
  *   - BLOCK SYMMETRY.  PCG needs symmetric S and Pinv, and the reference's are: it writes S[k,right] as the transposed copy of
  *     S[k+1,left] (include/pcg/linsys_setup.cuh:536-557, bit for bit) and forms the symmetric-stair Pinv[k,right] / Pinv[k+1,left] as the
- *     same triple product associated two ways (:97-136; in float they differ by ~3e-5 of the largest entry on the bench's systems).  The register-resident kernels that serve fp32 horizons above 36 knots by
- *     default ("last_kernel_family" 6 and 7) READ ONLY THE LEFT AND DIAGONAL block columns and apply L_{k+1}^T where the reference's kernel
+ *     same triple product associated two ways (:97-136; in float they differ by ~3e-5 of the largest entry on the bench's systems).  The register-resident kernels that serve fp32 horizons above 32 knots by
+ *     default ("last_kernel_family" 6, 7 and 11) READ ONLY THE LEFT AND DIAGONAL block columns and apply L_{k+1}^T where the reference's kernel
  *     reads block (k,right); the right blocks of d_S / d_Pinv may then hold anything (tests poison them with NaN).  On the reference's
  *     matrices the results agree to that round-off of Pinv (iterates after K iterations: 1e-6 .. 3e-5, inside the fp32 band; bit-identical for S).
  *     THE HANDLE CHECKS THIS ONCE, BY ITSELF (round 4): until it knows, every solve that would run a lower-triangle kernel is launched
@@ -70,7 +70,10 @@ extern "C" {
  * (check kernel + two gated kernels) until the handle's latch resolves, for good on a handle whose matrices violated the contract, and results
  * differ bitwise between batch sizes either side of the threshold.  mpcg_get_option("symmetry_state") = 2 / the warning in mpcg_last_error()
  * say when a handle has been sent to the three-column kernels; the C++ shim prints that warning once per handle to stderr.
- * Round 6, same ABI: "reserve_f64" (below, GRAPH CAPTURE); a latch that resolved on block-Jacobi calls re-opens at the first SS call. */
+ * Round 6, same ABI: "reserve_f64" (below, GRAPH CAPTURE); a latch that resolved on block-Jacobi calls re-opens at the first SS call; the
+ * default float kernel for 32 < knot_points <= 128 is the lane-quad kernel ("pcg_lqb", family 11) — another summation order: results differ
+ * from round 5's in the last float bits (inside the stated band), and latency-sized calls at 33..64 knots, which the three-column row-per-lane
+ * kernel served, now run a lower-triangle kernel too (guarded until the latch resolves; "pcg_lqb" = 0 restores round 5's choices). */
 #define MPCG_ABI_VERSION 2
 
 typedef enum mpcg_status {
@@ -317,9 +320,14 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  * Kernel selection of a float solve (state_size 14):
  *   "pcg_rpl" (-1 auto / 0 / 1): the row-per-lane kernel for knot_points <= 64 — a DPP row per knot, vectors in registers; automatic for
  *       knot_points <= 32 and for calls of at most one trajectory per CU up to 64; "rpl_waves" (its wavefronts per trajectory: 0 auto, 4, 8, 16);
- *   "pcg_lpk" (-1 auto / 0 / 1): the lane-pair-per-knot kernel, knot_points <= 128 — everything in registers; automatic for 36 < knot_points <= 128
- *       and, in its half build (one wavefront per matrix, four workgroups per CU), for 16 < knot_points <= 32 when the call brings at least 2.5
- *       trajectories per CU;
+ *   "pcg_lpk" (-1 auto / 0 / 1): the lane-pair-per-knot kernel, knot_points <= 128 — everything in registers, a matrix per wavefront; the automatic
+ *       choice for block-Jacobi calls at 64 < knot_points <= 128 and for fp16 storage; = 1 forces it (and keeps the lane-quad kernel out);
+ *   "pcg_lqb" (-1 auto / 0 / 1; round 6): the lane-quad-per-knot kernel, knot_points <= 128 — everything in registers, a QUARTER of both matrices
+ *       in every wavefront, so that all wavefronts of a workgroup run every pass (two working wavefronts per SIMD).  It takes the lane-pair
+ *       kernel's launches (same contract: block lower triangle, gated and fix-up launches, dispatch order); automatic for 32 < knot_points <= 64
+ *       at every batch and both preconditioners, for SS calls at 64 < knot_points <= 128, and — with workgroups of 32 knots, four per CU — for
+ *       16 < knot_points <= 32 when the call brings at least 2.5 trajectories per CU; = 0 gives those calls back to the lane-pair kernel (and
+ *       the row-per-lane / row-pair kernels their round-5 ranges), = 1 runs it wherever the lane-pair kernel would run;
  *   "cluster" (-1 auto / 0 off / G = 2..8 forced): workgroups (= CUs of one XCD) per trajectory of the clustered lane-pair kernel, automatic
  *       for knot_points > 128 (G = ceil(N / 128)).  Members exchange inner-product partials and boundary knots through the XCD's L2
  *       ("cluster_l2" = 0: always write-through), so all members of a cluster must be resident: the launch holds as many clusters as fit the
@@ -353,17 +361,18 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  *       batch size; same bits), "kkt_analytic" (mpcg_generate_kkt: 1 = the analytic gradient recursion of the inverse dynamics, the default;
  *       0 = one-sided float64 differences, the checker), "nt_loads" / "spmv_blocks_per_cu" (mpcg_bt_spmv), "spmv_mfma" (the MFMA experiment kernel).
  * "assume_symmetric" (0 / 1), "symmetry_state" (read-only; 0 unknown, 1 block-symmetric, 2 violated): see BLOCK SYMMETRY above.
+ * "reserve_f64" (= 1: allocate the double cluster kernels' buffers now; see GRAPH CAPTURE above).
  * Read-only: "cluster_fixups" (trajectories re-solved by fix-up launches since mpcg_create — each costs 1.5-4.5 ms of spinning; blocking 8-byte
  *       D2H read), "last_symmetry_violations", "num_cus", "pcg_resident" (1 if the single-workgroup configuration streams nothing inside the PCG
  *       loop), "last_schur_chunk" (block rows per chunk of the last mpcg_form_schur, 0 = the LDS kernels), "last_kernel_family" (kernel of the
  *       last solve: 0 single-workgroup row-pair, 3 generic, 5 row-per-lane, 6 lane-pair-per-knot, 7 clustered lane-pair, 8 clustered row-per-lane
- *       (double), 9 lane-quad-per-knot (double), 10 clustered lane-quad (double); 1, 2, 4 were kernels retired in round 4), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
- * WHICH kernel family serves a call depends on knot_points AND on the call's batch (e.g. 32 < N <= 64: row-per-lane kernel up to one
- * trajectory per CU, lane-pair kernel beyond; N <= 32: 8 waves x 1 slot or 4 x 2 by batch, 16 < N <= 32: the lane-pair kernel's half build
- * from 2.5 trajectories per CU).  Families sum the inner products in different
+ *       (double), 9 lane-quad-per-knot (double), 10 clustered lane-quad (double), 11 lane-quad-per-knot with both matrices per wavefront (float, round 6); 1, 2, 4 were kernels retired in round 4), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
+ * WHICH kernel family serves a call depends on knot_points, on the preconditioner (64 < N <= 128: SS the lane-quad kernel, block-Jacobi the
+ * lane-pair kernel) AND, up to 32 knots, on the call's batch (N <= 32: row-per-lane kernel, 8 waves x 1 slot or 4 x 2 by batch; 16 < N <= 32:
+ * the lane-quad kernel from 2.5 trajectories per CU; 32 < N <= 128: one kernel at every batch since round 6).  Families sum the inner products in different
  * orders, so the SAME trajectory solved alone and inside a large batch may differ in the last fp32 bits (and, near the tolerance, by an
  * iteration); within one family results are bitwise reproducible run to run and independent of batch composition.  Pin a family with
- * "pcg_rpl" / "pcg_lpk" / "rpl_waves" when bit-stability across batch sizes matters.  None of the residency knobs changes results within a
+ * "pcg_rpl" / "pcg_lpk" / "pcg_lqb" / "rpl_waves" when bit-stability across batch sizes matters.  None of the residency knobs changes results within a
  * lane-order family (bitwise identical, tested). */
 int mpcg_set_option(mpcg_handle *h, const char *key, int value);
 int mpcg_get_option(const mpcg_handle *h, const char *key, int *value);

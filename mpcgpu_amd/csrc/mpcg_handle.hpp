@@ -105,6 +105,16 @@ static inline int fail(mpcg_handle* h, int code, const std::string& msg) {
             return fail((h), MPCG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// hipFree / hipEventDestroy / hipHostFree are "unsafe" calls while ANOTHER stream of the calling thread is being captured in the default (global)
+// capture mode: they invalidate that capture.  A destroy can come at any time — a garbage collector finalising an old handle while the caller
+// captures a solve of a new one (tests/test_gpu_graph.py, seen as a one-in-two failure of a capture inside the full suite) — so the destroy
+// functions run in relaxed mode, which permits them.
+struct RelaxedCaptureScope {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    RelaxedCaptureScope() { (void)hipThreadExchangeStreamCaptureMode(&mode); }
+    ~RelaxedCaptureScope() { (void)hipThreadExchangeStreamCaptureMode(&mode); }
+};
+
 // Buffers the handle allocates at the first call that needs them (hipMalloc is not stream work): a call that would have to allocate while its
 // stream is being captured is refused — message, MPCG_ERR_INVALID, capture intact — instead of failing inside the capture.  (mpcg.h, GRAPH CAPTURE)
 static inline int alloc_allowed(mpcg_handle* h, hipStream_t st, const char* what) {

@@ -236,6 +236,7 @@ int mpcg_create(mpcg_handle** out, int device, uint32_t state_size, uint32_t kno
 
 int mpcg_destroy(mpcg_handle* h) {
     if (h) {
+        RelaxedCaptureScope relaxed;
         (void)hipSetDevice(h->device);
         if (h->lam_backup) (void)hipFree(h->lam_backup);
         if (h->block_scratch) (void)hipFree(h->block_scratch);
@@ -554,9 +555,19 @@ static int launch_lqb_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStr
     h->last = LastKernel{FAM_LQB, NMAXQ / 16, 0, 0, 0, 0, (int)lds, 0};
     return MPCG_OK;
 }
-static bool use_lqb(const mpcg_handle* h, int esz) { return esz == 4 && h->lqb == 1; }
+// The float lane-quad kernel takes the lane-pair kernel's launches (same contract: lower block triangle, gated / fix-up launches, dispatch order).
+// Automatic use (tools/_prof/lqb_policy.py, profiles/r06_lqb_policy.txt; "pcg_lqb" = 1 / 0 forces / forbids, an explicit "pcg_lpk" = 1 keeps the lane-pair kernel):
+//   * knot_points <= 64: both preconditioners — two independent workgroups per CU, all of their wavefronts working: 1.21-1.30x the lane-pair /
+//     row-per-lane / row-pair kernels at every batch for SS (one trajectory of 64 knots: 0.193 against 0.246 ms), 1.09-1.39x block-Jacobi;
+//   * 64 < knot_points <= 128: SS only (1.01-1.11x; block-Jacobi's Pinv pass keeps the whole skeleton for a third of the FMAs: 0.90-0.99x).
+static bool lqb_auto(const mpcg_handle* h, int esz) { return esz == 4 && h->lqb == -1 && h->lpk == -1 && h->rpl != 1 && h->auto_cfg && h->cluster <= 0; }
+static bool use_lqb(const mpcg_handle* h, int esz, int pcols) {
+    if (esz != 4 || h->lqb == 0) return false;
+    if (h->lqb == 1) return true;
+    return lqb_auto(h, esz) && (h->N <= 64 || pcols == 3);
+}
 static int launch_lpk(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
-    if (use_lqb(h, a.esz)) {
+    if (use_lqb(h, a.esz, a.pcols)) {
         if (h->N <= 32) return launch_lqb_t<32>(h, a, batch, st);
         return h->N <= 64 ? launch_lqb_t<64>(h, a, batch, st) : launch_lqb_t<128>(h, a, batch, st);
     }
@@ -574,7 +585,9 @@ static bool lpk_half(const mpcg_handle* h, int esz, uint32_t batch) {
 }
 static bool use_lpk(const mpcg_handle* h, int esz, uint32_t batch) {
     if ((esz != 4 && esz != 2) || h->N > kLpbMaxN || h->lpk == 0) return false;     // (fp16 storage: converted once at the load)
-    return h->lpk == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > 36) || lpk_half(h, esz, batch);
+    // (with the lane-quad kernel behind launch_lpk: from 33 knots, at every batch — it beats the row-pair kernel at 33..36 and the row-per-lane kernel's
+    //  latency-sized calls up to 64, use_lqb)
+    return h->lpk == 1 || (h->auto_cfg && h->cluster <= 0 && h->N > (lqb_auto(h, esz) ? 32u : 36u)) || lpk_half(h, esz, batch);
 }
 
 // ---- row-per-lane kernel (pcg_rpl.hip.h): short horizons, NW wavefronts x RHO slots of four knots ----
@@ -615,7 +628,7 @@ static bool use_rpl(const mpcg_handle* h, int esz, uint32_t batch) {
     if (h->rpl == 1) return true;
     if (h->lpk == 1) return false;
     if (lpk_half(h, esz, batch)) return false;
-    return h->auto_cfg && h->cluster <= 0 && (h->N <= 32 || batch <= (uint32_t)h->num_cus);
+    return h->auto_cfg && h->cluster <= 0 && (h->N <= 32 || (batch <= (uint32_t)h->num_cus && !lqb_auto(h, esz)));
 }
 
 static int launch_traj(mpcg_handle* h, const PcgKnobs& k, const PcgArgs& a, uint32_t batch, hipStream_t st, int esz, bool record);
@@ -871,8 +884,8 @@ static int occupancy(mpcg_handle* h, const PcgKnobs& k, int* per_cu) {
 
 // LDS bytes of the launch a default-configured batch-1 solve makes (what pcgSharedMemSize stands for)
 static size_t default_launch_lds_bytes(uint32_t N, int num_cus) {
-    if (N <= kRplMaxN) return pcg_rpl_lds_floats((int)N, N <= 16 ? 4 : 8) * sizeof(float);      // row-per-lane kernel (a batch-1 call)
-    if (N <= kLpbMaxN) return pcg_lpk_lds_floats(8) * sizeof(float);                    // lane-pair kernel
+    if (N <= 32) return pcg_rpl_lds_floats((int)N, N <= 16 ? 4 : 8) * sizeof(float);           // row-per-lane kernel (a batch-1 call)
+    if (N <= kLpbMaxN) return pcg_lqb_lds_floats(N <= 64 ? 64 : 128) * sizeof(float);  // lane-quad kernel (SS; block-Jacobi beyond 64 knots: the lane-pair kernel, pcg_lpk_lds_floats(8))
     mpcg_handle tmp;
     tmp.N = N; tmp.n = NS; tmp.num_cus = num_cus;
     if (lpkc_members(&tmp) > 0) return pcg_lpkc_lds_floats(8) * sizeof(float);          // clustered lane-pair kernel
@@ -1147,6 +1160,14 @@ int mpcg_check_pcg_occupancy(mpcg_handle* h, uint32_t* resident_trajectories) {
 #define X(NW_, RHO_) if (nw == NW_ && rho == RHO_) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_rpl_kernel<NW_, RHO_, true>, NW_ * 64, lds));
         MPCG_RPL_VARIANTS(X)
 #undef X
+    } else if (use_lpk(h, 4, h->max_batch) && use_lqb(h, 4, 3)) {      // (an SS call)
+        const int nmax = h->N <= 32 ? 32 : h->N <= 64 ? 64 : 128;
+        const size_t lds = pcg_lqb_lds_floats(nmax) * sizeof(float);
+        const void* kern = nmax == 32 ? reinterpret_cast<const void*>(pcg_lqb_kernel<32>) : nmax == 64 ? reinterpret_cast<const void*>(pcg_lqb_kernel<64>) : reinterpret_cast<const void*>(pcg_lqb_kernel<128>);
+        HIP_TRY(h, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (nmax == 32) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lqb_kernel<32>, 128, lds));
+        else if (nmax == 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lqb_kernel<64>, 256, lds));
+        else HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lqb_kernel<128>, 512, lds));
     } else if (use_lpk(h, 4, h->max_batch)) {
         const size_t lds = pcg_lpk_lds_floats(h->N <= 32 ? 2 : h->N <= 64 ? 4 : 8) * sizeof(float);
         if (h->N <= 32) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpk_kernel<0>, 128, lds));
@@ -1193,7 +1214,7 @@ int mpcg_pcg_solve(mpcg_handle* h, const float* d_S, const float* d_Pinv, const 
     const bool hinted = h->sched_hint && !h->generic && batch > (uint32_t)h->num_cus;
     if (hinted) { a.order = h->sched_order; a.order_tag = batch; }       // (used only if the stored permutation was made for this batch: sched_pick)
     const int rc = launch_pcg(h, a, batch, static_cast<hipStream_t>(stream), 4);
-    if (rc == MPCG_OK && hinted && (h->last.family == FAM_LPK || h->last.family == FAM_LPKC || h->last.family == FAM_RPL)) {
+    if (rc == MPCG_OK && hinted && (h->last.family == FAM_LPK || h->last.family == FAM_LQB || h->last.family == FAM_LPKC || h->last.family == FAM_RPL)) {
         hipLaunchKernelGGL(sched_order_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), d_iters, (int)batch, h->sched_order);
         HIP_TRY(h, hipGetLastError());
     }

@@ -175,7 +175,7 @@ int mpcg_plant_create_iiwa14(mpcg_plant** out, int device) {
 }
 
 int mpcg_plant_destroy(mpcg_plant* p) {
-    if (p && p->d) { (void)hipSetDevice(p->device); (void)hipFree(p->d); }
+    if (p && p->d) { RelaxedCaptureScope relaxed; (void)hipSetDevice(p->device); (void)hipFree(p->d); }
     delete p;
     return MPCG_OK;
 }

@@ -227,6 +227,9 @@ __device__ __forceinline__ void lqb_epilogue(float& part, LqbPiece& fin, const L
     fin.p[0] = f2{k0, k1}; fin.p[1] = f2{k2, k3}; fin.p[2] = f2{k4, k5}; fin.s = k6;
 }
 
+// (alpha = eta / v and beta = eta' / eta stay IEEE divisions: v_rcp_f32 + one residual correction behind a wave-uniform range test — v_rcp_f32 has
+//  no denormal support, pcg_lpk.hip.h — measured SLOWER here too: 1.64-1.67 against 1.60 us per iteration of one N = 128 trajectory; the second
+//  code path costs two registers and the branch more than the seven dependent instructions it saves.)
 template <int NMAXQ>
 __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
     typedef LqbLds<NMAXQ> L;
@@ -287,6 +290,9 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
     }
     lds_barrier();
 
+#ifdef MPCG_PROF
+    bool prof_on = false;
+#endif
     // the NW wave partials of an inner product: requested FIRST after a barrier (volatile: in program order, ahead of the operand loads), summed in the
     // same order in every thread — deterministic; packed adds on the loaded register pairs: a tree of depth three
     typedef __attribute__((address_space(3))) const volatile f4 lds_cv_f4;
@@ -325,8 +331,9 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
     // Order (register budget): transposed product in two column groups -> direct L (x_{k-1}) -> direct D (x_k), the parked pairs last.
     // The coupling term of the inner product comes from the DIRECT product: x_{k-1}^T (L^T x_k) = x_k^T (L x_{k-1}), so that x_{k-1}'s piece is
     // dead once the L columns are done: x^T M x = sum x_k[piece g] . (ypart + L-part of ypart).
-    auto pass = [&](const LqbSub& D, const LqbSub& Lb, const LqbPiece& mine, bool hasL, int TOUT, float* red, const f2* park) {
+    auto pass = [&](const LqbSub& D, const LqbSub& Lb, const LqbPiece& mine, bool hasL, int TOUT, float* red, const f2* park, int pb) {
         const LqbPiece xg = lqb_quad<LQB_QP_XG>(mine);
+        MPCG_STAMP(pb + 1);
         LqbPiece ypart, zpart;
         f2 acc[3], dd;
         float y6, ds;
@@ -405,6 +412,7 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
         dd = __builtin_elementwise_fma(ypart.p[0], xg.p[0], dd);
         dd = __builtin_elementwise_fma(ypart.p[1], xg.p[1], dd);
         dd = __builtin_elementwise_fma(ypart.p[2], xg.p[2], dd);
+        MPCG_STAMP(pb + 2);
         float part = fmaf(ypart.s, xg.s, ds) + lqb_hsum(dd);
         LqbPiece fin;
         lqb_epilogue(part, fin, ypart, zpart, diag_mask);
@@ -413,6 +421,7 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
 #pragma unroll
         for (int rp = 0; rp < 3; ++rp) *reinterpret_cast<f2*>(out + ob + K2 * rp) = fin.p[rp];
         out[os] = fin.s;
+        MPCG_STAMP(pb + 3);
     };
     // the carried piece after an update: MODE 1: old - c (T + Z<<1) (r, c = alpha); MODE 2: (T + Z<<1) + c old (p, c = beta)
     auto rebuild = [&](auto mode_tag, const LqbPiece& old, const Fetch& f, float c) -> LqbPiece {
@@ -431,11 +440,11 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) pv.p[i] = f2{0.f, 0.f};
     pv.s = 0.f;
-    pass(SD, SL, lam, true, L::US, red_v, parkS);
+    pass(SD, SL, lam, true, L::US, red_v, parkS, 16);
     lds_barrier();
     Fetch f = fetch(L::US);
     rv = rebuild(std::integral_constant<int, 1>{}, rv, f, 1.f);
-    pass(PD, PL, rv, p3, L::RT, red_e, parkP);
+    pass(PD, PL, rv, p3, L::RT, red_e, parkP, 16);
     lds_barrier();
     Red rd = load_red(red_e);
     f = fetch(L::RT);
@@ -448,10 +457,15 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
         max_iter_exit = 0;
     } else {
         for (int it = 0; it < a.max_iter; ++it) {
+#ifdef MPCG_PROF
+            prof_on = b == 0 && it == 20;
+#endif
+            MPCG_STAMP(0);
             // p = r~ + beta p ; upsilon = S p ; v = p . upsilon
             pv = rebuild(std::integral_constant<int, 2>{}, pv, f, beta);
-            pass(SD, SL, pv, true, L::US, red_v, parkS);
+            pass(SD, SL, pv, true, L::US, red_v, parkS, 0);
             lds_barrier();
+            MPCG_STAMP(4);
             rd = load_red(red_v);
             f = fetch(L::US);                                   // (the operand loads fly during the scalar chain)
             // alpha = eta / v ; lambda += alpha p ; r -= alpha upsilon ; r~ = Pinv r ; eta' = r . r~
@@ -464,8 +478,10 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
             for (int i = 0; i < 3; ++i) lam.p[i] = lam.p[i] + alpha * pv.p[i];
             lam.s = lam.s + alpha * pv.s;
             rv = rebuild(std::integral_constant<int, 1>{}, rv, f, alpha);
-            pass(PD, PL, rv, p3, L::RT, red_e, parkP);
+            MPCG_STAMP(5);
+            pass(PD, PL, rv, p3, L::RT, red_e, parkP, 5);
             lds_barrier();
+            MPCG_STAMP(9);
             rd = load_red(red_e);
             f = fetch(L::RT);
             // eta' ; exit test ; beta
@@ -478,6 +494,7 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
             beta = uniform(eta_new / eta);
 #endif
             eta = eta_new;
+            MPCG_STAMP(10);
         }
     }
     // ---- lambda, p, r of knot k from the g = 0 lanes into the staging vectors (free since the setup), then out ----

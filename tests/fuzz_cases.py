@@ -68,6 +68,7 @@ def run(cases=120, seed=7, verbose=True):
         cfgk = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
         sol.solve_f16(S16, P16, dev(g), l16, cfgk, pc)
         fam16 = sol.get_option("last_kernel_family")
+        sol.set_option("pcg_lqb", 0)                       # (fp16 storage lives in the lane-pair kernels: the fp32 twin of this comparison runs there too)
         sol.solve(S16.float().contiguous(), P16.float().contiguous(), dev(g), l32, cfgk, pc)
         torch.cuda.synchronize()
         f16_count[fam16] += 1

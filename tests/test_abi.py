@@ -40,17 +40,20 @@ def test_exports_are_plain_c(hiplib):
 def test_version_and_lds_size(hiplib):
     assert hiplib.mpcg_abi_version() == 2
     assert b"gfx950" in hiplib.mpcg_build_info()
-    # = the dynamic LDS of the launch a default batch-1 solve makes.  64 < N <= 128: the lane-pair-per-knot kernel, whose
-    # layout is compile-time per wave count (64 or 128 knots): seven pair-major vectors of 7 x (NMAX + 4) float2, one partial per
-    # wave, three parked matrix pairs per lane, and (round 4) a second 6,272-byte load tile per wave
+    # = the dynamic LDS of the launch a default batch-1 SS solve makes.
     r4 = lambda x: (x + 3) & ~3
-    lpk = lambda nmax, nw: 4 * (7 * 7 * (nmax + 4) * 2 + nw + 3 * 2 * nw * 64 + nw * 8 * 196)
-    # N <= 64: the row-per-lane kernel of a batch-1 call — six vectors padded by a knot either side + 2 partials per wave (4 waves
-    # for N <= 16, else 8), DESIGN.md §3.1e
-    for N in (2, 16, 32, 48, 64):
+    # N <= 32: the row-per-lane kernel of a batch-1 call — six vectors padded by a knot either side + 2 partials per wave (4 waves
+    # for N <= 16, else 8), DESIGN.md §3.1
+    for N in (2, 16, 32):
         assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (6 * r4((N + 2) * 14) + r4(2 * (4 if N <= 16 else 8)))
+    # 32 < N <= 128 (round 6): the lane-quad kernel, layout compile-time per knots-per-workgroup (64 or 128): seven pair-major vectors of
+    # 7 x (NMAX + 4) float2 padded by 24 floats (T / Z bank offset), two partials per wave, and a second 6,272-byte load tile per wave whose
+    # tail holds the parked matrix pairs
+    lqb = lambda nmax: 4 * (7 * (7 * (nmax + 4) * 2 + 24) + 2 * (nmax // 16) + (nmax // 16) * 8 * 196)
+    for N in (33, 48, 64):
+        assert hiplib.mpcg_pcg_lds_bytes(14, N) == lqb(64) == 52448
     for N in (65, 128):
-        assert hiplib.mpcg_pcg_lds_bytes(14, N) == lpk(128, 8) == 114240
+        assert hiplib.mpcg_pcg_lds_bytes(14, N) == lqb(128) == 102656
     # N > 128: a member of the clustered lane-pair kernel — the same seven vectors, broadcast cell, hand-off tables (5 x 64), parked pairs (§3.1g)
     for N in (129, 256, 512):
         assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (7 * 7 * 132 * 2 + 4 + 5 * 64 + 3 * 2 * 8 * 64) == 65328

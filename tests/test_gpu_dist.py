@@ -24,4 +24,4 @@ def test_bench_runs_its_collectives_over_rccl_at_world_size_one(scaling):
     assert out["scaling"] == scaling and out["n_gpus"] == 1
     g = out["results_gather"]
     assert g["backend"] == "nccl (RCCL)" and g["trajectories"] == 96 and g["consistent_with_allreduce_sum"] is True
-    assert out["value"] > 0 and out["config"]["kernel_family"] in ("pcg_lpk_kernel", "pcg_rpl_kernel")
+    assert out["value"] > 0 and out["config"]["kernel_family"] in ("pcg_lqb_kernel", "pcg_lpk_kernel", "pcg_rpl_kernel")

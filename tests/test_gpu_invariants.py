@@ -101,7 +101,7 @@ def step_quantities(S, P, g, lam0, st_a, st_b, N, K, EPS32=EPS32):
 LIMITS = {"lam": 4.0, "r": 8.0, "p": 8.0, "alpha": 8.0, "beta": 8.0, "gap": 2.0, "conjugacy": 2e-3, "orthogonality": 2e-3}
 
 
-@pytest.mark.parametrize("N,family", [(32, 5), (128, 6), (512, 7)])
+@pytest.mark.parametrize("N,family", [(32, 5), (64, 11), (128, 11), (128, 6), (512, 7)])
 @pytest.mark.parametrize("pc", ["ss", "jacobi"])
 def test_one_step_of_the_recurrences_and_the_cg_invariants(N, family, pc):
     from mpcgpu_amd import PcgSolver
@@ -111,6 +111,8 @@ def test_one_step_of_the_recurrences_and_the_cg_invariants(N, family, pc):
     rng = np.random.default_rng(N)
     lam0 = (0.1 * rng.standard_normal(n * N)).astype(np.float32)
     sol = PcgSolver(N, max_batch=1)
+    if family in (6, 11):                                      # (the lane-pair / the lane-quad kernel, pinned: the policy picks by horizon and preconditioner)
+        sol.set_option("pcg_lpk", 1); sol.set_option("pcg_lqb", int(family == 11))
     dS, dP, dg = (torch.from_numpy(a).cuda() for a in (S, P, g))
     for K in (10, 50, 167):
         st_a = state(sol, dS, dP, dg, lam0, K - 1)

@@ -1,5 +1,7 @@
-"""GPU (MI355X): the lane-pair-per-knot PCG kernel (mpcgpu_amd/csrc/pcg_lpk.hip.h) — round 3's default for fp32,
-36 < knot_points <= 128 — through the C ABI, against the CPU oracle, the golden vectors and the single-workgroup kernels.
+"""GPU (MI355X): the two lower-triangle single-CU PCG kernels — the lane-pair-per-knot kernel (mpcgpu_amd/csrc/pcg_lpk.hip.h, round 3, family 6)
+and the lane-quad kernel with both matrices in every wavefront (pcg_lqb.hip.h, round 6, family 11: the default for SS up to 128 knots and for
+both preconditioners up to 64) — through the C ABI, against the CPU oracle, the golden vectors and the single-workgroup kernels.  Every test
+of this file runs once per kernel (fixture `P`).
 
 It reads only the block lower triangle (left + diagonal blocks) of S and Pinv: S[k,right] is the bitwise transpose of
 S[k+1,left] in the reference's construction (include/pcg/linsys_setup.cuh:536-557) and the symmetric-stair Pinv
@@ -22,12 +24,34 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.fixture(scope="module")
-def P():
+class _Kern(tuple):
+    """(PcgSolver, pcg_config) + which of the two lower-triangle single-CU kernels the test runs: "lpk" = the lane-pair kernel (family 6),
+    "lqb" = round 6's lane-quad kernel with both matrices in every wavefront (family 11, pcg_lqb.hip.h) — same contract, same tests."""
+    kern = "lpk"
+
+    @property
+    def family(self):
+        return 11 if self.kern == "lqb" else 6
+
+    def pin(self, sol):
+        """Force this kernel on a handle (the automatic policy picks by horizon, batch and preconditioner)."""
+        sol.set_option("pcg_lpk", 1)
+        sol.set_option("pcg_lqb", 1 if self.kern == "lqb" else 0)
+
+    def default_policy(self, sol):
+        """Leave the automatic policy alone (it picks the lane-quad kernel for SS) or take the lane-quad kernel out of it."""
+        if self.kern == "lpk":
+            sol.set_option("pcg_lqb", 0)
+
+
+@pytest.fixture(scope="module", params=["lpk", "lqb"])
+def P(request):
     from mpcgpu_amd import PcgSolver, pcg_config, _lib
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
     _lib.load()
-    return PcgSolver, pcg_config
+    k = _Kern((PcgSolver, pcg_config))
+    k.kern = request.param
+    return k
 
 
 def poison_right(M, N, jacobi=False):
@@ -44,16 +68,15 @@ def lpk_solve(P, N, S, Pinv, g, lam0, max_iter, tol, pc="ss"):
     PcgSolver, pcg_config = P
     B = S.shape[0]
     sol = PcgSolver(N, max_batch=B)
-    if N <= 64:
-        sol.set_option("pcg_lpk", 1)          # (the automatic policy uses this kernel for 64 < N <= 128, and for 36 < N <= 64 beyond one trajectory per CU)
+    P.pin(sol)
     # these tests hand over matrices whose right block column is NaN (it must never be read): a lower-triangle-only caller says so,
     # otherwise the handle's first solves would CHECK the right blocks against the left ones (tests/test_gpu_contract.py: the symmetry latch)
     sol.set_option("assume_symmetric", 1)
     lam = dev(np.asarray(lam0, np.float32))
     it, ex = sol.solve(dev(S), dev(Pinv), dev(g), lam, pcg_config(pcg_exit_tol=tol, pcg_max_iter=max_iter), pc)
     torch.cuda.synchronize()
-    assert sol.get_option("last_kernel_family") == 6 and sol.get_option("last_kernel_waves") == (2 if N <= 32 else 4 if N <= 64 else 8)
-    assert N <= 64 or sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes(14, N)
+    assert sol.get_option("last_kernel_family") == P.family and sol.get_option("last_kernel_waves") == (2 if N <= 32 else 4 if N <= 64 else 8)
+    assert P.kern != "lqb" or N <= 32 or sol.get_option("last_kernel_lds_bytes") == sol.lib.mpcg_pcg_lds_bytes(14, N)      # (pcgSharedMemSize mirrors the default policy)
     return lam.cpu().numpy(), it.cpu().numpy(), ex.cpu().numpy()
 
 
@@ -136,7 +159,7 @@ def test_lpk_flags_warm_start_and_r_p_outputs(P, orc):
     G = golden(32)
     N = 32
     sol = P[0](N)
-    sol.set_option("pcg_lpk", 1)
+    P.pin(sol)
     sol.set_option("assume_symmetric", 1)      # (right blocks are NaN here: a lower-triangle-only caller)
     d_lambda = torch.zeros(n * N, device="cuda")
     d_r = torch.full((n * N,), 7.0, device="cuda")
@@ -146,7 +169,7 @@ def test_lpk_flags_warm_start_and_r_p_outputs(P, orc):
     sol.solve_ref(dev(poison_right(G["S"], N)[0]), dev(poison_right(G["Pinv"], N)[0]), dev(G["gamma"]), d_lambda, d_r, d_p,
                   torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda"), d_it, d_ex, 20, 0.0)
     torch.cuda.synchronize()
-    assert sol.get_option("last_kernel_family") == 6
+    assert sol.get_option("last_kernel_family") == P.family
     r64 = orc.pcg(G["S"].astype(np.float64), G["Pinv"].astype(np.float64), G["gamma"].astype(np.float64), np.zeros(n * N), N, 20, 0.0, "ss")
     assert relinf(d_r.cpu().numpy(), r64["r"]) < 5e-2 and relinf(d_p.cpu().numpy(), r64["p"]) < 5e-2
 
@@ -186,10 +209,12 @@ def test_lpk_agrees_with_single_workgroup_kernel(P):
         sol = PcgSolver(N, max_batch=B)
         if not lpb:
             sol.set_option("pcg_waves", 16); sol.set_option("pcg_reg_rows", 0); sol.set_option("pcg_lds_rows", 0)
+        else:
+            P.default_policy(sol)
         lam = torch.zeros(B, n * N, device="cuda")
         it, ex = sol.solve(dS, dP, dg, lam, cfg, "ss")
         torch.cuda.synchronize()
-        assert sol.get_option("last_kernel_family") == (6 if lpb else 0)
+        assert sol.get_option("last_kernel_family") == (P.family if lpb else 0)
         res.append((lam.cpu().numpy(), it.cpu().numpy().astype(int), ex.cpu().numpy()))
     assert np.abs(res[0][1] - res[1][1]).max() <= max(3, int(0.05 * res[1][1].max()))
     assert (res[0][2] == res[1][2]).all()
@@ -211,10 +236,11 @@ def test_lpk_config4_workload_n128_batch1024(P, orc):
     outs = []
     for rep in range(2):
         sol = PcgSolver(N, max_batch=B)
+        P.default_policy(sol)
         lam = torch.zeros(B, n * N, device="cuda")
         it, ex = sol.solve(dS, dP, dg, lam, cfg, "ss")
         torch.cuda.synchronize()
-        assert sol.get_option("last_kernel_family") == 6 and sol.get_option("last_kernel_waves") == 8
+        assert sol.get_option("last_kernel_family") == P.family and sol.get_option("last_kernel_waves") == 8
         outs.append((lam, it.cpu().numpy().astype(int), ex.cpu().numpy()))
     assert torch.equal(outs[0][0], outs[1][0]) and (outs[0][1] == outs[1][1]).all()
     lam, it, ex = outs[0]
@@ -257,6 +283,7 @@ def test_half_build_policy_on_short_horizons(P, orc):
     PcgSolver, pcg_config = P
     N, K = 24, 20
     sol = PcgSolver(N, max_batch=4096)
+    P.default_policy(sol)
     ncu = sol.get_option("num_cus")
     B = (5 * ncu + 1) // 2
     k = synth.make_kkt(N, 4, 515)
@@ -268,7 +295,7 @@ def test_half_build_policy_on_short_horizons(P, orc):
     lam = torch.zeros(B, n * N, device="cuda")
     it, ex = sol.solve(dS, dP, dg, lam, cfg, "ss")
     torch.cuda.synchronize()
-    assert sol.get_option("last_kernel_family") == 6 and sol.get_option("last_kernel_waves") == 2 and (it.cpu().numpy() == K).all()
+    assert sol.get_option("last_kernel_family") == P.family and sol.get_option("last_kernel_waves") == 2 and (it.cpu().numpy() == K).all()
     lamh = lam.cpu().numpy()
     for b in range(4, B):
         np.testing.assert_array_equal(lamh[b], lamh[b % 4])

@@ -115,10 +115,10 @@ def test_rpl_tolerance_exit_counts_flags_and_outputs(orc):
 
 def test_rpl_default_policy_and_batch_composition():
     """No knobs: N <= 32 runs this kernel at any batch (8 waves x 1 slot up to one trajectory per CU, 4 x 2 beyond); 32 < N <= 64
-    only for latency-sized calls (beyond: row-pair kernel up to N = 36, lane-pair kernel from there).  A trajectory's result does not depend on its neighbours in the batch."""
+    was its range for latency-sized calls until round 6 — from 33 knots the lane-quad kernel (family 11) now takes every call: it beats this kernel's one-trajectory latency there.  A trajectory's result does not depend on its neighbours in the batch."""
     from mpcgpu_amd import PcgSolver, pcg_config
     cfg = pcg_config(pcg_exit_tol=1e-4, pcg_max_iter=60)
-    for N, B, fam, shape in ((32, 1, 5, (8, 1)), (32, 600, 5, (4, 2)), (16, 600, 5, (4, 1)), (64, 3, 5, (8, 2)), (64, 600, 6, None), (48, 600, 6, None), (36, 600, 0, None)):
+    for N, B, fam, shape in ((32, 1, 5, (8, 1)), (32, 600, 5, (4, 2)), (16, 600, 5, (4, 1)), (64, 3, 11, None), (64, 600, 11, None), (48, 600, 11, None), (36, 600, 11, None)):
         k = synth.make_kkt(N, min(B, 8), 3)
         S, Pinv, g = synth.form_schur(k, poison_unused=True)
         rep = (B + S.shape[0] - 1) // S.shape[0]

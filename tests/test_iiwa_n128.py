@@ -75,7 +75,7 @@ def test_default_kernel_on_real_n128_systems(orc, G):
                 lam = dev(lam0.reshape(1, -1).astype(np.float32))
                 it, ex = sol.solve(dev(S.reshape(1, -1)), dev(P.reshape(1, -1)), dev(g.reshape(1, -1)), lam, pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K), "ss")
                 torch.cuda.synchronize()
-                assert sol.get_option("last_kernel_family") == 6 and int(it.item()) == K
+                assert sol.get_option("last_kernel_family") == 11 and int(it.item()) == K
                 want = G[f"s{i}_lam_{start}_K{K}"]
                 band = fp32_band(orc, S, P, g, lam0, N, K, "ss", want)
                 err = relinf(lam.cpu().numpy()[0], want)

@@ -37,8 +37,12 @@ IDX = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]
 LPK_NAMES = ["S transp", "S direct", "S merge+dot", "(to barrier)", "barrier A", "alpha+r/lam", "barrier B", "(P start)",
              "P transp", "P direct", "P merge+dot", "(to barrier)", "barrier C", "eta+p upd", "barrier D"]
 for spec in args.cfg or ["4:7:-1"]:
-    f = [int(x) for x in spec.split(":")] if spec != "lpk" else [4 if N <= 64 else 8]
-    if spec == "lpk":      # lane-pair-per-knot kernel (round 3 default for 36 < N <= 128): waves 0-3 S, 4-7 Pinv (stamps of the other role's pass stay 0)
+    f = [int(x) for x in spec.split(":")] if spec not in ("lpk", "lqb") else [4 if N <= 64 else 8]
+    if spec == "lqb":     # float lane-quad kernel: every wave runs both passes.  0 iteration start | 1 operand in place | 2 FMAs done | 3 published | 4 past barrier A | 5 alpha known | 6 operand | 7 FMAs done | 8 published | 9 past barrier C
+        f = [8 if N > 64 else 4 if N > 32 else 2]
+        NAMES = ["rebuild p", "S FMAs", "S epilogue", "barrier A", "alpha", "rebuild r", "P FMAs", "P epilogue", "barrier C", "beta"] + ["-"] * 5
+        sol.set_option("pcg_lpk", 1); sol.set_option("pcg_lqb", 1); sol.set_option("assume_symmetric", 1)
+    elif spec == "lpk":      # lane-pair-per-knot kernel (round 3 default for 36 < N <= 128): waves 0-3 S, 4-7 Pinv (stamps of the other role's pass stay 0)
         NAMES = LPK_NAMES
         sol.set_option("pcg_lpk", 1)
     else:
