@@ -557,17 +557,22 @@ static int launch_lqb_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStr
 }
 // The float lane-quad kernel takes the lane-pair kernel's launches (same contract: lower block triangle, gated / fix-up launches, dispatch order).
 // Automatic use (tools/_prof/lqb_policy.py, profiles/r06_lqb_policy.txt; "pcg_lqb" = 1 / 0 forces / forbids, an explicit "pcg_lpk" = 1 keeps the lane-pair kernel):
-//   * knot_points <= 64: both preconditioners — two independent workgroups per CU, all of their wavefronts working: 1.21-1.30x the lane-pair /
+//   * 32 < knot_points <= 64: both preconditioners — two independent workgroups per CU, all of their wavefronts working: 1.21-1.30x the lane-pair /
 //     row-per-lane / row-pair kernels at every batch for SS (one trajectory of 64 knots: 0.193 against 0.246 ms), 1.09-1.39x block-Jacobi;
 //   * 64 < knot_points <= 128: SS only (1.01-1.11x; block-Jacobi's Pinv pass keeps the whole skeleton for a third of the FMAs: 0.90-0.99x).
 static bool lqb_auto(const mpcg_handle* h, int esz) { return esz == 4 && h->lqb == -1 && h->lpk == -1 && h->rpl != 1 && h->auto_cfg && h->cluster <= 0; }
-static bool use_lqb(const mpcg_handle* h, int esz, int pcols) {
+//   * knot_points <= 32 (throughput-sized calls only, lpk_half): beyond ONE round of four 32-knot workgroups per CU — batch 2048 / 4096 at 24 and 32 knots:
+//     1.03-1.06x at the iteration cap, 1.08-1.15x at 26 iterations; exactly four per CU the lane-pair kernel's half build is 4-6 % ahead
+//     (tools/_prof/lqb_n32.py).
+static bool use_lqb(const mpcg_handle* h, int esz, int pcols, uint32_t batch) {
     if (esz != 4 || h->lqb == 0) return false;
     if (h->lqb == 1) return true;
-    return lqb_auto(h, esz) && (h->N <= 64 || pcols == 3);
+    if (!lqb_auto(h, esz)) return false;
+    if (h->N <= 32) return batch > 4u * (uint32_t)h->num_cus;
+    return h->N <= 64 || pcols == 3;
 }
 static int launch_lpk(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
-    if (use_lqb(h, a.esz, a.pcols)) {
+    if (use_lqb(h, a.esz, a.pcols, batch)) {
         if (h->N <= 32) return launch_lqb_t<32>(h, a, batch, st);
         return h->N <= 64 ? launch_lqb_t<64>(h, a, batch, st) : launch_lqb_t<128>(h, a, batch, st);
     }
@@ -1160,7 +1165,7 @@ int mpcg_check_pcg_occupancy(mpcg_handle* h, uint32_t* resident_trajectories) {
 #define X(NW_, RHO_) if (nw == NW_ && rho == RHO_) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_rpl_kernel<NW_, RHO_, true>, NW_ * 64, lds));
         MPCG_RPL_VARIANTS(X)
 #undef X
-    } else if (use_lpk(h, 4, h->max_batch) && use_lqb(h, 4, 3)) {      // (an SS call)
+    } else if (use_lpk(h, 4, h->max_batch) && use_lqb(h, 4, 3, h->max_batch)) {      // (an SS call)
         const int nmax = h->N <= 32 ? 32 : h->N <= 64 ? 64 : 128;
         const size_t lds = pcg_lqb_lds_floats(nmax) * sizeof(float);
         const void* kern = nmax == 32 ? reinterpret_cast<const void*>(pcg_lqb_kernel<32>) : nmax == 64 ? reinterpret_cast<const void*>(pcg_lqb_kernel<64>) : reinterpret_cast<const void*>(pcg_lqb_kernel<128>);
