@@ -23,7 +23,11 @@
 //              near 1); each lane turns its difference into ITS column of dqdd/d(q, qd) = -Minv dID in registers and writes its column
 //              of A (and of Q, B, R) as float in the reference's dense layouts (column-major blocks, C = -A, -B).
 // Arithmetic is float64 inside (the difference quotients need it; fp64 FMA is full rate on the MI355X), results are rounded to float
-// on the way out.  LDS is what bounds the resident wavefronts: 19.9 KB per wavefront = EIGHT per CU (two per SIMD, round 3; 30 KB =
+// on the way out.  Round 6: everything below the sine / cosine is templated on the arithmetic type R, and `"kkt_f32"` = 1 runs the analytic
+// kernel with R = float — linsys_t's own arithmetic, what the reference's GRiD code computes in (forwardDynamicsAndGradient<T>, T = float):
+// outputs within 1.5e-6 of the float64 restatement (relative to max(1, |block|); float64 inside: 2e-7) and only 8 % faster (0.303 against
+// 0.328 ms per 1024 x 127 knots): the kernel is bound by the dependent issue of ONE recursion per lane at two wavefronts per SIMD (7.6 clocks
+// per instruction and wavefront), not by the fp64 pipe — measured, which corrects round 4's "fp64 VALU issue bound".  Opt-in.  LDS is what bounds the resident wavefronts: 19.9 KB per wavefront = EIGHT per CU (two per SIMD, round 3; 30 KB =
 // five before), which is what hides the dependent-issue latency of the recursion.
 #pragma once
 // Float64 work checked by tolerance, not by bits: multiply-adds are FUSED here (the bit-exact headers switch contraction off and back on).
@@ -53,47 +57,52 @@ constexpr int RN_AW = 3, RN_AU = 9;      // rows (3 each) where a lane leaves th
 // X_k(q_k) = blkdiag(Rz, Rz) [[ET, 0], [BT, ET]],  Rz(q) = [[c, s, 0], [-s, c, 0], [0, 0, 1]]  (row-major 3x3 blocks)
 // Spatial inertia of a rigid body: [[Ibar, skew(h)], [skew(h)^T, m 1]] (Ibar symmetric about the link frame's origin, h = m c) — ten
 // numbers, I [w; u] = [Ibar w + h x u ; m u - h x w]: 24 multiply-adds instead of 36.
-struct PlantDev {
-    double ET[PJ][9], BT[PJ][9];
-    double Ib[PJ][10];                           // Ixx Ixy Ixz Iyy Iyz Izz  hx hy hz  m
+template <typename R> struct PlantDevT {
+    R ET[PJ][9], BT[PJ][9];
+    R Ib[PJ][10];                                // Ixx Ixy Ixz Iyy Iyz Izz  hx hy hz  m
 };
+typedef PlantDevT<double> PlantDev;              // R = double: the round-2..5 kernel (float64 inside, the checker of the float build); R = float (round 6): linsys_t's own
+                                                 // arithmetic, what the reference's GRiD code runs in (gato_plant::forwardDynamicsAndGradient<T>, T = linsys_t = float)
 
-struct KktArgs {
-    const PlantDev* plant;
+template <typename R> struct KktArgsT {
+    const PlantDevT<R>* plant;
     const float* eePos_traj;             // [batch][N][6]
     const float* xs;                     // [batch][n]
     const float* xu;                     // [batch][(n+m)N - m]
     float* G; float* C; float* g; float* c;
     int N; int batch;
-    double dt, qd_cost, r_cost;
+    R dt, qd_cost, r_cost;
     int analytic;                        // 1: round 1 = the analytic gradient recursion of the inverse dynamics (default); 0: one-sided differences
 };
+typedef KktArgsT<double> KktArgs;
 
 // The model tables are read through the CONSTANT address space (same 64-bit address as the global pointer): loads from it are
 // invariant by definition, so a uniform address makes them scalar loads (s_load, scalar cache).  Through the plain global
 // pointer the compiler must assume the kernel's own stores may clobber the table and emits ~1,300 vector loads per knot
 // (rocprofv3: SQ_INSTS_VMEM_RD; waves waited on memory half of their cycles).
-typedef const __attribute__((address_space(4))) double cdouble;
-struct PlantC {
-    cdouble* base;
-    __device__ __forceinline__ cdouble* at(size_t byte_off, int k, int per) const { return base + byte_off / sizeof(double) + (size_t)k * per; }
-    __device__ __forceinline__ cdouble* ET(int k) const { return at(offsetof(PlantDev, ET), k, 9); }
-    __device__ __forceinline__ cdouble* BT(int k) const { return at(offsetof(PlantDev, BT), k, 9); }
-    __device__ __forceinline__ cdouble* Ib(int k) const { return at(offsetof(PlantDev, Ib), k, 10); }
+template <typename R> struct PlantC {
+    typedef const __attribute__((address_space(4))) R creal;
+    creal* base;
+    __device__ __forceinline__ creal* at(size_t byte_off, int k, int per) const { return base + byte_off / sizeof(R) + (size_t)k * per; }
+    __device__ __forceinline__ creal* ET(int k) const { return at(offsetof(PlantDevT<R>, ET), k, 9); }
+    __device__ __forceinline__ creal* BT(int k) const { return at(offsetof(PlantDevT<R>, BT), k, 9); }
+    __device__ __forceinline__ creal* Ib(int k) const { return at(offsetof(PlantDevT<R>, Ib), k, 10); }
 };
 
-struct KktItemLds {                      // per-knot scratch in LDS (840 B)
-    double Minv[PJ][PJ];
-    double Qdd[PJ];
-    double Xq[2 * PJ], U[PJ];            // [q; qd], u of this knot
-    double Sc[2][PJ];                    // sin / cos of q
-    double Gq[PJ], Gq1[PJ];              // J^T (ee - goal_k), J^T (ee - goal_{k+1})
+template <typename R> struct KktItemLds {   // per-knot scratch in LDS (840 B in double)
+    R Minv[PJ][PJ];
+    R Qdd[PJ];
+    R Xq[2 * PJ], U[PJ];                 // [q; qd], u of this knot
+    R Sc[2][PJ];                         // sin / cos of q
+    R Gq[PJ], Gq1[PJ];                   // J^T (ee - goal_k), J^T (ee - goal_{k+1})
 };
 
 // LDS is addressed through explicit address-space pointers: through generic pointers the accesses become flat loads whose 64-bit
 // addresses (one per record row touched) the compiler hoists out of the knot loop and spills.
-typedef __attribute__((address_space(3))) volatile double kkt_lds_vd;
-typedef __attribute__((address_space(3))) KktItemLds kkt_lds_item;
+template <typename R> struct KktLds {
+    typedef __attribute__((address_space(3))) volatile R vr;
+    typedef __attribute__((address_space(3))) KktItemLds<R> item;
+};
 
 // sin and cos of a joint angle: Cody-Waite reduction by pi/2 in two fused steps + the classic minimax kernels on [-pi/4, pi/4] (the
 // coefficients every libm uses since fdlibm); absolute error 2.2e-16 for |x| <= 1e4 (checked against numpy on 2e6 points) — a fifth of the
@@ -114,10 +123,10 @@ __device__ __forceinline__ void kkt_sincos(double x, double& sn, double& cs) {
     cs = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
 }
 
-struct RneaTask {                        // what this lane's recursion evaluates
+template <typename R> struct RneaTask {                        // what this lane's recursion evaluates
     int sj;                              // joint whose angle is q + h (-1: none): (sin, cos) -> (s + h c, c - h s), exact to h^2 / 2 = 4.5e-16
     int pj;                              // joint whose velocity is qd + h (-1: none)
-    double qdscale;                      // 0: qd = 0, 1: qd of the knot
+    R qdscale;                      // 0: qd = 0, 1: qd of the knot
     bool knot_qdd;                       // qdd of the knot (round 1) / unit vector e_unit (round 0)
     int unit;
     int base;                            // unit angular base acceleration e_base (-1: none)
@@ -131,20 +140,22 @@ struct RneaTask {                        // what this lane's recursion evaluates
 // from scalar registers: one SGPR pair per FMA is what the ISA allows, so forming E(q) = E0 + Es sin + Ec cos first, as rounds 1-2 did,
 // cost three instructions per matrix entry and sweep) followed by the rotation about z: 4 instructions per 3-vector.
 // Returns the last link's spatial acceleration (aw, au) in its own frame.
-__device__ __forceinline__ void rnea(const PlantC& P, kkt_lds_vd* fl, kkt_lds_item* I, const RneaTask t, double (&aw_out)[3], double (&au_out)[3]) {
-    double vw[3] = {0, 0, 0}, vu[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, au[3] = {0, 0, 0};
-    if (t.base >= 0) aw[t.base] = 1.0;
-    double f[6] = {0, 0, 0, 0, 0, 0};
+template <typename R>
+__device__ __forceinline__ void rnea(const PlantC<R>& P, typename KktLds<R>::vr* fl, typename KktLds<R>::item* I, const RneaTask<R> t, R (&aw_out)[3], R (&au_out)[3]) {
+    typedef typename PlantC<R>::creal creal;
+    R vw[3] = {0, 0, 0}, vu[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, au[3] = {0, 0, 0};
+    if (t.base >= 0) aw[t.base] = R(1.0);
+    R f[6] = {0, 0, 0, 0, 0, 0};
 #pragma nounroll
     for (int kv = 0; kv < PJ; ++kv) {
         const int k = __builtin_amdgcn_readfirstlane(kv);    // uniform by construction; said so, the model tables come through s_load
-        const double qdk = t.qdscale * I->Xq[PJ + k] + (k == t.pj ? KKT_FD_H : 0.0);
-        const double qddk = t.knot_qdd ? I->Qdd[k] : (k == t.unit ? 1.0 : 0.0);
-        double sn = I->Sc[0][k], cs = I->Sc[1][k];
-        if (k == t.sj) { const double s0 = sn; sn = s0 + KKT_FD_H * cs; cs = cs - KKT_FD_H * s0; }
-        cdouble* E = P.ET(k);
-        cdouble* B = P.BT(k);
-        double tw[3], tu[3], sw[3], su[3];                   // tree part of v = X v_parent, a = X a_parent
+        const R qdk = t.qdscale * I->Xq[PJ + k] + (k == t.pj ? R(KKT_FD_H) : R(0.0));
+        const R qddk = t.knot_qdd ? I->Qdd[k] : (k == t.unit ? R(1.0) : R(0.0));
+        R sn = I->Sc[0][k], cs = I->Sc[1][k];
+        if (k == t.sj) { const R s0 = sn; sn = s0 + R(KKT_FD_H) * cs; cs = cs - R(KKT_FD_H) * s0; }
+        creal* E = P.ET(k);
+        creal* B = P.BT(k);
+        R tw[3], tu[3], sw[3], su[3];                   // tree part of v = X v_parent, a = X a_parent
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             tw[r] = E[3 * r] * vw[0] + E[3 * r + 1] * vw[1] + E[3 * r + 2] * vw[2];
@@ -152,7 +163,7 @@ __device__ __forceinline__ void rnea(const PlantC& P, kkt_lds_vd* fl, kkt_lds_it
             sw[r] = E[3 * r] * aw[0] + E[3 * r + 1] * aw[1] + E[3 * r + 2] * aw[2];
             su[r] = B[3 * r] * aw[0] + B[3 * r + 1] * aw[1] + B[3 * r + 2] * aw[2] + E[3 * r] * au[0] + E[3 * r + 1] * au[1] + E[3 * r + 2] * au[2];
         }
-        double w[3], u[3], bw[3], bu[3];                     // joint rotation about z
+        R w[3], u[3], bw[3], bu[3];                     // joint rotation about z
         w[0] = cs * tw[0] + sn * tw[1]; w[1] = cs * tw[1] - sn * tw[0]; w[2] = tw[2] + qdk;       // + S qd, S = e_z (angular)
         u[0] = cs * tu[0] + sn * tu[1]; u[1] = cs * tu[1] - sn * tu[0]; u[2] = tu[2];
         bw[0] = cs * sw[0] + sn * sw[1]; bw[1] = cs * sw[1] - sn * sw[0]; bw[2] = sw[2] + qddk;
@@ -161,9 +172,9 @@ __device__ __forceinline__ void rnea(const PlantC& P, kkt_lds_vd* fl, kkt_lds_it
         bw[0] += w[1] * qdk; bw[1] -= w[0] * qdk;
         bu[0] += u[1] * qdk; bu[1] -= u[0] * qdk;
         // f = I a + v x* (I v)
-        double Ia[6], Iv[6];
-        cdouble* Ik = P.Ib(k);
-        auto imul = [&](const double (&W)[3], const double (&U)[3], double (&o)[6]) {
+        R Ia[6], Iv[6];
+        creal* Ik = P.Ib(k);
+        auto imul = [&](const R (&W)[3], const R (&U)[3], R (&o)[6]) {
             o[0] = Ik[0] * W[0] + Ik[1] * W[1] + Ik[2] * W[2] + (Ik[7] * U[2] - Ik[8] * U[1]);
             o[1] = Ik[1] * W[0] + Ik[3] * W[1] + Ik[4] * W[2] + (Ik[8] * U[0] - Ik[6] * U[2]);
             o[2] = Ik[2] * W[0] + Ik[4] * W[1] + Ik[5] * W[2] + (Ik[6] * U[1] - Ik[7] * U[0]);
@@ -193,13 +204,13 @@ __device__ __forceinline__ void rnea(const PlantC& P, kkt_lds_vd* fl, kkt_lds_it
 #pragma nounroll
     for (int kv = PJ - 1; kv >= 1; --kv) {                   // f_parent += X^T f = Xtree^T blkdiag(Rz^T, Rz^T) [n; l] = [ET^T n' + BT^T l' ; ET^T l']
         const int k = __builtin_amdgcn_readfirstlane(kv);
-        double sn = I->Sc[0][k], cs = I->Sc[1][k];
-        if (k == t.sj) { const double s0 = sn; sn = s0 + KKT_FD_H * cs; cs = cs - KKT_FD_H * s0; }
-        cdouble* E = P.ET(k);
-        cdouble* B = P.BT(k);
-        const double n0 = cs * f[0] - sn * f[1], n1 = sn * f[0] + cs * f[1], n2 = f[2];
-        const double l0 = cs * f[3] - sn * f[4], l1 = sn * f[3] + cs * f[4], l2 = f[5];
-        double fp[6];
+        R sn = I->Sc[0][k], cs = I->Sc[1][k];
+        if (k == t.sj) { const R s0 = sn; sn = s0 + R(KKT_FD_H) * cs; cs = cs - R(KKT_FD_H) * s0; }
+        creal* E = P.ET(k);
+        creal* B = P.BT(k);
+        const R n0 = cs * f[0] - sn * f[1], n1 = sn * f[0] + cs * f[1], n2 = f[2];
+        const R l0 = cs * f[3] - sn * f[4], l1 = sn * f[3] + cs * f[4], l2 = f[5];
+        R fp[6];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             fp[r] = fl[6 * (k - 1) + r] + E[r] * n0 + E[3 + r] * n1 + E[6 + r] * n2 + B[r] * l0 + B[3 + r] * l1 + B[6 + r] * l2;
@@ -232,23 +243,29 @@ __device__ __forceinline__ double bc64(double x) {            // x of lane L of 
     const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x150 + L, 0xf, 0xf, true);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+template <int L>
+__device__ __forceinline__ float bc64(float x) {              // (the float build: one row_newbcast move)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + L, 0xf, 0xf, true));
+}
 constexpr int KKT_NOM = 2 * PJ;          // the lane of the nominal recursion
 // l: lane in the group (0..14 run).  On return this lane's record holds dtau_i (rows RN_TAU(i), float) for its column.
-__device__ __forceinline__ void rnea_grad(const PlantC& P, kkt_lds_vf* fl, kkt_lds_item* I, const int l) {
+template <typename R>
+__device__ __forceinline__ void rnea_grad(const PlantC<R>& P, kkt_lds_vf* fl, typename KktLds<R>::item* I, const int l) {
+    typedef typename PlantC<R>::creal creal;
     const bool nom = l == KKT_NOM;
     const bool isq = l < PJ;
     const int col = l < PJ ? l : l - PJ;                      // (lane 14: 7 — never equal to a link index)
-    const double nmask = nom ? 0.0 : 1.0;
-    double vw[3] = {0, 0, 0}, vu[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, au[3] = {0, 0, 0};
-    double f[6] = {0, 0, 0, 0, 0, 0};
+    const R nmask = nom ? R(0.0) : R(1.0);
+    R vw[3] = {0, 0, 0}, vu[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, au[3] = {0, 0, 0};
+    R f[6] = {0, 0, 0, 0, 0, 0};
 #pragma nounroll
     for (int kv = 0; kv < PJ; ++kv) {
         const int k = __builtin_amdgcn_readfirstlane(kv);
-        const double qdk = I->Xq[PJ + k], qddk = I->Qdd[k];
-        const double sn = I->Sc[0][k], cs = I->Sc[1][k];
-        cdouble* E = P.ET(k);
-        cdouble* B = P.BT(k);
-        double tw[3], tu[3], sw[3], su[3];
+        const R qdk = I->Xq[PJ + k], qddk = I->Qdd[k];
+        const R sn = I->Sc[0][k], cs = I->Sc[1][k];
+        creal* E = P.ET(k);
+        creal* B = P.BT(k);
+        R tw[3], tu[3], sw[3], su[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             tw[r] = E[3 * r] * vw[0] + E[3 * r + 1] * vw[1] + E[3 * r + 2] * vw[2];
@@ -256,32 +273,32 @@ __device__ __forceinline__ void rnea_grad(const PlantC& P, kkt_lds_vf* fl, kkt_l
             sw[r] = E[3 * r] * aw[0] + E[3 * r + 1] * aw[1] + E[3 * r + 2] * aw[2];
             su[r] = B[3 * r] * aw[0] + B[3 * r + 1] * aw[1] + B[3 * r + 2] * aw[2] + E[3 * r] * au[0] + E[3 * r + 1] * au[1] + E[3 * r + 2] * au[2];
         }
-        double w[3], u[3], bw[3], bu[3];
-        w[0] = cs * tw[0] + sn * tw[1]; w[1] = cs * tw[1] - sn * tw[0]; w[2] = tw[2] + (nom ? qdk : 0.0);
+        R w[3], u[3], bw[3], bu[3];
+        w[0] = cs * tw[0] + sn * tw[1]; w[1] = cs * tw[1] - sn * tw[0]; w[2] = tw[2] + (nom ? qdk : R(0.0));
         u[0] = cs * tu[0] + sn * tu[1]; u[1] = cs * tu[1] - sn * tu[0]; u[2] = tu[2];
         bw[0] = cs * sw[0] + sn * sw[1]; bw[1] = cs * sw[1] - sn * sw[0]; bw[2] = sw[2];
         bu[0] = cs * su[0] + sn * su[1]; bu[1] = cs * su[1] - sn * su[0]; bu[2] = su[2];
         // what the column lanes need of the nominal recursion at this link: v_k (after its S qd), X_k a_{k-1} (before S qdd and the cross term)
-        double nvw[3], nvu[3];
+        R nvw[3], nvu[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) { nvw[r] = bc64<KKT_NOM>(w[r]); nvu[r] = bc64<KKT_NOM>(u[r]); }
-        const double naw0 = bc64<KKT_NOM>(bw[0]), naw1 = bc64<KKT_NOM>(bw[1]), nau0 = bc64<KKT_NOM>(bu[0]), nau1 = bc64<KKT_NOM>(bu[1]);
+        const R naw0 = bc64<KKT_NOM>(bw[0]), naw1 = bc64<KKT_NOM>(bw[1]), nau0 = bc64<KKT_NOM>(bu[0]), nau1 = bc64<KKT_NOM>(bu[1]);
         if (k == col) {                                       // this lane's own joint: the sources of its column (everything above was zero)
             if (isq) {
-                w[0] = nvw[1]; w[1] = -nvw[0]; w[2] = 0.0; u[0] = nvu[1]; u[1] = -nvu[0]; u[2] = 0.0;            // dv = -S x v
-                bw[0] = naw1; bw[1] = -naw0; bw[2] = 0.0; bu[0] = nau1; bu[1] = -nau0; bu[2] = 0.0;               // da = -S x (X a_parent) [+ dv x S qd below]
+                w[0] = nvw[1]; w[1] = -nvw[0]; w[2] = R(0.0); u[0] = nvu[1]; u[1] = -nvu[0]; u[2] = R(0.0);            // dv = -S x v
+                bw[0] = naw1; bw[1] = -naw0; bw[2] = R(0.0); bu[0] = nau1; bu[1] = -nau0; bu[2] = R(0.0);               // da = -S x (X a_parent) [+ dv x S qd below]
             } else {
-                w[0] = 0.0; w[1] = 0.0; w[2] = 1.0; u[0] = 0.0; u[1] = 0.0; u[2] = 0.0;                            // dv = S
-                bw[0] = nvw[1]; bw[1] = -nvw[0]; bw[2] = 0.0; bu[0] = nvu[1]; bu[1] = -nvu[0]; bu[2] = 0.0;       // da = v x S
+                w[0] = R(0.0); w[1] = R(0.0); w[2] = R(1.0); u[0] = R(0.0); u[1] = R(0.0); u[2] = R(0.0);                            // dv = S
+                bw[0] = nvw[1]; bw[1] = -nvw[0]; bw[2] = R(0.0); bu[0] = nvu[1]; bu[1] = -nvu[0]; bu[2] = R(0.0);       // da = v x S
             }
         }
         if (nom) bw[2] += qddk;                               // + S qdd (nominal lane only)
         // + (v or dv) x (S qd_k): column 2 of crm(.) times qd_k — the same expression in the nominal and in the column lanes
         bw[0] += w[1] * qdk; bw[1] -= w[0] * qdk;
         bu[0] += u[1] * qdk; bu[1] -= u[0] * qdk;
-        double Ia[6], Iv[6];
-        cdouble* Ik = P.Ib(k);
-        auto imul = [&](const double (&W)[3], const double (&U)[3], double (&o)[6]) {
+        R Ia[6], Iv[6];
+        creal* Ik = P.Ib(k);
+        auto imul = [&](const R (&W)[3], const R (&U)[3], R (&o)[6]) {
             o[0] = Ik[0] * W[0] + Ik[1] * W[1] + Ik[2] * W[2] + (Ik[7] * U[2] - Ik[8] * U[1]);
             o[1] = Ik[1] * W[0] + Ik[3] * W[1] + Ik[4] * W[2] + (Ik[8] * U[0] - Ik[6] * U[2]);
             o[2] = Ik[2] * W[0] + Ik[4] * W[1] + Ik[5] * W[2] + (Ik[6] * U[1] - Ik[7] * U[0]);
@@ -292,10 +309,10 @@ __device__ __forceinline__ void rnea_grad(const PlantC& P, kkt_lds_vf* fl, kkt_l
         imul(bw, bu, Ia);
         imul(w, u, Iv);
         // f = I a + x x* (I v_nom) + v_nom x* (I x)        x = this lane's v-like vector; the nominal lane: x = v_nom, second cross term off
-        double nIv[6];
+        R nIv[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) nIv[r] = bc64<KKT_NOM>(Iv[r]);
-        const double zw0 = nmask * nvw[0], zw1 = nmask * nvw[1], zw2 = nmask * nvw[2], zu0 = nmask * nvu[0], zu1 = nmask * nvu[1], zu2 = nmask * nvu[2];
+        const R zw0 = nmask * nvw[0], zw1 = nmask * nvw[1], zw2 = nmask * nvw[2], zu0 = nmask * nvu[0], zu1 = nmask * nvu[1], zu2 = nmask * nvu[2];
         f[0] = Ia[0] + (w[1] * nIv[2] - w[2] * nIv[1]) + (u[1] * nIv[5] - u[2] * nIv[4]) + (zw1 * Iv[2] - zw2 * Iv[1]) + (zu1 * Iv[5] - zu2 * Iv[4]);
         f[1] = Ia[1] + (w[2] * nIv[0] - w[0] * nIv[2]) + (u[2] * nIv[3] - u[0] * nIv[5]) + (zw2 * Iv[0] - zw0 * Iv[2]) + (zu2 * Iv[3] - zu0 * Iv[5]);
         f[2] = Ia[2] + (w[0] * nIv[1] - w[1] * nIv[0]) + (u[0] * nIv[4] - u[1] * nIv[3]) + (zw0 * Iv[1] - zw1 * Iv[0]) + (zu0 * Iv[4] - zu1 * Iv[3]);
@@ -313,20 +330,20 @@ __device__ __forceinline__ void rnea_grad(const PlantC& P, kkt_lds_vf* fl, kkt_l
 #pragma nounroll
     for (int kv = PJ - 1; kv >= 1; --kv) {                   // F_parent += X_k^T (F_k [+ S x* F_k(nominal) in the d/dq_k lane])
         const int k = __builtin_amdgcn_readfirstlane(kv);
-        const double sn = I->Sc[0][k], cs = I->Sc[1][k];
-        cdouble* E = P.ET(k);
-        cdouble* B = P.BT(k);
+        const R sn = I->Sc[0][k], cs = I->Sc[1][k];
+        creal* E = P.ET(k);
+        creal* B = P.BT(k);
         // S x* [n; l] = [e_z x n ; e_z x l] = (-n1, n0, 0 ; -l1, l0, 0) of the nominal lane's accumulated force of link k
-        const double nf0 = bc64<KKT_NOM>(f[0]), nf1 = bc64<KKT_NOM>(f[1]), nf3 = bc64<KKT_NOM>(f[3]), nf4 = bc64<KKT_NOM>(f[4]);
+        const R nf0 = bc64<KKT_NOM>(f[0]), nf1 = bc64<KKT_NOM>(f[1]), nf3 = bc64<KKT_NOM>(f[3]), nf4 = bc64<KKT_NOM>(f[4]);
         const bool mine = isq && k == col;
-        const double g0 = f[0] - (mine ? nf1 : 0.0), g1 = f[1] + (mine ? nf0 : 0.0), g3 = f[3] - (mine ? nf4 : 0.0), g4 = f[4] + (mine ? nf3 : 0.0);
-        const double n0 = cs * g0 - sn * g1, n1 = sn * g0 + cs * g1, n2 = f[2];
-        const double l0 = cs * g3 - sn * g4, l1 = sn * g3 + cs * g4, l2 = f[5];
-        double fp[6];
+        const R g0 = f[0] - (mine ? nf1 : R(0.0)), g1 = f[1] + (mine ? nf0 : R(0.0)), g3 = f[3] - (mine ? nf4 : R(0.0)), g4 = f[4] + (mine ? nf3 : R(0.0));
+        const R n0 = cs * g0 - sn * g1, n1 = sn * g0 + cs * g1, n2 = f[2];
+        const R l0 = cs * g3 - sn * g4, l1 = sn * g3 + cs * g4, l2 = f[5];
+        R fp[6];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            fp[r] = (double)fl[6 * (k - 1) + r] + E[r] * n0 + E[3 + r] * n1 + E[6 + r] * n2 + B[r] * l0 + B[3 + r] * l1 + B[6 + r] * l2;
-            fp[3 + r] = (double)fl[6 * (k - 1) + 3 + r] + E[r] * l0 + E[3 + r] * l1 + E[6 + r] * l2;
+            fp[r] = (R)fl[6 * (k - 1) + r] + E[r] * n0 + E[3 + r] * n1 + E[6 + r] * n2 + B[r] * l0 + B[3 + r] * l1 + B[6 + r] * l2;
+            fp[3 + r] = (R)fl[6 * (k - 1) + 3 + r] + E[r] * l0 + E[3 + r] * l1 + E[6 + r] * l2;
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r) f[r] = fp[r];
@@ -341,8 +358,14 @@ constexpr int ST_G = 0, ST_Q1 = ST_G + 14 * 14 + 7 * 7, ST_C = ST_Q1 + 14 * 14, 
 // records of a group: round 0 runs PJ + 4 double records; round 1 either 2 PJ double records (differences) or 2 PJ + 1 FLOAT records (analytic)
 constexpr int KKT_R0 = PJ + 4;
 __host__ __device__ constexpr int kkt_rec_lanes(bool analytic) { return analytic ? KKT_R0 : KKT_RL; }
-static_assert(ST_END * sizeof(float) <= KKT_R0 * RN_ROWS * sizeof(double), "staging fits the group's records");
-static_assert((2 * PJ + 1) * RN_ROWS * sizeof(float) <= KKT_R0 * RN_ROWS * sizeof(double), "the analytic round's float records fit the round-0 records");
+// elements of type R a group's record region holds: the round-0 records, the analytic round's 2 PJ + 1 float records and the float staging area all fit
+// (double: the 11 (analytic) / 14 round-0 records are the largest of the three, as before; float: the staging area is — 3,192 B per group)
+template <typename R> __host__ __device__ constexpr int kkt_rec_elems(bool analytic) {
+    const int r0 = kkt_rec_lanes(analytic) * RN_ROWS;
+    const int r1 = (int)(((2 * PJ + 1) * RN_ROWS * sizeof(float) + sizeof(R) - 1) / sizeof(R)), st = (int)((ST_END * sizeof(float) + sizeof(R) - 1) / sizeof(R));
+    return r0 > r1 ? (r0 > st ? r0 : st) : (r1 > st ? r1 : st);
+}
+static_assert(kkt_rec_elems<double>(true) == KKT_R0 * RN_ROWS && kkt_rec_elems<double>(false) == KKT_RL * RN_ROWS, "the double build's LDS footprint is round 5's");
 template <int LEN>
 __device__ __forceinline__ void kkt_copy_out(float* dst, kkt_lds_f* src, int l) {
 #pragma unroll
@@ -353,22 +376,30 @@ __device__ __forceinline__ void kkt_copy_out(float* dst, kkt_lds_f* src, int l) 
 #ifndef KKT_WAVES_ANALYTIC
 #define KKT_WAVES_ANALYTIC 2
 #endif
-template <bool ANALYTIC>
-__global__ __launch_bounds__(KKT_THREADS, ANALYTIC ? KKT_WAVES_ANALYTIC : 2) void generate_kkt_kernel(KktArgs a) {
+#ifndef KKT_WAVES_F32
+#define KKT_WAVES_F32 2      // (the float build at three wavefronts per SIMD: 168 VGPRs, 17 spilled, 0.322 ms per 1024 x 127 knots; at two: 191, none, 0.303; double: 0.328)
+#endif
+template <bool ANALYTIC, typename R = double>
+__global__ __launch_bounds__(KKT_THREADS, sizeof(R) == 4 ? KKT_WAVES_F32 : ANALYTIC ? KKT_WAVES_ANALYTIC : 2) void generate_kkt_kernel(KktArgsT<R> a) {
+    static_assert(ANALYTIC || sizeof(R) == 8, "the difference quotients need float64");
+    typedef typename KktLds<R>::vr kkt_lds_vd;
+    typedef typename KktLds<R>::item kkt_lds_item;
+    typedef typename PlantC<R>::creal creal;
     constexpr int n = 2 * PJ, m = PJ, nn = n * n, mm = m * m, nm = n * m;
-    __shared__ KktItemLds sI[KKT_ITEMS];
-    constexpr int RL = kkt_rec_lanes(ANALYTIC);             // double records per group: 11 (analytic: 13.0 KB per wavefront) or 14 (16.6 KB)
-    __shared__ double sF[KKT_ITEMS * RL][RN_ROWS];          // the recursion records
-    static_assert(sizeof(KktItemLds) * KKT_ITEMS + sizeof(double) * KKT_ITEMS * RL * RN_ROWS <= (ANALYTIC ? 16384 : 20480), "ten / eight wavefronts per CU");
+    __shared__ KktItemLds<R> sI[KKT_ITEMS];
+    constexpr int RL = kkt_rec_lanes(ANALYTIC);             // round-0 records per group: 11 (analytic: 13.0 KB per wavefront in double) or 14 (16.6 KB)
+    constexpr int RE = kkt_rec_elems<R>(ANALYTIC);          // elements of a group's record region (float: the staging area decides, 14.4 KB per wavefront)
+    __shared__ R sF[KKT_ITEMS][RE];                         // the recursion records
+    static_assert(sizeof(KktItemLds<R>) * KKT_ITEMS + sizeof(R) * KKT_ITEMS * RE <= (ANALYTIC ? 16384 : 20480), "ten / eight wavefronts per CU");
     // The model tables are read with RUNTIME joint indices.  With compile-time indices (unrolled sweeps) all table entries are
     // loop-invariant loads that the compiler hoists into registers: 512 VGPR + AGPR and scratch.
     const int lane = threadIdx.x, gi = lane / KKT_GL, l = lane - gi * KKT_GL;
     kkt_lds_item* I = (kkt_lds_item*)&sI[gi];
-    kkt_lds_vd* recs = (kkt_lds_vd*)&sF[gi * RL][0];
+    kkt_lds_vd* recs = (kkt_lds_vd*)&sF[gi][0];
     auto rec = [&](int j) -> kkt_lds_vd* { return recs + j * RN_ROWS; };                // record of lane j of this group
     kkt_lds_vd* fl = rec(l < RL ? l : 0);                    // (lanes beyond the records never touch theirs)
-    kkt_lds_f* st = (kkt_lds_f*)&sF[gi * RL][0];
-    const PlantC P{reinterpret_cast<cdouble*>(reinterpret_cast<unsigned long long>(a.plant))};
+    kkt_lds_f* st = (kkt_lds_f*)&sF[gi][0];
+    const PlantC<R> P{reinterpret_cast<creal*>(reinterpret_cast<unsigned long long>(a.plant))};
     const int N = a.N;
     const long total = (long)a.batch * (N - 1);
     // A wavefront's trips cover CONSECUTIVE groups of four knots (not a grid stride): the knots' pieces of g (84 B), c (56 B), G (980 B) and
@@ -381,21 +412,21 @@ __global__ __launch_bounds__(KKT_THREADS, ANALYTIC ? KKT_WAVES_ANALYTIC : 2) voi
         const long item = live ? base + gi : total - 1;
         const int b = (int)(item / (N - 1)), k = (int)(item - (long)b * (N - 1));
         const float* xu = a.xu + (size_t)b * ((size_t)(n + m) * N - m) + (size_t)k * (n + m);      // x_k, u_k, x_{k+1}
-        if (l < n) I->Xq[l] = (double)xu[l];
+        if (l < n) I->Xq[l] = (R)xu[l];
         if (l < m) {
-            I->U[l] = (double)xu[n + l];
-            double sn_, cs_;
+            I->U[l] = (R)xu[n + l];
+            double sn_, cs_;                                  // (seven sine / cosine pairs per knot: in double in both builds, rounded to R)
             if (KKT_ABLATE & 4) { sn_ = (double)xu[l]; cs_ = 1.0 - sn_; } else
             kkt_sincos((double)xu[l], sn_, cs_);
-            I->Sc[0][l] = sn_;
-            I->Sc[1][l] = cs_;
+            I->Sc[0][l] = (R)sn_;
+            I->Sc[1][l] = (R)cs_;
         }
         __syncthreads();
         // ---- round 0: lanes 0..6 inertia-matrix columns ID(q, 0, e_l), lane 7 bias ID(q, qd, 0), lanes 8..10 the pose sweeps ----
-        double a6w[3], a6u[3];
+        R a6w[3], a6u[3];
         if (l < PJ + 4) {
-            RneaTask t;
-            t.sj = -1; t.pj = -1; t.qdscale = (l == PJ) ? 1.0 : 0.0; t.knot_qdd = false; t.unit = l < PJ ? l : -1; t.base = l > PJ ? l - PJ - 1 : -1;
+            RneaTask<R> t;
+            t.sj = -1; t.pj = -1; t.qdscale = (l == PJ) ? R(1.0) : R(0.0); t.knot_qdd = false; t.unit = l < PJ ? l : -1; t.base = l > PJ ? l - PJ - 1 : -1;
             if (!(KKT_ABLATE & 16)) rnea(P, fl, I, t, a6w, a6u);
 #pragma unroll
             for (int r = 0; r < 3; ++r) { fl[RN_AW + r] = a6w[r]; fl[RN_AU + r] = a6u[r]; }
@@ -404,41 +435,47 @@ __global__ __launch_bounds__(KKT_THREADS, ANALYTIC ? KKT_WAVES_ANALYTIC : 2) voi
         // ---- Minv (column l through a Cholesky solve of the symmetrised M), qdd_l = Minv_l . (u - bias)  (Minv is symmetric: row l = column l),
         //      end-effector position, Jacobian column l, cost gradient entries ----
         if (l < PJ && !(KKT_ABLATE & 2)) {
-            double Lm[PJ][PJ], rd[PJ];
+            R Lm[PJ][PJ], rd[PJ];
 #pragma unroll
             for (int i = 0; i < PJ; ++i)
 #pragma unroll
                 for (int jj = 0; jj <= i; ++jj) {
-                    double sv = 0.5 * (rec(jj)[RN_TAU(i)] + rec(i)[RN_TAU(jj)]);      // M[i][jj] = tau_i of lane jj
+                    R sv = R(0.5) * (rec(jj)[RN_TAU(i)] + rec(i)[RN_TAU(jj)]);      // M[i][jj] = tau_i of lane jj
 #pragma unroll
                     for (int t = 0; t < jj; ++t) sv -= Lm[i][t] * Lm[jj][t];
                     if (i == jj) {
                         // 1 / sqrt(pivot) from the hardware estimate + two Newton steps (full double precision for these O(1) pivots): the
                         // correctly rounded sqrt and division of the textbook form are ~30 instructions per pivot
-                        double y = __builtin_amdgcn_rsq(sv);
-                        y = fma(y * 0.5, fma(-sv * y, y, 1.0), y);
-                        y = fma(y * 0.5, fma(-sv * y, y, 1.0), y);
+                        R y;
+                        if constexpr (sizeof(R) == 8) {
+                            y = __builtin_amdgcn_rsq(sv);
+                            y = fma(y * R(0.5), fma(-sv * y, y, R(1.0)), y);
+                            y = fma(y * R(0.5), fma(-sv * y, y, R(1.0)), y);
+                        } else {
+                            y = __builtin_amdgcn_rsqf(sv);                                     // (1 ulp estimate + one Newton step: float precision)
+                            y = fmaf(y * R(0.5), fmaf(-sv * y, y, R(1.0)), y);
+                        }
                         rd[i] = y;
                         Lm[i][i] = sv * y;
                     }
                     else Lm[i][jj] = sv * rd[jj];
                 }
-            double y[PJ];
+            R y[PJ];
 #pragma unroll
             for (int i = 0; i < PJ; ++i) {
-                double sv = (i == l) ? 1.0 : 0.0;
+                R sv = (i == l) ? R(1.0) : R(0.0);
 #pragma unroll
                 for (int t = 0; t < i; ++t) sv -= Lm[i][t] * y[t];
                 y[i] = sv * rd[i];
             }
 #pragma unroll
             for (int i = PJ - 1; i >= 0; --i) {
-                double sv = y[i];
+                R sv = y[i];
 #pragma unroll
                 for (int t = i + 1; t < PJ; ++t) sv -= Lm[t][i] * y[t];
                 y[i] = sv * rd[i];
             }
-            double qdd = 0;
+            R qdd = 0;
 #pragma unroll
             for (int i = 0; i < PJ; ++i) {
                 I->Minv[i][l] = y[i];
@@ -448,14 +485,14 @@ __global__ __launch_bounds__(KKT_THREADS, ANALYTIC ? KKT_WAVES_ANALYTIC : 2) voi
             // pose of the last link from the three base-acceleration sweeps (lanes 8..10): their final acceleration is [W_i ; V_i] =
             // [R e_i ; R (e_i x p)], R = rotation world -> link.  Row i of R^T is W_i, so R^T x = (W_0.x, W_1.x, W_2.x);
             // e_x x p = (0, -pz, py), e_y x p = (pz, 0, -px).
-            double W[3][3], V0[3], V1[3];
+            R W[3][3], V0[3], V1[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int r = 0; r < 3; ++r) W[i][r] = rec(PJ + 1 + i)[RN_AW + r];
 #pragma unroll
             for (int r = 0; r < 3; ++r) { V0[r] = rec(PJ + 1)[RN_AU + r]; V1[r] = rec(PJ + 2)[RN_AU + r]; }
-            double ee[3], J[3];
+            R ee[3], J[3];
             ee[0] = -(W[2][0] * V1[0] + W[2][1] * V1[1] + W[2][2] * V1[2]);
             ee[1] = W[2][0] * V0[0] + W[2][1] * V0[1] + W[2][2] * V0[2];
             ee[2] = -(W[1][0] * V0[0] + W[1][1] * V0[1] + W[1][2] * V0[2]);
@@ -463,11 +500,11 @@ __global__ __launch_bounds__(KKT_THREADS, ANALYTIC ? KKT_WAVES_ANALYTIC : 2) voi
 #pragma unroll
             for (int r = 0; r < 3; ++r) J[r] = W[r][0] * a6u[0] + W[r][1] * a6u[1] + W[r][2] * a6u[2];
             const float* goal = a.eePos_traj + ((size_t)b * N + k) * 6;
-            double s0 = 0, s1 = 0;
+            R s0 = 0, s1 = 0;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                s0 += J[r] * (ee[r] - (double)goal[r]);
-                s1 += J[r] * (ee[r] - (double)goal[6 + r]);       // goal of knot k+1: used by the last block only
+                s0 += J[r] * (ee[r] - (R)goal[r]);
+                s1 += J[r] * (ee[r] - (R)goal[6 + r]);       // goal of knot k+1: used by the last block only
             }
             I->Gq[l] = s0;
             I->Gq1[l] = s1;
@@ -479,21 +516,21 @@ __global__ __launch_bounds__(KKT_THREADS, ANALYTIC ? KKT_WAVES_ANALYTIC : 2) voi
         kkt_lds_vf* flf = (kkt_lds_vf*)recs + (l <= KKT_NOM ? l : 0) * RN_ROWS;
         if (ANALYTIC && l <= KKT_NOM && !(KKT_ABLATE & 1)) rnea_grad(P, flf, I, l);
         if (l < n) {
-            double d[PJ], colv[PJ];
+            R d[PJ], colv[PJ];
             if constexpr (ANALYTIC) {
 #pragma unroll
-                for (int i = 0; i < PJ; ++i) d[i] = -(double)flf[RN_TAU(i)];
+                for (int i = 0; i < PJ; ++i) d[i] = -(R)flf[RN_TAU(i)];
             } else {
-                RneaTask t;
-                t.sj = l < PJ ? l : -1; t.pj = l < PJ ? -1 : l - PJ; t.qdscale = 1.0; t.knot_qdd = true; t.unit = -1; t.base = -1;
+                RneaTask<R> t;
+                t.sj = l < PJ ? l : -1; t.pj = l < PJ ? -1 : l - PJ; t.qdscale = R(1.0); t.knot_qdd = true; t.unit = -1; t.base = -1;
                 if (!(KKT_ABLATE & 1)) rnea(P, fl, I, t, a6w, a6u);
 #pragma unroll
-                for (int i = 0; i < PJ; ++i) d[i] = (fl[RN_TAU(i)] - I->U[i]) * (-1.0 / KKT_FD_H);
+                for (int i = 0; i < PJ; ++i) d[i] = (fl[RN_TAU(i)] - I->U[i]) * (-R(1.0) / R(KKT_FD_H));
             }
             asm volatile("" ::: "memory");                // (the float staging stores below reuse the records: keep them behind these loads)
 #pragma unroll
             for (int i = 0; i < PJ; ++i) {
-                double sv = 0;
+                R sv = 0;
 #pragma unroll
                 for (int tt = 0; tt < PJ; ++tt) sv += I->Minv[i][tt] * d[tt];
                 colv[i] = sv;
@@ -502,35 +539,35 @@ __global__ __launch_bounds__(KKT_THREADS, ANALYTIC ? KKT_WAVES_ANALYTIC : 2) voi
                 // The knot's outputs are STAGED in the group's (now free) records as float, in the order they have in memory, and
                 // copied out by all 16 lanes in 64-byte runs below.  Written straight from here — a lane per column, 14 lanes 56 bytes
                 // apart per store — the ~60 stores per lane were a fifth of the kernel's time (one cache line per lane and store).
-                const double dt = a.dt;
-                const double gql = l < PJ ? I->Gq[l] : 0.0, gq1l = l < PJ ? I->Gq1[l] : 0.0;
+                const R dt = a.dt;
+                const R gql = l < PJ ? I->Gq[l] : R(0.0), gq1l = l < PJ ? I->Gq1[l] : R(0.0);
                 // column l (column-major):  A = I + dt [[0, I], [dqdd/dq, dqdd/dqd]],  Q = blkdiag(g g^T, QD I)
 #pragma unroll
                 for (int r = 0; r < n; ++r) {
-                    double av = (r == l) ? 1.0 : 0.0;
-                    if (r < PJ) av += (l == r + PJ) ? dt : 0.0;
+                    R av = (r == l) ? R(1.0) : R(0.0);
+                    if (r < PJ) av += (l == r + PJ) ? dt : R(0.0);
                     else av += dt * colv[r - PJ];
                     st[ST_C + l * n + r] = (float)(-av);
-                    double qv, q1;
+                    R qv, q1;
                     if (r < PJ) { qv = I->Gq[r] * gql; q1 = I->Gq1[r] * gq1l; }
-                    else qv = q1 = (r == l) ? a.qd_cost : 0.0;
+                    else qv = q1 = (r == l) ? a.qd_cost : R(0.0);
                     st[ST_G + l * n + r] = (float)qv;
                     st[ST_Q1 + l * n + r] = (float)q1;
                 }
                 if (l < m) {
 #pragma unroll
-                    for (int r = 0; r < n; ++r) st[ST_C + nn + l * n + r] = (float)(-(r < PJ ? 0.0 : dt * I->Minv[r - PJ][l]));      // B = dt [0; Minv]
+                    for (int r = 0; r < n; ++r) st[ST_C + nn + l * n + r] = (float)(-(r < PJ ? R(0.0) : dt * I->Minv[r - PJ][l]));      // B = dt [0; Minv]
 #pragma unroll
-                    for (int r = 0; r < m; ++r) st[ST_G + nn + l * m + r] = (float)(r == l ? a.r_cost : 0.0);
+                    for (int r = 0; r < m; ++r) st[ST_G + nn + l * m + r] = (float)(r == l ? a.r_cost : R(0.0));
                     st[ST_g + n + l] = (float)(a.r_cost * I->U[l]);
                 }
-                const double qdl = I->Xq[l < PJ ? l + PJ : l];              // qd_{l mod 7}
+                const R qdl = I->Xq[l < PJ ? l + PJ : l];              // qd_{l mod 7}
                 st[ST_g + l] = (float)(l < PJ ? gql : a.qd_cost * qdl);
                 st[ST_g1 + l] = (float)(l < PJ ? gq1l : a.qd_cost * qdl);  // last block only (evaluated at x_{N-2}: iiwa_eepos_plant.cuh:407)
                 // integrator defect c_{k+1} = x_{k+1} - (x_k + dt [qd; qdd]);  c_0 = x_0 - x_s
-                const double pred = l < PJ ? I->Xq[l] + dt * qdl : qdl + dt * I->Qdd[l - PJ];
-                st[ST_c1 + l] = (float)((double)xu[(n + m) + l] - pred);
-                if (k == 0) st[ST_c0 + l] = (float)((double)xu[l] - (double)a.xs[(size_t)b * n + l]);
+                const R pred = l < PJ ? I->Xq[l] + dt * qdl : qdl + dt * I->Qdd[l - PJ];
+                st[ST_c1 + l] = (float)((R)xu[(n + m) + l] - pred);
+                if (k == 0) st[ST_c0 + l] = (float)((R)xu[l] - (R)a.xs[(size_t)b * n + l]);
             }
         }
         __syncthreads();

@@ -50,6 +50,7 @@ struct mpcg_handle {
     uint32_t* sched_order = nullptr;   // [1 + max_batch] {batch it was made for, dispatch order}: written after every hinted solve, checked on the device
     int schur_chunk = 0;      //   block rows per chunk of the walking kernel: 0 auto (by call size), 1..2048 forced
     int kkt_analytic = 1;     // mpcg_generate_kkt: 1 = analytic gradient recursion of the inverse dynamics (as the reference's GRiD code), 0 = one-sided float64 differences (the checker)
+    int kkt_f32 = 0;          // mpcg_generate_kkt: 1 = the analytic kernel in float arithmetic (linsys_t's own, as the reference's GRiD<float>); 0 = float64 inside
     int dz_dpp = 1;           // 1: four-knots-per-wavefront dz recovery (schur_walk.hip.h), 0: the one-workgroup-per-knot LDS kernel
     int last_schur_chunk = 0; //   what the last mpcg_form_schur used (0: the LDS kernels)
     void* seam_qinv = nullptr;       // schur_walk: one Q^-1 per chunk seam (float or double; ensure_seam_buffer)

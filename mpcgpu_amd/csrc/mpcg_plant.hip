@@ -8,7 +8,7 @@ using namespace mpcg;
 extern "C" {
 
 // ---- the producer of the path's inputs: KKT block assembly with the robot as data (kkt_plant.hip.h) ----
-struct mpcg_plant { int device = 0; PlantDev* d = nullptr; };
+struct mpcg_plant { int device = 0; PlantDev* d = nullptr; PlantDevT<float>* d32 = nullptr; };      // (d32: the same tables rounded to float, behind d in ONE allocation)
 
 int mpcg_plant_create(mpcg_plant** out, int device, uint32_t num_joints, const double* X_const, const double* I_spatial, const double* Xhom_const,
                       const int32_t* X_trig_idx, const double* X_trig_coef, const int32_t* X_trig_j, uint32_t n_X_trig,
@@ -155,12 +155,21 @@ int mpcg_plant_create(mpcg_plant** out, int device, uint32_t num_joints, const d
     if (!pl) { delete hp; return MPCG_ERR_NOMEM; }
     if (device < 0 && hipGetDevice(&device) != hipSuccess) { delete hp; delete pl; return fail(nullptr, MPCG_ERR_HIP, "mpcg_plant_create: no HIP device"); }
     pl->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&pl->d), sizeof(PlantDev)) != hipSuccess ||
-        hipMemcpy(pl->d, hp, sizeof(PlantDev), hipMemcpyHostToDevice) != hipSuccess) {
-        delete hp; delete pl;
+    // the float build of the kernel (linsys_t's own arithmetic, "kkt_f32") reads the same tables rounded to float
+    PlantDevT<float>* hp32 = new (std::nothrow) PlantDevT<float>();
+    if (!hp32) { delete hp; delete pl; return MPCG_ERR_NOMEM; }
+    for (int k = 0; k < PJ; ++k) {
+        for (int e = 0; e < 9; ++e) { hp32->ET[k][e] = (float)hp->ET[k][e]; hp32->BT[k][e] = (float)hp->BT[k][e]; }
+        for (int e = 0; e < 10; ++e) hp32->Ib[k][e] = (float)hp->Ib[k][e];
+    }
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&pl->d), sizeof(PlantDev) + sizeof(PlantDevT<float>)) != hipSuccess ||
+        hipMemcpy(pl->d, hp, sizeof(PlantDev), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(pl->d + 1, hp32, sizeof(PlantDevT<float>), hipMemcpyHostToDevice) != hipSuccess) {
+        delete hp; delete hp32; delete pl;
         return fail(nullptr, MPCG_ERR_HIP, "mpcg_plant_create: cannot place the model on the device");
     }
-    delete hp;
+    pl->d32 = reinterpret_cast<PlantDevT<float>*>(pl->d + 1);
+    delete hp; delete hp32;
     *out = pl;
     return MPCG_OK;
 }
@@ -199,8 +208,14 @@ int mpcg_generate_kkt(mpcg_handle* h, const mpcg_plant* plant, uint32_t control_
     long blocks = ((long)batch * (h->N - 1) + KKT_ITEMS - 1) / KKT_ITEMS;      // one wavefront per KKT_ITEMS (trajectory, knot) pairs
     const long cap = (long)h->num_cus * 32;
     if (blocks > cap) blocks = cap;
-    if (h->kkt_analytic) hipLaunchKernelGGL(generate_kkt_kernel<true>, dim3((unsigned)blocks), dim3(KKT_THREADS), 0, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(generate_kkt_kernel<false>, dim3((unsigned)blocks), dim3(KKT_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    if (h->kkt_analytic && h->kkt_f32) {                  // linsys_t = float arithmetic throughout, as the reference's GRiD code (kkt_plant.hip.h, R = float)
+        KktArgsT<float> f;
+        f.plant = plant->d32; f.eePos_traj = d_eePos_traj; f.xs = d_xs; f.xu = d_xu;
+        f.G = d_G_dense; f.C = d_C_dense; f.g = d_g; f.c = d_c;
+        f.N = (int)h->N; f.batch = (int)batch; f.dt = timestep; f.qd_cost = qd_cost; f.r_cost = r_cost; f.analytic = 1;
+        hipLaunchKernelGGL((generate_kkt_kernel<true, float>), dim3((unsigned)blocks), dim3(KKT_THREADS), 0, static_cast<hipStream_t>(stream), f);
+    } else if (h->kkt_analytic) hipLaunchKernelGGL((generate_kkt_kernel<true, double>), dim3((unsigned)blocks), dim3(KKT_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL((generate_kkt_kernel<false, double>), dim3((unsigned)blocks), dim3(KKT_THREADS), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRY(h, hipGetLastError());
     return MPCG_OK;
 }

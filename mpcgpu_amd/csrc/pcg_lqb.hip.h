@@ -230,6 +230,8 @@ __device__ __forceinline__ void lqb_epilogue(float& part, LqbPiece& fin, const L
 // (alpha = eta / v and beta = eta' / eta stay IEEE divisions: v_rcp_f32 + one residual correction behind a wave-uniform range test — v_rcp_f32 has
 //  no denormal support, pcg_lpk.hip.h — measured SLOWER here too: 1.64-1.67 against 1.60 us per iteration of one N = 128 trajectory; the second
 //  code path costs two registers and the branch more than the seven dependent instructions it saves.)
+// (Nor does taking beta's reciprocal off the critical path pay — 1 / eta formed half an iteration early, eta' * (1 / eta) behind the barrier, the division
+//  outside [2^-100, 2^100]: two more live registers, N = 64 one trajectory 1.07 -> 1.14 us per iteration, N = 128 unchanged.)
 template <int NMAXQ>
 __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
     typedef LqbLds<NMAXQ> L;

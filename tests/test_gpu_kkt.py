@@ -56,6 +56,32 @@ def test_generate_kkt_vs_host_restatement(env, N, B, analytic):
             assert np.abs(got - ref).max() <= tol, (b, name, np.abs(got - ref).max(), np.abs(ref).max())
 
 
+@pytest.mark.parametrize("N,B", [(8, 3), (32, 5), (128, 2)])
+def test_generate_kkt_in_float_arithmetic(env, N, B):
+    """"kkt_f32" = 1 (round 6, opt-in): the analytic kernel with every recursion in float — linsys_t's own arithmetic, what the reference's GRiD code
+    runs in (iiwa_eepos_plant.cuh:127-155, T = float).  Against the float64 host restatement: float-level agreement (measured 1.5e-6 of max(1, |block|);
+    the float64-inside default: 2e-7), limit 1e-5; against the default kernel's outputs likewise."""
+    PcgSolver, plant, _, M = env
+    xu, goals, xs = windows(N, B, 77 + N)
+    outs = {}
+    for f32 in (0, 1):
+        sol = PcgSolver(N, max_batch=B)
+        sol.set_option("kkt_f32", f32)
+        assert sol.get_option("kkt_f32") == f32
+        o = sol.generate_kkt(plant, dev(goals.reshape(B, -1)), dev(xs), dev(xu), iiwa.TIMESTEP, iiwa.QD_COST, iiwa.r_cost(N))
+        torch.cuda.synchronize()
+        outs[f32] = [t.cpu().numpy() for t in o]
+        assert all(np.isfinite(a).all() for a in outs[f32])
+    for b in range(B):
+        want = iiwa_ref.generate_kkt(M, xu[b].astype(np.float32).astype(np.float64), goals[b].astype(np.float32).astype(np.float64),
+                                 xs[b].astype(np.float32).astype(np.float64), N)
+        for i, name in enumerate("GCgc"):
+            scale = max(1.0, np.abs(want[i]).max())
+            e32, e64 = np.abs(outs[1][i][b] - want[i]).max() / scale, np.abs(outs[0][i][b] - want[i]).max() / scale
+            assert e32 <= 1e-5 and e64 <= 1e-6, (b, name, e32, e64)
+            assert np.abs(outs[1][i][b].astype(np.float64) - outs[0][i][b]).max() / scale <= 1e-5
+
+
 def test_generate_kkt_integrator_defects_vanish_on_the_reference_trajectory(env):
     """THE PIN OF THE DEVICE DYNAMICS ON REFERENCE-HELD DATA: with xu = consecutive rows of the reference's own
     0_0_traj.csv (tests/golden/iiwa_traj_0_0_full.npz, all 666 rows) and dt = 1/64, the integrator defects c_{k+1} that mpcg_generate_kkt
