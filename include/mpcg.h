@@ -319,14 +319,14 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
 /* Options (tuning / experiments; defaults are chosen by mpcg_create from knot_points and per call from the batch).
  * Kernel selection of a float solve (state_size 14):
  *   "pcg_rpl" (-1 auto / 0 / 1): the row-per-lane kernel for knot_points <= 64 — a DPP row per knot, vectors in registers; automatic for
- *       knot_points <= 32 and for calls of at most one trajectory per CU up to 64; "rpl_waves" (its wavefronts per trajectory: 0 auto, 4, 8, 16);
+ *       knot_points <= 32 (below 2.5 trajectories per CU at 16 < knot_points <= 32; with "pcg_lqb" = 0 also for calls of at most one trajectory per CU up to 64); "rpl_waves" (its wavefronts per trajectory: 0 auto, 4, 8, 16);
  *   "pcg_lpk" (-1 auto / 0 / 1): the lane-pair-per-knot kernel, knot_points <= 128 — everything in registers, a matrix per wavefront; the automatic
- *       choice for block-Jacobi calls at 64 < knot_points <= 128 and for fp16 storage; = 1 forces it (and keeps the lane-quad kernel out);
+ *       choice for fp16 storage only since round 6; = 1 forces it (and keeps the lane-quad kernel out);
  *   "pcg_lqb" (-1 auto / 0 / 1; round 6): the lane-quad-per-knot kernel, knot_points <= 128 — everything in registers, a QUARTER of both matrices
  *       in every wavefront, so that all wavefronts of a workgroup run every pass (two working wavefronts per SIMD).  It takes the lane-pair
- *       kernel's launches (same contract: block lower triangle, gated and fix-up launches, dispatch order); automatic for 32 < knot_points <= 64
- *       at every batch and both preconditioners, for SS calls at 64 < knot_points <= 128, and — with workgroups of 32 knots, four per CU — for
- *       16 < knot_points <= 32 when the call brings more than four trajectories per CU (from 2.5 to four: the lane-pair kernel's half build); = 0 gives those calls back to the lane-pair kernel (and
+ *       kernel's launches (same contract: block lower triangle, gated and fix-up launches, dispatch order); automatic, for both preconditioners, for 32 < knot_points <= 64
+ *       at every batch, at 64 < knot_points <= 128, and — with workgroups of 32 knots, four per CU — for
+ *       16 < knot_points <= 32 when the call brings at least 2.5 trajectories per CU (block-Jacobi calls run a build of their own); = 0 gives those calls back to the lane-pair kernel (and
  *       the row-per-lane / row-pair kernels their round-5 ranges), = 1 runs it wherever the lane-pair kernel would run;
  *   "cluster" (-1 auto / 0 off / G = 2..8 forced): workgroups (= CUs of one XCD) per trajectory of the clustered lane-pair kernel, automatic
  *       for knot_points > 128 (G = ceil(N / 128)).  Members exchange inner-product partials and boundary knots through the XCD's L2
@@ -369,9 +369,8 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  *       loop), "last_schur_chunk" (block rows per chunk of the last mpcg_form_schur, 0 = the LDS kernels), "last_kernel_family" (kernel of the
  *       last solve: 0 single-workgroup row-pair, 3 generic, 5 row-per-lane, 6 lane-pair-per-knot, 7 clustered lane-pair, 8 clustered row-per-lane
  *       (double), 9 lane-quad-per-knot (double), 10 clustered lane-quad (double), 11 lane-quad-per-knot with both matrices per wavefront (float, round 6); 1, 2, 4 were kernels retired in round 4), "last_kernel_{waves,reg_rows,lds_rows,lds_extra,stream_bufs,cluster,lds_bytes}".
- * WHICH kernel family serves a call depends on knot_points, on the preconditioner (64 < N <= 128: SS the lane-quad kernel, block-Jacobi the
- * lane-pair kernel) AND, up to 32 knots, on the call's batch (N <= 32: row-per-lane kernel, 8 waves x 1 slot or 4 x 2 by batch; 16 < N <= 32:
- * the lane-pair kernel's half build from 2.5 trajectories per CU, the lane-quad kernel beyond four; 32 < N <= 128: one kernel at every batch since round 6).  Families sum the inner products in different
+ * WHICH kernel family serves a call depends on knot_points AND, up to 32 knots, on the call's batch (N <= 32: row-per-lane kernel, 8 waves x 1 slot or 4 x 2 by batch; 16 < N <= 32:
+ * the lane-quad kernel from 2.5 trajectories per CU; 32 < N <= 128: one kernel at every batch since round 6).  Families sum the inner products in different
  * orders, so the SAME trajectory solved alone and inside a large batch may differ in the last fp32 bits (and, near the tolerance, by an
  * iteration); within one family results are bitwise reproducible run to run and independent of batch composition.  Pin a family with
  * "pcg_rpl" / "pcg_lpk" / "pcg_lqb" / "rpl_waves" when bit-stability across batch sizes matters.  None of the residency knobs changes results within a

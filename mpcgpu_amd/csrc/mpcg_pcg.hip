@@ -549,7 +549,7 @@ static int launch_lpk_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStr
 template <int NMAXQ>
 static int launch_lqb_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
     const size_t lds = pcg_lqb_lds_floats(NMAXQ) * sizeof(float);
-    auto kern = pcg_lqb_kernel<NMAXQ>;
+    void (*kern)(PcgArgs) = a.pcols == 3 ? pcg_lqb_kernel<NMAXQ, true> : pcg_lqb_kernel<NMAXQ, false>;      // (SS / block-Jacobi builds)
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(batch), dim3(NMAXQ * 4), lds, st, a);
@@ -558,23 +558,21 @@ static int launch_lqb_t(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStr
     return MPCG_OK;
 }
 // The float lane-quad kernel takes the lane-pair kernel's launches (same contract: lower block triangle, gated / fix-up launches, dispatch order).
-// Automatic use (tools/_prof/lqb_policy.py, profiles/r06_lqb_policy.txt; "pcg_lqb" = 1 / 0 forces / forbids, an explicit "pcg_lpk" = 1 keeps the lane-pair kernel):
-//   * 32 < knot_points <= 64: both preconditioners — two independent workgroups per CU, all of their wavefronts working: 1.21-1.30x the lane-pair /
-//     row-per-lane / row-pair kernels at every batch for SS (one trajectory of 64 knots: 0.193 against 0.246 ms), 1.09-1.39x block-Jacobi;
-//   * 64 < knot_points <= 128: SS only (1.01-1.11x; block-Jacobi's Pinv pass keeps the whole skeleton for a third of the FMAs: 0.90-0.99x).
+// Automatic use ("pcg_lqb" = 1 / 0 forces / forbids, an explicit "pcg_lpk" = 1 keeps the lane-pair kernel; steady clocks, tools/_prof/lqb_ab.py,
+// lqb_n32.py, lqb_n32_forced.py; the first sweep: profiles/r06_lqb_policy.txt): WHEREVER the lane-pair kernel ran in fp32, both preconditioners
+// (block-Jacobi is a build of its own, pcg_lqb_kernel<., false>: no off-diagonal Pinv blocks, no z) —
+//   * 32 < knot_points <= 64, every batch: two independent workgroups per CU, all of their wavefronts working: one trajectory of 64 knots 1.03 against
+//     1.44 us per iteration (block-Jacobi 0.94 / 1.22), batch 1024 3.02 / 3.71 (2.45 / 3.09); also ahead of the row-per-lane kernel's latency-sized calls;
+//   * 64 < knot_points <= 128: 1.58 / 1.62 us per iteration of one trajectory, 6.31 / 6.54 per 1024 (block-Jacobi 1.32 / 1.34, 5.29 / 5.51);
+//   * 16 < knot_points <= 32, throughput-sized calls (lpk_half): equal to the lane-pair kernel's half build at 2.5-4 trajectories per CU (+-1 %),
+//     1.10x (SS) / 1.13-1.19x (block-Jacobi) beyond.
 static bool lqb_auto(const mpcg_handle* h, int esz) { return esz == 4 && h->lqb == -1 && h->lpk == -1 && h->rpl != 1 && h->auto_cfg && h->cluster <= 0; }
-//   * knot_points <= 32 (throughput-sized calls only, lpk_half): beyond ONE round of four 32-knot workgroups per CU — batch 2048 / 4096 at 24 and 32 knots:
-//     1.03-1.06x at the iteration cap, 1.08-1.15x at 26 iterations; exactly four per CU the lane-pair kernel's half build is 4-6 % ahead
-//     (tools/_prof/lqb_n32.py).
-static bool use_lqb(const mpcg_handle* h, int esz, int pcols, uint32_t batch) {
+static bool use_lqb(const mpcg_handle* h, int esz) {
     if (esz != 4 || h->lqb == 0) return false;
-    if (h->lqb == 1) return true;
-    if (!lqb_auto(h, esz)) return false;
-    if (h->N <= 32) return batch > 4u * (uint32_t)h->num_cus;
-    return h->N <= 64 || pcols == 3;
+    return h->lqb == 1 || lqb_auto(h, esz);
 }
 static int launch_lpk(mpcg_handle* h, const PcgArgs& a, uint32_t batch, hipStream_t st) {
-    if (use_lqb(h, a.esz, a.pcols, batch)) {
+    if (use_lqb(h, a.esz)) {
         if (h->N <= 32) return launch_lqb_t<32>(h, a, batch, st);
         return h->N <= 64 ? launch_lqb_t<64>(h, a, batch, st) : launch_lqb_t<128>(h, a, batch, st);
     }
@@ -892,7 +890,7 @@ static int occupancy(mpcg_handle* h, const PcgKnobs& k, int* per_cu) {
 // LDS bytes of the launch a default-configured batch-1 solve makes (what pcgSharedMemSize stands for)
 static size_t default_launch_lds_bytes(uint32_t N, int num_cus) {
     if (N <= 32) return pcg_rpl_lds_floats((int)N, N <= 16 ? 4 : 8) * sizeof(float);           // row-per-lane kernel (a batch-1 call)
-    if (N <= kLpbMaxN) return pcg_lqb_lds_floats(N <= 64 ? 64 : 128) * sizeof(float);  // lane-quad kernel (SS; block-Jacobi beyond 64 knots: the lane-pair kernel, pcg_lpk_lds_floats(8))
+    if (N <= kLpbMaxN) return pcg_lqb_lds_floats(N <= 64 ? 64 : 128) * sizeof(float);  // lane-quad kernel
     mpcg_handle tmp;
     tmp.N = N; tmp.n = NS; tmp.num_cus = num_cus;
     if (lpkc_members(&tmp) > 0) return pcg_lpkc_lds_floats(8) * sizeof(float);          // clustered lane-pair kernel
@@ -1167,14 +1165,14 @@ int mpcg_check_pcg_occupancy(mpcg_handle* h, uint32_t* resident_trajectories) {
 #define X(NW_, RHO_) if (nw == NW_ && rho == RHO_) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_rpl_kernel<NW_, RHO_, true>, NW_ * 64, lds));
         MPCG_RPL_VARIANTS(X)
 #undef X
-    } else if (use_lpk(h, 4, h->max_batch) && use_lqb(h, 4, 3, h->max_batch)) {      // (an SS call)
+    } else if (use_lpk(h, 4, h->max_batch) && use_lqb(h, 4)) {
         const int nmax = h->N <= 32 ? 32 : h->N <= 64 ? 64 : 128;
         const size_t lds = pcg_lqb_lds_floats(nmax) * sizeof(float);
-        const void* kern = nmax == 32 ? reinterpret_cast<const void*>(pcg_lqb_kernel<32>) : nmax == 64 ? reinterpret_cast<const void*>(pcg_lqb_kernel<64>) : reinterpret_cast<const void*>(pcg_lqb_kernel<128>);
+        const void* kern = nmax == 32 ? reinterpret_cast<const void*>(pcg_lqb_kernel<32, true>) : nmax == 64 ? reinterpret_cast<const void*>(pcg_lqb_kernel<64, true>) : reinterpret_cast<const void*>(pcg_lqb_kernel<128, true>);
         HIP_TRY(h, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (nmax == 32) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lqb_kernel<32>, 128, lds));
-        else if (nmax == 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lqb_kernel<64>, 256, lds));
-        else HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lqb_kernel<128>, 512, lds));
+        if (nmax == 32) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lqb_kernel<32, true>, 128, lds));
+        else if (nmax == 64) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lqb_kernel<64, true>, 256, lds));
+        else HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lqb_kernel<128, true>, 512, lds));
     } else if (use_lpk(h, 4, h->max_batch)) {
         const size_t lds = pcg_lpk_lds_floats(h->N <= 32 ? 2 : h->N <= 64 ? 4 : 8) * sizeof(float);
         if (h->N <= 32) HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcg_lpk_kernel<0>, 128, lds));

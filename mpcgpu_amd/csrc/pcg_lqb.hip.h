@@ -226,13 +226,40 @@ __device__ __forceinline__ void lqb_epilogue(float& part, LqbPiece& fin, const L
           "s"(diag));                                                                                    // 29
     fin.p[0] = f2{k0, k1}; fin.p[1] = f2{k2, k3}; fin.p[2] = f2{k4, k5}; fin.s = k6;
 }
+// The same for a block-Jacobi Pinv pass (no off-diagonal blocks: nothing for knot k-1, z stays zero): the wavefront sum interleaved with the seven merge
+// adds of y — the lanes h == g publish, the others have nothing to select or send.  16 instructions instead of 27.
+__device__ __forceinline__ void lqb_epilogue_y(float& part, LqbPiece& fin, const LqbPiece& y) {
+    float k0, k1, k2, k3, k4, k5, k6;
+    asm volatile(
+        "v_add_f32_dpp %1, %8, %8 quad_perm:[1,3,0,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %9, %9 quad_perm:[1,3,0,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %10, %10 quad_perm:[1,3,0,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %4, %11, %11 quad_perm:[1,3,0,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %5, %12, %12 quad_perm:[1,3,0,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %6, %13, %13 quad_perm:[1,3,0,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %7, %14, %14 quad_perm:[1,3,0,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(part), "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3), "=&v"(k4), "=&v"(k5), "=&v"(k6)
+        : "v"(y.p[0].x), "v"(y.p[0].y), "v"(y.p[1].x), "v"(y.p[1].y), "v"(y.p[2].x), "v"(y.p[2].y), "v"(y.s));
+    fin.p[0] = f2{k0, k1}; fin.p[1] = f2{k2, k3}; fin.p[2] = f2{k4, k5}; fin.s = k6;
+}
 
 // (alpha = eta / v and beta = eta' / eta stay IEEE divisions: v_rcp_f32 + one residual correction behind a wave-uniform range test — v_rcp_f32 has
 //  no denormal support, pcg_lpk.hip.h — measured SLOWER here too: 1.64-1.67 against 1.60 us per iteration of one N = 128 trajectory; the second
 //  code path costs two registers and the branch more than the seven dependent instructions it saves.)
 // (Nor does taking beta's reciprocal off the critical path pay — 1 / eta formed half an iteration early, eta' * (1 / eta) behind the barrier, the division
 //  outside [2^-100, 2^100]: two more live registers, N = 64 one trajectory 1.07 -> 1.14 us per iteration, N = 128 unchanged.)
-template <int NMAXQ>
+// PC3: the preconditioner has off-diagonal blocks (SS); false = block-Jacobi — a build of its own, so that the SS build carries nothing of it (as a
+// wave-uniform branch inside one build the second epilogue cost the SS path 4-7 %: tools/_prof/lqb_ab.py).
+template <int NMAXQ, bool PC3>
 __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
     typedef LqbLds<NMAXQ> L;
     constexpr int NW = L::NW, NTHR = NW * 64;
@@ -256,7 +283,7 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
     const int k = 16 * w + (lane >> 2);
     const bool diag = h == g;                                  // publishes y (else z)
     const unsigned long long diag_mask = __builtin_amdgcn_ballot_w64(diag);      // (an SGPR pair: the v_cndmask operand of lqb_epilogue)
-    const bool p3 = a.pcols == 3;
+    constexpr bool p3 = PC3;                                   // (the launcher picks the build by a.pcols)
     constexpr int KN = L::KN, K2 = 2 * KN;
     // float offsets inside a vector: pairs 4 h + rp of knot j at 2 (j + 1) + (4 h + rp) K2; entry 6 + h at 2 (j + 1) + 3 K2 + h
     const int fb = 2 * (k - g + 1) + 4 * h * K2, fs = 2 * (k - g + 1) + 3 * K2 + h;       // the carried piece (knot k - g)
@@ -333,13 +360,14 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
     // Order (register budget): transposed product in two column groups -> direct L (x_{k-1}) -> direct D (x_k), the parked pairs last.
     // The coupling term of the inner product comes from the DIRECT product: x_{k-1}^T (L^T x_k) = x_k^T (L x_{k-1}), so that x_{k-1}'s piece is
     // dead once the L columns are done: x^T M x = sum x_k[piece g] . (ypart + L-part of ypart).
-    auto pass = [&](const LqbSub& D, const LqbSub& Lb, const LqbPiece& mine, bool hasL, int TOUT, float* red, const f2* park, int pb) {
+    auto pass = [&](auto hasl_tag, const LqbSub& D, const LqbSub& Lb, const LqbPiece& mine, int TOUT, float* red, const f2* park, int pb) {
+        constexpr bool hasL = decltype(hasl_tag)::value;
         const LqbPiece xg = lqb_quad<LQB_QP_XG>(mine);
         MPCG_STAMP(pb + 1);
         LqbPiece ypart, zpart;
         f2 acc[3], dd;
         float y6, ds;
-        if (hasL) {
+        if constexpr (hasL) {
             // transposed: zpart[piece h] = L^T x_k[piece g]
             const f2 xs = f2{xg.s, xg.s};
             {
@@ -384,11 +412,9 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
             dd = __builtin_elementwise_fma(acc[2], xg.p[2], dd);
             ds = y6 * xg.s;
         } else {
-            // (zeros made HERE: as plain constants the compiler materialises all 17 in front of the branch, on the SS path too)
-            auto zero = []() -> float { float v; asm volatile("v_mov_b32 %0, 0" : "=v"(v)); return v; };
 #pragma unroll
-            for (int cp = 0; cp < 3; ++cp) { zpart.p[cp] = f2{zero(), zero()}; acc[cp] = f2{zero(), zero()}; }
-            zpart.s = zero(); y6 = zero(); ds = zero(); dd = f2{zero(), zero()};
+            for (int cp = 0; cp < 3; ++cp) { acc[cp] = f2{0.f, 0.f}; zpart.p[cp] = f2{0.f, 0.f}; }      // (compile-time: folded away)
+            y6 = 0.f; ds = 0.f; dd = f2{0.f, 0.f}; zpart.s = 0.f;
         }
         // direct, diagonal block: D x_k[piece h]; the pairs parked in LDS are requested here (volatile: in program order) and used last
         const LqbPiece xh = lqb_quad<LQB_QP_XH>(mine);
@@ -417,12 +443,15 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
         MPCG_STAMP(pb + 2);
         float part = fmaf(ypart.s, xg.s, ds) + lqb_hsum(dd);
         LqbPiece fin;
-        lqb_epilogue(part, fin, ypart, zpart, diag_mask);
+        if constexpr (hasL) lqb_epilogue(part, fin, ypart, zpart, diag_mask);
+        else lqb_epilogue_y(part, fin, ypart);
         if (lane == 63) red[w] = part;
-        float* out = lds + TOUT;
+        if (hasL || diag) {                                  // (block-Jacobi: the z vector stays at its zeros)
+            float* out = lds + TOUT;
 #pragma unroll
-        for (int rp = 0; rp < 3; ++rp) *reinterpret_cast<f2*>(out + ob + K2 * rp) = fin.p[rp];
-        out[os] = fin.s;
+            for (int rp = 0; rp < 3; ++rp) *reinterpret_cast<f2*>(out + ob + K2 * rp) = fin.p[rp];
+            out[os] = fin.s;
+        }
         MPCG_STAMP(pb + 3);
     };
     // the carried piece after an update: MODE 1: old - c (T + Z<<1) (r, c = alpha); MODE 2: (T + Z<<1) + c old (p, c = beta)
@@ -442,11 +471,11 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) pv.p[i] = f2{0.f, 0.f};
     pv.s = 0.f;
-    pass(SD, SL, lam, true, L::US, red_v, parkS, 16);
+    pass(std::true_type{}, SD, SL, lam, L::US, red_v, parkS, 16);
     lds_barrier();
     Fetch f = fetch(L::US);
     rv = rebuild(std::integral_constant<int, 1>{}, rv, f, 1.f);
-    pass(PD, PL, rv, p3, L::RT, red_e, parkP, 16);
+    pass(std::integral_constant<bool, PC3>{}, PD, PL, rv, L::RT, red_e, parkP, 16);
     lds_barrier();
     Red rd = load_red(red_e);
     f = fetch(L::RT);
@@ -465,7 +494,7 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
             MPCG_STAMP(0);
             // p = r~ + beta p ; upsilon = S p ; v = p . upsilon
             pv = rebuild(std::integral_constant<int, 2>{}, pv, f, beta);
-            pass(SD, SL, pv, true, L::US, red_v, parkS, 0);
+            pass(std::true_type{}, SD, SL, pv, L::US, red_v, parkS, 0);
             lds_barrier();
             MPCG_STAMP(4);
             rd = load_red(red_v);
@@ -481,7 +510,7 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
             lam.s = lam.s + alpha * pv.s;
             rv = rebuild(std::integral_constant<int, 1>{}, rv, f, alpha);
             MPCG_STAMP(5);
-            pass(PD, PL, rv, p3, L::RT, red_e, parkP, 5);
+            pass(std::integral_constant<bool, PC3>{}, PD, PL, rv, L::RT, red_e, parkP, 5);
             lds_barrier();
             MPCG_STAMP(9);
             rd = load_red(red_e);

@@ -278,7 +278,7 @@ def test_batch_composition_independence(P):
 
 def test_half_build_policy_on_short_horizons(P, orc):
     """16 < N <= 32 (round 5): calls of at least 2.5 trajectories per CU run the lane-pair kernel's HALF build (family 6, two wavefronts, four
-    workgroups per CU) — beyond four per CU (round 6) the lane-quad kernel's 32-knot build (family 11, two wavefronts, four workgroups per CU) —
+    workgroups per CU; since round 6, by default, the lane-quad kernel's 32-knot build: family 11, two wavefronts, four workgroups per CU),
     smaller ones and N <= 16 the row-per-lane kernel (family 5).  Copies of four systems solve to the same bits wherever
     they land; a sub-batch below the threshold comes from the other kernel and agrees inside the float32 band."""
     PcgSolver, pcg_config = P
@@ -286,7 +286,7 @@ def test_half_build_policy_on_short_horizons(P, orc):
     sol = PcgSolver(N, max_batch=4096)
     P.default_policy(sol)
     ncu = sol.get_option("num_cus")
-    B = (5 * ncu + 1) // 2 if P.kern == "lpk" else 4 * ncu + 4      # (the lane-quad kernel takes such calls beyond ONE round of four workgroups per CU)
+    B = (5 * ncu + 1) // 2
     k = synth.make_kkt(N, 4, 515)
     S4, P4, g4 = synth.form_schur(k)
     rep = (B + 3) // 4
@@ -309,9 +309,6 @@ def test_half_build_policy_on_short_horizons(P, orc):
     sol.solve(dS[:Bs], dP[:Bs], dg[:Bs], lam_s, cfg, "ss")
     torch.cuda.synchronize()
     assert sol.get_option("last_kernel_family") == 5
-    if P.kern == "lqb":                                      # between 2.5 and four per CU: the lane-pair kernel's half build
-        sol.solve(dS[:3 * ncu], dP[:3 * ncu], dg[:3 * ncu], torch.zeros(3 * ncu, n * N, device="cuda"), cfg, "ss")
-        assert sol.get_option("last_kernel_family") == 6 and sol.get_option("last_kernel_waves") == 2
     assert relinf(lam_s.cpu().numpy()[:4], lamh[:4]) < 2e-3
     sol16 = PcgSolver(16, max_batch=B)
     k16 = synth.make_kkt(16, 2, 516)

@@ -79,10 +79,8 @@ def exit_iter_bounds(orc, S, Pinv, g, lam0, N, max_iter, tol, pc, trials=8):
 
 def default_family(N, pc="ss", batch_per_cu=0.0):
     """"last_kernel_family" of a default fp32 solve (state_size 14; include/mpcg.h, options): 5 row-per-lane up to 32 knots (16 < N <= 32 from 2.5
-    trajectories per CU: the lane-pair kernel's half build, beyond four: the lane-quad kernel), 11 lane-quad to 64 knots and, for SS, to 128;
-    6 lane-pair for block-Jacobi at 64 < N <= 128; 7 clustered lane-pair beyond."""
+    trajectories per CU: the lane-quad kernel's 32-knot build), 11 lane-quad to 128 knots (both preconditioners); 7 clustered
+    lane-pair beyond.  (6, the lane-pair kernel: fp16 storage and "pcg_lqb" = 0.)"""
     if N <= 32:
-        return (11 if batch_per_cu > 4 else 6) if N > 16 and batch_per_cu >= 2.5 else 5
-    if N <= 64 or (N <= 128 and pc == "ss"):
-        return 11
-    return 6 if N <= 128 else 7
+        return 11 if N > 16 and batch_per_cu >= 2.5 else 5
+    return 11 if N <= 128 else 7
