@@ -170,7 +170,10 @@ __device__ __forceinline__ void lqb_load_blocks_lds(rsrc_t MS, rsrc_t MP, int kf
 #ifndef LQB_NPARK
 #define LQB_NPARK 6      // pairs of each matrix's diagonal sub-block parked in LDS (lane-private slots inside the wavefront's second load tile, idle after the load)
 #endif
-static_assert(LQB_NPARK >= 0 && LQB_NPARK <= 6, "2 x NPARK x 512 B must fit the wavefront's 6,272-byte tile");
+#ifndef LQB_NPARK_J
+#define LQB_NPARK_J 0    // the same for the block-Jacobi build: none — it carries no off-diagonal Pinv sub-block (214 VGPRs); 0 / 3 / 6 parked: 1.287 / 1.295 / 1.319 us per iteration at N = 128
+#endif
+static_assert(LQB_NPARK >= 0 && LQB_NPARK <= 6 && LQB_NPARK_J >= 0 && LQB_NPARK_J <= 6, "2 x NPARK x 512 B must fit the wavefront's 6,272-byte tile");
 // x + y of a pair as ONE scalar add (left to the compiler, neighbouring horizontal sums are "vectorised": three moves + a packed add per two)
 __device__ __forceinline__ float lqb_hsum(f2 v) {
     float r;
@@ -301,9 +304,10 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
     // registers + the working set of a pass only just, and what the compiler spills goes to SCRATCH, reloaded in every pass (pcg_lpk.hip.h).
     // The slots live in this wavefront's own second load tile, idle from here on.
     f2* const parkS = reinterpret_cast<f2*>(lds + L::TILE2 + w * LPK_TILE_FLOATS) + lane;
-    f2* const parkP = parkS + LQB_NPARK * 64;
+    constexpr int NPK = PC3 ? LQB_NPARK : LQB_NPARK_J;
+    f2* const parkP = parkS + NPK * 64;
 #pragma unroll
-    for (int i = 0; i < LQB_NPARK; ++i) {
+    for (int i = 0; i < NPK; ++i) {
         parkS[i * 64] = SD.A[i % 3][6 - i / 3];
         parkP[i * 64] = PD.A[i % 3][6 - i / 3];
     }
@@ -418,9 +422,9 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
         }
         // direct, diagonal block: D x_k[piece h]; the pairs parked in LDS are requested here (volatile: in program order) and used last
         const LqbPiece xh = lqb_quad<LQB_QP_XH>(mine);
-        f2 pk_[LQB_NPARK > 0 ? LQB_NPARK : 1];
+        f2 pk_[NPK > 0 ? NPK : 1];
 #pragma unroll
-        for (int i = 0; i < LQB_NPARK; ++i) pk_[i] = lds_ld64(reinterpret_cast<const float*>(park + i * 64));
+        for (int i = 0; i < NPK; ++i) pk_[i] = lds_ld64(reinterpret_cast<const float*>(park + i * 64));
         f2 a6 = D.B[0] * xh.p[0];
         a6 = __builtin_elementwise_fma(D.B[1], xh.p[1], a6);
         a6 = __builtin_elementwise_fma(D.B[2], xh.p[2], a6);
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
 #pragma unroll
             for (int rp = 0; rp < 3; ++rp) {
                 const int pi = 3 * (6 - J) + rp;
-                acc[rp] = __builtin_elementwise_fma(pi < LQB_NPARK ? pk_[pi < LQB_NPARK ? pi : 0] : D.A[rp][J], xb, acc[rp]);
+                acc[rp] = __builtin_elementwise_fma(pi < NPK ? pk_[pi < NPK ? pi : 0] : D.A[rp][J], xb, acc[rp]);
             }
         });
 #pragma unroll
