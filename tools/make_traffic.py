@@ -13,7 +13,7 @@ out = {"source": f"profiles/{tag}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_S
 for name, k in pmc.items():
     if "hbm_traffic_bytes_per_launch" not in k:
         continue
-    if "pcg_lqb_kernel<128>" in name:          # the headline kernel since round 6 (the lane-pair kernel before: the same key with its name)
+    if "pcg_lqb_kernel<128, true>" in name:          # the headline kernel since round 6 (the lane-pair kernel before: the same key with its name)
         key = f"pcg_lqb_kernel|N{N}_B{B}_{pc}_it{mi}_tol{float(tol):g}"
     elif "pcg_lpk_kernel" in name:
         key = f"pcg_lpk_kernel|N{N}_B{B}_{pc}_it{mi}_tol{float(tol):g}"
