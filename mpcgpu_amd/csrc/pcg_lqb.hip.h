@@ -24,8 +24,11 @@
 // registers (7 + 7), fetches the two published vectors for that piece only (8 LDS loads), forms the updated piece with the very operations every
 // other holder uses, and the quad hands the three pieces a pass needs — x_k[piece h], x_{k-1}[piece h], x_k[piece g] — around by DPP quad_perm.
 // p and r never exist in LDS inside the loop; lambda (piece h of knot k - g) lives in registers too.  Two barriers per iteration.
-// Inner product without the assembled vector: x^T M x = sum over lanes of x_k[piece g] . ypart + x_{k-1}[piece h] . zpart — the partial sums
-// themselves, no weights, no duplicates.
+// Inner product without the assembled vector, from the partial sums themselves (no weights, no duplicates): x^T M x = sum over lanes of
+// x_k[piece g] . (ypart + its L part) — the coupling term x_{k-1}^T (L^T x_k) taken as x_k^T (L x_{k-1}) from the direct product.
+// Block-Jacobi (Pinv without off-diagonal blocks) is a build of its own, PC3 = false: no L sub-block of Pinv in registers, no z, a shorter epilogue.
+// Measured (steady clocks, tools/_prof/lqb_ab.py; lane-pair kernel in brackets): N = 128 SS 1.58 (1.62) us per iteration of one trajectory, 6.31 (6.54) per
+// 1024; block-Jacobi 1.29 (1.34); N = 64, two independent workgroups per CU: 1.03 (1.44), 3.02 (3.71); DESIGN.md §3.2b for where an iteration goes.
 //
 // Reads only the left + diagonal block columns (include/mpcg.h, BLOCK SYMMETRY), like the lane-pair kernel; same PCG, same exit rule, same
 // outputs (include/pcg/sqp.cuh:137-150); another summation order, so results agree with it to the fp32 band, not bit for bit.
