@@ -537,8 +537,8 @@ def producers_f64(cx):
 
 
 def short_horizon(cx):
-    """The short-horizon regime in throughput mode (N = 32, the reference's real-time horizon, 2048 trajectories: the lane-pair kernel's half build —
-    one wavefront per matrix, four workgroups per CU; the row-per-lane kernel serves latency-sized calls and N <= 16)."""
+    """The short-horizon regime in throughput mode (N = 32, the reference's real-time horizon, 2048 trajectories: the lane-quad kernel's 32-knot build —
+    two wavefronts, four workgroups per CU; until round 5 the lane-pair kernel's half build; the row-per-lane kernel serves latency-sized calls and N <= 16)."""
     sh = {}
     for pc_ in ("ss", "jacobi"):
         Ns, Bs = 32, 2048
