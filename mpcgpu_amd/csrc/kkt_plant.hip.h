@@ -26,8 +26,8 @@
 // on the way out.  Round 6: everything below the sine / cosine is templated on the arithmetic type R, and `"kkt_f32"` = 1 runs the analytic
 // kernel with R = float — linsys_t's own arithmetic, what the reference's GRiD code computes in (forwardDynamicsAndGradient<T>, T = float):
 // outputs within 1.5e-6 of the float64 restatement (relative to max(1, |block|); float64 inside: 2e-7) and only 8 % faster (0.303 against
-// 0.328 ms per 1024 x 127 knots): the kernel is bound by the dependent issue of ONE recursion per lane at two wavefronts per SIMD (7.6 clocks
-// per instruction and wavefront), not by the fp64 pipe — measured, which corrects round 4's "fp64 VALU issue bound".  Opt-in.  LDS is what bounds the resident wavefronts: 19.9 KB per wavefront = EIGHT per CU (two per SIMD, round 3; 30 KB =
+// 0.328 ms per 1024 x 127 knots): in double the fp64 pipe is 75 % busy at two wavefronts per SIMD, but below that bound sits a latency bound of
+// its own (7.6 clocks per instruction and wavefront either way; time is proportional to 1 / wavefronts up to the eight per CU the registers allow).  Opt-in.  LDS is what bounds the resident wavefronts: 19.9 KB per wavefront = EIGHT per CU (two per SIMD, round 3; 30 KB =
 // five before), which is what hides the dependent-issue latency of the recursion.
 #pragma once
 // Float64 work checked by tolerance, not by bits: multiply-adds are FUSED here (the bit-exact headers switch contraction off and back on).
