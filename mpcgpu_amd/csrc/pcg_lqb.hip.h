@@ -38,17 +38,21 @@
 
 namespace mpcg {
 
-// LDS layout of one vector: pair-major as LpkLds (V[q][slot] = entries (2q, 2q+1) of knot slot - 1; KN = 4 (mod 8) puts row pairs q and q + 4
-// 32 banks apart), and vectors are padded to VS = 16 (mod 64) floats: a publishing ds_write_b64 goes to TWO vectors at once (lanes h == g to
-// T, lanes h != g to Z = T + VS) — T pairs rp | Z pairs rp | T pairs 4 + rp | Z pairs 4 + rp of eight consecutive knots then cover the 64
-// banks exactly once.
+// LDS layout of one vector: pair-major as LpkLds (V[q][slot] = entries (2q, 2q+1) of knot slot - 1), with KN = 5 (mod 8) knot slots per row pair and
+// vectors padded to VS = 16 (mod 32) floats, for the two access shapes of the loop (MI355X_MICROARCH.md, LDS):
+//   * operand loads, ds_read_b64: 32-lane groups over 64 banks — a group is eight knots x (g, h): the h = 0 lanes read 2 (kl - g) + const (18 banks, the two g
+//     lanes of neighbouring knots share addresses), the h = 1 lanes 4 row pairs = 8 KN = 40 (mod 64) dwords further: disjoint;
+//   * publishing stores, ds_write_b64: 16-lane groups over a 32-BANK modulus — four knots x four lanes, to TWO vectors at once (lanes h == g to T, lanes
+//     h != g to Z = T + VS): T pairs rp at 2 kl, T pairs 4 + rp at 8 + 2 kl, Z pairs rp at 16 + 2 kl, Z pairs 4 + rp at 24 + 2 kl — the 32 banks exactly once.
+//     (The first layout, KN = 4 (mod 8) as in the lane-pair kernel, put the two halves of each vector on the SAME banks for a store: two-way conflicts in
+//     every publishing store, 20 % of the kernel's LDS cycles — profiles/r06d_pmc.json, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.)
 template <int NMAXQ> struct LqbLds {
     static constexpr int NMAX = NMAXQ, NW = NMAXQ / 16;
     static_assert(NMAXQ == 32 || NMAXQ == 64 || NMAXQ == 128, "knots per workgroup");
-    static constexpr int KN = NMAX + 4;
-    static_assert(KN % 8 == 4, "row pairs q and q + 4 must sit 32 banks apart");
-    static constexpr int VS = 7 * KN * 2 + 24;
-    static_assert(VS % 64 == 16, "T and Z = T + VS must sit 16 banks apart");
+    static constexpr int KN = NMAX + 5;
+    static_assert(KN % 8 == 5, "row pairs q and q + 4: 40 (mod 64) dwords apart for the loads, 8 (mod 32) for the stores");
+    static constexpr int VS = 7 * KN * 2 + 10;
+    static_assert(VS % 32 == 16 && VS % 2 == 0, "T and Z = T + VS must sit 16 banks apart (8-byte aligned)");
     // P0, R0: staging of lambda0 / gamma, at the end p and r for d_p / d_r | US, ZS: what the S pass publishes | RT, ZP: the Pinv pass |
     // LAM: lambda at the end | RED: wave partials of the two inner products | TILE2: second load tile of every wavefront (the first aliases the vectors)
     static constexpr int P0 = 0, R0 = VS, US = 2 * VS, ZS = 3 * VS, RT = 4 * VS, ZP = 5 * VS, LAM = 6 * VS, RED = 7 * VS, TILE2 = RED + 2 * NW,

@@ -47,7 +47,7 @@ def test_version_and_lds_size(hiplib):
     for N in (2, 16, 32):
         assert hiplib.mpcg_pcg_lds_bytes(14, N) == 4 * (6 * r4((N + 2) * 14) + r4(2 * (4 if N <= 16 else 8)))
     # 32 < N <= 128 (round 6): the lane-quad kernel, layout compile-time per knots-per-workgroup (64 or 128): seven pair-major vectors of
-    # 7 x (NMAX + 4) float2 padded by 24 floats (T / Z bank offset), two partials per wave, and a second 6,272-byte load tile per wave whose
+    # 7 x (NMAX + 5) float2 padded by 10 floats (T / Z bank offset; round 6 first had NMAX + 4 and 24: the same size), two partials per wave, and a second 6,272-byte load tile per wave whose
     # tail holds the parked matrix pairs
     lqb = lambda nmax: 4 * (7 * (7 * (nmax + 4) * 2 + 24) + 2 * (nmax // 16) + (nmax // 16) * 8 * 196)
     for N in (33, 48, 64):
