@@ -228,15 +228,17 @@ def test_cluster_falls_back_when_peers_are_not_resident(orc):
     assert int(it2.item()) == K and relinf(lam2.cpu().numpy()[0], r64["lam"]) <= max(1e-3, 4 * band)
 
 
-@pytest.mark.parametrize("precision", ["float", "double", "double-rpl"])
+@pytest.mark.parametrize("precision", ["float", "float-128-lpk", "float-128-lqb", "double", "double-rpl"])
 def test_fixup_starts_from_the_callers_lambda_even_if_some_members_finished(orc, precision):
     """A member that gives up AFTER its peers passed their last hand-off ("cluster_test_fail": the last member of cluster 0, at the write-back of
     its first trajectory): the peers have written their knots of lambda, the trajectory's completion count is short of G, the fix-up launch
     re-solves it — from the handle's copy of lambda0 (PcgArgs::lam0), not from the half-written array.  Warm start, few iterations: a wrong
-    start would be far outside the band.  The peers then wait for the member that left, give up on their next trajectory: two fix-ups."""
+    start would be far outside the band.  The peers then wait for the member that left, give up on their next trajectory: two fix-ups.
+    "float-128-*": a forced "cluster" = 2 at 128 knots, whose fix-up launch is the lane-pair or (round 6) the lane-quad kernel reading the redo flags."""
     from mpcgpu_amd import PcgSolver, pcg_config
-    dbl = precision != "float"
-    N, B, K = (128, 140 if precision == "double" else 70, 6) if dbl else (256, 140, 6)      # more trajectories than resident clusters (128 / 64 / 128): the queue is in use
+    dbl = precision.startswith("double")
+    short = precision.startswith("float-128")
+    N, B, K = (128, 140 if precision == "double" else 70, 6) if dbl else (128 if short else 256, 140, 6)      # more trajectories than resident clusters (128 / 64 / 128): the queue is in use
     k = synth.make_kkt(N, 3, 8800 + N)
     S3, P3, g3 = synth.form_schur(k, dtype=np.float64 if dbl else np.float32)
     rep = (B + 2) // 3
@@ -246,12 +248,18 @@ def test_fixup_starts_from_the_callers_lambda_even_if_some_members_finished(orc,
     sol = PcgSolver(N, max_batch=B)
     if precision == "double-rpl":
         sol.set_option("pcg_lqk", 0)                      # the row-per-lane clusters of four CUs instead of the lane-quad clusters of two
+    if short:
+        sol.set_option("cluster", 2)
+        sol.set_option("pcg_lqb", int(precision.endswith("lqb")))
+        sol.solve(dS, dP, dg, dev(lam0.copy()), pcg_config(pcg_exit_tol=0.0, pcg_max_iter=1))      # (the symmetry latch: the first call's launches are guarded)
+        torch.cuda.synchronize()
+        assert sol.get_option("symmetry_state") == 1
     cfg = pcg_config(pcg_exit_tol=0.0, pcg_max_iter=K)
     solve = sol.solve_f64 if dbl else sol.solve
     lam_ok = dev(lam0.copy())
     solve(dS, dP, dg, lam_ok, cfg)
     torch.cuda.synchronize()
-    assert sol.get_option("last_kernel_family") == {"float": 7, "double": 10, "double-rpl": 8}[precision] and sol.get_option("cluster_fixups") == 0
+    assert sol.get_option("last_kernel_family") == (7 if short else {"float": 7, "double": 10, "double-rpl": 8}[precision]) and sol.get_option("cluster_fixups") == 0
     sol.set_option("cluster_test_fail", 1)
     lam = dev(lam0.copy())
     it, ex = solve(dS, dP, dg, lam, cfg)
