@@ -1368,6 +1368,12 @@ int mpcg_debug_read_prof(long long* out, int count) {
     if (hipDeviceSynchronize() != hipSuccess) return MPCG_ERR_HIP;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(mpcg::g_pcg_prof), sizeof(long long) * (size_t)count) == hipSuccess ? MPCG_OK : MPCG_ERR_HIP;
 }
+// (entry time, exit time, HW_ID, XCC_ID) of the first `count` / 4 workgroups of the last lane-quad launch
+int mpcg_debug_read_wg_prof(long long* out, int count) {
+    if (!out || count < 0 || count > 4096 * 4) return MPCG_ERR_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return MPCG_ERR_HIP;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mpcg::g_wg_prof), sizeof(long long) * (size_t)count) == hipSuccess ? MPCG_OK : MPCG_ERR_HIP;
+}
 #endif
 
 }  // extern "C"

@@ -255,6 +255,23 @@ __device__ __forceinline__ f2 wave_shl1(f2 v) {
 // the phase boundaries of one iteration, one row of 32 stamps per wave.
 #ifdef MPCG_PROF
 __device__ long long g_pcg_prof[16 * 32];
+// per workgroup: s_memrealtime at entry and exit, HW_ID, XCC_ID (which CU it ran on: the gaps between consecutive workgroups of a CU)
+__device__ long long g_wg_prof[4096 * 4];
+#define MPCG_WG_STAMP(slot)                                                                                             \
+    do {                                                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                                                    \
+            long long t_;                                                                                               \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
+            g_wg_prof[blockIdx.x * 4 + (slot)] = t_;                                                                    \
+            if ((slot) == 0) {                                                                                          \
+                unsigned hw_, xcc_;                                                                                     \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                       \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                     \
+                g_wg_prof[blockIdx.x * 4 + 2] = hw_;                                                                    \
+                g_wg_prof[blockIdx.x * 4 + 3] = xcc_;                                                                   \
+            }                                                                                                           \
+        }                                                                                                               \
+    } while (0)
 #define MPCG_STAMP(i)                                                                                   \
     do {                                                                                                \
         if (prof_on) {                                                                                  \
@@ -265,6 +282,7 @@ __device__ long long g_pcg_prof[16 * 32];
     } while (0)
 #else
 #define MPCG_STAMP(i) do {} while (0)
+#define MPCG_WG_STAMP(slot) do {} while (0)
 #endif
 
 // RT = triples per matrix per wave held in registers.  SB = register buffers of the stream:

@@ -160,6 +160,9 @@ __device__ __forceinline__ void lqb_load_blocks_lds(rsrc_t MS, rsrc_t MP, int kf
         for (int cp = 0; cp < 3; ++cp) X.B[cp] = f2{lds_ld32(blkp + cb + NS * (2 * cp) + 6 + g), lds_ld32(blkp + cb + NS * (2 * cp + 1) + 6 + g)};
         X.e = lds_ld32(blkp + c6 + 6 + g);
     };
+    // (Two rounds in flight.  A third tile per wavefront — three in flight, 50 KB more LDS at 128 knots — changes nothing where the chip loads in lock-step
+    //  (a full batch of equal iteration counts: the stream is bound by HBM then, 4.3-4.9 TB/s) and costs 1 % at 64 knots; streaming L_k and D_k of the same
+    //  eight knots in consecutive rounds (1,568-byte instead of 784-byte runs in flight together) changes nothing either: tools/_prof/lqb_fixed.py, lqb_ab.py.)
     issue(0);
     issue(1);
 #pragma unroll
@@ -283,6 +286,15 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
     if (a.redo_flags && a.redo_count && tid == 0) __hip_atomic_fetch_add(a.redo_count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float* red_v = lds + L::RED;
     float* red_e = red_v + NW;
+#ifdef MPCG_PROF
+    // prologue / write-back stamps of one workgroup of the third round of a throughput-sized launch (slots 16.. of the wave's row: tools/prof_phases.py --cfg lqb)
+    const bool pro_on = (int)blockIdx.x == ((int)gridDim.x > 600 ? 600 : 0);
+#define LQB_PSTAMP(i) do { if (pro_on) { long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (lane == 0) g_pcg_prof[w * 32 + 16 + (i)] = t_; } } while (0)
+#else
+#define LQB_PSTAMP(i) do {} while (0)
+#endif
+    LQB_PSTAMP(0);
+    MPCG_WG_STAMP(0);
 
     const size_t mstride = (size_t)N * ROWF, vstride = (size_t)N * NS;
     const float* gam = a.gamma + (size_t)b * vstride;
@@ -299,6 +311,20 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
     const int fb = 2 * (k - g + 1) + 4 * h * K2, fs = 2 * (k - g + 1) + 3 * K2 + h;       // the carried piece (knot k - g)
     const int ob = 2 * (k + 1) + 4 * h * K2 + (diag ? 0 : L::VS), os = 2 * (k + 1) + 3 * K2 + h + (diag ? 0 : L::VS);   // what this lane publishes (knot k's slot; Z = T + VS)
 
+    // ---- lambda0 and gamma: requested in front of the matrix stream (in-order returns: the counted waits of the block load cover them), staged in LDS behind it —
+    //      their round trip (2 us under a full batch's load) hides behind the eight rounds of the matrices ----
+    constexpr int NVEC = (NMAXQ * NS + NTHR - 1) / NTHR;
+    float lam_in[NVEC], gam_in[NVEC];
+    {
+        const float* lam_src = a.lam0 ? a.lam0 + (size_t)b * vstride : lam_g;      // (a fix-up launch behind a forced cluster: PcgArgs::lam0)
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i) {
+            const int e = tid + i * NTHR;
+            lam_in[i] = e < N * NS ? lam_src[e] : 0.f;
+            gam_in[i] = e < N * NS ? gam[e] : 0.f;
+        }
+    }
+
     // ---- matrix registers ----
     LqbSub SD, SL, PD, PL;
     {
@@ -307,6 +333,7 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
         lqb_load_blocks_lds(MS, MP, 16 * w, N, p3, lane, lds + w * LPK_TILE_FLOATS, lds + L::TILE2 + w * LPK_TILE_FLOATS, SD, SL, PD, PL);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+    LQB_PSTAMP(1);
     // park the pairs the passes use last (the diagonal sub-blocks' last columns) in lane-private LDS slots: the register file holds 196 matrix
     // registers + the working set of a pass only just, and what the compiler spills goes to SCRATCH, reloaded in every pass (pcg_lpk.hip.h).
     // The slots live in this wavefront's own second load tile, idle from here on.
@@ -319,16 +346,22 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
         parkP[i * 64] = PD.A[i % 3][6 - i / 3];
     }
     lds_barrier();                                         // every wavefront is done with its load tiles: the vectors' region may be written
+    LQB_PSTAMP(2);
 
     // ---- stage vectors: P0 <- lambda0, R0 <- gamma, everything else (pads included) <- 0 ----
     for (int e = tid; e < L::RED + 2 * NW; e += NTHR) lds[e] = 0.f;
     lds_barrier();
-    for (int e = tid; e < N * NS; e += NTHR) {
-        const int kk = e / NS, i = e - kk * NS;
-        lds[L::P0 + L::at(kk, i)] = a.lam0 ? a.lam0[(size_t)b * vstride + e] : lam_g[e];      // (a fix-up launch behind a forced cluster: PcgArgs::lam0)
-        lds[L::R0 + L::at(kk, i)] = gam[e];
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+        const int e = tid + i * NTHR;
+        if (e < N * NS) {
+            const int kk = e / NS, ii = e - kk * NS;
+            lds[L::P0 + L::at(kk, ii)] = lam_in[i];
+            lds[L::R0 + L::at(kk, ii)] = gam_in[i];
+        }
     }
     lds_barrier();
+    LQB_PSTAMP(3);
 
 #ifdef MPCG_PROF
     bool prof_on = false;
@@ -491,6 +524,7 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
     Red rd = load_red(red_e);
     f = fetch(L::RT);
     float eta = uniform(sum_red(rd));
+    LQB_PSTAMP(4);
     uint32_t iters = 0;
     uint32_t max_iter_exit = 1;
     float beta = 0.f;                                          // scalar of the NEXT p update (the S half applies it)
@@ -539,6 +573,7 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
             MPCG_STAMP(10);
         }
     }
+    LQB_PSTAMP(5);
     // ---- lambda, p, r of knot k from the g = 0 lanes into the staging vectors (free since the setup), then out ----
     if (g == 0) {
         const int sb = 2 * (k + 1) + 4 * h * K2, ss = 2 * (k + 1) + 3 * K2 + h;
@@ -568,6 +603,9 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
         a.iters[b] = iters;
         a.max_iter_exit[b] = (uint8_t)max_iter_exit;
     }
+    LQB_PSTAMP(6);
+    MPCG_WG_STAMP(1);
+#undef LQB_PSTAMP
 }
 
 }  // namespace mpcg

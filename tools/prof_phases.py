@@ -59,6 +59,12 @@ for spec in args.cfg or ["4:7:-1"]:
     t = np.array(buf[:], dtype=np.int64).reshape(16, 32)[: f[0], :16]
     print(f"== N={N} batch={Bn} cfg={spec}  {ms:.3f} ms  {it.sum().item() / ms / 1e3:.2f} Miter/s (instrumented)   "
           f"[s_memtime ticks; one iteration of workgroup 0, per wave]")
+    if spec == "lqb":
+        pt = np.array(buf[:], dtype=np.int64).reshape(16, 32)[: f[0], 16:23]
+        print("prologue / write-back of workgroup 600 (third round), s_memtime ticks from the wave's entry: matrices loaded | parked + barrier | vectors staged | "
+              "set-up passes done (loop entry) | loop exit | written back")
+        for w in range(f[0]):
+            print(f"{w:4d} " + " ".join(f"{int(x - pt[w, 0]):9d}" for x in pt[w, 1:]) + f"   (entry {int(pt[w, 0] - pt[:, 0].min())} after the first wave)")
     d = np.diff(t, axis=1)
     tot = t[:, 15] - t[:, 0]
     print("raw stamps relative to the earliest stamp of the iteration (0 = not stamped by this wave):")
