@@ -44,6 +44,14 @@ for K in (0, 167):
             if j: gaps.append(us(ent[i] - ext[idx[j - 1]]))
     print(f"   workgroup duration: median {np.median(durs):.1f} us (min {np.min(durs):.1f}, max {np.max(durs):.1f}); gap between consecutive workgroups of a CU: "
           f"median {np.median(gaps) if gaps else 0:.2f} us (min {np.min(gaps) if gaps else 0:.2f}, max {np.max(gaps) if gaps else 0:.2f})")
+    if K:
+        per_x = {int(x): float(np.median((ext - ent)[(xcc & 0xF) == x])) / 100.0 for x in np.unique(xcc & 0xF)}
+        print("   median workgroup duration per XCD (us): " + "  ".join(f"{x}: {v:.1f}" for x, v in sorted(per_x.items())))
+        tot = {}
+        for c in np.unique(cu):
+            tot[c] = us(ext[cu == c].max() - t0)
+        v = np.array(list(tot.values()))
+        print(f"   last exit per CU: min {v.min():.1f}  median {np.median(v):.1f}  max {v.max():.1f} us  (the launch ends with the slowest CU: {100 * (v.max() / np.median(v) - 1):.1f} % above the median)")
     for j in sorted(rounds):
         a = np.array(rounds[j])
         print(f"   round {j}: {len(a)} workgroups, entries {a[:, 0].min():.1f} .. {a[:, 0].max():.1f} us, exits {a[:, 1].min():.1f} .. {a[:, 1].max():.1f} us")
