@@ -105,6 +105,7 @@ def compact_line(full: dict) -> dict:
         "linsolves_per_sec": full.get("linsolves_per_sec"),
         "sustained_value": sus.get("value"), "sustained_seconds": sus.get("seconds"), "sustained_sclk_mhz_median": _get(sus, "sclk_mhz", "median"),
         "iiwa_sqp_linear_step_ms": _get(ii, "sqp_linear_step_graph", "ms_per_batch"), "iiwa_generate_kkt_ms": ii.get("generate_kkt_ms"),
+        "iiwa_generate_kkt_f32_ms": ii.get("generate_kkt_f32_ms"), "iiwa_sqp_linear_step_kkt_f32_ms": _get(ii, "sqp_linear_step_graph", "ms_per_batch_kkt_f32"),
         "iiwa_form_schur_ms": ii.get("form_schur_ms"), "iiwa_warm_pcg_ms": warm.get("kernel_ms"), "iiwa_compute_dz_ms": ii.get("compute_dz_ms"),
         "iiwa_warm_mean_pcg_iters": warm.get("mean_pcg_iters"),
         "iiwa_warm_linsolves_per_sec_hint_exact": warm.get("linsolves_per_sec"),

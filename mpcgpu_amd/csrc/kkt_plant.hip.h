@@ -23,12 +23,15 @@
 //              near 1); each lane turns its difference into ITS column of dqdd/d(q, qd) = -Minv dID in registers and writes its column
 //              of A (and of Q, B, R) as float in the reference's dense layouts (column-major blocks, C = -A, -B).
 // Arithmetic is float64 inside (the difference quotients need it; fp64 FMA is full rate on the MI355X), results are rounded to float
-// on the way out.  Round 6: everything below the sine / cosine is templated on the arithmetic type R, and `"kkt_f32"` = 1 runs the analytic
-// kernel with R = float — linsys_t's own arithmetic, what the reference's GRiD code computes in (forwardDynamicsAndGradient<T>, T = float):
-// outputs within 1.5e-6 of the float64 restatement (relative to max(1, |block|); float64 inside: 2e-7) and only 8 % faster (0.303 against
-// 0.328 ms per 1024 x 127 knots): in double the fp64 pipe is 75 % busy at two wavefronts per SIMD, but below that bound sits a latency bound of
-// its own (7.6 clocks per instruction and wavefront either way; time is proportional to 1 / wavefronts up to the eight per CU the registers allow).  Opt-in.  LDS is what bounds the resident wavefronts: 19.9 KB per wavefront = EIGHT per CU (two per SIMD, round 3; 30 KB =
-// five before), which is what hides the dependent-issue latency of the recursion.
+// on the way out.  Round 6: everything below the sine / cosine is templated on the arithmetic type R, and `"kkt_f32"` = 1 (opt-in) runs the analytic
+// kernel in float — linsys_t's own arithmetic, what the reference's GRiD code computes in (forwardDynamicsAndGradient<T>, T = float): outputs within
+// 1.5e-6 of the float64 restatement (relative to max(1, |block|); float64 inside: 2e-7).  With R = float that is only 8 % faster (0.303 against 0.328 ms per
+// 1024 x 127 knots): in double the fp64 pipe is 75 % busy at two wavefronts per SIMD, and a float instruction takes the same issue slot as a double one.
+// What pays is R = kkt_f2: TWO knots per lane, every value a float pair, every multiply-add a v_pk_fma_f32 (model constants straight from scalar
+// registers through op_sel) — the same instruction stream as the double build (+15 %: pair moves, one-cycle packed hazards) for twice the knots:
+// **0.204 ms** (1.6x), bit-identical to the R = float build; launched for calls with more than one trip per wavefront slot of the chip (mpcg_plant.hip).
+// LDS is what bounds the resident wavefronts: 16.4 KB (double) / 19.9 KB (packed) per wavefront = EIGHT per CU (two per SIMD, round 3; 30 KB = five
+// before), which is what hides the dependent-issue latency of the recursion.
 #pragma once
 // Float64 work checked by tolerance, not by bits: multiply-adds are FUSED here (the bit-exact headers switch contraction off and back on).
 #pragma clang fp contract(fast)
@@ -89,6 +92,38 @@ template <typename R> struct PlantC {
     __device__ __forceinline__ creal* Ib(int k) const { return at(offsetof(PlantDevT<R>, Ib), k, 10); }
 };
 
+// ---- arithmetic types of the kernel: double (default), float ("kkt_f32" = 1 below a full batch), and kkt_f2 = TWO knots per lane in packed float
+//      (round 6: v_pk_fma_f32 does two knots' multiply-add in the issue slot of one — the recursions are bound by VALU issue, not by latency) ----
+typedef float kkt_f2 __attribute__((ext_vector_type(2)));
+template <typename R> struct KktR {                          // one knot per lane
+    typedef R scalar;                                        // type of the model tables and of the kernel's scalar arguments
+    typedef float rec;                                       // what the link forces of the analytic round wait as in LDS
+    static constexpr int KP = 1;
+    static constexpr bool is_double = sizeof(R) == 8;
+    __device__ static __forceinline__ R mk(scalar a, scalar) { return a; }
+    __device__ static __forceinline__ scalar get(R x, int) { return x; }
+    __device__ static __forceinline__ R splat(double v) { return (R)v; }
+    __device__ static __forceinline__ rec to_rec(R x) { return (float)x; }
+    __device__ static __forceinline__ R from_rec(rec x) { return (R)x; }
+    __device__ static __forceinline__ R rsq(R x) {
+        if constexpr (is_double) return __builtin_amdgcn_rsq(x);
+        else return __builtin_amdgcn_rsqf(x);
+    }
+};
+template <> struct KktR<kkt_f2> {                            // two knots per lane: .x = the even item of the lane group's pair, .y = the odd one
+    typedef float scalar;
+    typedef kkt_f2 rec;
+    static constexpr int KP = 2;
+    static constexpr bool is_double = false;
+    __device__ static __forceinline__ kkt_f2 mk(float a, float b) { return kkt_f2{a, b}; }
+    __device__ static __forceinline__ float get(kkt_f2 x, int h) { return h ? x.y : x.x; }
+    __device__ static __forceinline__ kkt_f2 splat(double v) { return kkt_f2{(float)v, (float)v}; }
+    __device__ static __forceinline__ kkt_f2 to_rec(kkt_f2 x) { return x; }
+    __device__ static __forceinline__ kkt_f2 from_rec(kkt_f2 x) { return x; }
+    __device__ static __forceinline__ kkt_f2 rsq(kkt_f2 x) { return kkt_f2{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)}; }
+};
+#define KR(v) (KktR<R>::splat(v))
+
 template <typename R> struct KktItemLds {   // per-knot scratch in LDS (840 B in double)
     R Minv[PJ][PJ];
     R Qdd[PJ];
@@ -141,18 +176,19 @@ template <typename R> struct RneaTask {                        // what this lane
 // cost three instructions per matrix entry and sweep) followed by the rotation about z: 4 instructions per 3-vector.
 // Returns the last link's spatial acceleration (aw, au) in its own frame.
 template <typename R>
-__device__ __forceinline__ void rnea(const PlantC<R>& P, typename KktLds<R>::vr* fl, typename KktLds<R>::item* I, const RneaTask<R> t, R (&aw_out)[3], R (&au_out)[3]) {
-    typedef typename PlantC<R>::creal creal;
-    R vw[3] = {0, 0, 0}, vu[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, au[3] = {0, 0, 0};
-    if (t.base >= 0) aw[t.base] = R(1.0);
-    R f[6] = {0, 0, 0, 0, 0, 0};
+__device__ __forceinline__ void rnea(const PlantC<typename KktR<R>::scalar>& P, typename KktLds<R>::vr* fl, typename KktLds<R>::item* I, const RneaTask<R> t, R (&aw_out)[3], R (&au_out)[3]) {
+    typedef typename PlantC<typename KktR<R>::scalar>::creal creal;
+    R vw[3], vu[3], aw[3], au[3], f[6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { vw[r] = KR(0.0); vu[r] = KR(0.0); aw[r] = KR(0.0); au[r] = KR(0.0); f[r] = KR(0.0); f[3 + r] = KR(0.0); }
+    if (t.base >= 0) aw[t.base] = KR(1.0);
 #pragma nounroll
     for (int kv = 0; kv < PJ; ++kv) {
         const int k = __builtin_amdgcn_readfirstlane(kv);    // uniform by construction; said so, the model tables come through s_load
-        const R qdk = t.qdscale * I->Xq[PJ + k] + (k == t.pj ? R(KKT_FD_H) : R(0.0));
-        const R qddk = t.knot_qdd ? I->Qdd[k] : (k == t.unit ? R(1.0) : R(0.0));
+        const R qdk = t.qdscale * I->Xq[PJ + k] + (k == t.pj ? KR(KKT_FD_H) : KR(0.0));
+        const R qddk = t.knot_qdd ? I->Qdd[k] : (k == t.unit ? KR(1.0) : KR(0.0));
         R sn = I->Sc[0][k], cs = I->Sc[1][k];
-        if (k == t.sj) { const R s0 = sn; sn = s0 + R(KKT_FD_H) * cs; cs = cs - R(KKT_FD_H) * s0; }
+        if (k == t.sj) { const R s0 = sn; sn = s0 + KR(KKT_FD_H) * cs; cs = cs - KR(KKT_FD_H) * s0; }
         creal* E = P.ET(k);
         creal* B = P.BT(k);
         R tw[3], tu[3], sw[3], su[3];                   // tree part of v = X v_parent, a = X a_parent
@@ -205,7 +241,7 @@ __device__ __forceinline__ void rnea(const PlantC<R>& P, typename KktLds<R>::vr*
     for (int kv = PJ - 1; kv >= 1; --kv) {                   // f_parent += X^T f = Xtree^T blkdiag(Rz^T, Rz^T) [n; l] = [ET^T n' + BT^T l' ; ET^T l']
         const int k = __builtin_amdgcn_readfirstlane(kv);
         R sn = I->Sc[0][k], cs = I->Sc[1][k];
-        if (k == t.sj) { const R s0 = sn; sn = s0 + R(KKT_FD_H) * cs; cs = cs - R(KKT_FD_H) * s0; }
+        if (k == t.sj) { const R s0 = sn; sn = s0 + KR(KKT_FD_H) * cs; cs = cs - KR(KKT_FD_H) * s0; }
         creal* E = P.ET(k);
         creal* B = P.BT(k);
         const R n0 = cs * f[0] - sn * f[1], n1 = sn * f[0] + cs * f[1], n2 = f[2];
@@ -235,7 +271,7 @@ __device__ __forceinline__ void rnea(const PlantC<R>& P, typename KktLds<R>::vr*
 // F_i coming down) exists in lane 14's registers at that very point and travels by DPP row broadcast — no nominal sweep of its own, nothing
 // of it in LDS.  The link forces wait for the backward sweep in the same LDS region as before, as FLOATS (15 records fit where 14 double
 // records were; a derivative needs no cancellation headroom: rounding its forces to 6e-8 relative moves dtau by that much).
-typedef __attribute__((address_space(3))) volatile float kkt_lds_vf;
+template <typename R> struct KktRecLds { typedef __attribute__((address_space(3))) volatile typename KktR<R>::rec vf; };
 template <int L>
 __device__ __forceinline__ double bc64(double x) {            // x of lane L of this lane's 16-lane group
     const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
@@ -247,17 +283,36 @@ template <int L>
 __device__ __forceinline__ float bc64(float x) {              // (the float build: one row_newbcast move)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + L, 0xf, 0xf, true));
 }
+template <int L>
+__device__ __forceinline__ kkt_f2 bc64(kkt_f2 x) {            // (the packed build: two moves, as for a double)
+    return kkt_f2{bc64<L>(x.x), bc64<L>(x.y)};
+}
 constexpr int KKT_NOM = 2 * PJ;          // the lane of the nominal recursion
+// Records of the analytic round: one per lane (15) — in the packed build 14: lanes 0..12 their own, lane 13 inside lane 6's, lane 14 (nominal) the 14th (see rnea_grad)
+template <typename R> struct KktGrad {
+    static constexpr bool SHARE = KktR<R>::KP == 2;
+    static constexpr int RECS = SHARE ? 2 * PJ : 2 * PJ + 1;
+    __device__ static __forceinline__ int rec(int l) { return !SHARE || l < 2 * PJ - 1 ? l : (l == 2 * PJ - 1 ? PJ - 1 : 2 * PJ - 1); }
+    // row of dtau_i in the record of lane l: RN_TAU(i); for lane 13 of the packed build the free row behind it (tau_6: row 0)
+    __device__ static __forceinline__ int tau(int l, int i) { return SHARE && l == 2 * PJ - 1 ? (i < PJ - 1 ? 6 * i + 3 : 0) : RN_TAU(i); }
+};
 // l: lane in the group (0..14 run).  On return this lane's record holds dtau_i (rows RN_TAU(i), float) for its column.
 template <typename R>
-__device__ __forceinline__ void rnea_grad(const PlantC<R>& P, kkt_lds_vf* fl, typename KktLds<R>::item* I, const int l) {
-    typedef typename PlantC<R>::creal creal;
+__device__ __forceinline__ void rnea_grad(const PlantC<typename KktR<R>::scalar>& P, typename KktRecLds<R>::vf* fl, typename KktLds<R>::item* I, const int l) {
+    typedef typename PlantC<typename KktR<R>::scalar>::creal creal;
     const bool nom = l == KKT_NOM;
     const bool isq = l < PJ;
     const int col = l < PJ ? l : l - PJ;                      // (lane 14: 7 — never equal to a link index)
-    const R nmask = nom ? R(0.0) : R(1.0);
-    R vw[3] = {0, 0, 0}, vu[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, au[3] = {0, 0, 0};
-    R f[6] = {0, 0, 0, 0, 0, 0};
+    const R nmask = nom ? KR(0.0) : KR(1.0);
+    // A column's link forces are ZERO below its own joint on the way up (dv = da = 0 there).  The packed build neither stores those rows nor uses what it reads
+    // from them — which leaves the whole force part of the records of lanes 6 and 13 (column joint 6) unused, so the two SHARE one record (KktGrad: lane 13's
+    // tau rows sit one row behind lane 6's): 14 pair records instead of 15 = 19.9 instead of 21.1 KB per wavefront = eight wavefronts per CU instead of seven.
+    // (The one-knot builds keep a record per lane and the plain accesses: the selects cost the double build 7 %.)
+    constexpr bool SHARE = KktGrad<R>::SHARE;
+    const int first = nom ? 0 : col;
+    R vw[3], vu[3], aw[3], au[3], f[6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { vw[r] = KR(0.0); vu[r] = KR(0.0); aw[r] = KR(0.0); au[r] = KR(0.0); f[r] = KR(0.0); f[3 + r] = KR(0.0); }
 #pragma nounroll
     for (int kv = 0; kv < PJ; ++kv) {
         const int k = __builtin_amdgcn_readfirstlane(kv);
@@ -274,7 +329,7 @@ __device__ __forceinline__ void rnea_grad(const PlantC<R>& P, kkt_lds_vf* fl, ty
             su[r] = B[3 * r] * aw[0] + B[3 * r + 1] * aw[1] + B[3 * r + 2] * aw[2] + E[3 * r] * au[0] + E[3 * r + 1] * au[1] + E[3 * r + 2] * au[2];
         }
         R w[3], u[3], bw[3], bu[3];
-        w[0] = cs * tw[0] + sn * tw[1]; w[1] = cs * tw[1] - sn * tw[0]; w[2] = tw[2] + (nom ? qdk : R(0.0));
+        w[0] = cs * tw[0] + sn * tw[1]; w[1] = cs * tw[1] - sn * tw[0]; w[2] = tw[2] + (nom ? qdk : KR(0.0));
         u[0] = cs * tu[0] + sn * tu[1]; u[1] = cs * tu[1] - sn * tu[0]; u[2] = tu[2];
         bw[0] = cs * sw[0] + sn * sw[1]; bw[1] = cs * sw[1] - sn * sw[0]; bw[2] = sw[2];
         bu[0] = cs * su[0] + sn * su[1]; bu[1] = cs * su[1] - sn * su[0]; bu[2] = su[2];
@@ -285,11 +340,11 @@ __device__ __forceinline__ void rnea_grad(const PlantC<R>& P, kkt_lds_vf* fl, ty
         const R naw0 = bc64<KKT_NOM>(bw[0]), naw1 = bc64<KKT_NOM>(bw[1]), nau0 = bc64<KKT_NOM>(bu[0]), nau1 = bc64<KKT_NOM>(bu[1]);
         if (k == col) {                                       // this lane's own joint: the sources of its column (everything above was zero)
             if (isq) {
-                w[0] = nvw[1]; w[1] = -nvw[0]; w[2] = R(0.0); u[0] = nvu[1]; u[1] = -nvu[0]; u[2] = R(0.0);            // dv = -S x v
-                bw[0] = naw1; bw[1] = -naw0; bw[2] = R(0.0); bu[0] = nau1; bu[1] = -nau0; bu[2] = R(0.0);               // da = -S x (X a_parent) [+ dv x S qd below]
+                w[0] = nvw[1]; w[1] = -nvw[0]; w[2] = KR(0.0); u[0] = nvu[1]; u[1] = -nvu[0]; u[2] = KR(0.0);            // dv = -S x v
+                bw[0] = naw1; bw[1] = -naw0; bw[2] = KR(0.0); bu[0] = nau1; bu[1] = -nau0; bu[2] = KR(0.0);               // da = -S x (X a_parent) [+ dv x S qd below]
             } else {
-                w[0] = R(0.0); w[1] = R(0.0); w[2] = R(1.0); u[0] = R(0.0); u[1] = R(0.0); u[2] = R(0.0);                            // dv = S
-                bw[0] = nvw[1]; bw[1] = -nvw[0]; bw[2] = R(0.0); bu[0] = nvu[1]; bu[1] = -nvu[0]; bu[2] = R(0.0);       // da = v x S
+                w[0] = KR(0.0); w[1] = KR(0.0); w[2] = KR(1.0); u[0] = KR(0.0); u[1] = KR(0.0); u[2] = KR(0.0);                            // dv = S
+                bw[0] = nvw[1]; bw[1] = -nvw[0]; bw[2] = KR(0.0); bu[0] = nvu[1]; bu[1] = -nvu[0]; bu[2] = KR(0.0);       // da = v x S
             }
         }
         if (nom) bw[2] += qddk;                               // + S qdd (nominal lane only)
@@ -319,14 +374,14 @@ __device__ __forceinline__ void rnea_grad(const PlantC<R>& P, kkt_lds_vf* fl, ty
         f[3] = Ia[3] + (w[1] * nIv[5] - w[2] * nIv[4]) + (zw1 * Iv[5] - zw2 * Iv[4]);
         f[4] = Ia[4] + (w[2] * nIv[3] - w[0] * nIv[5]) + (zw2 * Iv[3] - zw0 * Iv[5]);
         f[5] = Ia[5] + (w[0] * nIv[4] - w[1] * nIv[3]) + (zw0 * Iv[4] - zw1 * Iv[3]);
-        if (k < PJ - 1) {
+        if (k < PJ - 1 && (!SHARE || k >= first)) {
 #pragma unroll
-            for (int r = 0; r < 6; ++r) fl[6 * k + r] = (float)f[r];
+            for (int r = 0; r < 6; ++r) fl[6 * k + r] = KktR<R>::to_rec(f[r]);
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) { vw[r] = w[r]; vu[r] = u[r]; aw[r] = bw[r]; au[r] = bu[r]; }
     }
-    fl[RN_TAU(PJ - 1)] = (float)f[2];
+    fl[KktGrad<R>::tau(l, PJ - 1)] = KktR<R>::to_rec(f[2]);
 #pragma nounroll
     for (int kv = PJ - 1; kv >= 1; --kv) {                   // F_parent += X_k^T (F_k [+ S x* F_k(nominal) in the d/dq_k lane])
         const int k = __builtin_amdgcn_readfirstlane(kv);
@@ -336,18 +391,20 @@ __device__ __forceinline__ void rnea_grad(const PlantC<R>& P, kkt_lds_vf* fl, ty
         // S x* [n; l] = [e_z x n ; e_z x l] = (-n1, n0, 0 ; -l1, l0, 0) of the nominal lane's accumulated force of link k
         const R nf0 = bc64<KKT_NOM>(f[0]), nf1 = bc64<KKT_NOM>(f[1]), nf3 = bc64<KKT_NOM>(f[3]), nf4 = bc64<KKT_NOM>(f[4]);
         const bool mine = isq && k == col;
-        const R g0 = f[0] - (mine ? nf1 : R(0.0)), g1 = f[1] + (mine ? nf0 : R(0.0)), g3 = f[3] - (mine ? nf4 : R(0.0)), g4 = f[4] + (mine ? nf3 : R(0.0));
+        const R g0 = f[0] - (mine ? nf1 : KR(0.0)), g1 = f[1] + (mine ? nf0 : KR(0.0)), g3 = f[3] - (mine ? nf4 : KR(0.0)), g4 = f[4] + (mine ? nf3 : KR(0.0));
         const R n0 = cs * g0 - sn * g1, n1 = sn * g0 + cs * g1, n2 = f[2];
         const R l0 = cs * g3 - sn * g4, l1 = sn * g3 + cs * g4, l2 = f[5];
         R fp[6];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            fp[r] = (R)fl[6 * (k - 1) + r] + E[r] * n0 + E[3 + r] * n1 + E[6 + r] * n2 + B[r] * l0 + B[3 + r] * l1 + B[6 + r] * l2;
-            fp[3 + r] = (R)fl[6 * (k - 1) + 3 + r] + E[r] * l0 + E[3 + r] * l1 + E[6 + r] * l2;
+            R own_n = KktR<R>::from_rec(fl[6 * (k - 1) + r]), own_l = KktR<R>::from_rec(fl[6 * (k - 1) + 3 + r]);      // (read by every lane; SHARE: discarded below the column's joint)
+            if (SHARE && k - 1 < first) { own_n = KR(0.0); own_l = KR(0.0); }
+            fp[r] = own_n + E[r] * n0 + E[3 + r] * n1 + E[6 + r] * n2 + B[r] * l0 + B[3 + r] * l1 + B[6 + r] * l2;
+            fp[3 + r] = own_l + E[r] * l0 + E[3 + r] * l1 + E[6 + r] * l2;
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r) f[r] = fp[r];
-        fl[RN_TAU(k - 1)] = (float)f[2];
+        fl[KktGrad<R>::tau(l, k - 1)] = KktR<R>::to_rec(f[2]);
     }
 }
 
@@ -355,14 +412,14 @@ __device__ __forceinline__ void rnea_grad(const PlantC<R>& P, kkt_lds_vf* fl, ty
 typedef __attribute__((address_space(3))) float kkt_lds_f;
 constexpr int ST_G = 0, ST_Q1 = ST_G + 14 * 14 + 7 * 7, ST_C = ST_Q1 + 14 * 14, ST_g = ST_C + 14 * 14 + 14 * 7, ST_g1 = ST_g + 21, ST_c0 = ST_g1 + 14,
               ST_c1 = ST_c0 + 14, ST_END = ST_c1 + 14;
-// records of a group: round 0 runs PJ + 4 double records; round 1 either 2 PJ double records (differences) or 2 PJ + 1 FLOAT records (analytic)
+// records of a group: round 0 runs PJ + 4 records of R; round 1 either 2 PJ records of R (differences) or KktGrad<R>::RECS records of KktR<R>::rec (analytic: float; packed: float pairs)
 constexpr int KKT_R0 = PJ + 4;
 __host__ __device__ constexpr int kkt_rec_lanes(bool analytic) { return analytic ? KKT_R0 : KKT_RL; }
-// elements of type R a group's record region holds: the round-0 records, the analytic round's 2 PJ + 1 float records and the float staging area all fit
-// (double: the 11 (analytic) / 14 round-0 records are the largest of the three, as before; float: the staging area is — 3,192 B per group)
+// elements of type R a group's record region holds: the round-0 records, the analytic round's 15 (packed: 14) records and the float staging area (one knot at a time) all fit
+// (double: the 11 (analytic) / 14 round-0 records are the largest of the three, as before; float: the staging area is — 3,192 B per group; packed: the 14 pair records, 4,144 B)
 template <typename R> __host__ __device__ constexpr int kkt_rec_elems(bool analytic) {
     const int r0 = kkt_rec_lanes(analytic) * RN_ROWS;
-    const int r1 = (int)(((2 * PJ + 1) * RN_ROWS * sizeof(float) + sizeof(R) - 1) / sizeof(R)), st = (int)((ST_END * sizeof(float) + sizeof(R) - 1) / sizeof(R));
+    const int r1 = (int)((KktGrad<R>::RECS * RN_ROWS * sizeof(typename KktR<R>::rec) + sizeof(R) - 1) / sizeof(R)), st = (int)((ST_END * sizeof(float) + sizeof(R) - 1) / sizeof(R));
     return r0 > r1 ? (r0 > st ? r0 : st) : (r1 > st ? r1 : st);
 }
 static_assert(kkt_rec_elems<double>(true) == KKT_R0 * RN_ROWS && kkt_rec_elems<double>(false) == KKT_RL * RN_ROWS, "the double build's LDS footprint is round 5's");
@@ -379,18 +436,22 @@ __device__ __forceinline__ void kkt_copy_out(float* dst, kkt_lds_f* src, int l) 
 #ifndef KKT_WAVES_F32
 #define KKT_WAVES_F32 2      // (the float build at three wavefronts per SIMD: 168 VGPRs, 17 spilled, 0.322 ms per 1024 x 127 knots; at two: 191, none, 0.303; double: 0.328)
 #endif
+// R = double | float: a lane group of 16 = one (trajectory, knot) pair per trip; R = kkt_f2: TWO — items 2 i and 2 i + 1 of the wavefront's eight — in the halves of every value.
 template <bool ANALYTIC, typename R = double>
-__global__ __launch_bounds__(KKT_THREADS, sizeof(R) == 4 ? KKT_WAVES_F32 : ANALYTIC ? KKT_WAVES_ANALYTIC : 2) void generate_kkt_kernel(KktArgsT<R> a) {
-    static_assert(ANALYTIC || sizeof(R) == 8, "the difference quotients need float64");
+__global__ __launch_bounds__(KKT_THREADS, sizeof(R) == 4 ? KKT_WAVES_F32 : ANALYTIC ? KKT_WAVES_ANALYTIC : 2) void generate_kkt_kernel(KktArgsT<typename KktR<R>::scalar> a) {
+    typedef KktR<R> T;
+    typedef typename T::scalar S;
+    constexpr int KP = T::KP;
+    static_assert(ANALYTIC || T::is_double, "the difference quotients need float64");
     typedef typename KktLds<R>::vr kkt_lds_vd;
     typedef typename KktLds<R>::item kkt_lds_item;
-    typedef typename PlantC<R>::creal creal;
+    typedef typename PlantC<S>::creal creal;
     constexpr int n = 2 * PJ, m = PJ, nn = n * n, mm = m * m, nm = n * m;
     __shared__ KktItemLds<R> sI[KKT_ITEMS];
     constexpr int RL = kkt_rec_lanes(ANALYTIC);             // round-0 records per group: 11 (analytic: 13.0 KB per wavefront in double) or 14 (16.6 KB)
-    constexpr int RE = kkt_rec_elems<R>(ANALYTIC);          // elements of a group's record region (float: the staging area decides, 14.4 KB per wavefront)
+    constexpr int RE = kkt_rec_elems<R>(ANALYTIC);          // elements of a group's record region (float: the staging area decides, 14.4 KB per wavefront; packed: 20.6 KB)
     __shared__ R sF[KKT_ITEMS][RE];                         // the recursion records
-    static_assert(sizeof(KktItemLds<R>) * KKT_ITEMS + sizeof(R) * KKT_ITEMS * RE <= (ANALYTIC ? 16384 : 20480), "ten / eight wavefronts per CU");
+    static_assert(sizeof(KktItemLds<R>) * KKT_ITEMS + sizeof(R) * KKT_ITEMS * RE <= (ANALYTIC && KP == 1 ? 16384 : 20480), "ten / eight wavefronts per CU");
     // The model tables are read with RUNTIME joint indices.  With compile-time indices (unrolled sweeps) all table entries are
     // loop-invariant loads that the compiler hoists into registers: 512 VGPR + AGPR and scratch.
     const int lane = threadIdx.x, gi = lane / KKT_GL, l = lane - gi * KKT_GL;
@@ -399,34 +460,51 @@ __global__ __launch_bounds__(KKT_THREADS, sizeof(R) == 4 ? KKT_WAVES_F32 : ANALY
     auto rec = [&](int j) -> kkt_lds_vd* { return recs + j * RN_ROWS; };                // record of lane j of this group
     kkt_lds_vd* fl = rec(l < RL ? l : 0);                    // (lanes beyond the records never touch theirs)
     kkt_lds_f* st = (kkt_lds_f*)&sF[gi][0];
-    const PlantC<R> P{reinterpret_cast<creal*>(reinterpret_cast<unsigned long long>(a.plant))};
+    const PlantC<S> P{reinterpret_cast<creal*>(reinterpret_cast<unsigned long long>(a.plant))};
     const int N = a.N;
     const long total = (long)a.batch * (N - 1);
-    // A wavefront's trips cover CONSECUTIVE groups of four knots (not a grid stride): the knots' pieces of g (84 B), c (56 B), G (980 B) and
+    // A wavefront's trips cover CONSECUTIVE groups of four (packed: eight) knots (not a grid stride): the knots' pieces of g (84 B), c (56 B), G (980 B) and
     // C (1176 B) are then neighbours in memory and most 128-byte lines are completed inside one L2 instead of leaving two XCDs as partial writes.
-    const long groups = (total + KKT_ITEMS - 1) / KKT_ITEMS, per = (groups + gridDim.x - 1) / gridDim.x;
+    constexpr int PER_TRIP = KKT_ITEMS * KP;
+    const long groups = (total + PER_TRIP - 1) / PER_TRIP, per = (groups + gridDim.x - 1) / gridDim.x;
     const long g_begin = (long)blockIdx.x * per, g_end = g_begin + per < groups ? g_begin + per : groups;
     for (long grp = g_begin; grp < g_end; ++grp) {
-        const long base = grp * KKT_ITEMS;
-        const bool live = base + gi < total;                // (a group without a knot recomputes the last one and writes nothing)
-        const long item = live ? base + gi : total - 1;
-        const int b = (int)(item / (N - 1)), k = (int)(item - (long)b * (N - 1));
-        const float* xu = a.xu + (size_t)b * ((size_t)(n + m) * N - m) + (size_t)k * (n + m);      // x_k, u_k, x_{k+1}
-        if (l < n) I->Xq[l] = (R)xu[l];
+        const long base = grp * PER_TRIP + (long)gi * KP;
+        bool live[KP];                                      // (a half without a knot recomputes the last one and writes nothing)
+        int bb[KP], kk[KP];
+        const float* xu[KP];
+#pragma unroll
+        for (int hf = 0; hf < KP; ++hf) {
+            live[hf] = base + hf < total;
+            const long item = live[hf] ? base + hf : total - 1;
+            if (hf == 0 || !live[hf]) {
+                bb[hf] = (int)(item / (N - 1));              // (a 32-bit division where the knot count allows, behind a wave-uniform test, measured SLOWER: 0.336 against 0.330 ms in double)
+                kk[hf] = (int)(item - (long)bb[hf] * (N - 1));
+            } else {                                        // the knot behind the first half's
+                const bool wrap = kk[0] + 1 == N - 1;
+                bb[hf] = bb[0] + (wrap ? 1 : 0);
+                kk[hf] = wrap ? 0 : kk[0] + 1;
+            }
+            xu[hf] = a.xu + (size_t)bb[hf] * ((size_t)(n + m) * N - m) + (size_t)kk[hf] * (n + m);      // x_k, u_k, x_{k+1}
+        }
+        if (l < n) I->Xq[l] = T::mk((S)xu[0][l], (S)xu[KP - 1][l]);
         if (l < m) {
-            I->U[l] = (R)xu[n + l];
-            double sn_, cs_;                                  // (seven sine / cosine pairs per knot: in double in both builds, rounded to R)
-            if (KKT_ABLATE & 4) { sn_ = (double)xu[l]; cs_ = 1.0 - sn_; } else
-            kkt_sincos((double)xu[l], sn_, cs_);
-            I->Sc[0][l] = (R)sn_;
-            I->Sc[1][l] = (R)cs_;
+            I->U[l] = T::mk((S)xu[0][n + l], (S)xu[KP - 1][n + l]);
+            double sn_[KP], cs_[KP];                          // (seven sine / cosine pairs per knot: in double in every build, rounded to R)
+#pragma unroll
+            for (int hf = 0; hf < KP; ++hf) {
+                if (KKT_ABLATE & 4) { sn_[hf] = (double)xu[hf][l]; cs_[hf] = 1.0 - sn_[hf]; } else
+                kkt_sincos((double)xu[hf][l], sn_[hf], cs_[hf]);
+            }
+            I->Sc[0][l] = T::mk((S)sn_[0], (S)sn_[KP - 1]);
+            I->Sc[1][l] = T::mk((S)cs_[0], (S)cs_[KP - 1]);
         }
         __syncthreads();
         // ---- round 0: lanes 0..6 inertia-matrix columns ID(q, 0, e_l), lane 7 bias ID(q, qd, 0), lanes 8..10 the pose sweeps ----
         R a6w[3], a6u[3];
         if (l < PJ + 4) {
             RneaTask<R> t;
-            t.sj = -1; t.pj = -1; t.qdscale = (l == PJ) ? R(1.0) : R(0.0); t.knot_qdd = false; t.unit = l < PJ ? l : -1; t.base = l > PJ ? l - PJ - 1 : -1;
+            t.sj = -1; t.pj = -1; t.qdscale = (l == PJ) ? KR(1.0) : KR(0.0); t.knot_qdd = false; t.unit = l < PJ ? l : -1; t.base = l > PJ ? l - PJ - 1 : -1;
             if (!(KKT_ABLATE & 16)) rnea(P, fl, I, t, a6w, a6u);
 #pragma unroll
             for (int r = 0; r < 3; ++r) { fl[RN_AW + r] = a6w[r]; fl[RN_AU + r] = a6u[r]; }
@@ -440,21 +518,15 @@ __global__ __launch_bounds__(KKT_THREADS, sizeof(R) == 4 ? KKT_WAVES_F32 : ANALY
             for (int i = 0; i < PJ; ++i)
 #pragma unroll
                 for (int jj = 0; jj <= i; ++jj) {
-                    R sv = R(0.5) * (rec(jj)[RN_TAU(i)] + rec(i)[RN_TAU(jj)]);      // M[i][jj] = tau_i of lane jj
+                    R sv = KR(0.5) * (rec(jj)[RN_TAU(i)] + rec(i)[RN_TAU(jj)]);      // M[i][jj] = tau_i of lane jj
 #pragma unroll
                     for (int t = 0; t < jj; ++t) sv -= Lm[i][t] * Lm[jj][t];
                     if (i == jj) {
                         // 1 / sqrt(pivot) from the hardware estimate + two Newton steps (full double precision for these O(1) pivots): the
                         // correctly rounded sqrt and division of the textbook form are ~30 instructions per pivot
-                        R y;
-                        if constexpr (sizeof(R) == 8) {
-                            y = __builtin_amdgcn_rsq(sv);
-                            y = fma(y * R(0.5), fma(-sv * y, y, R(1.0)), y);
-                            y = fma(y * R(0.5), fma(-sv * y, y, R(1.0)), y);
-                        } else {
-                            y = __builtin_amdgcn_rsqf(sv);                                     // (1 ulp estimate + one Newton step: float precision)
-                            y = fmaf(y * R(0.5), fmaf(-sv * y, y, R(1.0)), y);
-                        }
+                        R y = T::rsq(sv);
+                        y = __builtin_elementwise_fma(y * KR(0.5), __builtin_elementwise_fma(-sv * y, y, KR(1.0)), y);
+                        if constexpr (T::is_double) y = __builtin_elementwise_fma(y * KR(0.5), __builtin_elementwise_fma(-sv * y, y, KR(1.0)), y);      // (float: 1 ulp estimate + one Newton step)
                         rd[i] = y;
                         Lm[i][i] = sv * y;
                     }
@@ -463,7 +535,7 @@ __global__ __launch_bounds__(KKT_THREADS, sizeof(R) == 4 ? KKT_WAVES_F32 : ANALY
             R y[PJ];
 #pragma unroll
             for (int i = 0; i < PJ; ++i) {
-                R sv = (i == l) ? R(1.0) : R(0.0);
+                R sv = (i == l) ? KR(1.0) : KR(0.0);
 #pragma unroll
                 for (int t = 0; t < i; ++t) sv -= Lm[i][t] * y[t];
                 y[i] = sv * rd[i];
@@ -475,7 +547,7 @@ __global__ __launch_bounds__(KKT_THREADS, sizeof(R) == 4 ? KKT_WAVES_F32 : ANALY
                 for (int t = i + 1; t < PJ; ++t) sv -= Lm[t][i] * y[t];
                 y[i] = sv * rd[i];
             }
-            R qdd = 0;
+            R qdd = KR(0.0);
 #pragma unroll
             for (int i = 0; i < PJ; ++i) {
                 I->Minv[i][l] = y[i];
@@ -499,12 +571,14 @@ __global__ __launch_bounds__(KKT_THREADS, sizeof(R) == 4 ? KKT_WAVES_F32 : ANALY
             // Jacobian column l = R^T (linear velocity of the last link's origin for qd = e_l) = R^T au of this lane's own sweep
 #pragma unroll
             for (int r = 0; r < 3; ++r) J[r] = W[r][0] * a6u[0] + W[r][1] * a6u[1] + W[r][2] * a6u[2];
-            const float* goal = a.eePos_traj + ((size_t)b * N + k) * 6;
-            R s0 = 0, s1 = 0;
+            const float* goal[KP];
+#pragma unroll
+            for (int hf = 0; hf < KP; ++hf) goal[hf] = a.eePos_traj + ((size_t)bb[hf] * N + kk[hf]) * 6;
+            R s0 = KR(0.0), s1 = KR(0.0);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                s0 += J[r] * (ee[r] - (R)goal[r]);
-                s1 += J[r] * (ee[r] - (R)goal[6 + r]);       // goal of knot k+1: used by the last block only
+                s0 += J[r] * (ee[r] - T::mk((S)goal[0][r], (S)goal[KP - 1][r]));
+                s1 += J[r] * (ee[r] - T::mk((S)goal[0][6 + r], (S)goal[KP - 1][6 + r]));       // goal of knot k+1: used by the last block only
             }
             I->Gq[l] = s0;
             I->Gq1[l] = s1;
@@ -512,82 +586,89 @@ __global__ __launch_bounds__(KKT_THREADS, sizeof(R) == 4 ? KKT_WAVES_F32 : ANALY
         __syncthreads();
         // ---- round 1: lanes 0..6 ID(q + h e_l, qd, qdd), 7..13 ID(q, qd + h e_(l-7), qdd); each lane then owns column l of
         //      [dqdd/dq, dqdd/dqd] = -Minv (ID(. + h e) - u) / h  and writes column l of A and Q (lanes 0..6: of B and R too) ----
-        // analytic gradient (default): 15 lanes — 14 columns + the nominal recursion in lane 14; records re-used as 15 x RN_ROWS floats
-        kkt_lds_vf* flf = (kkt_lds_vf*)recs + (l <= KKT_NOM ? l : 0) * RN_ROWS;
-        if (ANALYTIC && l <= KKT_NOM && !(KKT_ABLATE & 1)) rnea_grad(P, flf, I, l);
+        // analytic gradient (default): 15 lanes — 14 columns + the nominal recursion in lane 14; records re-used as 15 x RN_ROWS floats (packed: float pairs)
+        typename KktRecLds<R>::vf* flf = (typename KktRecLds<R>::vf*)recs + (l <= KKT_NOM ? KktGrad<R>::rec(l) : 0) * RN_ROWS;
+        if (ANALYTIC && l <= KKT_NOM && !(KKT_ABLATE & 1)) rnea_grad<R>(P, flf, I, l);
+        R colv[PJ];
         if (l < n) {
-            R d[PJ], colv[PJ];
+            R d[PJ];
             if constexpr (ANALYTIC) {
 #pragma unroll
-                for (int i = 0; i < PJ; ++i) d[i] = -(R)flf[RN_TAU(i)];
+                for (int i = 0; i < PJ; ++i) d[i] = -T::from_rec(flf[KktGrad<R>::tau(l, i)]);
             } else {
                 RneaTask<R> t;
-                t.sj = l < PJ ? l : -1; t.pj = l < PJ ? -1 : l - PJ; t.qdscale = R(1.0); t.knot_qdd = true; t.unit = -1; t.base = -1;
+                t.sj = l < PJ ? l : -1; t.pj = l < PJ ? -1 : l - PJ; t.qdscale = KR(1.0); t.knot_qdd = true; t.unit = -1; t.base = -1;
                 if (!(KKT_ABLATE & 1)) rnea(P, fl, I, t, a6w, a6u);
 #pragma unroll
-                for (int i = 0; i < PJ; ++i) d[i] = (fl[RN_TAU(i)] - I->U[i]) * (-R(1.0) / R(KKT_FD_H));
+                for (int i = 0; i < PJ; ++i) d[i] = (fl[RN_TAU(i)] - I->U[i]) * (-KR(1.0) / KR(KKT_FD_H));
             }
             asm volatile("" ::: "memory");                // (the float staging stores below reuse the records: keep them behind these loads)
 #pragma unroll
             for (int i = 0; i < PJ; ++i) {
-                R sv = 0;
+                R sv = KR(0.0);
 #pragma unroll
                 for (int tt = 0; tt < PJ; ++tt) sv += I->Minv[i][tt] * d[tt];
                 colv[i] = sv;
             }
-            if (!(KKT_ABLATE & 8)) {
-                // The knot's outputs are STAGED in the group's (now free) records as float, in the order they have in memory, and
-                // copied out by all 16 lanes in 64-byte runs below.  Written straight from here — a lane per column, 14 lanes 56 bytes
-                // apart per store — the ~60 stores per lane were a fifth of the kernel's time (one cache line per lane and store).
-                const R dt = a.dt;
-                const R gql = l < PJ ? I->Gq[l] : R(0.0), gq1l = l < PJ ? I->Gq1[l] : R(0.0);
+        }
+        // The knot's outputs are STAGED in the group's (now free) records as float, in the order they have in memory, and
+        // copied out by all 16 lanes in 64-byte runs below.  Written straight from here — a lane per column, 14 lanes 56 bytes
+        // apart per store — the ~60 stores per lane were a fifth of the kernel's time (one cache line per lane and store).
+        // Packed build: one knot of the pair at a time through the same staging area.
+#pragma unroll
+        for (int hf = 0; hf < KP; ++hf) {
+            const int k = kk[hf], b = bb[hf];
+            if (l < n && !(KKT_ABLATE & 8)) {
+                const S dt = a.dt;
+                const S gql = l < PJ ? T::get(I->Gq[l], hf) : S(0.0), gq1l = l < PJ ? T::get(I->Gq1[l], hf) : S(0.0);
                 // column l (column-major):  A = I + dt [[0, I], [dqdd/dq, dqdd/dqd]],  Q = blkdiag(g g^T, QD I)
 #pragma unroll
                 for (int r = 0; r < n; ++r) {
-                    R av = (r == l) ? R(1.0) : R(0.0);
-                    if (r < PJ) av += (l == r + PJ) ? dt : R(0.0);
-                    else av += dt * colv[r - PJ];
+                    S av = (r == l) ? S(1.0) : S(0.0);
+                    if (r < PJ) av += (l == r + PJ) ? dt : S(0.0);
+                    else av += dt * T::get(colv[r - PJ], hf);
                     st[ST_C + l * n + r] = (float)(-av);
-                    R qv, q1;
-                    if (r < PJ) { qv = I->Gq[r] * gql; q1 = I->Gq1[r] * gq1l; }
-                    else qv = q1 = (r == l) ? a.qd_cost : R(0.0);
+                    S qv, q1;
+                    if (r < PJ) { qv = T::get(I->Gq[r], hf) * gql; q1 = T::get(I->Gq1[r], hf) * gq1l; }
+                    else qv = q1 = (r == l) ? a.qd_cost : S(0.0);
                     st[ST_G + l * n + r] = (float)qv;
                     st[ST_Q1 + l * n + r] = (float)q1;
                 }
                 if (l < m) {
 #pragma unroll
-                    for (int r = 0; r < n; ++r) st[ST_C + nn + l * n + r] = (float)(-(r < PJ ? R(0.0) : dt * I->Minv[r - PJ][l]));      // B = dt [0; Minv]
+                    for (int r = 0; r < n; ++r) st[ST_C + nn + l * n + r] = (float)(-(r < PJ ? S(0.0) : dt * T::get(I->Minv[r - PJ][l], hf)));      // B = dt [0; Minv]
 #pragma unroll
-                    for (int r = 0; r < m; ++r) st[ST_G + nn + l * m + r] = (float)(r == l ? a.r_cost : R(0.0));
-                    st[ST_g + n + l] = (float)(a.r_cost * I->U[l]);
+                    for (int r = 0; r < m; ++r) st[ST_G + nn + l * m + r] = (float)(r == l ? a.r_cost : S(0.0));
+                    st[ST_g + n + l] = (float)(a.r_cost * T::get(I->U[l], hf));
                 }
-                const R qdl = I->Xq[l < PJ ? l + PJ : l];              // qd_{l mod 7}
+                const S qdl = T::get(I->Xq[l < PJ ? l + PJ : l], hf);              // qd_{l mod 7}
                 st[ST_g + l] = (float)(l < PJ ? gql : a.qd_cost * qdl);
                 st[ST_g1 + l] = (float)(l < PJ ? gq1l : a.qd_cost * qdl);  // last block only (evaluated at x_{N-2}: iiwa_eepos_plant.cuh:407)
                 // integrator defect c_{k+1} = x_{k+1} - (x_k + dt [qd; qdd]);  c_0 = x_0 - x_s
-                const R pred = l < PJ ? I->Xq[l] + dt * qdl : qdl + dt * I->Qdd[l - PJ];
-                st[ST_c1 + l] = (float)((R)xu[(n + m) + l] - pred);
-                if (k == 0) st[ST_c0 + l] = (float)((R)xu[l] - (R)a.xs[(size_t)b * n + l]);
+                const S pred = l < PJ ? T::get(I->Xq[l], hf) + dt * qdl : qdl + dt * T::get(I->Qdd[l - PJ], hf);
+                st[ST_c1 + l] = (float)((S)xu[hf][(n + m) + l] - pred);
+                if (k == 0) st[ST_c0 + l] = (float)((S)xu[hf][l] - (S)a.xs[(size_t)b * n + l]);
             }
-        }
-        __syncthreads();
-        if (live && !(KKT_ABLATE & 8)) {
-            float* G = a.G + (size_t)b * ((size_t)(nn + mm) * N - mm) + (size_t)(nn + mm) * k;
-            float* Cm = a.C + (size_t)b * (size_t)(nn + nm) * (N - 1) + (size_t)(nn + nm) * k;
-            float* g = a.g + (size_t)b * ((size_t)(n + m) * N - m) + (size_t)(n + m) * k;
-            float* c = a.c + (size_t)b * (size_t)n * N + (size_t)n * (k + 1);
-            kkt_copy_out<nn + mm>(G, st + ST_G, l);
-            kkt_copy_out<nn + nm>(Cm, st + ST_C, l);
-            kkt_copy_out<n + m>(g, st + ST_g, l);
-            kkt_copy_out<n>(c, st + ST_c1, l);
-            if (k == N - 2) {                                 // the last block: Q_{N-1}, q_{N-1} follow R_{N-2}, r_{N-2} in memory
-                kkt_copy_out<nn>(G + nn + mm, st + ST_Q1, l);
-                kkt_copy_out<n>(g + n + m, st + ST_g1, l);
+            __syncthreads();
+            if (live[hf] && !(KKT_ABLATE & 8)) {
+                float* G = a.G + (size_t)b * ((size_t)(nn + mm) * N - mm) + (size_t)(nn + mm) * k;
+                float* Cm = a.C + (size_t)b * (size_t)(nn + nm) * (N - 1) + (size_t)(nn + nm) * k;
+                float* g = a.g + (size_t)b * ((size_t)(n + m) * N - m) + (size_t)(n + m) * k;
+                float* c = a.c + (size_t)b * (size_t)n * N + (size_t)n * (k + 1);
+                kkt_copy_out<nn + mm>(G, st + ST_G, l);
+                kkt_copy_out<nn + nm>(Cm, st + ST_C, l);
+                kkt_copy_out<n + m>(g, st + ST_g, l);
+                kkt_copy_out<n>(c, st + ST_c1, l);
+                if (k == N - 2) {                                 // the last block: Q_{N-1}, q_{N-1} follow R_{N-2}, r_{N-2} in memory
+                    kkt_copy_out<nn>(G + nn + mm, st + ST_Q1, l);
+                    kkt_copy_out<n>(g + n + m, st + ST_g1, l);
+                }
+                if (k == 0) kkt_copy_out<n>(c - n, st + ST_c0, l);
             }
-            if (k == 0) kkt_copy_out<n>(c - n, st + ST_c0, l);
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
+#undef KR
 
 }  // namespace mpcg

@@ -321,7 +321,7 @@ int mpcg_set_option(mpcg_handle* h, const char* key, int value) {
     if (!strcmp(key, "schur_chunk")) { if (value < 0 || value > 2048) return fail(h, MPCG_ERR_INVALID, "schur_chunk must be 0 (auto) or 1..2048 block rows"); h->schur_chunk = value; return MPCG_OK; }
     if (!strcmp(key, "dz_dpp")) { h->dz_dpp = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "kkt_analytic")) { h->kkt_analytic = value ? 1 : 0; return MPCG_OK; }
-    if (!strcmp(key, "kkt_f32")) { h->kkt_f32 = value ? 1 : 0; return MPCG_OK; }
+    if (!strcmp(key, "kkt_f32")) { h->kkt_f32 = value == 2 ? 2 : value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "sched_hint")) { h->sched_hint = value ? 1 : 0; return MPCG_OK; }
     if (!strcmp(key, "cluster")) {
         if (value < -1 || value > 32) return fail(h, MPCG_ERR_INVALID, "cluster must be -1 (auto), 0 (off) or 1..32 workgroups per trajectory");

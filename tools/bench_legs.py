@@ -372,6 +372,10 @@ def iiwa_run(cx):
     d_xu, d_goal, d_xs = f32(xu_h), f32(goals_h.reshape(B, -1)), f32(xs_h)
     rc = iiwa.r_cost(N)
     ms_kkt = timed(lambda: sol.generate_kkt(plant, d_goal, d_xs, d_xu, iiwa.TIMESTEP, iiwa.QD_COST, rc), 3, warm=1)
+    # "kkt_f32" = 1 (opt-in): linsys_t's own arithmetic as in the reference's GRiD code, two knots per lane in packed float for a call of this size
+    sol.set_option("kkt_f32", 1)
+    ms_kkt_f32 = timed(lambda: sol.generate_kkt(plant, d_goal, d_xs, d_xu, iiwa.TIMESTEP, iiwa.QD_COST, rc), 3, warm=1)
+    sol.set_option("kkt_f32", 0)
     Gk, Ck, gk, ck = sol.generate_kkt(plant, d_goal, d_xs, d_xu, iiwa.TIMESTEP, iiwa.QD_COST, rc)
     Gk0 = Gk.clone()
     ms_schur = timed(lambda: (Gk.copy_(Gk0), sol.form_schur(Gk, Ck, gk, ck, synth.RHO_INIT, "ss")), 3, warm=1) - timed(lambda: Gk.copy_(Gk0), 3, warm=1)
@@ -394,6 +398,9 @@ def iiwa_run(cx):
             prod[nm_]["traffic"] = tr["hbm_traffic_bytes_per_launch"]
             prod[nm_]["traffic_over_algorithmic"] = tr["hbm_traffic_bytes_per_launch"] / (knots * mdl["bytes_per_unit"])
             prod[nm_]["traffic_source"] = src
+    prod["generate_kkt"]["kernel_ms_kkt_f32"] = ms_kkt_f32
+    prod["generate_kkt"]["kkt_f32"] = ("option \"kkt_f32\" = 1 (opt-in): float arithmetic (the reference's GRiD code: T = float), two knots per lane in v_pk_*_f32; "
+                                       "outputs within 1.5e-6 of the float64 restatement instead of 2e-7")
     prod["generate_kkt"]["bound"] = "fp64 VALU issue: ~6,000 instructions per wavefront of four knots at 4 clocks each = 0.32 ms (its HBM floor is 0.04 ms)"
     prod["form_schur"]["kernels"] = "schur_walk_kernel + schur_seam_kernel (chunk length %d)" % sol.get_option("last_schur_chunk")
     prod["form_schur"]["bound"] = ("hbm: its output pattern alone (8,192 row streams of the bd layout, no arithmetic) takes 0.20 ms = 3.7 TB/s on this chip, "
@@ -439,7 +446,7 @@ def iiwa_run(cx):
     res["warm"]["linsolves_per_sec_sched_hint_off"] = B / (ms_nh * 1e-3)
     out = {"inputs": f"{B} windows of the reference trajectory examples/trajfiles/0_0_traj.csv (first 400 rows), random offset, goals 0..8 steps ahead, "
                      "state / iterate noise <= 0.05; KKT blocks by mpcg_generate_kkt (IIWA-14 dynamics on the device), Schur by mpcg_form_schur, rho = 1e-3",
-           "pcg": {"max_iter": cx.max_iter, "exit_tol": args.exit_tol, "precond": "ss"}, "generate_kkt_ms": ms_kkt, "form_schur_ms": ms_schur, "compute_dz_ms": ms_dz,
+           "pcg": {"max_iter": cx.max_iter, "exit_tol": args.exit_tol, "precond": "ss"}, "generate_kkt_ms": ms_kkt, "generate_kkt_f32_ms": ms_kkt_f32, "form_schur_ms": ms_schur, "compute_dz_ms": ms_dz,
            "cold_start": res["cold"], "warm_start_from_previous_sqp_iterate": res["warm"],
            "note": "cond(-S) of these systems is 1e7-2e7 at N=128 (synthetic generator: ~1e5): from lambda0 = 0 most solves hit the reference's iteration "
                    "cap, which presupposes the MPC loop's warm starts (tests/make_iiwa_golden.py prints the study)"}
@@ -503,9 +510,22 @@ def iiwa_run(cx):
             step()
         ms_step = timed(gr.replay, 4, warm=1)
         it_step = d_it.cpu().numpy().astype(np.int64)
+        sol.set_option("kkt_f32", 1)
+        try:
+            step()
+            torch.cuda.synchronize()
+            gr32 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr32):
+                step()
+            ms_step_f32 = timed(gr32.replay, 4, warm=1)
+            it_step_f32 = float(d_it.cpu().numpy().astype(np.int64).mean())
+            del gr32
+        finally:
+            sol.set_option("kkt_f32", 0)
         sqp_step = {"what": "generate_kkt -> form_schur (ss) -> PCG warm-started from the previous iterate's multipliers -> compute_dz, one hipGraph replay",
                     "ms_per_batch": ms_step, "batch": B, "sqp_linear_steps_per_sec": B / (ms_step * 1e-3), "us_per_trajectory_step": ms_step * 1e3 / B,
-                    "mean_pcg_iters": float(it_step.mean()), "dz_finite": bool(torch.isfinite(dz_g).all().item())}
+                    "mean_pcg_iters": float(it_step.mean()), "dz_finite": bool(torch.isfinite(dz_g).all().item()),
+                    "ms_per_batch_kkt_f32": ms_step_f32, "mean_pcg_iters_kkt_f32": it_step_f32}
         del gr
     except Exception as e_:
         sqp_step = {"error": repr(e_)}
