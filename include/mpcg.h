@@ -360,10 +360,11 @@ int mpcg_qdldl_solve_schur(mpcg_handle *h, mpcg_ldl *l, const float *d_val, cons
  *       per wavefront, 0: one workgroup per knot; same bits), "block_solve_wide" (mpcg_block_solve: 1 one trajectory per wavefront, 0 four, -1 by
  *       batch size; same bits), "kkt_analytic" (mpcg_generate_kkt: 1 = the analytic gradient recursion of the inverse dynamics, the default;
  *       0 = one-sided float64 differences, the checker), "kkt_f32" (round 6; 1 = the analytic kernel with every recursion in float — linsys_t's own
- *       arithmetic, as the reference's GRiD<float>: outputs within 1.5e-6 of the float64 restatement instead of 2e-7; throughput-sized calls (more than
- *       32 knots per CU) run TWO knots per lane in packed float, 1.6x faster than the default — 0.204 against 0.330 ms per 1024 x 127 knots — with the
- *       same bits as the one-knot float build that smaller calls get (8 % faster); 2 = the packed build for every call; 0, the default: float64 inside,
- *       results rounded to float on the way out), "nt_loads" / "spmv_blocks_per_cu" (mpcg_bt_spmv), "spmv_mfma" (the MFMA experiment kernel).
+ *       arithmetic, as the reference's GRiD<float> — and TWO knots per lane in packed float: outputs within 5e-6 of the float64 restatement (relative to max(1, |block|); worst of 1024 windows: 4e-6) instead of
+ *       2e-7, 1.6x faster than the default on throughput-sized calls (0.204 against 0.330 ms per 1024 x 127 knots; a single trajectory: 20 against 16 us —
+ *       the default is the one for latency-sized calls), a trajectory's results independent of the rest of the batch; 2 = the same arithmetic with one
+ *       knot per lane (8 % faster than the default; differs from 1 by float rounding); 0, the default: float64 inside, results rounded to float on
+ *       the way out), "nt_loads" / "spmv_blocks_per_cu" (mpcg_bt_spmv), "spmv_mfma" (the MFMA experiment kernel).
  * "assume_symmetric" (0 / 1), "symmetry_state" (read-only; 0 unknown, 1 block-symmetric, 2 violated): see BLOCK SYMMETRY above.
  * "reserve_f64" (= 1: allocate the double cluster kernels' buffers now; see GRAPH CAPTURE above).
  * Read-only: "cluster_fixups" (trajectories re-solved by fix-up launches since mpcg_create — each costs 1.5-4.5 ms of spinning; blocking 8-byte

@@ -29,7 +29,8 @@
 // 1024 x 127 knots): in double the fp64 pipe is 75 % busy at two wavefronts per SIMD, and a float instruction takes the same issue slot as a double one.
 // What pays is R = kkt_f2: TWO knots per lane, every value a float pair, every multiply-add a v_pk_fma_f32 (model constants straight from scalar
 // registers through op_sel) — the same instruction stream as the double build (+15 %: pair moves, one-cycle packed hazards) for twice the knots:
-// **0.204 ms** (1.6x), bit-identical to the R = float build; launched for calls with more than one trip per wavefront slot of the chip (mpcg_plant.hip).
+// **0.204 ms** (1.6x); the R = float build's results to float rounding (the compiler contracts the two builds' expressions differently: 2e-6; either within 5e-6 of the float64 restatement over 1024 windows), and
+// independent of the batch (which knots share a lane is; a half's arithmetic is not).  "kkt_f32" = 1 is this build, = 2 the one-knot float build.
 // LDS is what bounds the resident wavefronts: 16.4 KB (double) / 19.9 KB (packed) per wavefront = EIGHT per CU (two per SIMD, round 3; 30 KB = five
 // before), which is what hides the dependent-issue latency of the recursion.
 #pragma once

@@ -60,8 +60,8 @@ def test_generate_kkt_vs_host_restatement(env, N, B, analytic):
 def test_generate_kkt_in_float_arithmetic(env, N, B):
     """"kkt_f32" = 1 (round 6, opt-in): the analytic kernel with every recursion in float — linsys_t's own arithmetic, what the reference's GRiD code
     runs in (iiwa_eepos_plant.cuh:127-155, T = float).  Against the float64 host restatement: float-level agreement (measured 1.5e-6 of max(1, |block|);
-    the float64-inside default: 2e-7), limit 1e-5; against the default kernel's outputs likewise.  "kkt_f32" = 2: the build with TWO knots per lane in
-    packed float (what = 1 launches for throughput-sized calls) — the same operations on each half, so the same limits; odd knot counts leave a half idle."""
+    the float64-inside default: 2e-7), limit 1e-5; against the default kernel's outputs likewise.  "kkt_f32" = 1 is the build with TWO knots per lane in
+    packed float, = 2 the one with one knot per lane: the same recursions, the same limits; odd knot counts leave a half of the last lane pair idle."""
     PcgSolver, plant, _, M = env
     xu, goals, xs = windows(N, B, 77 + N)
     outs = {}
@@ -87,6 +87,37 @@ def test_generate_kkt_in_float_arithmetic(env, N, B):
                 e32 = np.abs(outs[f32][i][b] - want[i]).max() / scale
                 assert e32 <= 1e-5, (b, name, f32, e32)
                 assert np.abs(outs[f32][i][b].astype(np.float64) - outs[0][i][b]).max() / scale <= 1e-5
+
+
+def test_generate_kkt_packed_float_does_not_depend_on_the_batch(env):
+    """"kkt_f32" = 1: two knots per lane in packed float, whatever the size of the call.  Which knot shares a lane with which depends on the batch; the arithmetic
+    of a half does not — a trajectory inside 70 (an odd number of knots: the last lane pair has an idle half) and the same trajectory in a call of three
+    give the same bits.  Against the one-knot float build ("kkt_f32" = 2) and the default: float rounding (the compiler contracts the two builds' expressions
+    differently; measured 2e-6 of max(1, |block|)), limit 1e-5."""
+    PcgSolver, plant, _, M = env
+    N, B = 128, 70
+    xu, goals, xs = windows(N, B, 4242)
+    args = lambda lo, hi: (plant, dev(goals[lo:hi].reshape(hi - lo, -1)), dev(xs[lo:hi]), dev(xu[lo:hi]), iiwa.TIMESTEP, iiwa.QD_COST, iiwa.r_cost(N))
+    sol = PcgSolver(N, max_batch=B)
+    sol.set_option("kkt_f32", 1)
+    big = [t.cpu().numpy() for t in sol.generate_kkt(*args(0, B))]
+    small = [t.cpu().numpy() for t in sol.generate_kkt(*args(B - 3, B))]
+    one = [t.cpu().numpy() for t in sol.generate_kkt(*args(B - 2, B - 1))]
+    sol.set_option("kkt_f32", 2)
+    knot = [t.cpu().numpy() for t in sol.generate_kkt(*args(B - 3, B))]
+    sol.set_option("kkt_f32", 0)
+    dflt = [t.cpu().numpy() for t in sol.generate_kkt(*args(B - 3, B))]
+    for i, name in enumerate("GCgc"):
+        assert np.isfinite(big[i]).all()
+        assert np.array_equal(big[i][B - 3:], small[i]), name
+        assert np.array_equal(one[i][0], small[i][1]), name
+        scale = max(1.0, np.abs(dflt[i]).max())
+        assert np.abs(small[i].astype(np.float64) - dflt[i]).max() / scale <= 1e-5, name
+        assert np.abs(small[i].astype(np.float64) - knot[i]).max() / scale <= 1e-5, name
+    want = iiwa_ref.generate_kkt(M, xu[B - 1].astype(np.float32).astype(np.float64), goals[B - 1].astype(np.float32).astype(np.float64),
+                                 xs[B - 1].astype(np.float32).astype(np.float64), N)
+    for i, name in enumerate("GCgc"):
+        assert np.abs(big[i][B - 1] - want[i]).max() / max(1.0, np.abs(want[i]).max()) <= 1e-5, name
 
 
 def test_generate_kkt_integrator_defects_vanish_on_the_reference_trajectory(env):

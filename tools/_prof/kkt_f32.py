@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""mpcg_generate_kkt in float arithmetic ("kkt_f32" = 1) against the float64-inside kernel: worst difference per output array (relative to the array's
+"""mpcg_generate_kkt in float arithmetic ("kkt_f32" = 1: two knots per lane in packed float; = 2: one knot per lane) against the float64-inside kernel: worst difference per output array (relative to the array's
 largest entry, and to the float64 host restatement on a few knots) and time per 1024 x 127 knots at steady clocks."""
 import os, sys, time
 import numpy as np, torch
@@ -35,7 +35,7 @@ for f32 in (0, 1, 2):
 for nm, a64, a32, apk in zip("GCgc", outs[0], outs[1], outs[2]):
     d = np.abs(a64 - a32)
     print(f"  {nm}: max |f32 - f64| = {d.max():.3e}  (max |{nm}| = {np.abs(a64).max():.3e}; relative {d.max() / np.abs(a64).max():.2e}; rms {np.sqrt((d ** 2).mean()):.2e})"
-          f"   packed vs scalar float: max {np.abs(apk - a32).max():.3e}, identical {np.array_equal(apk, a32)}")
+          f"   one-knot float vs packed float: max {np.abs(apk - a32).max():.3e}, identical {np.array_equal(apk, a32)}")
 # against the float64 host restatement on a few windows
 import iiwa_ref
 M = iiwa_ref.Model()

@@ -372,7 +372,7 @@ def iiwa_run(cx):
     d_xu, d_goal, d_xs = f32(xu_h), f32(goals_h.reshape(B, -1)), f32(xs_h)
     rc = iiwa.r_cost(N)
     ms_kkt = timed(lambda: sol.generate_kkt(plant, d_goal, d_xs, d_xu, iiwa.TIMESTEP, iiwa.QD_COST, rc), 3, warm=1)
-    # "kkt_f32" = 1 (opt-in): linsys_t's own arithmetic as in the reference's GRiD code, two knots per lane in packed float for a call of this size
+    # "kkt_f32" = 1 (opt-in): linsys_t's own arithmetic as in the reference's GRiD code, two knots per lane in packed float
     sol.set_option("kkt_f32", 1)
     ms_kkt_f32 = timed(lambda: sol.generate_kkt(plant, d_goal, d_xs, d_xu, iiwa.TIMESTEP, iiwa.QD_COST, rc), 3, warm=1)
     sol.set_option("kkt_f32", 0)
@@ -400,7 +400,7 @@ def iiwa_run(cx):
             prod[nm_]["traffic_source"] = src
     prod["generate_kkt"]["kernel_ms_kkt_f32"] = ms_kkt_f32
     prod["generate_kkt"]["kkt_f32"] = ("option \"kkt_f32\" = 1 (opt-in): float arithmetic (the reference's GRiD code: T = float), two knots per lane in v_pk_*_f32; "
-                                       "outputs within 1.5e-6 of the float64 restatement instead of 2e-7")
+                                       "outputs within 5e-6 of the float64 restatement instead of 2e-7")
     prod["generate_kkt"]["bound"] = "fp64 VALU issue: ~6,000 instructions per wavefront of four knots at 4 clocks each = 0.32 ms (its HBM floor is 0.04 ms)"
     prod["form_schur"]["kernels"] = "schur_walk_kernel + schur_seam_kernel (chunk length %d)" % sol.get_option("last_schur_chunk")
     prod["form_schur"]["bound"] = ("hbm: its output pattern alone (8,192 row streams of the bd layout, no arithmetic) takes 0.20 ms = 3.7 TB/s on this chip, "
