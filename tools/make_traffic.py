@@ -21,7 +21,7 @@ for name, k in pmc.items():
         key = f"bt_spmv_kernel|N{N}_B{spB}"
     elif "pcg_traj_kernel<16, 0, 2" in name:
         key = f"pcg_traj_kernel<16,0,2>|N512_B{B}_ss_it67_tol0"          # bench.py's streaming leg: N = 512, batch B, 67 fixed iterations
-    elif "generate_kkt_kernel<true>" in name:
+    elif "generate_kkt_kernel<true, double>" in name or "generate_kkt_kernel<true>" in name:       # (the default build: float64 inside)
         key = f"generate_kkt|N{N}_B{B}"
     elif "compute_dz_dpp_kernel" in name:
         key = f"compute_dz|N{N}_B{B}"
