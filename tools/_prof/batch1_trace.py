@@ -11,6 +11,8 @@ dev = torch.device("cuda", 0)
 plant = Plant(device=0)
 f32 = lambda a_: torch.from_numpy(np.ascontiguousarray(a_, np.float32)).to(dev)
 sol = PcgSolver(N, max_batch=1, device=0)
+if os.environ.get("KKT_F32"):
+    sol.set_option("kkt_f32", int(os.environ["KKT_F32"]))
 xu_h, goals_h, xs_h = iiwa.random_windows(N, 1, 77 + N)
 rc = iiwa.r_cost(N)
 cfg = pcg_config(pcg_exit_tol=1e-4, pcg_max_iter=synth.pcg_max_iter(N))
@@ -30,7 +32,7 @@ for _ in range(3):
     step(); torch.cuda.synchronize()
 # warm start = the solution itself shifted a little: a handful of iterations, as in the MPC loop
 step(); torch.cuda.synchronize()
-lam_prev.copy_(lam * 0.98)
+lam_prev.copy_(lam)              # (warm start = the converged multipliers: a few iterations, as in the MPC loop)
 gr = torch.cuda.CUDAGraph()
 with torch.cuda.graph(gr):
     step()
