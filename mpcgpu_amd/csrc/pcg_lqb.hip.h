@@ -545,11 +545,7 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
             rd = load_red(red_v);
             f = fetch(L::US);                                   // (the operand loads fly during the scalar chain)
             // alpha = eta / v ; lambda += alpha p ; r -= alpha upsilon ; r~ = Pinv r ; eta' = r . r~
-#if defined(LQB_ABLATE) && (LQB_ABLATE & 1)     // (timing experiments only: results are wrong with any bit set)
-            const float alpha = uniform(eta * sum_red(rd));
-#else
-            const float alpha = uniform(eta / sum_red(rd));
-#endif
+            const float alpha = uniform(eta / sum_red(rd));    // (IEEE division: 75 clocks of the chain, measured by ablation; the reciprocal forms were slower, see above)
 #pragma unroll
             for (int i = 0; i < 3; ++i) lam.p[i] = lam.p[i] + alpha * pv.p[i];
             lam.s = lam.s + alpha * pv.s;
@@ -564,11 +560,7 @@ __global__ __launch_bounds__(NMAXQ * 4, 2) void pcg_lqb_kernel(PcgArgs a) {
             const float eta_new = uniform(sum_red(rd));
             iters = (uint32_t)(it + 1);
             if (fabsf(eta_new) < a.exit_tol) { max_iter_exit = 0; p_pending = false; break; }     // (the reference leaves p as it is on this exit)
-#if defined(LQB_ABLATE) && (LQB_ABLATE & 1)
-            beta = uniform(eta_new * eta);
-#else
             beta = uniform(eta_new / eta);
-#endif
             eta = eta_new;
             MPCG_STAMP(10);
         }
