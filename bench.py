@@ -144,6 +144,7 @@ def compact_line(full: dict) -> dict:
         "headline_hbm_algorithmic_bytes": rr.get("hbm_algorithmic_bytes_per_launch"),
         "form_schur_frac": _get(prod, "form_schur", "frac"), "form_schur_traffic_over_algorithmic": _get(prod, "form_schur", "traffic_over_algorithmic"),
         "compute_dz_frac": _get(prod, "compute_dz", "frac"), "generate_kkt_frac_of_fp64_valu_peak": _get(prod, "generate_kkt", "frac_of_valu_peak"),
+        "generate_kkt_f32_frac_of_fp32_valu_peak": _get(prod, "generate_kkt", "frac_of_fp32_valu_peak_kkt_f32"),
         "pcg_streaming_N512_frac": _get(full, "roofline_pcg_streaming", "frac"),
         "traffic_source": sp.get("traffic_source"),
     }

@@ -399,6 +399,7 @@ def iiwa_run(cx):
             prod[nm_]["traffic_over_algorithmic"] = tr["hbm_traffic_bytes_per_launch"] / (knots * mdl["bytes_per_unit"])
             prod[nm_]["traffic_source"] = src
     prod["generate_kkt"]["kernel_ms_kkt_f32"] = ms_kkt_f32
+    prod["generate_kkt"]["frac_of_fp32_valu_peak_kkt_f32"] = knots * PRODUCER_MODEL["generate_kkt"]["flops_per_unit"] / (ms_kkt_f32 * 1e-3) / 1e12 / FP32_VALU_PEAK_TF
     prod["generate_kkt"]["kkt_f32"] = ("option \"kkt_f32\" = 1 (opt-in): float arithmetic (the reference's GRiD code: T = float), two knots per lane in v_pk_*_f32; "
                                        "outputs within 5e-6 of the float64 restatement instead of 2e-7")
     prod["generate_kkt"]["bound"] = "fp64 VALU issue: ~6,000 instructions per wavefront of four knots at 4 clocks each = 0.32 ms (its HBM floor is 0.04 ms)"
