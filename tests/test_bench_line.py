@@ -107,3 +107,20 @@ def test_no_extras_record_still_makes_a_line():
                                                     "dtype", "data", "config", "results_gather", "per_rank_kernel_ms", "self_launched", "roofline_resident")}
     o = _strict(json.dumps(bench.compact_line(f), allow_nan=False))
     assert o["roofline"]["headline_kernel"] == "pcg_lpk_kernel" and o["roofline"]["traffic"] is None and "cpu_baseline" not in o
+
+
+def test_committed_traffic_file_has_every_key_the_bench_looks_up():
+    """profiles/traffic.json (tools/make_traffic.py from the round's PMC passes) is where bench.py takes the HBM-side traffic of its roofline objects from.
+    tools/make_traffic.py matches kernels by NAME: when round 6 templated generate_kkt_kernel on its arithmetic type the name changed and its entry silently
+    disappeared for two profile rounds.  The keys of the default workload (bench_legs.load_traffic call sites) must all be there, with plausible byte counts."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert os.path.exists(os.path.join(root, t["source"].split(" ")[0])), t["source"]
+    want = ["pcg_lqb_kernel|N128_B1024_ss_it167_tol0.0001", "bt_spmv_kernel|N128_B4096", "generate_kkt|N128_B1024", "form_schur|N128_B1024", "compute_dz|N128_B1024",
+            "pcg_traj_kernel<16,0,2>|N512_B1024_ss_it67_tol0"]
+    for k in want:
+        assert k in t["kernels"], (k, sorted(t["kernels"]))
+        e = t["kernels"][k]
+        assert e["hbm_traffic_bytes_per_launch"] > 1e6 and e["fetch_bytes_corrected"] >= 0 and e["write_bytes"] >= 0 and e["launches_averaged"] >= 1, (k, e)
